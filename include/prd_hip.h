@@ -1,0 +1,145 @@
+/* libprd_hip.so -- C ABI of the MI355X-native ProteinReDiff denoiser hot path.
+ *
+ * The reference (HySonLab/Protein_Redesign) is pure eager PyTorch: it has no FFI of its own.  The
+ * entry points below are therefore the operator boundary a maintainer would bind from Python
+ * (ctypes): one function per nn.Module.forward on the hot path,
+ * plus the building blocks they are composed of and a whole-step driver.  Each comment cites the
+ * reference code the function replaces (paths relative to the reference repository).
+ *
+ * Rules of the boundary
+ *   - extern "C", plain pointers / ints / floats only.  All pointers are DEVICE pointers to
+ *     contiguous fp32 (or int64 where stated) buffers owned by the caller (PyTorch's allocator).
+ *   - The library never allocates or frees device memory and keeps no global state; scratch is
+ *     passed in as `ws` with its size in bytes (query with prd_workspace_bytes).
+ *   - Every call only enqueues kernels on `stream` (the caller's current HIP stream), never
+ *     synchronises, and is therefore capturable into a hipGraph.
+ *   - Return value: 0 on success, a positive hipError_t from the launch, or a negative PRD_ERR_*.
+ *   - Layouts: single [b,N,S], pair [b,N,N,P] channel-last, masks [b,N] fp32 0/1, weights in
+ *     nn.Linear layout [out,in] row-major.  P must be 32 or 64; H*c must be 64 (4 heads x 16);
+ *     S, dist_dim and S/4 must be multiples of 8.
+ */
+#ifndef PRD_HIP_H
+#define PRD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define PRD_VERSION 100
+#define PRD_ERR_ARG (-1)        /* null pointer / non-positive dimension */
+#define PRD_ERR_ALIGN (-2)      /* leading dimension not a multiple of 4 floats */
+#define PRD_ERR_UNSUPPORTED (-3)/* pair_dim / head layout outside the compiled set */
+#define PRD_ERR_WORKSPACE (-4)  /* workspace too small */
+
+int prd_version(void);
+
+/* ---- generic batched GEMM:  C[g] = epilogue(A[g] * B[g]^T)  (b_kn = 1: A[g] * B[g]) -------------
+ * Replaces aten::linear / bmm / matmul on the single track (modules.py:185-225, 306-311;
+ * models/AF2_modules.py:251-293, 613-628) and the triangle-multiplication einsum (modules.py:272).
+ * Batch index g = g1 * G2 + g2.  Epilogue, in this order:
+ *   v = acc*alpha + bias[n];  v += addmat[g][m][n];  if colmask[g1][n] < 0.5: v = fill;
+ *   act (0 none, 1 relu, 2 sigmoid) applied to columns n >= act_from;  v *= rowmask[g1][m];
+ *   v *= mulmat[g][m][n];  v += resid[g][m][n];  C[g][m][n] = v.
+ * lda/ldb must be multiples of 4 floats (rows 16-byte aligned). */
+typedef struct PrdGemm {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int G1, G2;
+    long long sa1, sa2, sb1, sb2, sc1, sc2;
+    int b_kn;
+    float alpha;
+    const float* bias;
+    int act, act_from;
+    const float* addmat; long long sad1, sad2; int ldadd;
+    const float* colmask; long long scm1; float fill;
+    const float* rowmask; long long srm1;
+    const float* mulmat; long long smu1, smu2; int ldmul;
+    const float* resid; long long sr1, sr2; int ldr;
+} PrdGemm;
+int prd_gemm(const PrdGemm* args, hipStream_t stream);
+
+/* nn.LayerNorm over the last axis, eps 1e-5; gamma/beta may be NULL (elementwise_affine=False). */
+int prd_ln_rows(const float* x, float* y, const float* gamma, const float* beta,
+                int rows, int C, int ldx, int ldy, hipStream_t stream);
+/* In-place softmax over the first n entries of every row; entries [n, ld) are set to 0. */
+int prd_softmax_rows(float* x, int rows, int n, int ld, hipStream_t stream);
+
+/* ---- input stage (model.py:342-361; modules.py:35-97) ------------------------------------------- */
+/* step-invariant part of the pair input: atom-atom bond / bond-distance embeddings and
+ * residue-residue relative-position embedding (model.py:348-358).  Index tensors are int64. */
+int prd_static_pair(float* out, const float* atom_mask, const float* residue_mask, const float* bond_mask,
+                    const int64_t* bond_feats, const int64_t* bond_distance,
+                    const int64_t* residue_index, const int64_t* chain_index,
+                    const float* tab_b0, const float* tab_b1, const float* tab_b2,
+                    const float* tab_bdist, const float* tab_relpos,
+                    int max_bond_distance, int max_relpos, int b, int N, int P, hipStream_t stream);
+/* atom part of the single input: atom_mask * sum_f E_f[atom_feats_f] / 3 (model.py:342, modules.py:47-51).
+ * tables = the nine tables concatenated row-wise [sum(card), S]; offsets[9] = first row of each. */
+int prd_atom_embed(float* out, const int64_t* atom_feats, const float* atom_mask, const float* tables,
+                   const int* offsets, int n_feats, int b, int N, int S, hipStream_t stream);
+/* per-step single input: single = static_single + residue_mask * relu(W_rt * LN(seq_t)) (model.py:343-346) */
+int prd_single_init(float* single, const float* static_single, const float* seq_t, const float* residue_mask,
+                    const float* w_rt, int rows, int S, int n_cls, hipStream_t stream);
+/* embed_beta: ebeta[b,P] = W_beta * [sin(w t/T), cos(w t/T)] (modules.py:85-97, model.py:341,360) */
+int prd_time_embed(float* ebeta, const int64_t* t, const float* freqs, const float* w_beta,
+                   int num_steps, int b, int P, int time_dim, hipStream_t stream);
+/* pair = static_pair + m_i m_j (W_d rbf(|z_i - z_j|) + ebeta)  (model.py:339-340, 359-361; modules.py:73-82) */
+int prd_pair_init(float* pair, const float* static_pair, const float* z, const float* mask,
+                  const float* centers, const float* w_dist, const float* ebeta,
+                  int b, int N, int P, int dist_dim, hipStream_t stream);
+
+/* ---- trunk operators ------------------------------------------------------------------------------ */
+/* pair[b,N,N,P] -> bias[b,H,N,N] = Linear(LN(pair)) permuted (modules.py:300-304 with bias, no LN affine;
+ * models/AF2_modules.py:406-411,454-459 with LN affine gamma/beta and no bias). */
+int prd_pair_bias(float* bias_out, const float* pair, const float* gamma, const float* beta,
+                  const float* w, const float* bvec, int b, int N, int P, int H, hipStream_t stream);
+/* OuterProductUpdate tail (models/AF2_modules.py:532-545 + modules.py:395-397):
+ * out[i,j,:] = (flags&1 ? pair : 0) + (flags&2 ? m_i m_j : 1) * (W_o (a_i * b_j) + b_o) / (m_i m_j + 1e-3);
+ * ab = [a | b] of shape [b,N,2C].  `out` may alias `pair` (in-place residual update), here and below. */
+int prd_opm_pair(float* out, const float* pair, const float* ab, const float* mask, const float* w_out,
+                 const float* b_out, int flags, int b, int N, int P, int C, hipStream_t stream);
+/* OuterLinear (modules.py:283-287): out[i,j,:] = (residual ? pair : 0) + W1 (x_i * x_j) + u_i - u_j + bias,
+ * x = LN(single), u = x W2^T [b,N,P] (computed by prd_gemm), w = [W1 | W2] of shape [P, 2S]. */
+int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
+                     const float* bias, int residual, int b, int N, int P, int S, hipStream_t stream);
+/* TriangleMultiplication (modules.py:262-274): out = (residual ? pair : 0) + update(pair).
+ * ws: 3 * b * P * N * round_up(N,32) floats. */
+int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w_proj, const float* b_proj,
+                const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
+                const float* w_ogate, const float* b_ogate, int incoming, int residual,
+                int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream);
+/* TriangleAttention (modules.py:236-243 -> 185-225): out = (residual ? pair : 0) + update(pair).
+ * ws: b * N * N * 64 floats. */
+int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
+                 const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
+                 int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, hipStream_t stream);
+/* pair transition (modules.py:321-326): out = (residual ? pair : 0) + W2 relu(W1 LN(pair) + b1) + b2, hidden = 4P */
+int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
+                        const float* b2, int residual, int b, int N, int P, hipStream_t stream);
+/* coordinate head (modules.py:403 + model.py:364-372): symmetrise, LN -> Linear -> ReLU -> Linear(1),
+ * eps_raw[b,N,3] = sum_j m_i m_j w_ij (z_i - z_j) rsqrt(|z_i - z_j|^2 + 1e-4)  (mean not yet removed) */
+int prd_coord_head(float* eps_raw, const float* pair, const float* z, const float* mask,
+                   const float* w1, const float* b1, const float* w2, int b, int N, int P, hipStream_t stream);
+/* remove_mean (utils.py:32-36) applied to eps_raw -> noise_pred */
+int prd_remove_mean(float* out, const float* x, const float* mask, int b, int N, int D, hipStream_t stream);
+/* reverse-diffusion update (model.py:405-420): z <- (z - w_t eps)/sqrt(alpha_t) [+ sqrt(beta_t) remove_mean(noise)],
+ * seq_t <- 2 softmax(seq_pred) - 1, t <- t - 1.  coef = [T][4] = {w_noise, 1/sqrt_alpha, sqrt_beta, 0}. */
+int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pred, const float* seq_pred,
+                       const float* noise, const float* mask, const float* coef,
+                       int b, int N, int n_cls, hipStream_t stream);
+
+/* bytes of scratch an operator needs: op = "tri_mul" | "tri_attn" */
+size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRD_HIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libprd_hip.so (include/prd_hip.h).  The product path is HIP only: importing an
+operator without the built library, or calling it on a CPU tensor, raises -- there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libprd_hip.so")
+
+vp, ci, cf, cz, cll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+
+
+class PrdGemm(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("M", ci), ("N", ci), ("K", ci),
+        ("lda", ci), ("ldb", ci), ("ldc", ci),
+        ("G1", ci), ("G2", ci),
+        ("sa1", cll), ("sa2", cll), ("sb1", cll), ("sb2", cll), ("sc1", cll), ("sc2", cll),
+        ("b_kn", ci), ("alpha", cf),
+        ("bias", vp), ("act", ci), ("act_from", ci),
+        ("addmat", vp), ("sad1", cll), ("sad2", cll), ("ldadd", ci),
+        ("colmask", vp), ("scm1", cll), ("fill", cf),
+        ("rowmask", vp), ("srm1", cll),
+        ("mulmat", vp), ("smu1", cll), ("smu2", cll), ("ldmul", ci),
+        ("resid", vp), ("sr1", cll), ("sr2", cll), ("ldr", ci),
+    ]
+
+
+# name -> argtypes (every entry point of include/prd_hip.h; tests check the export list against the header)
+SIGNATURES = {
+    "prd_version": [],
+    "prd_gemm": [C.POINTER(PrdGemm), vp],
+    "prd_ln_rows": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
+    "prd_softmax_rows": [vp, ci, ci, ci, vp],
+    "prd_static_pair": [vp] * 13 + [ci] * 5 + [vp],
+    "prd_atom_embed": [vp] * 5 + [ci] * 4 + [vp],
+    "prd_single_init": [vp] * 5 + [ci] * 3 + [vp],
+    "prd_time_embed": [vp] * 4 + [ci] * 4 + [vp],
+    "prd_pair_init": [vp] * 7 + [ci] * 4 + [vp],
+    "prd_pair_bias": [vp] * 6 + [ci] * 4 + [vp],
+    "prd_opm_pair": [vp] * 6 + [ci] * 5 + [vp],
+    "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp],
+    "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp],
+    "prd_tri_attn": [vp] * 10 + [ci] * 6 + [vp, cz, vp],
+    "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp],
+    "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
+    "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
+    "prd_reverse_update": [vp] * 8 + [ci] * 3 + [vp],
+    "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m protein_redesign_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = cz if name == "prd_workspace_bytes" else ci
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        names = {-1: "PRD_ERR_ARG", -2: "PRD_ERR_ALIGN", -3: "PRD_ERR_UNSUPPORTED", -4: "PRD_ERR_WORKSPACE"}
+        raise RuntimeError(f"{what} failed: {names.get(code, 'hipError_t ' + str(code))}")
+
+
+def dptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("protein_redesign_amd operators run on the GPU only (got a CPU tensor); "
+                           "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,209 @@
+// Generic fp32 building blocks of the single track and of the triangle-multiplication contraction:
+//   * prd_gemm:     batched C = epilogue(A * B^T) (or A * B) on v_mfma_f32_32x32x2_f32, LDS tiled
+//   * prd_ln_rows:  LayerNorm over the last axis (optional affine)
+//   * prd_softmax_rows: in-place row softmax with zero fill of the padded tail
+// Replaces the ATen linear / bmm / layer_norm / softmax calls of the reference
+// (ProteinReDiff/modules.py:185-225, 306-311; models/AF2_modules.py:251-293, 613-628).
+#include "prd_common.h"
+#include "../../include/prd_hip.h"
+
+namespace {
+
+constexpr int KC = 32;          // K chunk staged in LDS per iteration
+constexpr int LDT = KC + 4;     // LDS row pitch (floats): conflict-free ds_read_b128 down a column
+
+template <int WM, int WN>       // wave tile (multiples of 32); workgroup = 2 x 2 waves
+__global__ __launch_bounds__(256) void gemm_kernel(PrdGemm g) {
+    constexpr int TM = 2 * WM, TN = 2 * WN, MI = WM / 32, NI = WN / 32;
+    __shared__ __attribute__((aligned(16))) float As[TM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[TN * LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int tiles_n = (g.N + TN - 1) / TN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+    const int gb = blockIdx.y, g1 = gb / g.G2, g2 = gb - g1 * g.G2;
+
+    const float* __restrict__ A = g.A + g1 * g.sa1 + g2 * g.sa2;
+    const float* __restrict__ B = g.B + g1 * g.sb1 + g2 * g.sb2;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+
+    for (int k0 = 0; k0 < g.K; k0 += KC) {
+        // ---- stage A tile: TM rows x 32 floats, 8 threads per row, 16 B each ----
+#pragma unroll
+        for (int rep = 0; rep < TM / 32; ++rep) {
+            const int row = (tid >> 3) + 32 * rep, f = tid & 7;
+            const int m = m0 + row, k = k0 + 4 * f;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < g.M && k < g.K) {
+                v = *reinterpret_cast<const float4*>(A + (size_t)m * g.lda + k);
+                if (k + 1 >= g.K) v.y = 0.f;
+                if (k + 2 >= g.K) v.z = 0.f;
+                if (k + 3 >= g.K) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(&As[row * LDT + 4 * f]) = v;
+        }
+        if (!g.b_kn) {
+#pragma unroll
+            for (int rep = 0; rep < TN / 32; ++rep) {
+                const int row = (tid >> 3) + 32 * rep, f = tid & 7;
+                const int n = n0 + row, k = k0 + 4 * f;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < g.N && k < g.K) {
+                    v = *reinterpret_cast<const float4*>(B + (size_t)n * g.ldb + k);
+                    if (k + 1 >= g.K) v.y = 0.f;
+                    if (k + 2 >= g.K) v.z = 0.f;
+                    if (k + 3 >= g.K) v.w = 0.f;
+                }
+                *reinterpret_cast<float4*>(&Bs[row * LDT + 4 * f]) = v;
+            }
+        } else {
+            // B is [K][N]: read 16 B along n, scatter transposed into Bs[n][k]
+            constexpr int F = TN / 4;                 // float4 per k row of the tile
+            for (int idx = tid; idx < KC * F; idx += 256) {
+                const int kk = idx / F, f = idx - kk * F;
+                const int k = k0 + kk, n = n0 + 4 * f;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < g.K && n < g.N) {
+                    v = *reinterpret_cast<const float4*>(B + (size_t)k * g.ldb + n);
+                    if (n + 1 >= g.N) v.y = 0.f;
+                    if (n + 2 >= g.N) v.z = 0.f;
+                    if (n + 3 >= g.N) v.w = 0.f;
+                }
+                Bs[(4 * f + 0) * LDT + kk] = v.x;
+                Bs[(4 * f + 1) * LDT + kk] = v.y;
+                Bs[(4 * f + 2) * LDT + kk] = v.z;
+                Bs[(4 * f + 3) * LDT + kk] = v.w;
+            }
+        }
+        __syncthreads();
+        // ---- 16 k-steps of 2: lane (r,hi) feeds k = hi*16 + 4t + e for both operands ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float4 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = *reinterpret_cast<const float4*>(&As[(wm0 + 32 * mi + r) * LDT + hi * 16 + 4 * t]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                b[ni] = *reinterpret_cast<const float4*>(&Bs[(wn0 + 32 * ni + r) * LDT + hi * 16 + 4 * t]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    acc[mi][ni] = mfma32(a[mi].x, b[ni].x, acc[mi][ni]);
+                    acc[mi][ni] = mfma32(a[mi].y, b[ni].y, acc[mi][ni]);
+                    acc[mi][ni] = mfma32(a[mi].z, b[ni].z, acc[mi][ni]);
+                    acc[mi][ni] = mfma32(a[mi].w, b[ni].w, acc[mi][ni]);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column n = ... + r, rows drow32(q, hi) ----
+    float* __restrict__ C = g.C + g1 * g.sc1 + g2 * g.sc2;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn0 + 32 * ni + r;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+        const bool filled = g.colmask && g.colmask[g1 * g.scm1 + n] < 0.5f;
+        const int act = (n >= g.act_from) ? g.act : 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm0 + 32 * mi + drow32(q, hi);
+                if (m >= g.M) continue;
+                float v = acc[mi][ni][q] * g.alpha + bias;
+                if (g.addmat) v += g.addmat[g1 * g.sad1 + g2 * g.sad2 + (size_t)m * g.ldadd + n];
+                if (filled) v = g.fill;
+                if (act == 1) v = fmaxf(v, 0.f);
+                else if (act == 2) v = sigmoidf_(v);
+                if (g.rowmask) v *= g.rowmask[g1 * g.srm1 + m];
+                if (g.mulmat) v *= g.mulmat[g1 * g.smu1 + g2 * g.smu2 + (size_t)m * g.ldmul + n];
+                if (g.resid) v += g.resid[g1 * g.sr1 + g2 * g.sr2 + (size_t)m * g.ldr + n];
+                C[(size_t)m * g.ldc + n] = v;
+            }
+    }
+}
+
+// ---- LayerNorm rows: one wave per row ------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int rows, int C, int ldx, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / C + 1e-5f);
+    float* yr = y + (size_t)row * ldy;
+    for (int c = lane; c < C; c += 64) {
+        float t = (xr[c] - mean) * rstd;
+        if (gamma) t = t * gamma[c] + beta[c];
+        yr[c] = t;
+    }
+}
+
+// ---- softmax rows (in place), one wave per row, zero-fills [n, ld) ---------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int rows, int n, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < n; c += 64) m = fmaxf(m, xr[c]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += expf(xr[c] - m);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    for (int c = lane; c < ld; c += 64) xr[c] = (c < n) ? expf(xr[c] - m) / s : 0.f;
+}
+
+}  // namespace
+
+extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
+    const PrdGemm& g = *args;
+    if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.G1 <= 0 || g.G2 <= 0) return PRD_ERR_ARG;
+    if ((g.lda & 3) || (g.ldb & 3)) return PRD_ERR_ALIGN;
+    const int batches = g.G1 * g.G2;
+    // small problems: 64x64 workgroup tiles fill the chip better; large: 128x128
+    const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
+    if (tiles64 <= 1024 || g.M <= 64 || g.N <= 64) {
+        dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
+        hipLaunchKernelGGL((gemm_kernel<32, 32>), grid, dim3(256), 0, stream, g);
+    } else {
+        dim3 grid(prd_ceil_div(g.M, 128) * prd_ceil_div(g.N, 128), batches);
+        hipLaunchKernelGGL((gemm_kernel<64, 64>), grid, dim3(256), 0, stream, g);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_ln_rows(const float* x, float* y, const float* gamma, const float* beta,
+                           int rows, int C, int ldx, int ldy, hipStream_t stream) {
+    if (!x || !y || rows <= 0 || C <= 0 || (gamma && !beta)) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(prd_ceil_div(rows, 4)), dim3(256), 0, stream, x, y, gamma, beta, rows, C, ldx, ldy);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_softmax_rows(float* x, int rows, int n, int ld, hipStream_t stream) {
+    if (!x || rows <= 0 || n <= 0 || ld < n) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(prd_ceil_div(rows, 4)), dim3(256), 0, stream, x, rows, n, ld);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,666 @@
+// Pair-track kernels, part 1: input stage, pair bias, outer-product update, outer-linear,
+// pair transition, coordinate head.  All follow the "lane owns a pair row" scheme of prd_common.h:
+// a wave processes 32 pair rows, each row's P channels split over lanes (r, hi); Linear layers run
+// as transposed MFMA GEMMs with the weights in LDS, so LayerNorm / gates / residuals stay in
+// registers and every pair row is read and written exactly once per operator.
+#include "prd_common.h"
+#include "../../include/prd_hip.h"
+
+namespace {
+
+constexpr int WG = 256;   // 4 waves
+
+PRD_DEV void decode_pos(long pos, int N, int& bb, int& i, int& j) {
+    const long nn = (long)N * N;
+    bb = (int)(pos / nn);
+    const int rem = (int)(pos - (long)bb * nn);
+    i = rem / N;
+    j = rem - i * N;
+}
+
+// ------------------------------------------------------------------------------------------------
+// static pair: embeddings gathered once per sample() (model.py:348-358)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void static_pair_kernel(
+    float* __restrict__ out, const float* __restrict__ am, const float* __restrict__ rm, const float* __restrict__ bond_mask,
+    const int64_t* __restrict__ bond_feats, const int64_t* __restrict__ bond_distance,
+    const int64_t* __restrict__ residue_index, const int64_t* __restrict__ chain_index,
+    const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ t2,
+    const float* __restrict__ tbd, const float* __restrict__ trp, int maxbd, int maxrel, int b, int N, int P) {
+    const int F = P / 4;
+    const long total = (long)b * N * N * F;
+    const float s = (float)(1.0 / sqrt(3.0));
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long pos = idx / F;
+        const int f = (int)(idx - pos * F);
+        int bb, i, j;
+        decode_pos(pos, N, bb, i, j);
+        const float ami = am[bb * N + i], amj = am[bb * N + j], rmi = rm[bb * N + i], rmj = rm[bb * N + j];
+        const float bm = bond_mask[pos];
+        const int64_t* bf = bond_feats + pos * 3;
+        long bd = bond_distance[pos];
+        if (bd > maxbd) bd = maxbd;
+        long rel = residue_index[bb * N + i] - residue_index[bb * N + j];
+        rel = rel < -maxrel ? -maxrel : (rel > maxrel ? maxrel : rel);
+        const float chain = chain_index[bb * N + i] == chain_index[bb * N + j] ? 1.f : 0.f;
+        const float4 e0 = *reinterpret_cast<const float4*>(t0 + bf[0] * P + 4 * f);
+        const float4 e1 = *reinterpret_cast<const float4*>(t1 + bf[1] * P + 4 * f);
+        const float4 e2 = *reinterpret_cast<const float4*>(t2 + bf[2] * P + 4 * f);
+        const float4 ed = *reinterpret_cast<const float4*>(tbd + bd * P + 4 * f);
+        const float4 er = *reinterpret_cast<const float4*>(trp + (maxrel + rel) * P + 4 * f);
+        const float am2 = ami * amj, rm2 = rmi * rmj;
+        float4 o;
+#define PRD_SP(c) o.c = am2 * (bm * (((0.f + s * e0.c) + s * e1.c) + s * e2.c) + ed.c) + rm2 * (chain * er.c)
+        PRD_SP(x); PRD_SP(y); PRD_SP(z); PRD_SP(w);
+#undef PRD_SP
+        *reinterpret_cast<float4*>(out + pos * P + 4 * f) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void atom_embed_kernel(float* __restrict__ out, const int64_t* __restrict__ feats,
+                                                         const float* __restrict__ am, const float* __restrict__ tables,
+                                                         const int* __restrict__ offsets, int nf, int rows, int S) {
+    const long total = (long)rows * S;
+    const float s = (float)(1.0 / sqrt((double)nf));
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / S;
+        const int c = (int)(idx - row * S);
+        float acc = 0.f;
+        for (int f = 0; f < nf; ++f) acc += s * tables[(offsets[f] + feats[row * nf + f]) * (long)S + c];
+        out[idx] = am[row] * acc;
+    }
+}
+
+// single = static + rm * relu(W_rt LN(seq_t));  one workgroup per node
+__global__ __launch_bounds__(128) void single_init_kernel(float* __restrict__ single, const float* __restrict__ stat,
+                                                          const float* __restrict__ seq_t, const float* __restrict__ rm,
+                                                          const float* __restrict__ w, int S, int ncls) {
+    __shared__ float xs[64];
+    const long row = blockIdx.x;
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        const float v = c < ncls ? seq_t[row * ncls + c] : 0.f;
+        float s = v;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / ncls;
+        const float d = c < ncls ? v - mean : 0.f;
+        float q = d * d;
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        xs[c] = d * (1.0f / sqrtf(q / ncls + 1e-5f));
+    }
+    __syncthreads();
+    const float m = rm[row];
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < ncls; ++k) acc += xs[k] * w[c * ncls + k];
+        single[row * S + c] = stat[row * S + c] + m * fmaxf(acc, 0.f);
+    }
+}
+
+__global__ void time_embed_kernel(float* __restrict__ eb, const int64_t* __restrict__ t, const float* __restrict__ freqs,
+                                  const float* __restrict__ w, int T, int P, int TD) {
+    extern __shared__ float feat[];
+    const int bb = blockIdx.x;
+    const float tau = (float)t[bb] / (float)T;
+    const int half = TD / 2;
+    for (int k = threadIdx.x; k < half; k += blockDim.x) {
+        const float wx = freqs[k] * tau;
+        feat[k] = sinf(wx);
+        feat[half + k] = cosf(wx);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < TD; ++k) acc += feat[k] * w[p * TD + k];
+        eb[bb * P + p] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair_init: pair = static + m2 * (W_d rbf(d) + ebeta).  B operand (rbf features) generated in
+// registers, A operand W_d from LDS; never materialises [N,N,dist_dim].
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(WG) void pair_init_kernel(float* __restrict__ pair, const float* __restrict__ stat,
+                                                       const float* __restrict__ z, const float* __restrict__ mask,
+                                                       const float* __restrict__ centers, const float* __restrict__ wd,
+                                                       const float* __restrict__ ebeta, int b, int N, int DK) {
+    constexpr int NB = P / 32, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                       // [P][DK+4]
+    float* cl = smem + P * (DK + 4);        // [DK]
+    stage_weight_plain(Wl, wd, P, DK, DK, 0, threadIdx.x, WG);
+    for (int k = threadIdx.x; k < DK; k += WG) cl[k] = centers[k];
+    __syncthreads();
+    const float scale = (float)((DK - 1) / 2.0);
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long rows = (long)b * N * N;
+    const long ntask = (rows + 31) / 32;
+    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+        const long pos = task * 32 + r;
+        const bool valid = pos < rows;
+        int bb = 0, i = 0, j = 0;
+        if (valid) decode_pos(pos, N, bb, i, j);
+        const float* zi = z + ((long)bb * N + i) * 3;
+        const float* zj = z + ((long)bb * N + j) * 3;
+        const float dx = zi[0] - zj[0], dy = zi[1] - zj[1], dz = zi[2] - zj[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float m2 = mask[bb * N + i] * mask[bb * N + j];
+        f32x16 acc[NB];
+        zero_acc(acc);
+        const int kb = hi * (DK / 2);
+        for (int m = 0; m < DK / 8; ++m) {
+            const float4 c4 = *reinterpret_cast<const float4*>(cl + kb + 4 * m);
+            float f0 = d - c4.x, f1 = d - c4.y, f2 = d - c4.z, f3 = d - c4.w;
+            f0 = expf(-scale * (f0 * f0)); f1 = expf(-scale * (f1 * f1));
+            f2 = expf(-scale * (f2 * f2)); f3 = expf(-scale * (f3 * f3));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float4 w = *reinterpret_cast<const float4*>(Wl + (nb * 32 + r) * (DK + 4) + kb + 4 * m);
+                acc[nb] = mfma32(w.x, f0, acc[nb]);
+                acc[nb] = mfma32(w.y, f1, acc[nb]);
+                acc[nb] = mfma32(w.z, f2, acc[nb]);
+                acc[nb] = mfma32(w.w, f3, acc[nb]);
+            }
+        }
+        float st[KH], eb[KH];
+        load_row_cll<P>(stat + pos * P, hi, valid, st);
+        load_row_cll<P>(ebeta + bb * P, hi, true, eb);
+        float o[KH];
+#pragma unroll
+        for (int s = 0; s < KH; ++s) o[s] = st[s] + m2 * (acc[s >> 4][s & 15] + eb[s]);
+        store_row_cll<P>(pair + pos * P, hi, valid, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair bias: [b,H,N,N] = Linear(LN(pair))  (HBM bound: one read of pair, H/P of it written)
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(WG) void pair_bias_kernel(float* __restrict__ out, const float* __restrict__ pair,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ w, const float* __restrict__ bvec,
+                                                       int b, int N, int H) {
+    constexpr int KH = P / 2;
+    __shared__ __attribute__((aligned(16))) float wl[8 * P];
+    __shared__ __attribute__((aligned(16))) float gl[P];
+    __shared__ __attribute__((aligned(16))) float bl[P];
+    for (int h = 0; h < H; ++h) stage_vec_cll(wl + h * P, w + h * P, P, threadIdx.x, WG);
+    stage_vec_cll(gl, gamma, P, threadIdx.x, WG);
+    stage_vec_cll(bl, beta, P, threadIdx.x, WG);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long nn = (long)N * N, rows = (long)b * nn, ntask = (rows + 31) / 32;
+    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+        const long pos = task * 32 + r;
+        const bool valid = pos < rows;
+        float x[KH];
+        load_row_cll<P>(pair + pos * P, hi, valid, x);
+        ln_cll<KH>(x);
+        if (gamma) {
+#pragma unroll
+            for (int s = 0; s < KH; ++s) x[s] = x[s] * gl[hi * KH + s] + bl[hi * KH + s];
+        }
+        const long bb = pos / nn, rem = pos - bb * nn;
+        for (int h = 0; h < H; ++h) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) acc += x[s] * wl[h * P + hi * KH + s];
+            acc = xhalf_sum(acc);
+            if (bvec) acc += bvec[h];
+            if (valid && hi == 0) out[(bb * H + h) * nn + rem] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// OPM tail: pair[i,j,:] += m2 * (W_o (a_i*b_j) + b_o) / (m2 + 1e-3)
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(WG) void opm_pair_kernel(float* out, const float* pair, const float* __restrict__ ab,
+                                                      const float* __restrict__ mask, const float* __restrict__ wo,
+                                                      const float* __restrict__ bo, int b, int N, int C, int flags) {
+    constexpr int NB = P / 32, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                    // [P][C+4]
+    float* bl = smem + P * (C + 4);      // [P] CLL
+    stage_weight_plain(Wl, wo, P, C, C, 0, threadIdx.x, WG);
+    stage_vec_cll(bl, bo, P, threadIdx.x, WG);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int nvb = (N + 31) / 32;
+    const long ntask = (long)b * N * nvb;
+    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+        const int vb = (int)(task % nvb);
+        const long bi = task / nvb;            // bb*N + i
+        const int bb = (int)(bi / N);
+        const int j = vb * 32 + r;
+        const bool valid = j < N;
+        const int jj = valid ? j : 0;
+        const float* ai = ab + bi * 2 * C + hi * (C / 2);
+        const float* bj = ab + ((long)bb * N + jj) * 2 * C + C + hi * (C / 2);
+        f32x16 acc[NB];
+        zero_acc(acc);
+        for (int m = 0; m < C / 8; ++m) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ai + 4 * m);
+            const float4 b4 = *reinterpret_cast<const float4*>(bj + 4 * m);
+            const float f0 = a4.x * b4.x, f1 = a4.y * b4.y, f2 = a4.z * b4.z, f3 = a4.w * b4.w;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float4 w = *reinterpret_cast<const float4*>(Wl + (nb * 32 + r) * (C + 4) + hi * (C / 2) + 4 * m);
+                acc[nb] = mfma32(w.x, f0, acc[nb]);
+                acc[nb] = mfma32(w.y, f1, acc[nb]);
+                acc[nb] = mfma32(w.z, f2, acc[nb]);
+                acc[nb] = mfma32(w.w, f3, acc[nb]);
+            }
+        }
+        const float m2 = mask[bi] * mask[(long)bb * N + jj];
+        const float norm = m2 + 1e-3f;
+        const long off = (bi * N + jj) * P;
+        float x[KH];
+        load_row_cll<P>(pair + off, hi, valid && (flags & 1), x);
+        const float mm = (flags & 2) ? m2 : 1.f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) x[s] = x[s] + mm * ((acc[s >> 4][s & 15] + bl[hi * KH + s]) / norm);
+        store_row_cll<P>(out + off, hi, valid, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// outer-linear: pair[i,j,:] += W1 (x_i*x_j) + u_i - u_j + bias.  The [N,N,2S] concat of the
+// reference (419 MB at N=320) is never formed: the product operand is generated per MFMA step.
+// K = S streamed in chunks of KCH through LDS (weights); x_i / x_j come straight from L2.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(WG) void outer_linear_kernel(float* out, const float* pair, const float* __restrict__ x,
+                                                          const float* __restrict__ u, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int b, int N, int S, int residual) {
+    constexpr int NB = P / 32, KH = P / 2, KCH = 128;
+    __shared__ __attribute__((aligned(16))) float Wl[P * (KCH + 4)];
+    __shared__ __attribute__((aligned(16))) float bl[P];
+    stage_vec_cll(bl, bias, P, threadIdx.x, WG);
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int nvb = (N + 31) / 32;
+    const long ntask = (long)b * N * nvb;
+    const long ngroups = (ntask + 3) / 4;
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long task = grp * 4 + (threadIdx.x >> 6);
+        const bool live = task < ntask;
+        const long tk = live ? task : 0;
+        const int vb = (int)(tk % nvb);
+        const long bi = tk / nvb;
+        const int bb = (int)(bi / N);
+        const int j = vb * 32 + r;
+        const bool valid = live && j < N;
+        const int jj = (j < N) ? j : 0;
+        const float* xi = x + bi * S;
+        const float* xj = x + ((long)bb * N + jj) * S;
+        f32x16 acc[NB];
+        zero_acc(acc);
+        for (int k0 = 0; k0 < S; k0 += KCH) {
+            const int kc = (S - k0 < KCH) ? (S - k0) : KCH;     // multiple of 8
+            __syncthreads();
+            stage_weight_plain(Wl, w, P, kc, 2 * S, k0, threadIdx.x, WG);
+            __syncthreads();
+            const int kb = hi * (kc / 2);
+            for (int m = 0; m < kc / 8; ++m) {
+                const float4 a4 = *reinterpret_cast<const float4*>(xi + k0 + kb + 4 * m);
+                const float4 b4 = *reinterpret_cast<const float4*>(xj + k0 + kb + 4 * m);
+                const float f0 = a4.x * b4.x, f1 = a4.y * b4.y, f2 = a4.z * b4.z, f3 = a4.w * b4.w;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float4 wv = *reinterpret_cast<const float4*>(Wl + (nb * 32 + r) * (kc + 4) + kb + 4 * m);
+                    acc[nb] = mfma32(wv.x, f0, acc[nb]);
+                    acc[nb] = mfma32(wv.y, f1, acc[nb]);
+                    acc[nb] = mfma32(wv.z, f2, acc[nb]);
+                    acc[nb] = mfma32(wv.w, f3, acc[nb]);
+                }
+            }
+        }
+        float ui[KH], uj[KH], pr[KH];
+        load_row_cll<P>(u + bi * P, hi, true, ui);
+        load_row_cll<P>(u + ((long)bb * N + jj) * P, hi, true, uj);
+        const long off = (bi * N + jj) * P;
+        load_row_cll<P>(pair + off, hi, valid && residual, pr);
+#pragma unroll
+        for (int s = 0; s < KH; ++s) pr[s] = pr[s] + (((acc[s >> 4][s & 15] + ui[s]) - uj[s]) + bl[hi * KH + s]);
+        store_row_cll<P>(out + off, hi, valid, pr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair transition: pair += W2 relu(W1 LN(pair) + b1) + b2  (hidden 4P kept in registers)
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(WG) void pair_transition_kernel(float* out, const float* pair, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1, const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, long rows, int residual) {
+    constexpr int KH = P / 2, HID = 4 * P, HB = HID / 32, HH = HID / 2, NB = P / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W1l = smem;                         // [HID][P+4]
+    float* W2l = W1l + HID * (P + 4);          // [P][HID+4]
+    float* b1l = W2l + P * (HID + 4);          // [HID] CLL
+    float* b2l = b1l + HID;                    // [P] CLL
+    stage_weight_cll<P>(W1l, w1, HID, P, threadIdx.x, WG);
+    stage_weight_cll<HID>(W2l, w2, P, HID, threadIdx.x, WG);
+    stage_vec_cll(b1l, b1, HID, threadIdx.x, WG);
+    stage_vec_cll(b2l, b2, P, threadIdx.x, WG);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long ntask = (rows + 31) / 32;
+    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+        const long pos = task * 32 + r;
+        const bool valid = pos < rows;
+        float x[KH];
+        load_row_cll<P>(pair + pos * P, hi, valid, x);
+        ln_cll<KH>(x);
+        // hidden units in two halves of 2P (CLL elements [0,HH/2) and [HH/2,HH)) to bound live registers
+        f32x16 acc2[NB];
+        zero_acc(acc2);
+        {
+            float h[HH / 2];
+            f32x16 acc[HB / 2];
+            zero_acc(acc);
+            rowgemm<P, HB / 2>(W1l, x, acc, r, hi);
+#pragma unroll
+            for (int s = 0; s < HH / 2; ++s) h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + s], 0.f);
+            rowgemm_part<HID, NB, 0, HID / 16>(W2l, h, acc2, r, hi);
+        }
+        {
+            float h[HH / 2];
+            f32x16 acc[HB / 2];
+            zero_acc(acc);
+            rowgemm<P, HB / 2>(W1l + (HID / 2) * (P + 4), x, acc, r, hi);
+#pragma unroll
+            for (int s = 0; s < HH / 2; ++s) h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + HH / 2 + s], 0.f);
+            rowgemm_part<HID, NB, HID / 16, HID / 8>(W2l, h, acc2, r, hi);
+        }
+        load_row_cll<P>(pair + pos * P, hi, valid && residual, x);      // raw row again (L2 hit) for the residual
+#pragma unroll
+        for (int s = 0; s < KH; ++s) x[s] = x[s] + (acc2[s >> 4][s & 15] + b2l[hi * KH + s]);
+        store_row_cll<P>(out + pos * P, hi, valid, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// coordinate head: one workgroup per (b,i); 4 waves split the j blocks; fixed-order reduction
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(WG) void coord_head_kernel(float* __restrict__ eps, const float* __restrict__ pair,
+                                                        const float* __restrict__ z, const float* __restrict__ mask,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, int b, int N) {
+    constexpr int NB = P / 32, KH = P / 2;
+    __shared__ __attribute__((aligned(16))) float W1l[P * (P + 4)];
+    __shared__ __attribute__((aligned(16))) float b1l[P];
+    __shared__ __attribute__((aligned(16))) float w2l[P];
+    __shared__ float red[4][3];
+    stage_weight_cll<P>(W1l, w1, P, P, threadIdx.x, WG);
+    stage_vec_cll(b1l, b1, P, threadIdx.x, WG);
+    stage_vec_cll(w2l, w2, P, threadIdx.x, WG);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5, wave = threadIdx.x >> 6;
+    const int nvb = (N + 31) / 32;
+    for (long bi = blockIdx.x; bi < (long)b * N; bi += gridDim.x) {
+        const int bb = (int)(bi / N), i = (int)(bi - (long)bb * N);
+        const float zi0 = z[bi * 3], zi1 = z[bi * 3 + 1], zi2 = z[bi * 3 + 2];
+        const float mi = mask[bi];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int vb = wave; vb < nvb; vb += 4) {
+            const int j = vb * 32 + r;
+            const bool valid = j < N;
+            const int jj = valid ? j : 0;
+            float a[KH], t[KH];
+            load_row_cll<P>(pair + (bi * N + jj) * P, hi, valid, a);
+            load_row_cll<P>(pair + (((long)bb * N + jj) * N + i) * P, hi, valid, t);
+#pragma unroll
+            for (int s = 0; s < KH; ++s) a[s] = 0.5f * (a[s] + t[s]);
+            ln_cll<KH>(a);
+            f32x16 acc[NB];
+            zero_acc(acc);
+            rowgemm<P, NB>(W1l, a, acc, r, hi);
+            float wsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) wsum += fmaxf(acc[s >> 4][s & 15] + b1l[hi * KH + s], 0.f) * w2l[hi * KH + s];
+            wsum = xhalf_sum(wsum);
+            const float* zj = z + ((long)bb * N + jj) * 3;
+            const float d0 = zi0 - zj[0], d1 = zi1 - zj[1], d2 = zi2 - zj[2];
+            const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-4f);
+            const float m2 = (valid && hi == 0) ? mi * mask[(long)bb * N + jj] : 0.f;
+            const float f = m2 * wsum;
+            s0 += f * (d0 * inv); s1 += f * (d1 * inv); s2 += f * (d2 * inv);
+        }
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        __syncthreads();
+        if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            eps[bi * 3 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
+// remove_mean over the node axis; one workgroup per sample
+__global__ __launch_bounds__(256) void remove_mean_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                          const float* __restrict__ mask, int N, int D) {
+    __shared__ float red[256];
+    __shared__ float mean[64];
+    const int bb = blockIdx.x;
+    float cnt = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) cnt += mask[bb * N + i];
+    red[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const float norm = red[0];
+    __syncthreads();
+    for (int d = 0; d < D; ++d) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < N; i += 256) s += mask[bb * N + i] * x[((long)bb * N + i) * D + d];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) mean[d] = red[0];
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < N * D; idx += 256) {
+        const int i = idx / D, d = idx - i * D;
+        const float m = mask[bb * N + i];
+        out[(long)bb * N * D + idx] = x[(long)bb * N * D + idx] - m * mean[d] / norm;
+    }
+}
+
+// reverse-diffusion update; one workgroup per sample.  Also advances the device-side step counter.
+__global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__ z, float* __restrict__ seq_t,
+                                                             int64_t* __restrict__ t, const float* __restrict__ eps,
+                                                             const float* __restrict__ seq_pred, const float* __restrict__ noise,
+                                                             const float* __restrict__ mask, const float* __restrict__ coef,
+                                                             int N, int ncls) {
+    __shared__ float red[256];
+    __shared__ float mean[4];
+    const int bb = blockIdx.x;
+    const long tt = t[bb];
+    const float wn = coef[tt * 4 + 0], isa = coef[tt * 4 + 1], sb = coef[tt * 4 + 2];
+    const float* nz = noise + (long)bb * N * 3;
+    if (tt > 0) {
+        for (int d = 0; d < 4; ++d) {
+            float s = 0.f;
+            for (int i = threadIdx.x; i < N; i += 256) s += mask[bb * N + i] * (d < 3 ? nz[i * 3 + d] : 1.f);
+            red[threadIdx.x] = s;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+            if (threadIdx.x == 0) mean[d] = red[0];
+            __syncthreads();
+        }
+    }
+    for (int idx = threadIdx.x; idx < N * 3; idx += 256) {
+        const int i = idx / 3, d = idx - i * 3;
+        const long g = (long)bb * N * 3 + idx;
+        const float mu = isa * (z[g] - wn * eps[g]);
+        float out = mu;
+        if (tt > 0) out = mu + sb * (nz[idx] - mask[bb * N + i] * mean[d] / mean[3]);
+        z[g] = out;
+    }
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float* lp = seq_pred + ((long)bb * N + i) * ncls;
+        float m = -INFINITY;
+        for (int c = 0; c < ncls; ++c) m = fmaxf(m, lp[c]);
+        float s = 0.f;
+        for (int c = 0; c < ncls; ++c) s += expf(lp[c] - m);
+        for (int c = 0; c < ncls; ++c) seq_t[((long)bb * N + i) * ncls + c] = expf(lp[c] - m) / s * 2.f - 1.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) t[bb] = tt - 1;
+}
+
+int grid_for(long tasks, int per_wg, int cap) {
+    long g = (tasks + per_wg - 1) / per_wg;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define PRD_CHECK_P(P) if ((P) != 32 && (P) != 64) return PRD_ERR_UNSUPPORTED
+
+extern "C" int prd_version(void) { return PRD_VERSION; }
+
+extern "C" int prd_static_pair(float* out, const float* atom_mask, const float* residue_mask, const float* bond_mask,
+                               const int64_t* bond_feats, const int64_t* bond_distance,
+                               const int64_t* residue_index, const int64_t* chain_index,
+                               const float* tab_b0, const float* tab_b1, const float* tab_b2,
+                               const float* tab_bdist, const float* tab_relpos,
+                               int max_bond_distance, int max_relpos, int b, int N, int P, hipStream_t stream) {
+    if (!out || !atom_mask || !residue_mask || !bond_mask || !bond_feats || !bond_distance || !residue_index ||
+        !chain_index || !tab_b0 || !tab_b1 || !tab_b2 || !tab_bdist || !tab_relpos || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (P & 3) return PRD_ERR_ALIGN;
+    const long total = (long)b * N * N * (P / 4);
+    hipLaunchKernelGGL(static_pair_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, out, atom_mask,
+                       residue_mask, bond_mask, bond_feats, bond_distance, residue_index, chain_index, tab_b0, tab_b1,
+                       tab_b2, tab_bdist, tab_relpos, max_bond_distance, max_relpos, b, N, P);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_atom_embed(float* out, const int64_t* atom_feats, const float* atom_mask, const float* tables,
+                              const int* offsets, int n_feats, int b, int N, int S, hipStream_t stream) {
+    if (!out || !atom_feats || !atom_mask || !tables || !offsets || n_feats <= 0 || b <= 0 || N <= 0 || S <= 0) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(atom_embed_kernel, dim3(grid_for((long)b * N * S, 256, 2048)), dim3(256), 0, stream, out,
+                       atom_feats, atom_mask, tables, offsets, n_feats, b * N, S);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_single_init(float* single, const float* static_single, const float* seq_t, const float* residue_mask,
+                               const float* w_rt, int rows, int S, int n_cls, hipStream_t stream) {
+    if (!single || !static_single || !seq_t || !residue_mask || !w_rt || rows <= 0 || S <= 0 || n_cls <= 0 || n_cls > 64) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(single_init_kernel, dim3(rows), dim3(128), 0, stream, single, static_single, seq_t, residue_mask, w_rt, S, n_cls);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_time_embed(float* ebeta, const int64_t* t, const float* freqs, const float* w_beta,
+                              int num_steps, int b, int P, int time_dim, hipStream_t stream) {
+    if (!ebeta || !t || !freqs || !w_beta || num_steps <= 0 || b <= 0 || P <= 0 || time_dim <= 0 || (time_dim & 1)) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(time_embed_kernel, dim3(b), dim3(64), time_dim * sizeof(float), stream, ebeta, t, freqs, w_beta, num_steps, P, time_dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_pair_init(float* pair, const float* static_pair, const float* z, const float* mask,
+                             const float* centers, const float* w_dist, const float* ebeta,
+                             int b, int N, int P, int dist_dim, hipStream_t stream) {
+    if (!pair || !static_pair || !z || !mask || !centers || !w_dist || !ebeta || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    if (dist_dim <= 0 || (dist_dim & 7)) return PRD_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)P * (dist_dim + 4) + dist_dim) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    const long ntask = ((long)b * N * N + 31) / 32;
+    const int grid = grid_for(ntask, 4, 512);
+    if (P == 64) {
+        (void)hipFuncSetAttribute((const void*)pair_init_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(pair_init_kernel<64>, dim3(grid), dim3(WG), lds, stream, pair, static_pair, z, mask, centers, w_dist, ebeta, b, N, dist_dim);
+    } else {
+        (void)hipFuncSetAttribute((const void*)pair_init_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(pair_init_kernel<32>, dim3(grid), dim3(WG), lds, stream, pair, static_pair, z, mask, centers, w_dist, ebeta, b, N, dist_dim);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_pair_bias(float* bias_out, const float* pair, const float* gamma, const float* beta,
+                             const float* w, const float* bvec, int b, int N, int P, int H, hipStream_t stream) {
+    if (!bias_out || !pair || !w || b <= 0 || N <= 0 || H <= 0 || H > 8 || (gamma && !beta)) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    const long ntask = ((long)b * N * N + 31) / 32;
+    const int grid = grid_for(ntask, 4, 2048);
+    if (P == 64) hipLaunchKernelGGL(pair_bias_kernel<64>, dim3(grid), dim3(WG), 0, stream, bias_out, pair, gamma, beta, w, bvec, b, N, H);
+    else hipLaunchKernelGGL(pair_bias_kernel<32>, dim3(grid), dim3(WG), 0, stream, bias_out, pair, gamma, beta, w, bvec, b, N, H);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, const float* mask, const float* w_out,
+                            const float* b_out, int flags, int b, int N, int P, int C, hipStream_t stream) {
+    if (!out || !pair || !ab || !mask || !w_out || !b_out || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    if (C <= 0 || (C & 7)) return PRD_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)P * (C + 4) + P) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    const long ntask = (long)b * N * prd_ceil_div(N, 32);
+    const int grid = grid_for(ntask, 4, 1024);
+    if (P == 64) {
+        (void)hipFuncSetAttribute((const void*)opm_pair_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(opm_pair_kernel<64>, dim3(grid), dim3(WG), lds, stream, out, pair, ab, mask, w_out, b_out, b, N, C, flags);
+    } else {
+        (void)hipFuncSetAttribute((const void*)opm_pair_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(opm_pair_kernel<32>, dim3(grid), dim3(WG), lds, stream, out, pair, ab, mask, w_out, b_out, b, N, C, flags);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
+                                const float* bias, int residual, int b, int N, int P, int S, hipStream_t stream) {
+    if (!out || !pair || !x || !u || !w || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
+    const long ntask = (long)b * N * prd_ceil_div(N, 32);
+    const int grid = grid_for(ntask, 4, 1024);
+    if (P == 64) hipLaunchKernelGGL(outer_linear_kernel<64>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual);
+    else hipLaunchKernelGGL(outer_linear_kernel<32>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
+                                   const float* b2, int residual, int b, int N, int P, hipStream_t stream) {
+    if (!out || !pair || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    const long rows = (long)b * N * N;
+    const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + 5 * P) * sizeof(float);
+    const int grid = grid_for((rows + 31) / 32, 4, 256);
+    if (P == 64) {
+        (void)hipFuncSetAttribute((const void*)pair_transition_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(pair_transition_kernel<64>, dim3(grid), dim3(WG), lds, stream, out, pair, w1, b1, w2, b2, rows, residual);
+    } else {
+        (void)hipFuncSetAttribute((const void*)pair_transition_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(pair_transition_kernel<32>, dim3(grid), dim3(WG), lds, stream, out, pair, w1, b1, w2, b2, rows, residual);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_coord_head(float* eps_raw, const float* pair, const float* z, const float* mask,
+                              const float* w1, const float* b1, const float* w2, int b, int N, int P, hipStream_t stream) {
+    if (!eps_raw || !pair || !z || !mask || !w1 || !b1 || !w2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    const int grid = grid_for((long)b * N, 1, 2048);
+    if (P == 64) hipLaunchKernelGGL(coord_head_kernel<64>, dim3(grid), dim3(WG), 0, stream, eps_raw, pair, z, mask, w1, b1, w2, b, N);
+    else hipLaunchKernelGGL(coord_head_kernel<32>, dim3(grid), dim3(WG), 0, stream, eps_raw, pair, z, mask, w1, b1, w2, b, N);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_remove_mean(float* out, const float* x, const float* mask, int b, int N, int D, hipStream_t stream) {
+    if (!out || !x || !mask || b <= 0 || N <= 0 || D <= 0 || D > 64) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(remove_mean_kernel, dim3(b), dim3(256), 0, stream, out, x, mask, N, D);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pred, const float* seq_pred,
+                                  const float* noise, const float* mask, const float* coef,
+                                  int b, int N, int n_cls, hipStream_t stream) {
+    if (!z || !seq_t || !t || !noise_pred || !seq_pred || !noise || !mask || !coef || b <= 0 || N <= 0 || n_cls <= 0) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(reverse_update_kernel, dim3(b), dim3(256), 0, stream, z, seq_t, t, noise_pred, seq_pred, noise, mask, coef, N, n_cls);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,371 @@
+"""``ProteinReDiffModel`` with the reference's LightningModule surface and a HIP hot path.
+
+Mirrors reference ProteinReDiff/model.py:55-549 for everything ``generate.py`` / ``train.py`` touch:
+constructor from Namespace|Mapping, ``add_argparse_args``, ``run_setup_schedule``, ``prepare_batch``
+(eval branch), ``forward`` / ``sample_step`` (same signature, returns (noise_pred, seq_pred)),
+``sample``, ``predict_step``, checkpoint hooks and ``state_dict`` key names.  The arithmetic of
+``sample_step`` and of the reverse-diffusion loop runs in libprd_hip.so; nothing falls back to
+PyTorch ops on the hot path.
+
+Differences that are deliberate and documented:
+* randomness is injected: every sample k draws its mask permutation and noise from a CPU fp32
+  generator keyed (seed, global sample index) (``synthetic.NoiseSource``), so results do not depend
+  on device RNG, batch size or on how samples are sharded over GPUs;
+* the redesign mask is drawn per sample (identical to the reference at its default batch_size=1).
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from argparse import ArgumentParser, Namespace
+from typing import Dict, List, Mapping, Optional, Sequence, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .constants import ATOM_FEATURE_CARDS, BOND_FEATURE_CARDS, NUM_RESIDUE_CLASSES
+from .schedule import reverse_coefficients, schedule_tables
+from .synthetic import NoiseSource
+from .trunk import Denoiser, Linear
+
+try:  # the reference subclasses pl.LightningModule (model.py:55); absent in this image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - depends on the environment
+    pl = None
+
+    class _Base(nn.Module):
+        """Minimal stand-in for pl.LightningModule: what model.py actually calls on ``self``."""
+
+        def save_hyperparameters(self, args=None):
+            self.hparams = args
+
+        def log(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+        @classmethod
+        def load_from_checkpoint(cls, path, map_location="cpu", **overrides):
+            ckpt = torch.load(path, map_location=map_location, weights_only=False)
+            args = ckpt.get("hyper_parameters", {})
+            args = dict(vars(args)) if isinstance(args, Namespace) else dict(args)
+            if "args" in args and len(args) == 1:
+                inner = args["args"]
+                args = dict(vars(inner)) if isinstance(inner, Namespace) else dict(inner)
+            args.update(overrides)
+            model = cls(args)
+            model.load_state_dict(ckpt["state_dict"])
+            model.on_load_checkpoint(ckpt)
+            return model
+
+
+class _TableSum(nn.Module):
+    """AtomEmbedding / BondEmbedding parameter container (modules.py:35-70): ``embeddings.{f}.weight``.
+    The lookups are fused into prd_atom_embed / prd_static_pair."""
+
+    def __init__(self, cards: Sequence[int], embed_dim: int):
+        super().__init__()
+        self.embeddings = nn.ModuleList([nn.Embedding(n, embed_dim) for n in cards])
+        self.num_features = len(cards)
+        self.scale = 1.0 / math.sqrt(self.num_features)
+
+
+class AtomEmbedding(_TableSum):
+    def __init__(self, embed_dim: int):
+        super().__init__(ATOM_FEATURE_CARDS, embed_dim)
+
+
+class BondEmbedding(_TableSum):
+    def __init__(self, embed_dim: int):
+        super().__init__(BOND_FEATURE_CARDS, embed_dim)
+
+
+class RadialBasisProjection(nn.Module):
+    """modules.py:73-82 (centres only; exp(-scale (d-c)^2) is generated inside prd_pair_init)."""
+
+    def __init__(self, embed_dim: int, min_val: float = 0.0, max_val: float = 2.0):
+        super().__init__()
+        self.scale = (embed_dim - 1) / (max_val - min_val)
+        self.center = nn.Parameter(torch.linspace(min_val, max_val, embed_dim), requires_grad=False)
+
+
+class SinusoidalProjection(nn.Module):
+    """modules.py:85-97 (frequencies only; sin/cos evaluated inside prd_time_embed)."""
+
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        if embed_dim % 2 != 0:
+            raise ValueError(f"embed_dim must be even: {embed_dim}.")
+        self.embed_dim = embed_dim
+        self.weight = nn.Parameter(torch.logspace(-4.0, 0.0, embed_dim // 2), requires_grad=False)
+
+
+class _Ema:
+    """Shadow-parameter EMA with torch-ema's call surface (model.py:124,194-201,217,238,250)."""
+
+    def __init__(self, params, decay: float):
+        self.decay = decay
+        self.shadow = [p.detach().clone() for p in params if p.requires_grad]
+        self.active = False          # becomes True once updated or loaded: until then shadow == init copy
+
+    def to(self, device=None, dtype=None):
+        self.shadow = [s.to(device=device) if device is not None else s for s in self.shadow]
+        return self
+
+    def update(self, params):
+        self.active = True
+        with torch.no_grad():
+            for s, p in zip(self.shadow, [q for q in params if q.requires_grad]):
+                s.mul_(self.decay).add_(p.detach().to(s.device), alpha=1.0 - self.decay)
+
+    def state_dict(self):
+        return {"decay": self.decay, "shadow_params": self.shadow}
+
+    def load_state_dict(self, sd):
+        shadow = sd.get("shadow_params")
+        if shadow is not None:
+            self.shadow = [s.detach().clone() for s in shadow]
+            self.active = True
+        self.decay = sd.get("decay", self.decay)
+
+    @contextlib.contextmanager
+    def average_parameters(self, params=None):
+        if not self.active or params is None:
+            yield
+            return
+        params = list(params)
+        train = [p for p in params if p.requires_grad]
+        shadow = self.shadow
+        if len(shadow) == len(params):      # torch-ema kept every parameter (SURVEY.md §5 checkpoint row)
+            train = params
+        saved = [p.detach().clone() for p in train]
+        with torch.no_grad():
+            for p, s in zip(train, shadow):
+                p.copy_(s.to(p.device))
+        try:
+            yield
+        finally:
+            with torch.no_grad():
+                for p, s in zip(train, saved):
+                    p.copy_(s)
+
+
+class ProteinReDiffModel(_Base):
+    def __init__(self, args: Union[Namespace, Mapping]):
+        super().__init__()
+        if isinstance(args, Mapping):
+            args = Namespace(**args)
+        self.pair_dim, self.single_dim = args.pair_dim, args.single_dim
+        self.dist_dim, self.time_dim = args.dist_dim, args.time_dim
+        self.max_bond_distance, self.max_relpos, self.esm_dim = args.max_bond_distance, args.max_relpos, args.esm_dim
+        self.setup_schedule = False
+        self.setup_esm = False
+        self.mask_prob, self.num_steps = args.mask_prob, args.num_steps
+        self.diffusion_schedule = args.diffusion_schedule
+        self.learning_rate, self.warmup_steps, self.ema_decay = args.learning_rate, args.warmup_steps, args.ema_decay
+        self.n_recycles, self.training_mode = args.n_recycles, args.training_mode
+        self.sample_seed = 0                    # key of the injected randomness (see module docstring)
+        self._sample_counter = 0
+
+        self.Denoiser = Denoiser(args)
+        S, P = self.single_dim, self.pair_dim
+        self.embed_atom_feats = AtomEmbedding(S)
+        self.embed_beta = nn.Sequential(SinusoidalProjection(self.time_dim), Linear(self.time_dim, P, bias=False, init="normal"))
+        self.embed_residue_type = nn.Sequential(
+            nn.LayerNorm(NUM_RESIDUE_CLASSES, elementwise_affine=False),
+            Linear(NUM_RESIDUE_CLASSES, S, bias=False, init="normal"), nn.ReLU())
+        self.embed_bond_feats = BondEmbedding(P)
+        self.embed_bond_distance = nn.Embedding(self.max_bond_distance + 1, P)
+        self.embed_residue_esm = nn.Sequential(nn.LayerNorm(self.esm_dim, elementwise_affine=False),
+                                               Linear(self.esm_dim, S, bias=False, init="normal"))
+        self.embed_relpos = nn.Embedding(self.max_relpos * 2 + 1, P)
+        self.embed_dist = nn.Sequential(RadialBasisProjection(self.dist_dim), Linear(self.dist_dim, P, bias=False, init="normal"))
+        self.weight_radial = nn.Sequential(nn.LayerNorm(P, elementwise_affine=False), Linear(P, P, init="relu"),
+                                           nn.ReLU(), Linear(P, 1, bias=False, init="final"))
+        self.seq_mlp = nn.Sequential(nn.LayerNorm(S, elementwise_affine=False), Linear(S, S, init="relu"), nn.ReLU(),
+                                     Linear(S, NUM_RESIDUE_CLASSES, bias=False, init="final"))
+        self.ema = _Ema(self.parameters(), decay=self.ema_decay)
+        self.save_hyperparameters(args)
+
+    # ------------------------------------------------------------------ argparse (model.py:130-170)
+    @staticmethod
+    def add_argparse_args(parent_parser: ArgumentParser) -> ArgumentParser:
+        g = parent_parser.add_argument_group("DiffusionModel")
+        g.add_argument("--training_mode", action="store_true")
+        for name, typ, default in (
+                ("mask_prob", float, 1.0), ("esm_dim", int, 1280), ("time_dim", int, 256), ("dist_dim", int, 256),
+                ("single_dim", int, 512), ("pair_dim", int, 64), ("head_dim", int, 16), ("num_heads", int, 4),
+                ("transition_factor", int, 4), ("num_blocks", int, 12), ("max_bond_distance", int, 7),
+                ("max_relpos", int, 32), ("num_steps", int, 64), ("diffusion_schedule", str, "linear"),
+                ("learning_rate", float, 4e-4), ("warmup_steps", int, 1000), ("ema_decay", float, 0.999)):
+            g.add_argument(f"--{name}", type=typ, default=default)
+        g2 = parent_parser.add_argument_group("IterativeDenoiser")   # parsed, unused
+        for name, typ, default in (
+                ("n_recycles", int, 4), ("top_k_neighbors", int, 30), ("dropout", float, 0.3),
+                ("num_gvp_encoder_layers", int, 3), ("num_positional_embeddings", int, 16),
+                ("gvp_edge_hidden_dim_scalar", int, 32), ("gvp_edge_hidden_dim_vector", int, 32)):
+            g2.add_argument(f"--{name}", type=typ, default=default)
+        return parent_parser
+
+    # ------------------------------------------------------------------ schedule / hooks
+    def run_setup_schedule(self):
+        dev = self.device
+        for k, v in schedule_tables(self.num_steps, self.diffusion_schedule).items():
+            setattr(self, k, v.to(dev))
+        self._coef = reverse_coefficients({k: getattr(self, k).cpu() for k in
+                                           ("alphas", "sqrt_one_minus_alphas_cumprod", "sqrt_alphas", "sqrt_betas")}).to(dev)
+
+    def to(self, *args, **kwargs):
+        out = torch._C._nn._parse_to(*args, **kwargs)
+        self.ema.to(device=out[0], dtype=out[1])
+        self.setup_schedule = False
+        return super().to(*args, **kwargs)
+
+    def on_save_checkpoint(self, checkpoint):
+        checkpoint["ema_state_dict"] = self.ema.state_dict()
+
+    def on_load_checkpoint(self, checkpoint):
+        if "ema_state_dict" in checkpoint:
+            self.ema.load_state_dict(checkpoint["ema_state_dict"])
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.learning_rate)
+        sched = torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=1.0 / self.warmup_steps,
+                                                  total_iters=self.warmup_steps - 1)
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": sched, "interval": "step"}}
+
+    def optimizer_step(self, *args, **kwargs):
+        if pl is not None:
+            super().optimizer_step(*args, **kwargs)
+        self.ema.update(self.parameters())
+
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("training (backward of the HIP kernels) is SURVEY.md §8f 'next #1'; "
+                                  "this build covers inference / sampling")
+
+    validation_step = training_step
+
+    def predict_step(self, batch, batch_idx):
+        with self.ema.average_parameters(self.parameters()):
+            return self.sample(batch)
+
+    # ------------------------------------------------------------------ batch preparation (model.py:424-468)
+    def _sources(self, b: int) -> List[NoiseSource]:
+        src = [NoiseSource(self.sample_seed, self._sample_counter + k) for k in range(b)]
+        self._sample_counter += b
+        return src
+
+    def prepare_batch(self, batch, id=None, sources: Optional[Sequence] = None):
+        """Eval branch (:459-468).  The training-mode branches need ``residue_esm_tokens`` that no
+        published code produces and are out of scope."""
+        if self.training_mode:
+            raise NotImplementedError("training-mode masking is out of scope (SURVEY.md §2)")
+        am, rm = batch["atom_mask"], batch["residue_mask"]
+        dev = am.device
+        b = am.shape[0]
+        if sources is None:
+            sources = self._sources(b)
+        one_hot = F.one_hot(batch["residue_type"], num_classes=NUM_RESIDUE_CLASSES) * 2.0 - 1.0
+        pos = am.unsqueeze(-1) * batch["atom_pos"] + rm.unsqueeze(-1) * batch["residue_atom_pos"][:, :, 1]
+        rm_cpu = rm.detach().cpu()
+        extra = rm_cpu.clone()
+        inv = torch.zeros_like(rm_cpu)
+        for k in range(b):        # RandomMaskingModule(stochastic=False), per sample (mask_utils.py:77-102)
+            ones = torch.where(rm_cpu[k] == 1)[0]
+            n = int(ones.numel() * self.mask_prob)
+            sel = ones[sources[k].randperm(ones.numel())[:n]]
+            extra[k, sel] = 0
+            inv[k, sel] = 1
+        extra, inv = extra.to(dev), inv.to(dev)
+        batch["residue_one_hot"] = one_hot * extra.unsqueeze(-1)
+        batch["residue_esm"] = batch["residue_esm"] * extra.unsqueeze(-1)
+        batch["residue_type_masked"] = (batch["residue_type"] * extra).long()
+        batch["residue_extra_mask"] = extra
+        batch["residue_inv_extra_mask"] = inv
+        batch["x"] = 0.1 * pos
+        batch["residue_and_atom_mask"] = am + rm
+        return batch
+
+    # ------------------------------------------------------------------ the network (model.py:254-375)
+    def _static_inputs(self, batch) -> Dict[str, torch.Tensor]:
+        """Step-invariant embeddings: computed once per ``sample``."""
+        am, rm = batch["atom_mask"].contiguous(), batch["residue_mask"].contiguous()
+        S, P = self.single_dim, self.pair_dim
+        bond_tabs = [e.weight for e in self.embed_bond_feats.embeddings]
+        sp = ops.static_pair({k: batch[k].contiguous() for k in (
+            "atom_mask", "residue_mask", "bond_mask", "bond_feats", "bond_distance", "residue_index",
+            "residue_chain_index")}, bond_tabs + [self.embed_bond_distance.weight, self.embed_relpos.weight],
+            self.max_bond_distance, self.max_relpos, P)
+        tabs = torch.cat([e.weight for e in self.embed_atom_feats.embeddings], dim=0).contiguous()
+        offs, acc = [], 0
+        for n in ATOM_FEATURE_CARDS:
+            offs.append(acc)
+            acc += n
+        offsets = torch.tensor(offs, dtype=torch.int32, device=am.device)
+        ss = ops.atom_embed(batch["atom_feats"].contiguous(), am, tabs, offsets, S)
+        esm = ops.layer_norm(batch["residue_esm"].contiguous())
+        ss = ops.linear(esm, self.embed_residue_esm[1].weight, rowmask=rm, resid=ss)
+        return {"pair": sp, "single": ss}
+
+    def _network(self, batch, z, seq_t, mask, t, static=None):
+        if static is None:
+            static = self._static_inputs(batch)
+        rm = batch["residue_mask"].contiguous()
+        mask = mask.contiguous()
+        z = z.contiguous()
+        single = ops.single_init(static["single"], seq_t.contiguous(), rm, self.embed_residue_type[1].weight)
+        eb = ops.time_embed(t.contiguous(), self.embed_beta[0].weight, self.embed_beta[1].weight, self.num_steps)
+        pair = ops.pair_init(static["pair"], z, mask, self.embed_dist[0].center, self.embed_dist[1].weight, eb)
+        single, pair = self.Denoiser.run_(single, pair, mask)
+        wr = self.weight_radial
+        eps_raw = ops.coord_head(pair, z, mask, wr[1].weight, wr[1].bias, wr[3].weight)
+        noise_pred = ops.remove_mean(eps_raw, mask)
+        sm = self.seq_mlp
+        h = ops.linear(ops.layer_norm(single), sm[1].weight, sm[1].bias, act=1)
+        seq_pred = ops.linear(h, sm[3].weight)
+        return noise_pred, seq_pred
+
+    def forward(self, batch, z, seq_t, mask, t):
+        return self._network(batch, z, seq_t, mask, t)
+
+    def sample_step(self, batch, z, seq_t, mask, t):
+        return self._network(batch, z, seq_t, mask, t)
+
+    # ------------------------------------------------------------------ reverse diffusion (model.py:377-422)
+    @torch.inference_mode()
+    def sample(self, batch, sources: Optional[Sequence] = None):
+        if not self.setup_schedule:
+            self.run_setup_schedule()
+            self.setup_schedule = True
+        dev = self.device
+        b, N = batch["atom_mask"].shape
+        if sources is None:
+            sources = self._sources(b)
+        batch = self.prepare_batch(batch, sources=sources)
+        mask = batch["residue_and_atom_mask"].contiguous()
+        rm = batch["residue_mask"].contiguous()
+        T = self.num_steps
+        # all randomness up front, in the reference's draw order per sample
+        z0 = torch.stack([s.randn(N, 3) for s in sources])
+        s0 = torch.stack([s.randn(N, NUM_RESIDUE_CLASSES) for s in sources])
+        if T > 1:
+            noise = torch.stack([torch.stack([s.randn(N, 3) for _ in range(T - 1)]) for s in sources], dim=1)
+        else:
+            noise = torch.zeros(1, b, N, 3)
+        noise = noise.to(dev).contiguous()                      # [T-1, b, N, 3]
+        z = ops.remove_mean(z0.to(dev).contiguous(), mask)
+        seq_t = ops.remove_mean(s0.to(dev).contiguous(), rm)
+        seq_t = (batch["residue_extra_mask"].unsqueeze(-1) * batch["residue_one_hot"]
+                 + batch["residue_inv_extra_mask"].unsqueeze(-1) * seq_t).contiguous()
+        static = self._static_inputs(batch)
+        t = torch.full((b,), T - 1, dtype=torch.int64, device=dev)
+        seq_pred = None
+        for i in range(T):
+            noise_pred, seq_pred = self._network(batch, z, seq_t, mask, t, static=static)
+            ops.reverse_update_(z, seq_t, t, noise_pred, seq_pred, noise[min(i, noise.shape[0] - 1)], mask, self._coef)
+        return 10.0 * z, rm.unsqueeze(-1) * seq_pred

@@ -1,0 +1,258 @@
+"""Python-side operator wrappers over the C ABI (include/prd_hip.h).
+
+Each function takes CUDA fp32 tensors, allocates outputs / scratch with PyTorch's caching allocator,
+and enqueues HIP kernels on the current torch stream.  Weight tensors are passed as they sit in the
+``state_dict`` (nn.Linear layout).  Nothing here has a CPU implementation.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import PrdGemm, check, dptr, lib, stream
+
+F32 = torch.float32
+
+
+def _off(t: torch.Tensor, elem_offset: int = 0) -> int:
+    return dptr(t) + 4 * elem_offset
+
+
+def round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1, G2=1,
+         sa=(0, 0), sb=(0, 0), sc=(0, 0), b_kn=False, alpha=1.0, bias=None, act=0, act_from=0,
+         addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
+         mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0):
+    """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h)."""
+    g = PrdGemm()
+    g.A, g.B, g.C = _off(A, a_off), _off(B, b_off), _off(Cout, c_off)
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.G1, g.G2 = M, N, K, lda, ldb, ldc, G1, G2
+    g.sa1, g.sa2, g.sb1, g.sb2, g.sc1, g.sc2 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
+    g.b_kn, g.alpha = int(b_kn), float(alpha)
+    g.bias, g.act, g.act_from = dptr(bias), act, act_from
+    g.addmat, g.sad1, g.sad2, g.ldadd = dptr(addmat), sad[0], sad[1], ldadd
+    g.colmask, g.scm1, g.fill = dptr(colmask), scm1, float(fill)
+    g.rowmask, g.srm1 = dptr(rowmask), srm1
+    g.mulmat = (_off(mulmat, mul_off) if mulmat is not None else None)
+    g.smu1, g.smu2, g.ldmul = smu[0], smu[1], ldmul
+    g.resid = (_off(resid, res_off) if resid is not None else None)
+    g.sr1, g.sr2, g.ldr = sr[0], sr[1], ldr
+    import ctypes
+    check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
+    return Cout
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = 0,
+           alpha: float = 1.0, resid: Optional[torch.Tensor] = None, rowmask: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(alpha * x W^T + bias) [* rowmask] [+ resid] for x [..., K], W [N, K]."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
+    gemm(x, w, out, M, N, K, K, w.stride(0), N, alpha=alpha, bias=bias, act=act,
+         rowmask=rowmask, resid=resid, ldr=N)
+    return out
+
+
+def layer_norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    y = torch.empty_like(x)
+    check(lib().prd_ln_rows(dptr(x), dptr(y), dptr(gamma), dptr(beta), rows, Cn, Cn, Cn, stream()), "prd_ln_rows")
+    return y
+
+
+def softmax_rows_(x: torch.Tensor, n: int) -> torch.Tensor:
+    ld = x.shape[-1]
+    check(lib().prd_softmax_rows(dptr(x), x.numel() // ld, n, ld, stream()), "prd_softmax_rows")
+    return x
+
+
+# ---------------------------------------------------------------------------------------------------
+# input stage
+# ---------------------------------------------------------------------------------------------------
+
+def static_pair(batch, tabs, max_bond_distance: int, max_relpos: int, P: int) -> torch.Tensor:
+    am = batch["atom_mask"]
+    b, N = am.shape
+    out = torch.empty(b, N, N, P, device=am.device, dtype=F32)
+    i64 = torch.int64
+    check(lib().prd_static_pair(
+        dptr(out), dptr(am), dptr(batch["residue_mask"]), dptr(batch["bond_mask"]),
+        dptr(batch["bond_feats"], i64), dptr(batch["bond_distance"], i64),
+        dptr(batch["residue_index"], i64), dptr(batch["residue_chain_index"], i64),
+        dptr(tabs[0]), dptr(tabs[1]), dptr(tabs[2]), dptr(tabs[3]), dptr(tabs[4]),
+        max_bond_distance, max_relpos, b, N, P, stream()), "prd_static_pair")
+    return out
+
+
+def atom_embed(atom_feats, atom_mask, tables_cat, offsets, S: int) -> torch.Tensor:
+    b, N, nf = atom_feats.shape
+    out = torch.empty(b, N, S, device=atom_mask.device, dtype=F32)
+    check(lib().prd_atom_embed(dptr(out), dptr(atom_feats, torch.int64), dptr(atom_mask), dptr(tables_cat),
+                               dptr(offsets, torch.int32), nf, b, N, S, stream()), "prd_atom_embed")
+    return out
+
+
+def single_init(static_single, seq_t, residue_mask, w_rt, out=None) -> torch.Tensor:
+    b, N, S = static_single.shape
+    if out is None:
+        out = torch.empty_like(static_single)
+    check(lib().prd_single_init(dptr(out), dptr(static_single), dptr(seq_t), dptr(residue_mask), dptr(w_rt),
+                                b * N, S, seq_t.shape[-1], stream()), "prd_single_init")
+    return out
+
+
+def time_embed(t, freqs, w_beta, num_steps: int, out=None) -> torch.Tensor:
+    b = t.shape[0]
+    P, TD = w_beta.shape
+    if out is None:
+        out = torch.empty(b, P, device=t.device, dtype=F32)
+    check(lib().prd_time_embed(dptr(out), dptr(t, torch.int64), dptr(freqs), dptr(w_beta), num_steps, b, P, TD,
+                               stream()), "prd_time_embed")
+    return out
+
+
+def pair_init(static_pair_t, z, mask, centers, w_dist, ebeta, out=None) -> torch.Tensor:
+    b, N, _, P = static_pair_t.shape
+    if out is None:
+        out = torch.empty_like(static_pair_t)
+    check(lib().prd_pair_init(dptr(out), dptr(static_pair_t), dptr(z), dptr(mask), dptr(centers), dptr(w_dist),
+                              dptr(ebeta), b, N, P, w_dist.shape[1], stream()), "prd_pair_init")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# pair-track operators
+# ---------------------------------------------------------------------------------------------------
+
+def pair_bias(pair, w, bvec=None, gamma=None, beta=None) -> torch.Tensor:
+    b, N, _, P = pair.shape
+    H = w.shape[0]
+    out = torch.empty(b, H, N, N, device=pair.device, dtype=F32)
+    check(lib().prd_pair_bias(dptr(out), dptr(pair), dptr(gamma), dptr(beta), dptr(w), dptr(bvec), b, N, P, H,
+                              stream()), "prd_pair_bias")
+    return out
+
+
+def opm_pair(pair, ab, mask, w_out, b_out, *, residual: bool, apply_mask: bool, out=None) -> torch.Tensor:
+    b, N, _, P = pair.shape
+    Cc = ab.shape[-1] // 2
+    if out is None:
+        out = torch.empty_like(pair)
+    flags = (1 if residual else 0) | (2 if apply_mask else 0)
+    check(lib().prd_opm_pair(dptr(out), dptr(pair), dptr(ab), dptr(mask), dptr(w_out), dptr(b_out), flags,
+                             b, N, P, Cc, stream()), "prd_opm_pair")
+    return out
+
+
+def outer_linear_pair(pair, x, u, w, bias, *, residual: bool, out=None) -> torch.Tensor:
+    b, N, _, P = pair.shape
+    if out is None:
+        out = torch.empty_like(pair)
+    check(lib().prd_outer_linear(dptr(out), dptr(pair), dptr(x), dptr(u), dptr(w), dptr(bias), int(residual),
+                                 b, N, P, x.shape[-1], stream()), "prd_outer_linear")
+    return out
+
+
+def workspace_bytes(op: str, b: int, N: int, S: int, P: int) -> int:
+    return int(lib().prd_workspace_bytes(op.encode(), b, N, S, P))
+
+
+def tri_mul(pair, mask, wts, *, incoming: bool, residual: bool, out=None, ws=None) -> torch.Tensor:
+    """wts = (ab_proj.w, ab_proj.b, ab_gate.w, ab_gate.b, out_proj.w, out_proj.b, out_gate.w, out_gate.b)"""
+    b, N, _, P = pair.shape
+    if out is None:
+        out = torch.empty_like(pair)
+    nbytes = workspace_bytes("tri_mul", b, N, 0, P)
+    if ws is None:
+        ws = torch.empty(nbytes // 4, device=pair.device, dtype=F32)
+    check(lib().prd_tri_mul(dptr(out), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(incoming), int(residual),
+                            b, N, P, dptr(ws), ws.numel() * 4, stream()), "prd_tri_mul")
+    return out
+
+
+def tri_attn(pair, mask, wts, H: int, c: int, *, ending: bool, residual: bool, out=None, ws=None) -> torch.Tensor:
+    """wts = (q.w, k.w, v.w, gate.w, gate.b, out.w, out.b)"""
+    b, N, _, P = pair.shape
+    if out is None:
+        out = torch.empty_like(pair)
+    nbytes = workspace_bytes("tri_attn", b, N, 0, P)
+    if ws is None:
+        ws = torch.empty(nbytes // 4, device=pair.device, dtype=F32)
+    check(lib().prd_tri_attn(dptr(out), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending), int(residual),
+                             b, N, P, H, c, dptr(ws), ws.numel() * 4, stream()), "prd_tri_attn")
+    return out
+
+
+def pair_transition(pair, w1, b1, w2, b2, *, residual: bool, out=None) -> torch.Tensor:
+    b, N, _, P = pair.shape
+    if out is None:
+        out = torch.empty_like(pair)
+    check(lib().prd_pair_transition(dptr(out), dptr(pair), dptr(w1), dptr(b1), dptr(w2), dptr(b2), int(residual),
+                                    b, N, P, stream()), "prd_pair_transition")
+    return out
+
+
+def coord_head(pair, z, mask, w1, b1, w2) -> torch.Tensor:
+    b, N, _, P = pair.shape
+    out = torch.empty(b, N, 3, device=pair.device, dtype=F32)
+    check(lib().prd_coord_head(dptr(out), dptr(pair), dptr(z), dptr(mask), dptr(w1), dptr(b1), dptr(w2), b, N, P,
+                               stream()), "prd_coord_head")
+    return out
+
+
+def remove_mean(x, mask) -> torch.Tensor:
+    b, N, D = x.shape
+    out = torch.empty_like(x)
+    check(lib().prd_remove_mean(dptr(out), dptr(x), dptr(mask), b, N, D, stream()), "prd_remove_mean")
+    return out
+
+
+def reverse_update_(z, seq_t, t, noise_pred, seq_pred, noise, mask, coef):
+    b, N, _ = z.shape
+    check(lib().prd_reverse_update(dptr(z), dptr(seq_t), dptr(t, torch.int64), dptr(noise_pred), dptr(seq_pred),
+                                   dptr(noise), dptr(mask), dptr(coef), b, N, seq_pred.shape[-1], stream()),
+          "prd_reverse_update")
+
+
+# ---------------------------------------------------------------------------------------------------
+# single-track composites (LayerNorm + GEMMs + softmax)
+# ---------------------------------------------------------------------------------------------------
+
+def gated_attention_single(x_normed, mask, bias, wq, wk, wv, wg, bg, wo, bo, H: int, c: int, *,
+                           q_scale: float, key_mask: bool, resid: Optional[torch.Tensor]) -> torch.Tensor:
+    """Multi-head gated attention over the node axis with an additive [b,H,N,N] bias.
+
+    Covers reference modules.py:185-225 (c = head_dim, key mask filled with -2**15, q pre-scaled by
+    1/sqrt(c)) and models/AF2_modules.py:251-293,613-628 (c = single_dim, no mask).  Returns
+    ``resid + out_proj(...)`` (or the bare update when ``resid`` is None)."""
+    b, N, S = x_normed.shape
+    HC = H * c
+    q = linear(x_normed, wq, alpha=q_scale)
+    k = linear(x_normed, wk)
+    v = linear(x_normed, wv)
+    g = linear(x_normed, wg, bg, act=2)
+    ldp = round_up(N, 4)
+    logits = torch.empty(b, H, N, ldp, device=x_normed.device, dtype=F32)
+    gemm(q, k, logits, N, N, c, HC, HC, ldp, G1=b, G2=H, sa=(N * HC, c), sb=(N * HC, c), sc=(H * N * ldp, N * ldp),
+         addmat=bias, sad=(H * N * N, N * N), ldadd=N,
+         colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15))
+    softmax_rows_(logits, N)
+    o = torch.empty(b, N, HC, device=x_normed.device, dtype=F32)
+    gemm(logits, v, o, N, c, N, ldp, HC, HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * HC, c), sc=(N * HC, c),
+         b_kn=True, mulmat=g, smu=(N * HC, c), ldmul=HC)
+    return linear(o, wo, bo, resid=resid)
+
+
+def transition_single(single, w1, b1, w2, b2, *, residual: bool) -> torch.Tensor:
+    x = layer_norm(single)
+    h = linear(x, w1, b1, act=1)
+    return linear(h, w2, b2, resid=single if residual else None)

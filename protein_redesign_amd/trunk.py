@@ -1,0 +1,271 @@
+"""Host-side mirror of the reference's trunk modules, with every ``forward`` running on HIP.
+
+Class names, constructor arguments, ``forward`` signatures and ``state_dict`` keys follow the
+reference (ProteinReDiff/modules.py:129-404) so that these classes drop into code written against
+it; the bodies only marshal tensors into the C ABI (ops.py -> libprd_hip.so).  Inputs must be CUDA
+fp32 tensors -- there is no CPU path.  Inference only for now (no autograd through the kernels).
+
+``mask_2d`` arguments: the reference always passes the outer product of a 0/1 node mask; the kernels
+take the node mask itself, recovered here as the diagonal of ``mask_2d``.
+"""
+from __future__ import annotations
+
+import math
+from argparse import Namespace
+from typing import Mapping, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .af2_blocks import OuterProductUpdate, SPAttention
+
+_VARIANCE_INITS = {            # init name -> (scale, fan mode, distribution)   (modules.py:142-157)
+    "default": (1.0, "fan_in", "truncated_normal"),
+    "relu": (2.0, "fan_in", "truncated_normal"),
+    "glorot": (1.0, "fan_avg", "uniform"),
+    "normal": (1.0, "fan_in", "normal"),
+}
+_TRUNC_STD_CORRECTION = 0.87962566103423978   # std of N(0,1) truncated to [-2, 2]
+
+
+def _variance_scaling_(weight: torch.Tensor, scale: float, mode: str, distribution: str) -> None:
+    fan_out, fan_in = weight.shape
+    fan = {"fan_in": fan_in, "fan_out": fan_out, "fan_avg": 0.5 * (fan_in + fan_out)}[mode]
+    var = scale / max(1.0, fan)
+    if distribution == "truncated_normal":
+        nn.init.trunc_normal_(weight, 0.0, math.sqrt(var) / _TRUNC_STD_CORRECTION)
+    elif distribution == "normal":
+        nn.init.normal_(weight, 0.0, math.sqrt(var))
+    else:
+        lim = math.sqrt(3.0 * var)
+        nn.init.uniform_(weight, -lim, lim)
+
+
+class Linear(nn.Linear):
+    """nn.Linear with the named initialisers of reference modules.py:129-167."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, init: str = "default", init_fn=None):
+        super().__init__(in_features, out_features, bias=bias)
+        with torch.no_grad():
+            if init_fn is not None:
+                init_fn(self.weight, self.bias)
+            elif init in _VARIANCE_INITS:
+                _variance_scaling_(self.weight, *_VARIANCE_INITS[init])
+                if bias:
+                    self.bias.zero_()
+            elif init in ("gating", "final"):
+                self.weight.zero_()
+                if bias:
+                    self.bias.fill_(1.0 if init == "gating" else 0.0)
+            else:
+                raise ValueError(f"Invalid init: {init}")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.linear(x.contiguous(), self.weight, self.bias)
+
+
+def _node_mask(mask_2d: torch.Tensor) -> torch.Tensor:
+    return torch.diagonal(mask_2d, dim1=-2, dim2=-1).contiguous()
+
+
+class Attention(nn.Module):
+    """Gated multi-head attention (modules.py:170-225).  ``x`` is [b,N,E] (node axis) -- the
+    row-batched use over the pair tensor goes through TriangleAttention's fused kernel instead."""
+
+    def __init__(self, embed_dim: int, head_dim: int, num_heads: int):
+        super().__init__()
+        self.embed_dim, self.head_dim, self.num_heads = embed_dim, head_dim, num_heads
+        self.scale = 1.0 / math.sqrt(head_dim)
+        self.inf = 2.0 ** 15
+        self.norm = nn.LayerNorm(embed_dim, elementwise_affine=False)
+        self.q_proj = Linear(embed_dim, num_heads * head_dim, bias=False, init="glorot")
+        self.k_proj = Linear(embed_dim, num_heads * head_dim, bias=False, init="glorot")
+        self.v_proj = Linear(embed_dim, num_heads * head_dim, bias=False, init="glorot")
+        self.gate_proj = Linear(embed_dim, num_heads * head_dim, init="gating")
+        self.out_proj = Linear(num_heads * head_dim, embed_dim, init="final")
+
+    def weights(self):
+        return (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.gate_proj.weight,
+                self.gate_proj.bias, self.out_proj.weight, self.out_proj.bias)
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor, attn_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if x.dim() != 3:
+            raise RuntimeError("Attention.forward expects [b, N, E]; use TriangleAttention for pair rows")
+        b, N, _ = x.shape
+        if attn_bias is None:
+            attn_bias = torch.zeros(b, self.num_heads, N, N, device=x.device, dtype=torch.float32)
+        xn = ops.layer_norm(x.contiguous())
+        q, k, v, g, bg, wo, bo = self.weights()
+        return ops.gated_attention_single(xn, mask.contiguous(), attn_bias.contiguous(), q, k, v, g, bg, wo, bo,
+                                          self.num_heads, self.head_dim, q_scale=self.scale, key_mask=True, resid=None)
+
+
+class TriangleAttention(nn.Module):
+    """modules.py:228-243; one fused HIP operator (prd_tri_attn)."""
+
+    def __init__(self, pair_dim: int, head_dim: int, num_heads: int, mode: str):
+        super().__init__()
+        if mode not in ("starting", "ending"):
+            raise ValueError(f"Invalid mode: {mode}")
+        self.attn = Attention(pair_dim, head_dim, num_heads)
+        self.mode = mode
+
+    def run(self, pair, mask, *, residual: bool, out=None, ws=None):
+        a = self.attn
+        return ops.tri_attn(pair, mask, a.weights(), a.num_heads, a.head_dim, ending=self.mode == "ending",
+                            residual=residual, out=out, ws=ws)
+
+    def forward(self, pair: torch.Tensor, mask_2d: torch.Tensor) -> torch.Tensor:
+        return self.run(pair.contiguous(), _node_mask(mask_2d), residual=False)
+
+
+class TriangleMultiplication(nn.Module):
+    """modules.py:246-274; HIP operator prd_tri_mul (projection, batched contraction, gated output)."""
+
+    def __init__(self, pair_dim: int, mode: str):
+        super().__init__()
+        if mode not in ("outgoing", "incoming"):
+            raise ValueError(f"Invalid mode: {mode}")
+        self.mode = mode
+        self.norm = nn.LayerNorm(pair_dim, elementwise_affine=False)
+        self.ab_proj = Linear(pair_dim, pair_dim * 2, init="default")
+        self.ab_gate = Linear(pair_dim, pair_dim * 2, init="gating")
+        self.ab_norm = nn.LayerNorm(pair_dim, elementwise_affine=False)
+        self.out_proj = Linear(pair_dim, pair_dim, init="final")
+        self.out_gate = Linear(pair_dim, pair_dim, init="gating")
+
+    def weights(self):
+        return (self.ab_proj.weight, self.ab_proj.bias, self.ab_gate.weight, self.ab_gate.bias,
+                self.out_proj.weight, self.out_proj.bias, self.out_gate.weight, self.out_gate.bias)
+
+    def run(self, pair, mask, *, residual: bool, out=None, ws=None):
+        return ops.tri_mul(pair, mask, self.weights(), incoming=self.mode == "incoming", residual=residual, out=out, ws=ws)
+
+    def forward(self, pair: torch.Tensor, mask_2d: torch.Tensor) -> torch.Tensor:
+        return self.run(pair.contiguous(), _node_mask(mask_2d), residual=False)
+
+
+class OuterLinear(nn.Module):
+    """modules.py:277-287, without the [N,N,2S] concat: W1 (x_i*x_j) + W2 x_i - W2 x_j + b."""
+
+    def __init__(self, single_dim: int, pair_dim: int):
+        super().__init__()
+        self.single_dim, self.pair_dim = single_dim, pair_dim
+        self.norm = nn.LayerNorm(single_dim, elementwise_affine=False)
+        self.linear = Linear(single_dim * 2, pair_dim, init="final")
+
+    def run(self, single, pair, *, residual: bool, out=None):
+        b, N, S = single.shape
+        x = ops.layer_norm(single)
+        w = self.linear.weight
+        u = torch.empty(b, N, self.pair_dim, device=single.device, dtype=torch.float32)
+        ops.gemm(x, w, u, b * N, self.pair_dim, S, S, 2 * S, self.pair_dim, b_off=S)      # u = x W2^T
+        return ops.outer_linear_pair(pair, x, u, w, self.linear.bias, residual=residual, out=out)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        b, N, _ = x.shape
+        dummy = torch.empty(b, N, N, self.pair_dim, device=x.device, dtype=torch.float32)
+        return self.run(x.contiguous(), dummy, residual=False, out=dummy)
+
+
+class _Rearrange(nn.Module):
+    """Parameter-free stand-in for einops' Rearrange("... i j h -> ... h i j") in attn_bias (modules.py:303)."""
+
+    def forward(self, x):
+        return x.movedim(-1, -3)
+
+
+class FoldingBlock(nn.Module):
+    """modules.py:290-343: eight residual updates; here every pair update is applied in place."""
+
+    def __init__(self, single_dim: int, pair_dim: int, head_dim: int, num_heads: int, transition_factor: int):
+        super().__init__()
+        self.attn_bias = nn.Sequential(
+            nn.LayerNorm(pair_dim, elementwise_affine=False),
+            Linear(pair_dim, num_heads, init="normal"),
+            _Rearrange(),
+        )
+        self.single_attn = Attention(single_dim, head_dim, num_heads)
+        self.single_fc = nn.Sequential(
+            nn.LayerNorm(single_dim, elementwise_affine=False),
+            Linear(single_dim, single_dim * transition_factor, init="relu"),
+            nn.ReLU(),
+            Linear(single_dim * transition_factor, single_dim, init="final"),
+        )
+        self.outer_linear = OuterLinear(single_dim, pair_dim)
+        self.pair_mul_outgoing = TriangleMultiplication(pair_dim, "outgoing")
+        self.pair_mul_incoming = TriangleMultiplication(pair_dim, "incoming")
+        self.pair_attn_starting = TriangleAttention(pair_dim, head_dim, num_heads, "starting")
+        self.pair_attn_ending = TriangleAttention(pair_dim, head_dim, num_heads, "ending")
+        self.pair_fc = nn.Sequential(
+            nn.LayerNorm(pair_dim, elementwise_affine=False),
+            Linear(pair_dim, pair_dim * transition_factor, init="relu"),
+            nn.ReLU(),
+            Linear(pair_dim * transition_factor, pair_dim, init="final"),
+        )
+
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """In-place on ``pair``; returns the new single and the same pair tensor."""
+        sa = self.single_attn
+        bias = ops.pair_bias(pair, self.attn_bias[1].weight, self.attn_bias[1].bias)
+        xn = ops.layer_norm(single)
+        q, k, v, g, bg, wo, bo = sa.weights()
+        single = ops.gated_attention_single(xn, mask, bias, q, k, v, g, bg, wo, bo, sa.num_heads, sa.head_dim,
+                                            q_scale=sa.scale, key_mask=True, resid=single)
+        fc = self.single_fc
+        single = ops.transition_single(single, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=True)
+        self.outer_linear.run(single, pair, residual=True, out=pair)
+        self.pair_mul_outgoing.run(pair, mask, residual=True, out=pair, ws=ws)
+        self.pair_mul_incoming.run(pair, mask, residual=True, out=pair, ws=ws)
+        self.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)
+        self.pair_attn_ending.run(pair, mask, residual=True, out=pair, ws=ws)
+        pf = self.pair_fc
+        ops.pair_transition(pair, pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias, residual=True, out=pair)
+        return single, pair
+
+    def forward(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.run_(single.contiguous(), pair.contiguous().clone(), mask.contiguous())
+
+
+class Denoiser(nn.Module):
+    """modules.py:346-404."""
+
+    def __init__(self, args):
+        super().__init__()
+        if isinstance(args, Mapping):
+            args = Namespace(**args)
+        self.single_dim, self.esm_dim, self.pair_dim = args.single_dim, args.esm_dim, args.pair_dim
+        self.head_dim, self.num_heads = args.head_dim, args.num_heads
+        self.transition_factor, self.num_blocks = args.transition_factor, args.num_blocks
+        self.n_recycles = args.n_recycles
+        self.SPAAttnBlock = SPAttention(c_in=self.single_dim, c_hidden=self.single_dim, no_heads=self.num_heads,
+                                        pair_bias=True, c_z=self.pair_dim)
+        self.opm = OuterProductUpdate(c_m=self.single_dim, c_z=self.pair_dim, c_hidden=self.single_dim // 4)
+        self.folding_blocks = nn.ModuleList(
+            [FoldingBlock(self.single_dim, self.pair_dim, self.head_dim, self.num_heads, self.transition_factor)
+             for _ in range(self.num_blocks)])
+
+    def ws_floats(self, b: int, N: int) -> int:
+        P = self.pair_dim
+        return max(ops.workspace_bytes("tri_mul", b, N, 0, P), ops.workspace_bytes("tri_attn", b, N, 0, P)) // 4
+
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None):
+        """OPM, SPA and the folding blocks, in place on ``pair``, WITHOUT the final symmetrisation
+        (the fused coordinate head symmetrises on the fly, so the hot path never writes it back)."""
+        b, N = mask.shape
+        if ws is None:
+            ws = torch.empty(self.ws_floats(b, N), device=pair.device, dtype=torch.float32)
+        self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair)
+        single = self.SPAAttnBlock(single, pair, mask)
+        for block in self.folding_blocks:
+            single, pair = block.run_(single, pair, mask, ws=ws)
+        return single, pair
+
+    def forward(self, batch, z, t, single, pair, cache):
+        """Like the reference, updates ``pair`` in place up to the final symmetrisation (modules.py:395)
+        and ignores ``z`` / ``t``."""
+        mask = batch["residue_and_atom_mask"].contiguous()
+        single, pair = self.run_(single.contiguous(), pair, mask)
+        pair = 0.5 * (pair + pair.transpose(1, 2))
+        return single, pair, cache

@@ -1,0 +1,312 @@
+"""GPU parity: every HIP operator, the folding block, the whole network step and the reverse-diffusion
+trajectory, against the CPU oracle on identical seeded inputs and against the golden vectors captured
+from the imported reference.  All calls go through the C ABI (protein_redesign_amd.ops -> ctypes).
+
+Tolerances (relative L2, fp32): 1e-5 per operator, 2e-5 per block / step, 1e-4 per trajectory
+(BASELINE.json north_star bound)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import prd_oracle as O
+from conftest import rel_l2
+from protein_redesign_amd import ops
+from protein_redesign_amd.constants import make_args
+from protein_redesign_amd.diffusion_model import ProteinReDiffModel
+from protein_redesign_amd.synthetic import (NoiseSource, batch_to, clone_batch, deterministic_state_dict,
+                                            synthetic_batch)
+from protein_redesign_amd.weights import spec_tensors
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NOISE_SEED = 7
+OP_TOL, BLOCK_TOL, TRAJ_TOL = 1e-5, 2e-5, 1e-4
+
+CFG = {
+    32: dict(single_dim=64, pair_dim=32, head_dim=16, num_heads=4, num_blocks=2, esm_dim=32, num_steps=8, mask_prob=0.3),
+    64: dict(single_dim=64, pair_dim=64, head_dim=16, num_heads=4, num_blocks=2, esm_dim=32, num_steps=8, mask_prob=0.3),
+}
+
+
+def build(args, seed):
+    params = deterministic_state_dict(spec_tensors(args), seed=seed)
+    model = ProteinReDiffModel(args)
+    model.load_state_dict(params)
+    return model.to(DEV).eval(), params
+
+
+def cu(x):
+    return x.to(DEV).contiguous()
+
+
+@pytest.fixture(scope="module", params=[32, 64])
+def setup(request):
+    P = request.param
+    args = make_args(**CFG[P])
+    model, params = build(args, seed=10 + P)
+    sizes = [(6, 30), (3, 22)]
+    batch = synthetic_batch(sizes, esm_dim=args["esm_dim"], seed=20 + P, n_total=40)   # N=40: ragged + padded tail
+    perms = [NoiseSource(NOISE_SEED, 100 + k).randperm(n) for k, (_, n) in enumerate(sizes)]
+    pb = O.prepare_batch(batch, args["mask_prob"], perms)
+    g = torch.Generator().manual_seed(99 + P)
+    b, N = pb["atom_mask"].shape
+    single = torch.randn(b, N, args["single_dim"], generator=g)
+    pair = torch.randn(b, N, N, P, generator=g)
+    return dict(P=P, args=args, model=model, params=params, batch=pb, single=single, pair=pair,
+                mask=pb["residue_and_atom_mask"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K,G", [(37, 64, 64, 1), (320, 2048, 512, 1), (70, 21, 512, 1), (140, 140, 16, 8),
+                                     (200, 200, 200, 3), (129, 257, 36, 2)])
+def test_gemm_nt(M, N, K, G):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(G, M, K, generator=g)
+    B = torch.randn(G, N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(G, M, N, generator=g)
+    want = torch.relu(0.5 * torch.matmul(A.double(), B.double().transpose(1, 2)) + bias.double()) + res.double()
+    out = torch.empty(G, M, N, device=DEV)
+    ops.gemm(cu(A), cu(B), out, M, N, K, K, K, N, G1=G, sa=(M * K, 0), sb=(N * K, 0), sc=(M * N, 0), alpha=0.5,
+             bias=cu(bias), act=1, resid=cu(res), sr=(M * N, 0), ldr=N)
+    assert rel_l2(out.cpu(), want) < 2e-6
+
+
+def test_gemm_nn_masked_and_gated():
+    g = torch.Generator().manual_seed(5)
+    b, H, N, c = 2, 4, 45, 16
+    Pm = torch.rand(b, H, N, 48, generator=g)            # attention-like, ld padded to 48
+    Pm[..., N:] = 0
+    V = torch.randn(b, N, H * c, generator=g)
+    gate = torch.rand(b, N, H * c, generator=g)
+    want = torch.einsum("bhij,bjhc->bihc", Pm[..., :N].double(), V.view(b, N, H, c).double()).reshape(b, N, H * c) * gate.double()
+    out = torch.empty(b, N, H * c, device=DEV)
+    ops.gemm(cu(Pm), cu(V), out, N, c, N, 48, H * c, H * c, G1=b, G2=H, sa=(H * N * 48, N * 48), sb=(N * H * c, c),
+             sc=(N * H * c, c), b_kn=True, mulmat=cu(gate), smu=(N * H * c, c), ldmul=H * c)
+    assert rel_l2(out.cpu(), want) < 2e-6
+
+
+def test_layer_norm_and_softmax():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(77, 1280, generator=g) * 3 + 1
+    gamma, beta = torch.randn(1280, generator=g), torch.randn(1280, generator=g)
+    assert rel_l2(ops.layer_norm(cu(x)).cpu(), O.ln(x)) < 2e-6
+    assert rel_l2(ops.layer_norm(cu(x), cu(gamma), cu(beta)).cpu(), O.ln(x, gamma, beta)) < 2e-6
+    y = torch.randn(50, 144, generator=g) * 4
+    got = ops.softmax_rows_(cu(y), 141).cpu()
+    assert rel_l2(got[:, :141], torch.softmax(y[:, :141], -1)) < 2e-6
+    assert torch.all(got[:, 141:] == 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# operators vs the oracle (module-level API of the mirror classes)
+# ---------------------------------------------------------------------------------------------------
+
+def test_pair_bias(setup):
+    s = setup
+    fb = s["model"].Denoiser.folding_blocks[0]
+    got = ops.pair_bias(cu(s["pair"]), fb.attn_bias[1].weight, fb.attn_bias[1].bias)
+    assert rel_l2(got.cpu(), O.pair_bias(s["params"], "Denoiser.folding_blocks.0.attn_bias", s["pair"])) < OP_TOL
+
+
+def test_single_attention(setup):
+    s = setup
+    fb = s["model"].Denoiser.folding_blocks[0]
+    bias = O.pair_bias(s["params"], "Denoiser.folding_blocks.0.attn_bias", s["pair"])
+    want = O.gated_attention(s["params"], "Denoiser.folding_blocks.0.single_attn", s["single"], s["mask"],
+                             s["args"]["num_heads"], s["args"]["head_dim"], bias=bias)
+    got = fb.single_attn(cu(s["single"]), cu(s["mask"]), attn_bias=cu(bias))
+    assert rel_l2(got.cpu(), want) < OP_TOL
+
+
+def test_single_transition(setup):
+    s = setup
+    fc = s["model"].Denoiser.folding_blocks[0].single_fc
+    got = ops.transition_single(cu(s["single"]), fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=False)
+    assert rel_l2(got.cpu(), O.transition(s["params"], "Denoiser.folding_blocks.0.single_fc", s["single"])) < OP_TOL
+
+
+def test_outer_linear(setup):
+    s = setup
+    got = s["model"].Denoiser.folding_blocks[0].outer_linear(cu(s["single"]))
+    assert rel_l2(got.cpu(), O.outer_linear(s["params"], "Denoiser.folding_blocks.0.outer_linear", s["single"])) < OP_TOL
+
+
+@pytest.mark.parametrize("mode", ["outgoing", "incoming"])
+def test_triangle_multiplication(setup, mode):
+    s = setup
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_mul_{mode}")
+    m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
+    want = O.triangle_multiplication(s["params"], f"Denoiser.folding_blocks.0.pair_mul_{mode}", s["pair"], m2, mode == "incoming")
+    got = mod(cu(s["pair"]), cu(m2))
+    assert rel_l2(got.cpu(), want) < OP_TOL
+
+
+@pytest.mark.parametrize("mode", ["starting", "ending"])
+def test_triangle_attention(setup, mode):
+    s = setup
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
+    m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
+    want = O.triangle_attention(s["params"], f"Denoiser.folding_blocks.0.pair_attn_{mode}", s["pair"], m2,
+                                s["args"]["num_heads"], s["args"]["head_dim"], mode == "ending")
+    got = mod(cu(s["pair"]), cu(m2))
+    assert rel_l2(got.cpu(), want) < OP_TOL
+
+
+def test_pair_transition(setup):
+    s = setup
+    pf = s["model"].Denoiser.folding_blocks[0].pair_fc
+    got = ops.pair_transition(cu(s["pair"]), pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias, residual=False)
+    assert rel_l2(got.cpu(), O.transition(s["params"], "Denoiser.folding_blocks.0.pair_fc", s["pair"])) < OP_TOL
+
+
+def test_outer_product_update(setup):
+    s = setup
+    got = s["model"].Denoiser.opm(cu(s["single"]), cu(s["mask"]))
+    assert rel_l2(got.cpu(), O.outer_product_update(s["params"], "Denoiser.opm", s["single"], s["mask"])) < OP_TOL
+
+
+def test_single_pair_attention(setup):
+    s = setup
+    got = s["model"].Denoiser.SPAAttnBlock(cu(s["single"]), cu(s["pair"]), cu(s["mask"]))
+    want = O.single_pair_attention(s["params"], "Denoiser.SPAAttnBlock", s["single"], s["pair"], s["args"]["num_heads"])
+    assert rel_l2(got.cpu(), want) < OP_TOL
+
+
+def test_folding_block(setup):
+    s = setup
+    with torch.inference_mode():
+        ws, wp = O.folding_block(s["params"], "Denoiser.folding_blocks.0", s["single"], s["pair"], s["mask"],
+                                 s["args"]["num_heads"], s["args"]["head_dim"])
+    gs, gp = s["model"].Denoiser.folding_blocks[0](cu(s["single"]), cu(s["pair"]), cu(s["mask"]))
+    assert rel_l2(gs.cpu(), ws) < BLOCK_TOL
+    assert rel_l2(gp.cpu(), wp) < BLOCK_TOL
+
+
+def test_denoiser(setup):
+    s = setup
+    with torch.inference_mode():
+        ws, wp = O.denoiser(s["params"], s["args"], s["single"], s["pair"], s["mask"])
+    gs, gp, _ = s["model"].Denoiser(batch_to(s["batch"], DEV), None, None, cu(s["single"]), cu(s["pair"]), None)
+    assert rel_l2(gs.cpu(), ws) < BLOCK_TOL
+    assert rel_l2(gp.cpu(), wp) < BLOCK_TOL
+
+
+def test_input_embedding_and_heads(setup):
+    s = setup
+    m, p, args, pb = s["model"], s["params"], s["args"], s["batch"]
+    g = torch.Generator().manual_seed(3)
+    b, N = s["mask"].shape
+    z = torch.randn(b, N, 3, generator=g)
+    seq_t = torch.randn(b, N, 21, generator=g)
+    t = torch.tensor([5, 2])
+    with torch.inference_mode():
+        single, pair, zij, m2 = O.embed_inputs(p, args, pb, z, seq_t, s["mask"], t)
+    dbatch = batch_to(pb, DEV)
+    st = m._static_inputs(dbatch)
+    gs = ops.single_init(st["single"], cu(seq_t), cu(pb["residue_mask"]), m.embed_residue_type[1].weight)
+    eb = ops.time_embed(cu(t), m.embed_beta[0].weight, m.embed_beta[1].weight, args["num_steps"])
+    gp = ops.pair_init(st["pair"], cu(z), cu(s["mask"]), m.embed_dist[0].center, m.embed_dist[1].weight, eb)
+    assert rel_l2(gs.cpu(), single) < OP_TOL
+    assert rel_l2(gp.cpu(), pair) < OP_TOL
+    # heads on the symmetrised oracle pair vs the fused head on the raw pair
+    with torch.inference_mode():
+        sym = 0.5 * (s["pair"] + s["pair"].transpose(1, 2))
+        want_eps, want_logits = O.heads(p, s["single"], sym, zij, m2, s["mask"])
+    wr = m.weight_radial
+    eps = ops.remove_mean(ops.coord_head(cu(s["pair"]), cu(z), cu(s["mask"]), wr[1].weight, wr[1].bias, wr[3].weight), cu(s["mask"]))
+    assert rel_l2(eps.cpu(), want_eps) < OP_TOL
+    sm = m.seq_mlp
+    logits = ops.linear(ops.linear(ops.layer_norm(cu(s["single"])), sm[1].weight, sm[1].bias, act=1), sm[3].weight)
+    assert rel_l2(logits.cpu(), want_logits) < OP_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole step and trajectory vs the golden vectors of the imported reference
+# ---------------------------------------------------------------------------------------------------
+
+def golden_case(golden, name):
+    case, z = golden(name)
+    args = make_args(**case["args"])
+    model, params = build(args, case["weight_seed"])
+    return case, z, args, model, params
+
+
+@pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
+def test_network_step_vs_reference_golden(golden, name):
+    case, z, args, model, params = golden_case(golden, name)
+    sizes = [tuple(s) for s in case["sizes"]]
+    batch = synthetic_batch(sizes, esm_dim=args["esm_dim"], seed=case["batch_seed"], n_total=case["n_total"])
+    perms = [NoiseSource(NOISE_SEED, 100 + k).randperm(n) for k, (_, n) in enumerate(sizes)]
+    pb = batch_to(O.prepare_batch(batch, args["mask_prob"], perms), DEV)
+    with torch.inference_mode():
+        eps, logits = model.sample_step(pb, cu(torch.from_numpy(z["step_z"])), cu(torch.from_numpy(z["step_seq_t"])),
+                                        pb["residue_and_atom_mask"], cu(torch.from_numpy(z["step_t"])))
+    assert rel_l2(eps.cpu(), z["step_noise_pred"]) < BLOCK_TOL * 2
+    assert rel_l2(logits.cpu(), z["step_seq_pred"]) < BLOCK_TOL * 2
+
+
+@pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
+def test_trajectory_vs_reference_golden(golden, name):
+    case, z, args, model, params = golden_case(golden, name)
+    one = batch_to(synthetic_batch([tuple(case["traj_sample"])], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500), DEV)
+    pos, logits = model.sample(one, sources=[NoiseSource(NOISE_SEED, 0)])
+    assert rel_l2(pos.cpu(), z["traj_pos"]) < TRAJ_TOL
+    assert rel_l2(logits.cpu(), z["traj_logits"]) < TRAJ_TOL
+
+
+def test_full_size_step_vs_oracle():
+    """BASELINE config 2 shape (N=320, S=512, P=64) with 1 block so the CPU oracle finishes in seconds."""
+    args = make_args(single_dim=512, pair_dim=64, num_blocks=1, num_steps=1000, mask_prob=0.3)
+    model, params = build(args, seed=4)
+    batch = synthetic_batch([(64, 256)], seed=0)
+    pb = O.prepare_batch(batch, 0.3, [NoiseSource(NOISE_SEED, 0).randperm(256)])
+    g = torch.Generator().manual_seed(8)
+    z, seq_t, t = torch.randn(1, 320, 3, generator=g), torch.randn(1, 320, 21, generator=g), torch.tensor([500])
+    with torch.inference_mode():
+        want = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
+        dpb = batch_to(pb, DEV)
+        got = model.sample_step(dpb, cu(z), cu(seq_t), dpb["residue_and_atom_mask"], cu(t))
+    assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2
+    assert rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# size-independent properties at full size
+# ---------------------------------------------------------------------------------------------------
+
+def test_se3_equivariance_full_size():
+    args = make_args(single_dim=512, pair_dim=64, num_blocks=2, num_steps=1000, mask_prob=0.3)
+    model, _ = build(args, seed=6)
+    batch = synthetic_batch([(64, 256)], seed=1)
+    pb = batch_to(O.prepare_batch(batch, 0.3, [NoiseSource(NOISE_SEED, 1).randperm(256)]), DEV)
+    g = torch.Generator().manual_seed(9)
+    z, seq_t, t = torch.randn(1, 320, 3, generator=g), torch.randn(1, 320, 21, generator=g), torch.tensor([321])
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    shift = torch.randn(1, 1, 3, generator=g)
+    mask = pb["residue_and_atom_mask"]
+    with torch.inference_mode():
+        e1, l1 = model.sample_step(pb, cu(z), cu(seq_t), mask, cu(t))
+        e2, l2 = model.sample_step(pb, cu(z @ q + shift), cu(seq_t), mask, cu(t))
+    assert rel_l2(e2.cpu(), e1.cpu() @ q) < 1e-5          # rotation equivariance / translation invariance
+    assert rel_l2(l2.cpu(), l1.cpu()) < 1e-5
+    assert float((mask.unsqueeze(-1) * e1).sum(1).abs().max()) < 1e-3   # masked mean removed
+
+
+def test_long_sequence_stress_runs():
+    """BASELINE config 5: 768 residues + 1 dummy atom (N = 769): finite outputs, zero masked mean."""
+    args = make_args(single_dim=512, pair_dim=64, num_blocks=1, num_steps=1000, mask_prob=0.3)
+    model, _ = build(args, seed=7)
+    batch = synthetic_batch([(1, 768)], seed=2)
+    pb = batch_to(O.prepare_batch(batch, 0.3, [NoiseSource(NOISE_SEED, 2).randperm(768)]), DEV)
+    g = torch.Generator().manual_seed(10)
+    z, seq_t, t = torch.randn(1, 769, 3, generator=g), torch.randn(1, 769, 21, generator=g), torch.tensor([10])
+    with torch.inference_mode():
+        eps, logits = model.sample_step(pb, cu(z), cu(seq_t), pb["residue_and_atom_mask"], cu(t))
+    assert torch.isfinite(eps).all() and torch.isfinite(logits).all()
+    assert float(eps.sum(1).abs().max()) < 1e-2
