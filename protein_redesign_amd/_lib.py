@@ -45,7 +45,7 @@ SIGNATURES = {
     "prd_opm_pair": [vp] * 6 + [ci] * 5 + [vp],
     "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp],
     "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp],
-    "prd_tri_attn": [vp] * 10 + [ci] * 6 + [vp, cz, vp],
+    "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp],
     "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
