@@ -121,6 +121,12 @@ int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w
 int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
                  const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
                  int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, hipStream_t stream);
+/* the two launches of prd_tri_attn, exposed separately (og = gated per-head output [b,N,N,64]) */
+int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
+                      const float* wv, const float* wg, const float* bg, int ending,
+                      int b, int N, int P, int H, int c, hipStream_t stream);
+int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
+                     int residual, int b, int N, int P, hipStream_t stream);
 /* pair transition (modules.py:321-326): out = (residual ? pair : 0) + W2 relu(W1 LN(pair) + b1) + b2, hidden = 4P */
 int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
                         const float* b2, int residual, int b, int N, int P, hipStream_t stream);
@@ -131,10 +137,11 @@ int prd_coord_head(float* eps_raw, const float* pair, const float* z, const floa
 /* remove_mean (utils.py:32-36) applied to eps_raw -> noise_pred */
 int prd_remove_mean(float* out, const float* x, const float* mask, int b, int N, int D, hipStream_t stream);
 /* reverse-diffusion update (model.py:405-420): z <- (z - w_t eps)/sqrt(alpha_t) [+ sqrt(beta_t) remove_mean(noise)],
- * seq_t <- 2 softmax(seq_pred) - 1, t <- t - 1.  coef = [T][4] = {w_noise, 1/sqrt_alpha, sqrt_beta, 0}. */
+ * seq_t <- 2 softmax(seq_pred) - 1, t <- t - 1.  coef = [T][4] = {w_noise, 1/sqrt_alpha, sqrt_beta, 0};
+ * noise = [T-1][b][N][3], row T-1-t is consumed at step t > 0 (so one captured hipGraph serves every step). */
 int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pred, const float* seq_pred,
                        const float* noise, const float* mask, const float* coef,
-                       int b, int N, int n_cls, hipStream_t stream);
+                       int b, int N, int n_cls, int num_steps, hipStream_t stream);
 
 /* bytes of scratch an operator needs: op = "tri_mul" | "tri_attn" */
 size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P);

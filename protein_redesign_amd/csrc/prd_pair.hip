@@ -473,13 +473,14 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
                                                              int64_t* __restrict__ t, const float* __restrict__ eps,
                                                              const float* __restrict__ seq_pred, const float* __restrict__ noise,
                                                              const float* __restrict__ mask, const float* __restrict__ coef,
-                                                             int N, int ncls) {
+                                                             int N, int ncls, int num_steps) {
     __shared__ float red[256];
     __shared__ float mean[4];
     const int bb = blockIdx.x;
     const long tt = t[bb];
     const float wn = coef[tt * 4 + 0], isa = coef[tt * 4 + 1], sb = coef[tt * 4 + 2];
-    const float* nz = noise + (long)bb * N * 3;
+    // noise table [T-1][b][N][3]: row (T-1-t) is the draw consumed at step t (t > 0)
+    const float* nz = noise + ((long)(tt > 0 ? num_steps - 1 - tt : 0) * gridDim.x + bb) * N * 3;
     if (tt > 0) {
         for (int d = 0; d < 4; ++d) {
             float s = 0.f;
@@ -520,6 +521,15 @@ int grid_for(long tasks, int per_wg, int cap) {
 
 }  // namespace
 
+// raise the dynamic-LDS limit of a kernel once per process (idempotent; not a stream operation)
+#define PRD_SET_LDS(kernel, bytes)                                                                              \
+    do {                                                                                                        \
+        static size_t prd_lds_set = 0;                                                                          \
+        if ((size_t)(bytes) > prd_lds_set) {                                                                    \
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            prd_lds_set = (size_t)(bytes);                                                                      \
+        }                                                                                                       \
+    } while (0)
 #define PRD_CHECK_P(P) if ((P) != 32 && (P) != 64) return PRD_ERR_UNSUPPORTED
 
 extern "C" int prd_version(void) { return PRD_VERSION; }
@@ -573,10 +583,10 @@ extern "C" int prd_pair_init(float* pair, const float* static_pair, const float*
     const long ntask = ((long)b * N * N + 31) / 32;
     const int grid = grid_for(ntask, 4, 512);
     if (P == 64) {
-        (void)hipFuncSetAttribute((const void*)pair_init_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PRD_SET_LDS(pair_init_kernel<64>, lds);
         hipLaunchKernelGGL(pair_init_kernel<64>, dim3(grid), dim3(WG), lds, stream, pair, static_pair, z, mask, centers, w_dist, ebeta, b, N, dist_dim);
     } else {
-        (void)hipFuncSetAttribute((const void*)pair_init_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PRD_SET_LDS(pair_init_kernel<32>, lds);
         hipLaunchKernelGGL(pair_init_kernel<32>, dim3(grid), dim3(WG), lds, stream, pair, static_pair, z, mask, centers, w_dist, ebeta, b, N, dist_dim);
     }
     return (int)hipGetLastError();
@@ -603,10 +613,10 @@ extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, cons
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const int grid = grid_for(ntask, 4, 1024);
     if (P == 64) {
-        (void)hipFuncSetAttribute((const void*)opm_pair_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PRD_SET_LDS(opm_pair_kernel<64>, lds);
         hipLaunchKernelGGL(opm_pair_kernel<64>, dim3(grid), dim3(WG), lds, stream, out, pair, ab, mask, w_out, b_out, b, N, C, flags);
     } else {
-        (void)hipFuncSetAttribute((const void*)opm_pair_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PRD_SET_LDS(opm_pair_kernel<32>, lds);
         hipLaunchKernelGGL(opm_pair_kernel<32>, dim3(grid), dim3(WG), lds, stream, out, pair, ab, mask, w_out, b_out, b, N, C, flags);
     }
     return (int)hipGetLastError();
@@ -632,10 +642,10 @@ extern "C" int prd_pair_transition(float* out, const float* pair, const float* w
     const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + 5 * P) * sizeof(float);
     const int grid = grid_for((rows + 31) / 32, 4, 256);
     if (P == 64) {
-        (void)hipFuncSetAttribute((const void*)pair_transition_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PRD_SET_LDS(pair_transition_kernel<64>, lds);
         hipLaunchKernelGGL(pair_transition_kernel<64>, dim3(grid), dim3(WG), lds, stream, out, pair, w1, b1, w2, b2, rows, residual);
     } else {
-        (void)hipFuncSetAttribute((const void*)pair_transition_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PRD_SET_LDS(pair_transition_kernel<32>, lds);
         hipLaunchKernelGGL(pair_transition_kernel<32>, dim3(grid), dim3(WG), lds, stream, out, pair, w1, b1, w2, b2, rows, residual);
     }
     return (int)hipGetLastError();
@@ -659,8 +669,8 @@ extern "C" int prd_remove_mean(float* out, const float* x, const float* mask, in
 
 extern "C" int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pred, const float* seq_pred,
                                   const float* noise, const float* mask, const float* coef,
-                                  int b, int N, int n_cls, hipStream_t stream) {
+                                  int b, int N, int n_cls, int num_steps, hipStream_t stream) {
     if (!z || !seq_t || !t || !noise_pred || !seq_pred || !noise || !mask || !coef || b <= 0 || N <= 0 || n_cls <= 0) return PRD_ERR_ARG;
-    hipLaunchKernelGGL(reverse_update_kernel, dim3(b), dim3(256), 0, stream, z, seq_t, t, noise_pred, seq_pred, noise, mask, coef, N, n_cls);
+    hipLaunchKernelGGL(reverse_update_kernel, dim3(b), dim3(256), 0, stream, z, seq_t, t, noise_pred, seq_pred, noise, mask, coef, N, n_cls, num_steps);
     return (int)hipGetLastError();
 }

@@ -298,6 +298,15 @@ int grid_for(long tasks, int per_wg, int cap) {
 
 }  // namespace
 
+#define PRD_SET_LDS(kernel, bytes)                                                                              \
+    do {                                                                                                        \
+        static size_t prd_lds_set = 0;                                                                          \
+        if ((size_t)(bytes) > prd_lds_set) {                                                                    \
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            prd_lds_set = (size_t)(bytes);                                                                      \
+        }                                                                                                       \
+    } while (0)
+
 extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P) {
     (void)S;
     if (!op || b <= 0 || N <= 0) return 0;
@@ -323,10 +332,10 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
         const long ntask = (long)b * N * (ldn / 32);
         const int grid = grid_for(ntask, 4, 1024);
         if (P == 64) {
-            (void)hipFuncSetAttribute((const void*)tri_mul_proj_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            PRD_SET_LDS(tri_mul_proj_kernel<64>, lds);
             hipLaunchKernelGGL(tri_mul_proj_kernel<64>, dim3(grid), dim3(WG), lds, stream, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
         } else {
-            (void)hipFuncSetAttribute((const void*)tri_mul_proj_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            PRD_SET_LDS(tri_mul_proj_kernel<32>, lds);
             hipLaunchKernelGGL(tri_mul_proj_kernel<32>, dim3(grid), dim3(WG), lds, stream, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
         }
         int e = (int)hipGetLastError();
@@ -354,12 +363,11 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     return (int)hipGetLastError();
 }
 
-extern "C" int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
-                            const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
-                            int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, hipStream_t stream) {
-    if (!out || !pair || !mask || !wq || !wk || !wv || !wg || !bg || !wo || !bo || !ws || b <= 0 || N <= 0) return PRD_ERR_ARG;
+extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
+                                 const float* wv, const float* wg, const float* bg, int ending,
+                                 int b, int N, int P, int H, int c, hipStream_t stream) {
+    if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
-    if (ws_bytes < prd_workspace_bytes("tri_attn", b, N, 0, P)) return PRD_ERR_WORKSPACE;
     const int npad = prd_round_up(N, 32);
     const size_t lds_fixed = (size_t)2 * 32 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad;
     // 8 waves (2 per SIMD) while the row's K/V fit next to 8 query scratch tiles, else 4 waves
@@ -370,17 +378,32 @@ extern "C" int prd_tri_attn(float* out, const float* pair, const float* mask, co
     const int grid = grid_for(ntask, 1, 4096);
 #define PRD_TA_LAUNCH(PP, NW)                                                                                          \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)tri_attn_core_kernel<PP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((tri_attn_core_kernel<PP, NW>), dim3(grid), dim3(NW * 64), lds, stream, ws, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
+        PRD_SET_LDS((tri_attn_core_kernel<PP, NW>), lds);                                                              \
+        hipLaunchKernelGGL((tri_attn_core_kernel<PP, NW>), dim3(grid), dim3(NW * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
     } while (0)
     if (P == 64) { if (nw == 8) PRD_TA_LAUNCH(64, 8); else PRD_TA_LAUNCH(64, 4); }
     else { if (nw == 8) PRD_TA_LAUNCH(32, 8); else PRD_TA_LAUNCH(32, 4); }
 #undef PRD_TA_LAUNCH
-    int e = (int)hipGetLastError();
-    if (e) return e;
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
+                                int residual, int b, int N, int P, hipStream_t stream) {
+    if (!out || !pair || !og || !wo || !bo || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     const long rows = (long)b * N * N;
     const int grid2 = grid_for((rows + 31) / 32, 4, 2048);
-    if (P == 64) hipLaunchKernelGGL(tri_attn_out_kernel<64>, dim3(grid2), dim3(WG), 0, stream, out, pair, ws, wo, bo, rows, residual);
-    else hipLaunchKernelGGL(tri_attn_out_kernel<32>, dim3(grid2), dim3(WG), 0, stream, out, pair, ws, wo, bo, rows, residual);
+    if (P == 64) hipLaunchKernelGGL(tri_attn_out_kernel<64>, dim3(grid2), dim3(WG), 0, stream, out, pair, og, wo, bo, rows, residual);
+    else hipLaunchKernelGGL(tri_attn_out_kernel<32>, dim3(grid2), dim3(WG), 0, stream, out, pair, og, wo, bo, rows, residual);
     return (int)hipGetLastError();
+}
+
+extern "C" int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
+                            const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
+                            int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!ws) return PRD_ERR_ARG;
+    if (ws_bytes < prd_workspace_bytes("tri_attn", b, N, 0, P)) return PRD_ERR_WORKSPACE;
+    int e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
+    if (e) return e;
+    return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, stream);
 }

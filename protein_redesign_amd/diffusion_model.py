@@ -170,6 +170,7 @@ class ProteinReDiffModel(_Base):
         self.learning_rate, self.warmup_steps, self.ema_decay = args.learning_rate, args.warmup_steps, args.ema_decay
         self.n_recycles, self.training_mode = args.n_recycles, args.training_mode
         self.sample_seed = 0                    # key of the injected randomness (see module docstring)
+        self.use_hip_graph = True               # replay one captured step graph inside sample()
         self._sample_counter = 0
 
         self.Denoiser = Denoiser(args)
@@ -339,33 +340,86 @@ class ProteinReDiffModel(_Base):
     # ------------------------------------------------------------------ reverse diffusion (model.py:377-422)
     @torch.inference_mode()
     def sample(self, batch, sources: Optional[Sequence] = None):
-        if not self.setup_schedule:
-            self.run_setup_schedule()
-            self.setup_schedule = True
-        dev = self.device
+        loop = ReverseDiffusion(self, batch, sources)
+        loop.run()
+        return loop.result()
+
+
+class ReverseDiffusion:
+    """State and driver of one ``sample()`` call (reference model.py:377-422) on one GPU.
+
+    Everything the loop needs is resident in HBM before the first step: the step-invariant
+    embeddings, the complete noise table ``[T-1, b, N, 3]`` (drawn on the host from the keyed
+    generators, in the reference's per-sample order) and the per-step scalar
+    table.  ``z``, ``seq_t`` and the step counter ``t`` live on the device and are advanced by the
+    kernels themselves, so ONE captured hipGraph of a whole step (network forward + reverse update)
+    is replayed for every remaining step: no per-step host work and no ``(t == 0).all()``
+    device->host sync (model.py:415)."""
+
+    def __init__(self, model: "ProteinReDiffModel", batch, sources: Optional[Sequence] = None):
+        m = self.model = model
+        if not m.setup_schedule:
+            m.run_setup_schedule()
+            m.setup_schedule = True
+        dev = m.device
         b, N = batch["atom_mask"].shape
         if sources is None:
-            sources = self._sources(b)
-        batch = self.prepare_batch(batch, sources=sources)
-        mask = batch["residue_and_atom_mask"].contiguous()
-        rm = batch["residue_mask"].contiguous()
-        T = self.num_steps
-        # all randomness up front, in the reference's draw order per sample
+            sources = m._sources(b)
+        self.batch = batch = m.prepare_batch(batch, sources=sources)
+        self.mask = batch["residue_and_atom_mask"].contiguous()
+        self.rm = batch["residue_mask"].contiguous()
+        self.T = T = m.num_steps
         z0 = torch.stack([s.randn(N, 3) for s in sources])
         s0 = torch.stack([s.randn(N, NUM_RESIDUE_CLASSES) for s in sources])
         if T > 1:
             noise = torch.stack([torch.stack([s.randn(N, 3) for _ in range(T - 1)]) for s in sources], dim=1)
         else:
             noise = torch.zeros(1, b, N, 3)
-        noise = noise.to(dev).contiguous()                      # [T-1, b, N, 3]
-        z = ops.remove_mean(z0.to(dev).contiguous(), mask)
-        seq_t = ops.remove_mean(s0.to(dev).contiguous(), rm)
-        seq_t = (batch["residue_extra_mask"].unsqueeze(-1) * batch["residue_one_hot"]
-                 + batch["residue_inv_extra_mask"].unsqueeze(-1) * seq_t).contiguous()
-        static = self._static_inputs(batch)
-        t = torch.full((b,), T - 1, dtype=torch.int64, device=dev)
-        seq_pred = None
-        for i in range(T):
-            noise_pred, seq_pred = self._network(batch, z, seq_t, mask, t, static=static)
-            ops.reverse_update_(z, seq_t, t, noise_pred, seq_pred, noise[min(i, noise.shape[0] - 1)], mask, self._coef)
-        return 10.0 * z, rm.unsqueeze(-1) * seq_pred
+        self.noise = noise.to(dev).contiguous()                      # [T-1, b, N, 3]
+        self.z = ops.remove_mean(z0.to(dev).contiguous(), self.mask)
+        seq_t = ops.remove_mean(s0.to(dev).contiguous(), self.rm)
+        self.seq_t = (batch["residue_extra_mask"].unsqueeze(-1) * batch["residue_one_hot"]
+                      + batch["residue_inv_extra_mask"].unsqueeze(-1) * seq_t).contiguous()
+        self.static = m._static_inputs(batch)
+        self.t = torch.full((b,), T - 1, dtype=torch.int64, device=dev)
+        self._init = (self.z.clone(), self.seq_t.clone())
+        self.steps_done = 0
+        self.graph = None
+        self.seq_pred = None
+
+    def reset(self):
+        """Back to step T-1 with the same initial noise (bench / repeated runs)."""
+        self.z.copy_(self._init[0])
+        self.seq_t.copy_(self._init[1])
+        self.t.fill_(self.T - 1)
+        self.steps_done = 0
+
+    def _enqueue_step(self):
+        m = self.model
+        noise_pred, seq_pred = m._network(self.batch, self.z, self.seq_t, self.mask, self.t, static=self.static)
+        ops.reverse_update_(self.z, self.seq_t, self.t, noise_pred, seq_pred, self.noise, self.mask, m._coef, self.T)
+        return seq_pred
+
+    @torch.inference_mode()
+    def step(self):
+        """One denoising step: network forward + reverse update (asynchronous)."""
+        if self.steps_done >= self.T:
+            raise RuntimeError("all num_steps denoising steps already done; call reset()")
+        if self.graph is not None:
+            self.graph.replay()
+        elif self.model.use_hip_graph and self.steps_done >= 1:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.seq_pred = self._enqueue_step()      # capture only; the replay below executes it
+            self.graph.replay()
+        else:
+            self.seq_pred = self._enqueue_step()          # first step eager: warms every kernel up
+        self.steps_done += 1
+
+    def run(self):
+        while self.steps_done < self.T:
+            self.step()
+
+    def result(self):
+        """(positions in Angstrom, residue-masked logits) as in model.py:421-422."""
+        return 10.0 * self.z, self.rm.unsqueeze(-1) * self.seq_pred

@@ -216,11 +216,22 @@ def remove_mean(x, mask) -> torch.Tensor:
     return out
 
 
-def reverse_update_(z, seq_t, t, noise_pred, seq_pred, noise, mask, coef):
+def reverse_update_(z, seq_t, t, noise_pred, seq_pred, noise, mask, coef, num_steps: int):
+    """noise: the whole table [T-1, b, N, 3]; the kernel picks row T-1-t and decrements t."""
     b, N, _ = z.shape
     check(lib().prd_reverse_update(dptr(z), dptr(seq_t), dptr(t, torch.int64), dptr(noise_pred), dptr(seq_pred),
-                                   dptr(noise), dptr(mask), dptr(coef), b, N, seq_pred.shape[-1], stream()),
+                                   dptr(noise), dptr(mask), dptr(coef), b, N, seq_pred.shape[-1], num_steps, stream()),
           "prd_reverse_update")
+
+
+def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> torch.Tensor:
+    """First launch of tri_attn alone (bench / profiling): og[b,N,N,64]; wts = (q.w, k.w, v.w, gate.w, gate.b)."""
+    b, N, _, P = pair.shape
+    if og is None:
+        og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
+    check(lib().prd_tri_attn_core(dptr(og), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
+                                  b, N, P, H, c, stream()), "prd_tri_attn_core")
+    return og
 
 
 # ---------------------------------------------------------------------------------------------------
