@@ -1,0 +1,69 @@
+"""Sharding ``num_samples`` reverse-diffusion samples over the GPUs of one node.
+
+Samples never interact, so the path shards by GLOBAL sample index with no collective
+inside the loop: rank r runs a contiguous block of indices through the full T-step loop on its own
+GPU, then ONE all_gather (RCCL over xGMI when the backend is "nccl"; ~2 MB for 64 x 320-node samples)
+returns every sample to every rank in index order.  Noise and the redesign mask of sample k are keyed
+by (seed, k) (synthetic.NoiseSource), so 1-, 2-, 4- and 8-GPU runs give identical per-sample results --
+unlike the reference's DDP scripts, which reseed every rank identically (generate.py:95).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .synthetic import NoiseSource, clone_batch
+
+
+def shard_range(num_samples: int, world_size: int, rank: int) -> range:
+    """Contiguous block of global sample indices owned by ``rank`` (sizes differ by at most one)."""
+    base, extra = divmod(num_samples, world_size)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def repeat_batch(batch: Dict[str, torch.Tensor], n: int) -> Dict[str, torch.Tensor]:
+    """RepeatDataset + collate of the reference (data.py:145-155, generate.py:138-153): n copies of one complex."""
+    out = {}
+    for k, v in batch.items():
+        out[k] = v.repeat(n, *([1] * (v.dim() - 1))) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 1 else v
+    return out
+
+
+def sample_sharded(sampler: Callable[[Dict[str, torch.Tensor], Sequence[NoiseSource]], Tuple[torch.Tensor, torch.Tensor]],
+                   complex_batch: Dict[str, torch.Tensor], num_samples: int, seed: int = 0, batch_size: int = 1,
+                   group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Draw ``num_samples`` samples of ONE complex (a batch dict with leading dim 1).
+
+    ``sampler(batch, sources) -> (pos [b,N,3], logits [b,N,21])`` is ``ProteinReDiffModel.sample`` on a
+    GPU rank (tests inject a CPU stand-in).  Works without an initialised process group (world size 1).
+    Returns all samples, ordered by global index, on every rank."""
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    mine = list(shard_range(num_samples, world, rank))
+    pos_l: List[torch.Tensor] = []
+    log_l: List[torch.Tensor] = []
+    for s in range(0, len(mine), batch_size):
+        idx = mine[s:s + batch_size]
+        sources = [NoiseSource(seed, k) for k in idx]
+        pos, logits = sampler(repeat_batch(clone_batch(complex_batch), len(idx)), sources)
+        pos_l.append(pos)
+        log_l.append(logits)
+    N = complex_batch["atom_mask"].shape[1]
+    ref = pos_l[0] if pos_l else None
+    device = ref.device if ref is not None else complex_batch["atom_mask"].device
+    cap = len(shard_range(num_samples, world, 0))              # largest shard
+    packed = torch.zeros(cap, N, 3 + 21, device=device, dtype=torch.float32)
+    if pos_l:
+        packed[:len(mine)] = torch.cat([torch.cat(pos_l), torch.cat(log_l)], dim=-1)
+    if world == 1:
+        gathered = [packed]
+    else:
+        gathered = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(gathered, packed, group=group)
+    rows = [gathered[r][:len(shard_range(num_samples, world, r))] for r in range(world)]
+    allr = torch.cat(rows)
+    return allr[..., :3].contiguous(), allr[..., 3:].contiguous()
