@@ -44,7 +44,7 @@ int prd_version(void);
  * Replaces aten::linear / bmm / matmul on the single track (modules.py:185-225, 306-311;
  * models/AF2_modules.py:251-293, 613-628) and the triangle-multiplication einsum (modules.py:272).
  * Batch index g = g1 * G2 + g2.  Epilogue, in this order:
- *   v = acc*alpha + bias[n];  v += addmat[g][m][n];  if colmask[g1][n] < 0.5: v = fill;
+ *   v = acc*alpha*colscale[n] + bias[n];  v += addmat[g][m][n];  if colmask[g1][n] < 0.5: v = fill;
  *   act (0 none, 1 relu, 2 sigmoid) applied to columns n >= act_from;  v *= rowmask[g1][m];
  *   v *= mulmat[g][m][n];  v += resid[g][m][n];  C[g][m][n] = v.
  * lda/ldb must be multiples of 4 floats (rows 16-byte aligned). */
@@ -56,6 +56,7 @@ typedef struct PrdGemm {
     long long sa1, sa2, sb1, sb2, sc1, sc2;
     int b_kn;
     float alpha;
+    const float* colscale;          /* optional per-column factor (e.g. the query scale of packed q|k|v|g weights) */
     const float* bias;
     int act, act_from;
     const float* addmat; long long sad1, sad2; int ldadd;
@@ -63,6 +64,7 @@ typedef struct PrdGemm {
     const float* rowmask; long long srm1;
     const float* mulmat; long long smu1, smu2; int ldmul;
     const float* resid; long long sr1, sr2; int ldr;
+    int tile_hint;                  /* 0 = automatic; 32 / 64 / 128 force the workgroup tile */
 } PrdGemm;
 int prd_gemm(const PrdGemm* args, hipStream_t stream);
 

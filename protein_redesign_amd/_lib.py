@@ -20,13 +20,14 @@ class PrdGemm(C.Structure):
         ("lda", ci), ("ldb", ci), ("ldc", ci),
         ("G1", ci), ("G2", ci),
         ("sa1", cll), ("sa2", cll), ("sb1", cll), ("sb2", cll), ("sc1", cll), ("sc2", cll),
-        ("b_kn", ci), ("alpha", cf),
+        ("b_kn", ci), ("alpha", cf), ("colscale", vp),
         ("bias", vp), ("act", ci), ("act_from", ci),
         ("addmat", vp), ("sad1", cll), ("sad2", cll), ("ldadd", ci),
         ("colmask", vp), ("scm1", cll), ("fill", cf),
         ("rowmask", vp), ("srm1", cll),
         ("mulmat", vp), ("smu1", cll), ("smu2", cll), ("ldmul", ci),
         ("resid", vp), ("sr1", cll), ("sr2", cll), ("ldr", ci),
+        ("tile_hint", ci),
     ]
 
 

@@ -95,11 +95,11 @@ class SPAttention(nn.Module):
             bias = torch.zeros(b, self.no_heads, N, N, device=m.device, dtype=torch.float32)
         mn = ops.layer_norm(m.contiguous(), self.layer_norm_m.weight, self.layer_norm_m.bias)
         a = self.mha
-        dummy_mask = mn  # unused: the reference builds a mask bias and drops it (AF2_modules.py:447 vs 461-463)
-        return ops.gated_attention_single(mn, dummy_mask, bias, a.linear_q.weight, a.linear_k.weight, a.linear_v.weight,
-                                          a.linear_g.weight, a.linear_g.bias, a.linear_o.weight, a.linear_o.bias,
-                                          self.no_heads, self.c_hidden, q_scale=1.0 / math.sqrt(self.c_hidden),
-                                          key_mask=False, resid=mn)
+        ws = (a.linear_q.weight, a.linear_k.weight, a.linear_v.weight, a.linear_g.weight, a.linear_g.bias)
+        packed = ops.cached_pack(self, "qkvg", ws, lambda: ops.pack_attention(*ws, 1.0 / math.sqrt(self.c_hidden)))
+        # the mask argument is unused: the reference builds a mask bias and drops it (AF2_modules.py:447 vs 461-463)
+        return ops.gated_attention_single(mn, mn, bias, packed, a.linear_o.weight, a.linear_o.bias,
+                                          self.no_heads, self.c_hidden, key_mask=False, resid=mn)
 
 
 class OuterProductUpdate(nn.Module):
@@ -118,8 +118,9 @@ class OuterProductUpdate(nn.Module):
         Ch = self.c_hidden
         x = ops.layer_norm(m, self.layer_norm.weight, self.layer_norm.bias)
         ab = torch.empty(b, N, 2 * Ch, device=m.device, dtype=torch.float32)
-        ops.gemm(x, self.linear_1.weight, ab, b * N, Ch, S, S, S, 2 * Ch, bias=self.linear_1.bias, rowmask=mask)
-        ops.gemm(x, self.linear_2.weight, ab, b * N, Ch, S, S, S, 2 * Ch, c_off=Ch, bias=self.linear_2.bias, rowmask=mask)
+        ws = (self.linear_1.weight, self.linear_2.weight, self.linear_1.bias, self.linear_2.bias)
+        w12, b12 = ops.cached_pack(self, "ab", ws, lambda: (torch.cat(ws[:2]).contiguous(), torch.cat(ws[2:]).contiguous()))
+        ops.gemm(x, w12, ab, b * N, 2 * Ch, S, S, S, 2 * Ch, bias=b12, rowmask=mask)
         return ops.opm_pair(pair, ab, mask, self.linear_out.weight, self.linear_out.bias,
                             residual=residual, apply_mask=apply_mask, out=out)
 

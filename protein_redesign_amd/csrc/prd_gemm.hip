@@ -12,6 +12,22 @@ namespace {
 constexpr int KC = 32;          // K chunk staged in LDS per iteration
 constexpr int LDT = KC + 4;     // LDS row pitch (floats): conflict-free ds_read_b128 down a column
 
+// epilogue of one output element (order documented in include/prd_hip.h)
+PRD_DEV void epilogue_store(const PrdGemm& g, int g1, int g2, int m, int n, float v, float* __restrict__ C) {
+    v = v * g.alpha;
+    if (g.colscale) v *= g.colscale[n];
+    if (g.bias) v += g.bias[n];
+    if (g.addmat) v += g.addmat[g1 * g.sad1 + g2 * g.sad2 + (size_t)m * g.ldadd + n];
+    if (g.colmask && g.colmask[g1 * g.scm1 + n] < 0.5f) v = g.fill;
+    const int act = (n >= g.act_from) ? g.act : 0;
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = sigmoidf_(v);
+    if (g.rowmask) v *= g.rowmask[g1 * g.srm1 + m];
+    if (g.mulmat) v *= g.mulmat[g1 * g.smu1 + g2 * g.smu2 + (size_t)m * g.ldmul + n];
+    if (g.resid) v += g.resid[g1 * g.sr1 + g2 * g.sr2 + (size_t)m * g.ldr + n];
+    C[(size_t)m * g.ldc + n] = v;
+}
+
 template <int WM, int WN>       // wave tile (multiples of 32); workgroup = 2 x 2 waves
 __global__ __launch_bounds__(256) void gemm_kernel(PrdGemm g) {
     constexpr int TM = 2 * WM, TN = 2 * WN, MI = WM / 32, NI = WN / 32;
@@ -115,25 +131,92 @@ __global__ __launch_bounds__(256) void gemm_kernel(PrdGemm g) {
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn0 + 32 * ni + r;
         if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.f;
-        const bool filled = g.colmask && g.colmask[g1 * g.scm1 + n] < 0.5f;
-        const int act = (n >= g.act_from) ? g.act : 0;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int m = m0 + wm0 + 32 * mi + drow32(q, hi);
-                if (m >= g.M) continue;
-                float v = acc[mi][ni][q] * g.alpha + bias;
-                if (g.addmat) v += g.addmat[g1 * g.sad1 + g2 * g.sad2 + (size_t)m * g.ldadd + n];
-                if (filled) v = g.fill;
-                if (act == 1) v = fmaxf(v, 0.f);
-                else if (act == 2) v = sigmoidf_(v);
-                if (g.rowmask) v *= g.rowmask[g1 * g.srm1 + m];
-                if (g.mulmat) v *= g.mulmat[g1 * g.smu1 + g2 * g.smu2 + (size_t)m * g.ldmul + n];
-                if (g.resid) v += g.resid[g1 * g.sr1 + g2 * g.sr2 + (size_t)m * g.ldr + n];
-                C[(size_t)m * g.ldc + n] = v;
+                if (m < g.M) epilogue_store(g, g1, g2, m, n, acc[mi][ni][q], C);
             }
+    }
+}
+
+// ---- skinny GEMM: one 32x32 output tile per workgroup, the 4 waves split K (in-workgroup split-K),
+// operands go global -> registers directly (they are L2 resident: M is a few hundred rows).  For the
+// single-track linears (M = b*N rows) the generic kernel above launches fewer workgroups than there
+// are CUs and is latency bound on its K loop; this one launches (M/32)*(N/32) workgroups and cuts the
+// dependent K chain by 4. ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(PrdGemm g) {
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int tiles_n = (g.N + 31) / 32;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int gb = blockIdx.y, g1 = gb / g.G2, g2 = gb - g1 * g.G2;
+    const float* __restrict__ A = g.A + g1 * g.sa1 + g2 * g.sa2;
+    const float* __restrict__ B = g.B + g1 * g.sb1 + g2 * g.sb2;
+    // K range of this wave, in groups of 8
+    const int groups = (g.K + 7) / 8;
+    const int gper = (groups + 3) / 4;
+    const int kbeg = wave * gper * 8;
+    int kend = kbeg + gper * 8;
+    if (kend > g.K) kend = g.K;
+    const bool mv = (m0 + r) < g.M, nv = (n0 + r) < g.N;
+    const float* arow = A + (size_t)(mv ? m0 + r : 0) * g.lda;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const bool k4 = (g.K & 3) == 0;                      // every 16-byte group inside K is complete
+    if (!g.b_kn) {
+        const float* brow = B + (size_t)(nv ? n0 + r : 0) * g.ldb;
+        if (k4) {
+            const float am = mv ? 1.f : 0.f, bm = nv ? 1.f : 0.f;     // rows past the edge contribute zeros
+#pragma unroll 4
+            for (int k = kbeg + 4 * hi; k < kend; k += 8) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + k);
+                const float4 b = *reinterpret_cast<const float4*>(brow + k);
+                acc = mfma32(a.x * am, b.x * bm, acc);
+                acc = mfma32(a.y * am, b.y * bm, acc);
+                acc = mfma32(a.z * am, b.z * bm, acc);
+                acc = mfma32(a.w * am, b.w * bm, acc);
+            }
+        } else {
+            for (int k = kbeg + 4 * hi; k < kend; k += 8) {
+                float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < g.K) { if (mv) ta[e] = arow[k + e]; if (nv) tb[e] = brow[k + e]; }
+                acc = mfma32(ta[0], tb[0], acc);
+                acc = mfma32(ta[1], tb[1], acc);
+                acc = mfma32(ta[2], tb[2], acc);
+                acc = mfma32(ta[3], tb[3], acc);
+            }
+        }
+    } else {
+        const float* bcol = B + (nv ? n0 + r : 0);
+        for (int k = kbeg + 4 * hi; k < kend; k += 8) {
+            float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < g.K) { if (mv) ta[e] = arow[k + e]; if (nv) tb[e] = bcol[(size_t)(k + e) * g.ldb]; }
+            acc = mfma32(ta[0], tb[0], acc);
+            acc = mfma32(ta[1], tb[1], acc);
+            acc = mfma32(ta[2], tb[2], acc);
+            acc = mfma32(ta[3], tb[3], acc);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wave][q][lane] = acc[q];
+    __syncthreads();
+    // thread (wave w, lane) finishes registers q = 4w .. 4w+3 of the tile: fixed summation order
+    float* __restrict__ C = g.C + g1 * g.sc1 + g2 * g.sc2;
+    const int n = n0 + r;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int q = 4 * wave + qq;
+        const float v = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
+        const int m = m0 + drow32(q, hi);
+        if (m < g.M && n < g.N) epilogue_store(g, g1, g2, m, n, v, C);
     }
 }
 
@@ -183,9 +266,13 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.G1 <= 0 || g.G2 <= 0) return PRD_ERR_ARG;
     if ((g.lda & 3) || (g.ldb & 3)) return PRD_ERR_ALIGN;
     const int batches = g.G1 * g.G2;
-    // small problems: 64x64 workgroup tiles fill the chip better; large: 128x128
     const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
-    if (tiles64 <= 1024 || g.M <= 64 || g.N <= 64) {
+    int tile = g.tile_hint;
+    if (tile == 0) tile = (tiles64 < 512) ? 32 : ((tiles64 <= 1024 || g.M <= 64 || g.N <= 64) ? 64 : 128);
+    if (tile == 32) {          // fewer 64x64 tiles than two per CU: skinny kernel, 32x32 tiles + in-workgroup split-K
+        dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
+        hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(256), 0, stream, g);
+    } else if (tile == 64) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
         hipLaunchKernelGGL((gemm_kernel<32, 32>), grid, dim3(256), 0, stream, g);
     } else {

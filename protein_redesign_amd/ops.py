@@ -27,7 +27,8 @@ def round_up(a: int, b: int) -> int:
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1, G2=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), b_kn=False, alpha=1.0, bias=None, act=0, act_from=0,
          addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
-         mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0):
+         mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0,
+         colscale=None, tile_hint=0):
     """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h)."""
     g = PrdGemm()
     g.A, g.B, g.C = _off(A, a_off), _off(B, b_off), _off(Cout, c_off)
@@ -42,6 +43,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.smu1, g.smu2, g.ldmul = smu[0], smu[1], ldmul
     g.resid = (_off(resid, res_off) if resid is not None else None)
     g.sr1, g.sr2, g.ldr = sr[0], sr[1], ldr
+    g.colscale, g.tile_hint = dptr(colscale), tile_hint
     import ctypes
     check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
     return Cout
@@ -238,28 +240,49 @@ def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> 
 # single-track composites (LayerNorm + GEMMs + softmax)
 # ---------------------------------------------------------------------------------------------------
 
-def gated_attention_single(x_normed, mask, bias, wq, wk, wv, wg, bg, wo, bo, H: int, c: int, *,
-                           q_scale: float, key_mask: bool, resid: Optional[torch.Tensor]) -> torch.Tensor:
+def cached_pack(module, name: str, params, build):
+    """Memoise a packed copy of several parameters on ``module`` until any of them changes in place."""
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cache = module.__dict__.setdefault("_prd_pack_cache", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            cache[name] = (key, build())
+    return cache[name][1]
+
+
+def pack_attention(wq, wk, wv, wg, bg, q_scale: float):
+    """[q | k | v | gate] projections as ONE GEMM: weight [4HC, S], bias (gate only), per-column scale (q only)."""
+    HC = wq.shape[0]
+    w = torch.cat([wq, wk, wv, wg], dim=0).contiguous()
+    bias = torch.cat([torch.zeros(3 * HC, device=w.device, dtype=F32), bg]).contiguous()
+    colscale = torch.cat([torch.full((HC,), q_scale, device=w.device, dtype=F32),
+                          torch.ones(3 * HC, device=w.device, dtype=F32)]).contiguous()
+    return w, bias, colscale
+
+
+def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int, *,
+                           key_mask: bool, resid: Optional[torch.Tensor]) -> torch.Tensor:
     """Multi-head gated attention over the node axis with an additive [b,H,N,N] bias.
 
     Covers reference modules.py:185-225 (c = head_dim, key mask filled with -2**15, q pre-scaled by
-    1/sqrt(c)) and models/AF2_modules.py:251-293,613-628 (c = single_dim, no mask).  Returns
-    ``resid + out_proj(...)`` (or the bare update when ``resid`` is None)."""
+    1/sqrt(c)) and models/AF2_modules.py:251-293,613-628 (c = single_dim, no mask).  ``packed`` comes
+    from ``pack_attention``.  Returns ``resid + out_proj(...)`` (or the bare update when ``resid`` is None)."""
     b, N, S = x_normed.shape
     HC = H * c
-    q = linear(x_normed, wq, alpha=q_scale)
-    k = linear(x_normed, wk)
-    v = linear(x_normed, wv)
-    g = linear(x_normed, wg, bg, act=2)
+    w, pbias, colscale = packed
+    L = 4 * HC
+    qkvg = torch.empty(b, N, L, device=x_normed.device, dtype=F32)
+    gemm(x_normed, w, qkvg, b * N, L, S, S, S, L, bias=pbias, colscale=colscale, act=2, act_from=3 * HC)
     ldp = round_up(N, 4)
     logits = torch.empty(b, H, N, ldp, device=x_normed.device, dtype=F32)
-    gemm(q, k, logits, N, N, c, HC, HC, ldp, G1=b, G2=H, sa=(N * HC, c), sb=(N * HC, c), sc=(H * N * ldp, N * ldp),
-         addmat=bias, sad=(H * N * N, N * N), ldadd=N,
+    gemm(qkvg, qkvg, logits, N, N, c, L, L, ldp, b_off=HC, G1=b, G2=H, sa=(N * L, c), sb=(N * L, c),
+         sc=(H * N * ldp, N * ldp), addmat=bias, sad=(H * N * N, N * N), ldadd=N,
          colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15))
     softmax_rows_(logits, N)
     o = torch.empty(b, N, HC, device=x_normed.device, dtype=F32)
-    gemm(logits, v, o, N, c, N, ldp, HC, HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * HC, c), sc=(N * HC, c),
-         b_kn=True, mulmat=g, smu=(N * HC, c), ldmul=HC)
+    gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
+         sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L)
     return linear(o, wo, bo, resid=resid)
 
 

@@ -89,6 +89,14 @@ class Attention(nn.Module):
         return (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.gate_proj.weight,
                 self.gate_proj.bias, self.out_proj.weight, self.out_proj.bias)
 
+    def packed(self):
+        ws = self.weights()[:5]
+        return ops.cached_pack(self, "qkvg", ws, lambda: ops.pack_attention(*ws, self.scale))
+
+    def run_single(self, xn, mask, attn_bias, resid):
+        return ops.gated_attention_single(xn, mask, attn_bias, self.packed(), self.out_proj.weight, self.out_proj.bias,
+                                          self.num_heads, self.head_dim, key_mask=True, resid=resid)
+
     def forward(self, x: torch.Tensor, mask: torch.Tensor, attn_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         if x.dim() != 3:
             raise RuntimeError("Attention.forward expects [b, N, E]; use TriangleAttention for pair rows")
@@ -96,9 +104,7 @@ class Attention(nn.Module):
         if attn_bias is None:
             attn_bias = torch.zeros(b, self.num_heads, N, N, device=x.device, dtype=torch.float32)
         xn = ops.layer_norm(x.contiguous())
-        q, k, v, g, bg, wo, bo = self.weights()
-        return ops.gated_attention_single(xn, mask.contiguous(), attn_bias.contiguous(), q, k, v, g, bg, wo, bo,
-                                          self.num_heads, self.head_dim, q_scale=self.scale, key_mask=True, resid=None)
+        return self.run_single(xn, mask.contiguous(), attn_bias.contiguous(), None)
 
 
 class TriangleAttention(nn.Module):
@@ -210,9 +216,7 @@ class FoldingBlock(nn.Module):
         sa = self.single_attn
         bias = ops.pair_bias(pair, self.attn_bias[1].weight, self.attn_bias[1].bias)
         xn = ops.layer_norm(single)
-        q, k, v, g, bg, wo, bo = sa.weights()
-        single = ops.gated_attention_single(xn, mask, bias, q, k, v, g, bg, wo, bo, sa.num_heads, sa.head_dim,
-                                            q_scale=sa.scale, key_mask=True, resid=single)
+        single = sa.run_single(xn, mask, bias, single)
         fc = self.single_fc
         single = ops.transition_single(single, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=True)
         self.outer_linear.run(single, pair, residual=True, out=pair)

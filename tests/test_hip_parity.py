@@ -62,9 +62,10 @@ def setup(request):
 # building blocks
 # ---------------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("tile", [0, 32, 64, 128])
 @pytest.mark.parametrize("M,N,K,G", [(37, 64, 64, 1), (320, 2048, 512, 1), (70, 21, 512, 1), (140, 140, 16, 8),
                                      (200, 200, 200, 3), (129, 257, 36, 2)])
-def test_gemm_nt(M, N, K, G):
+def test_gemm_nt(M, N, K, G, tile):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(G, M, K, generator=g)
     B = torch.randn(G, N, K, generator=g)
@@ -73,11 +74,12 @@ def test_gemm_nt(M, N, K, G):
     want = torch.relu(0.5 * torch.matmul(A.double(), B.double().transpose(1, 2)) + bias.double()) + res.double()
     out = torch.empty(G, M, N, device=DEV)
     ops.gemm(cu(A), cu(B), out, M, N, K, K, K, N, G1=G, sa=(M * K, 0), sb=(N * K, 0), sc=(M * N, 0), alpha=0.5,
-             bias=cu(bias), act=1, resid=cu(res), sr=(M * N, 0), ldr=N)
+             bias=cu(bias), act=1, resid=cu(res), sr=(M * N, 0), ldr=N, tile_hint=tile)
     assert rel_l2(out.cpu(), want) < 2e-6
 
 
-def test_gemm_nn_masked_and_gated():
+@pytest.mark.parametrize("tile", [32, 64])
+def test_gemm_nn_masked_and_gated(tile):
     g = torch.Generator().manual_seed(5)
     b, H, N, c = 2, 4, 45, 16
     Pm = torch.rand(b, H, N, 48, generator=g)            # attention-like, ld padded to 48
@@ -87,7 +89,7 @@ def test_gemm_nn_masked_and_gated():
     want = torch.einsum("bhij,bjhc->bihc", Pm[..., :N].double(), V.view(b, N, H, c).double()).reshape(b, N, H * c) * gate.double()
     out = torch.empty(b, N, H * c, device=DEV)
     ops.gemm(cu(Pm), cu(V), out, N, c, N, 48, H * c, H * c, G1=b, G2=H, sa=(H * N * 48, N * 48), sb=(N * H * c, c),
-             sc=(N * H * c, c), b_kn=True, mulmat=cu(gate), smu=(N * H * c, c), ldmul=H * c)
+             sc=(N * H * c, c), b_kn=True, mulmat=cu(gate), smu=(N * H * c, c), ldmul=H * c, tile_hint=tile)
     assert rel_l2(out.cpu(), want) < 2e-6
 
 
@@ -258,6 +260,18 @@ def test_trajectory_vs_reference_golden(golden, name):
     pos, logits = model.sample(one, sources=[NoiseSource(NOISE_SEED, 0)])
     assert rel_l2(pos.cpu(), z["traj_pos"]) < TRAJ_TOL
     assert rel_l2(logits.cpu(), z["traj_logits"]) < TRAJ_TOL
+
+
+def test_batched_sampling_equals_single_samples(golden):
+    """Shard / batch invariance on the GPU: samples k = 0, 1 drawn together equal the same samples drawn alone."""
+    case, z, args, model, params = golden_case(golden, "small64")
+    one = synthetic_batch([tuple(case["traj_sample"])], esm_dim=args["esm_dim"], seed=77)
+    from protein_redesign_amd.distributed import repeat_batch
+    both = model.sample(batch_to(repeat_batch(clone_batch(one), 2), DEV), sources=[NoiseSource(3, 0), NoiseSource(3, 1)])
+    for k in range(2):
+        alone = model.sample(batch_to(clone_batch(one), DEV), sources=[NoiseSource(3, k)])
+        assert torch.equal(both[0][k], alone[0][0]) and torch.equal(both[1][k], alone[1][0])
+    assert not torch.allclose(both[0][0], both[0][1])
 
 
 def test_full_size_step_vs_oracle():
