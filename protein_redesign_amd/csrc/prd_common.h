@@ -145,6 +145,21 @@ PRD_DEV void zero_acc(f32x16 (&acc)[NB]) {
         for (int q = 0; q < 16; ++q) acc[nb][q] = 0.f;
 }
 
+// cross-lane reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the
+// gfx950 half/row swap instructions: VALU only, no LDS round trip (ds_bpermute)
+PRD_DEV float rows4_max(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+PRD_DEV float rows4_sum(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // order LDS traffic of one wave against itself (cross-lane hand-off through LDS without s_barrier)
 PRD_DEV void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

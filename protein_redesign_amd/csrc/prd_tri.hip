@@ -123,43 +123,57 @@ __global__ __launch_bounds__(WG) void tri_mul_out_kernel(float* out, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// triangle attention core.  HC = H*c = 64, c = 16.  Workgroup = 8 waves, one (b, row u, head h).
+// triangle attention core.  HC = H*c = 64, c = 16.  One workgroup per (b, row u, head h), NW waves.
+//   phase 1: every wave projects K_h / V_h for 32-position blocks of the row into LDS
+//   phase 2: every wave projects q_h / gate_h for its 32 queries, then streams the keys in blocks of
+//            64: S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_16x16x4_f32 for BOTH 16-query tiles at once
+//            (two independent dependency chains), online softmax in the exp2 domain (log2(e)/sqrt(c)
+//            folded into q), one cross-lane max (permlane swaps) per 64 keys.
+// Key padding / masking is an fma with per-key (mul, add): valid (1, 0); masked (0, -2^15 log2 e),
+// i.e. masked_fill(-2**15) of modules.py:220; beyond N (0, -inf) = excluded.
 // ---------------------------------------------------------------------------------------------
 constexpr int KP = 20;          // LDS pitch (floats) of the [*, 16] K / Q / G tiles
+constexpr float LOG2E = 1.4426950408889634f;
 
-template <int P, int TA_WAVES>
-__global__ __launch_bounds__(TA_WAVES * 64) void tri_attn_core_kernel(
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
-    constexpr int KH = P / 2, C = 16, HC = 64;
+    constexpr int KH = P / 2, C = 16, HC = 64, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wkv = smem;                         // [32][P+4]: rows 0-15 = k_h, 16-31 = v_h
     float* Wqg = Wkv + 32 * (P + 4);           // [32][P+4]: rows 0-15 = q_h, 16-31 = g_h
-    float* Kl = Wqg + 32 * (P + 4);            // [npad][KP]
+    float* Kl = Wqg + 32 * (P + 4);            // [npad][KP]           (npad = round_up(N, 64))
     float* Vt = Kl + npad * KP;                // [16][npad+4]
-    float* km = Vt + C * (npad + 4);           // [npad] key mask value of this row
-    float* scratch = km + npad;                // per wave: Q [32][KP], G [32][KP]
+    float* kmul = Vt + C * (npad + 4);         // [npad]
+    float* kadd = kmul + npad;                 // [npad]
+    float* scratch = kadd + npad;              // per wave [32][KP]: Q, then reused for the gate
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    float* Qs = scratch + wave * (2 * 32 * KP);
-    float* Gs = Qs + 32 * KP;
+    float* Qs = scratch + wave * (32 * KP);
     const int nvb = npad / 32;
+    const int nqb = (N + 31) / 32;
     const long ntask = (long)b * N * H;
     for (long task = blockIdx.x; task < ntask; task += gridDim.x) {
         const int h = (int)(task % H);
         const long bu = task / H;
         const int bb = (int)(bu / N), u = (int)(bu - (long)bb * N);
         __syncthreads();                        // previous task's LDS fully consumed
-        stage_weight_cll<P>(Wkv, wk + (long)h * C * P, C, P, tid, TA_WAVES * 64);
-        stage_weight_cll<P>(Wkv + C * (P + 4), wv + (long)h * C * P, C, P, tid, TA_WAVES * 64);
-        stage_weight_cll<P>(Wqg, wq + (long)h * C * P, C, P, tid, TA_WAVES * 64);
-        stage_weight_cll<P>(Wqg + C * (P + 4), wg + (long)h * C * P, C, P, tid, TA_WAVES * 64);
+        stage_weight_cll<P>(Wkv, wk + (long)h * C * P, C, P, tid, NT);
+        stage_weight_cll<P>(Wkv + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
+        stage_weight_cll<P>(Wqg, wq + (long)h * C * P, C, P, tid, NT);
+        stage_weight_cll<P>(Wqg + C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
         const float mu = mask[bu];
-        for (int k = tid; k < npad; k += TA_WAVES * 64) km[k] = (k < N) ? mu * mask[(long)bb * N + k] : 0.f;
+        for (int k = tid; k < npad; k += NT) {
+            const bool inside = k < N;
+            const bool keep = inside && (mu * mask[(long)bb * N + (inside ? k : 0)] >= 0.5f);
+            kmul[k] = keep ? 1.f : 0.f;
+            kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
+        }
         __syncthreads();
-        // ---- phase 1: K_h, V_h of every position of the row ----
-        for (int vb = wave; vb < nvb; vb += TA_WAVES) {
+        // ---- phase 1: K_h, V_h of every position of the row (zeros beyond N) ----
+        for (int vb = wave; vb < nvb; vb += NW) {
             const int v = vb * 32 + r;
             const bool valid = v < N;
             const int vv = valid ? v : 0;
@@ -182,7 +196,8 @@ __global__ __launch_bounds__(TA_WAVES * 64) void tri_attn_core_kernel(
         __syncthreads();
         // ---- phase 2: queries in blocks of 32 per wave ----
         const int ql = lane & 15, g4 = lane >> 4;
-        for (int qb = wave; qb < nvb; qb += TA_WAVES) {
+        for (int qb = wave; qb < nqb; qb += NW) {
+            float gate[8];                                   // this lane's 8 gate channels of query r
             {
                 const int v = qb * 32 + r;
                 const bool valid = v < N;
@@ -194,67 +209,98 @@ __global__ __launch_bounds__(TA_WAVES * 64) void tri_attn_core_kernel(
                 f32x16 acc[1];
                 zero_acc(acc);
                 rowgemm<P, 1>(Wqg, x, acc, r, hi);
-                const float sc = 0.25f;                    // 1/sqrt(c), c = 16 (modules.py:176, 216)
+                const float sc = 0.25f * LOG2E;            // 1/sqrt(c) (modules.py:176,216) in the exp2 domain
                 *reinterpret_cast<float4*>(Qs + r * KP + 4 * hi) = make_float4(sc * acc[0][0], sc * acc[0][1], sc * acc[0][2], sc * acc[0][3]);
                 *reinterpret_cast<float4*>(Qs + r * KP + 8 + 4 * hi) = make_float4(sc * acc[0][4], sc * acc[0][5], sc * acc[0][6], sc * acc[0][7]);
                 const float* bgh = bg + h * C;
-                *reinterpret_cast<float4*>(Gs + r * KP + 4 * hi) =
-                    make_float4(sigmoidf_(acc[0][8] + bgh[4 * hi]), sigmoidf_(acc[0][9] + bgh[4 * hi + 1]),
-                                sigmoidf_(acc[0][10] + bgh[4 * hi + 2]), sigmoidf_(acc[0][11] + bgh[4 * hi + 3]));
-                *reinterpret_cast<float4*>(Gs + r * KP + 8 + 4 * hi) =
-                    make_float4(sigmoidf_(acc[0][12] + bgh[8 + 4 * hi]), sigmoidf_(acc[0][13] + bgh[8 + 4 * hi + 1]),
-                                sigmoidf_(acc[0][14] + bgh[8 + 4 * hi + 2]), sigmoidf_(acc[0][15] + bgh[8 + 4 * hi + 3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gate[e] = sigmoidf_(acc[0][8 + e] + bgh[4 * hi + e]);
+                    gate[4 + e] = sigmoidf_(acc[0][12 + e] + bgh[8 + 4 * hi + e]);
+                }
             }
             wave_lds_fence();
-#pragma unroll 1
-            for (int qt = 0; qt < 2; ++qt) {
-                const int qrow = qt * 16 + ql;                          // row inside the 32-block
-                const float4 qf = *reinterpret_cast<const float4*>(Qs + qrow * KP + 4 * g4);
-                float m_run = -1e30f, l_run = 0.f;
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};                         // O^T[c = 4*g4 + e][q = ql]
-                for (int kt = 0; kt < npad / 16; ++kt) {
-                    const int key0 = kt * 16;
-                    const float4 kf = *reinterpret_cast<const float4*>(Kl + (key0 + ql) * KP + 4 * g4);
-                    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-                    s = mfma16(kf.x, qf.x, s);                          // S^T[key = key0 + 4*g4 + e][q = ql]
-                    s = mfma16(kf.y, qf.y, s);
-                    s = mfma16(kf.z, qf.z, s);
-                    s = mfma16(kf.w, qf.w, s);
-                    const float4 mk = *reinterpret_cast<const float4*>(km + key0 + 4 * g4);
-                    const int kbase = key0 + 4 * g4;
-                    float sv[4] = {s[0], s[1], s[2], s[3]};
-                    const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
+            float4 qf[2];
+            qf[0] = *reinterpret_cast<const float4*>(Qs + ql * KP + 4 * g4);
+            qf[1] = *reinterpret_cast<const float4*>(Qs + (16 + ql) * KP + 4 * g4);
+            wave_lds_fence();
+            // the gate goes through the same scratch into the (query = ql, channels 4*g4..) layout of O^T
+            *reinterpret_cast<float4*>(Qs + r * KP + 4 * hi) = make_float4(gate[0], gate[1], gate[2], gate[3]);
+            *reinterpret_cast<float4*>(Qs + r * KP + 8 + 4 * hi) = make_float4(gate[4], gate[5], gate[6], gate[7]);
+            float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+            f32x4 o[2];
+            o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o[1] = o[0];                                    // O^T[c = 4*g4 + e][q = ql] of the two query tiles
+            for (int key0 = 0; key0 < npad; key0 += 64) {
+                float4 kf[4], vf[4], mm[4], ma[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (mv[e] < 0.5f) sv[e] = -32768.0f;            // masked_fill(-2**15), modules.py:220
-                        if (kbase + e >= N) sv[e] = -INFINITY;          // padding beyond the sequence: excluded
-                    }
-                    float tmax = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                    const float m_new = fmaxf(m_run, tmax);
-                    const float alpha = expf(m_run - m_new);
-                    float p[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) p[e] = expf(sv[e] - m_new);
-                    l_run = l_run * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
-                    m_run = m_new;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] *= alpha;
-                    const float4 vf = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 4 * g4);
-                    o = mfma16(vf.x, p[0], o);                          // O^T += V^T[c = ql][key] * P^T[key][q]
-                    o = mfma16(vf.y, p[1], o);
-                    o = mfma16(vf.z, p[2], o);
-                    o = mfma16(vf.w, p[3], o);
+                for (int j = 0; j < 4; ++j) {
+                    kf[j] = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
+                    vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
+                    mm[j] = *reinterpret_cast<const float4*>(kmul + key0 + 16 * j + 4 * g4);
+                    ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
                 }
-                float l_tot = l_run + __shfl_xor(l_run, 16);
-                l_tot = l_tot + __shfl_xor(l_tot, 32);
+                f32x4 s[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                        z4 = mfma16(kf[j].x, qf[t].x, z4);          // S^T[key = key0+16j+4*g4+e][q]
+                        z4 = mfma16(kf[j].y, qf[t].y, z4);
+                        z4 = mfma16(kf[j].z, qf[t].z, z4);
+                        z4 = mfma16(kf[j].w, qf[t].w, z4);
+                        s[t][j] = z4;
+                    }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float tmax = -INFINITY;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s[t][j][0] = fmaf(s[t][j][0], mm[j].x, ma[j].x);
+                        s[t][j][1] = fmaf(s[t][j][1], mm[j].y, ma[j].y);
+                        s[t][j][2] = fmaf(s[t][j][2], mm[j].z, ma[j].z);
+                        s[t][j][3] = fmaf(s[t][j][3], mm[j].w, ma[j].w);
+                        tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][j][0], s[t][j][1]), fmaxf(s[t][j][2], s[t][j][3])));
+                    }
+                    tmax = rows4_max(tmax);
+                    const float m_new = fmaxf(m_run[t], tmax);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+                    m_run[t] = m_new;
+                    float psum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pe = __builtin_amdgcn_exp2f(s[t][j][e] - m_new);
+                            s[t][j][e] = pe;
+                            psum += pe;
+                        }
+                    l_run[t] = l_run[t] * alpha + psum;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        o[t] = mfma16(vf[j].x, s[t][j][0], o[t]);    // O^T += V^T[c = ql][key] * P^T[key][q]
+                        o[t] = mfma16(vf[j].y, s[t][j][1], o[t]);
+                        o[t] = mfma16(vf[j].z, s[t][j][2], o[t]);
+                        o[t] = mfma16(vf[j].w, s[t][j][3], o[t]);
+                    }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float l_tot = rows4_sum(l_run[t]);
+                const int qrow = 16 * t + ql;
                 const int v = qb * 32 + qrow;
                 if (v < N) {
-                    const float4 gf = *reinterpret_cast<const float4*>(Gs + qrow * KP + 4 * g4);
+                    const float4 gf = *reinterpret_cast<const float4*>(Qs + qrow * KP + 4 * g4);
                     const long pos = ending ? (((long)bb * N + v) * N + u) : (bu * N + v);
                     *reinterpret_cast<float4*>(og + pos * HC + h * C + 4 * g4) =
-                        make_float4(gf.x * (o[0] / l_tot), gf.y * (o[1] / l_tot), gf.z * (o[2] / l_tot), gf.w * (o[3] / l_tot));
+                        make_float4(gf.x * (o[t][0] / l_tot), gf.y * (o[t][1] / l_tot), gf.z * (o[t][2] / l_tot), gf.w * (o[t][3] / l_tot));
                 }
             }
             wave_lds_fence();
@@ -368,21 +414,38 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
                                  int b, int N, int P, int H, int c, hipStream_t stream) {
     if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
-    const int npad = prd_round_up(N, 32);
-    const size_t lds_fixed = (size_t)2 * 32 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad;
-    // 8 waves (2 per SIMD) while the row's K/V fit next to 8 query scratch tiles, else 4 waves
-    const int nw = ((lds_fixed + 8 * 2 * 32 * KP) * sizeof(float) <= 120 * 1024) ? 8 : 4;
-    const size_t lds = (lds_fixed + (size_t)nw * 2 * 32 * KP) * sizeof(float);
-    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    const int npad = prd_round_up(N, 64);
+    const int nqb = prd_ceil_div(N, 32);
+    const size_t lds_fixed = (size_t)2 * 32 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + 2 * npad;
+    // waves per workgroup: the candidate that wastes the fewest 32-query slots (ties -> more waves),
+    // among those whose per-wave scratch still fits the 160 KiB LDS next to the row's K/V
+    static const int cand[4] = {10, 8, 5, 4};          // (13 / 16 waves would cap the kernel at 128 VGPRs and spill)
+    int nw = 0;
+    long best = -1;
+    for (int i = 0; i < 4; ++i) {
+        const size_t need = (lds_fixed + (size_t)cand[i] * 32 * KP) * sizeof(float);
+        if (need > 160 * 1024) continue;
+        const long slots = (long)prd_ceil_div(nqb, cand[i]) * cand[i];
+        if (best < 0 || slots < best) { best = slots; nw = cand[i]; }
+    }
+    if (nw == 0) return PRD_ERR_UNSUPPORTED;
+    const size_t lds = (lds_fixed + (size_t)nw * 32 * KP) * sizeof(float);
     const long ntask = (long)b * N * H;
-    const int grid = grid_for(ntask, 1, 4096);
+    const int grid = grid_for(ntask, 1, 8192);
 #define PRD_TA_LAUNCH(PP, NW)                                                                                          \
     do {                                                                                                               \
         PRD_SET_LDS((tri_attn_core_kernel<PP, NW>), lds);                                                              \
         hipLaunchKernelGGL((tri_attn_core_kernel<PP, NW>), dim3(grid), dim3(NW * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
     } while (0)
-    if (P == 64) { if (nw == 8) PRD_TA_LAUNCH(64, 8); else PRD_TA_LAUNCH(64, 4); }
-    else { if (nw == 8) PRD_TA_LAUNCH(32, 8); else PRD_TA_LAUNCH(32, 4); }
+#define PRD_TA_SWITCH(PP)                                                                                              \
+    switch (nw) {                                                                                                      \
+        case 10: PRD_TA_LAUNCH(PP, 10); break;                                                                         \
+        case 8: PRD_TA_LAUNCH(PP, 8); break;                                                                           \
+        case 5: PRD_TA_LAUNCH(PP, 5); break;                                                                           \
+        default: PRD_TA_LAUNCH(PP, 4); break;                                                                          \
+    }
+    if (P == 64) { PRD_TA_SWITCH(64) } else { PRD_TA_SWITCH(32) }
+#undef PRD_TA_SWITCH
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();
 }
