@@ -135,114 +135,138 @@ __global__ __launch_bounds__(WG) void tri_mul_out_kernel(float* out, const float
 constexpr int KP = 20;          // LDS pitch (floats) of the [*, 16] K / Q / G tiles
 constexpr float LOG2E = 1.4426950408889634f;
 
+// One 32-position block of the row: load, LayerNorm, project.  NB = 1: [k_h; v_h] only; NB = 2: also [q_h; g_h].
+template <int P, int NB>
+PRD_DEV void ta_project(const float* __restrict__ pair, long pos, bool valid, const float* W, f32x16 (&acc)[NB], int r, int hi) {
+    float x[P / 2];
+    load_row_cll<P>(pair + pos * P, hi, valid, x);
+    ln_cll<P / 2>(x);
+    zero_acc(acc);
+    rowgemm<P, NB>(W, x, acc, r, hi);
+}
+
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
-    constexpr int KH = P / 2, C = 16, HC = 64, NT = NW * 64;
+    constexpr int C = 16, HC = 64, NT = NW * 64;
+    constexpr int JT = 2;                      // 16-key tiles per online-softmax update (32 keys): register budget
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wkv = smem;                         // [32][P+4]: rows 0-15 = k_h, 16-31 = v_h
-    float* Wqg = Wkv + 32 * (P + 4);           // [32][P+4]: rows 0-15 = q_h, 16-31 = g_h
-    float* Kl = Wqg + 32 * (P + 4);            // [npad][KP]           (npad = round_up(N, 64))
+    float* Wl = smem;                          // [64][P+4]: rows 0-15 k_h, 16-31 v_h, 32-47 q_h, 48-63 g_h
+    float* Kl = Wl + 64 * (P + 4);             // [npad][KP]           (npad = round_up(N, 64))
     float* Vt = Kl + npad * KP;                // [16][npad+4]
-    float* kmul = Vt + C * (npad + 4);         // [npad]
-    float* kadd = kmul + npad;                 // [npad]
-    float* scratch = kadd + npad;              // per wave [32][KP]: Q, then reused for the gate
+    float* kadd = Vt + C * (npad + 4);         // [npad]: 0 = keep the logit, else the value that replaces it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    float* Qs = scratch + wave * (32 * KP);
+    const int ql = lane & 15, g4 = lane >> 4;
     const int nvb = npad / 32;
     const int nqb = (N + 31) / 32;
-    const long ntask = (long)b * N * H;
-    for (long task = blockIdx.x; task < ntask; task += gridDim.x) {
-        const int h = (int)(task % H);
-        const long bu = task / H;
+    const bool fused = nqb <= NW;              // every wave owns at most one query block: q/g stay in registers
+    // persistent workgroups: workgroup w serves head w % H for rows w / H, w / H + gridDim/H, ...
+    const int h = blockIdx.x % H;
+    const int rstride = gridDim.x / H;
+    stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
+    const float sc = 0.25f * LOG2E;            // 1/sqrt(c) (modules.py:176,216) in the exp2 domain
+    for (long bu = blockIdx.x / H; bu < (long)b * N; bu += rstride) {
         const int bb = (int)(bu / N), u = (int)(bu - (long)bb * N);
-        __syncthreads();                        // previous task's LDS fully consumed
-        stage_weight_cll<P>(Wkv, wk + (long)h * C * P, C, P, tid, NT);
-        stage_weight_cll<P>(Wkv + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
-        stage_weight_cll<P>(Wqg, wq + (long)h * C * P, C, P, tid, NT);
-        stage_weight_cll<P>(Wqg + C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
+        __syncthreads();                        // previous row's LDS fully consumed (and weights staged)
         const float mu = mask[bu];
         for (int k = tid; k < npad; k += NT) {
             const bool inside = k < N;
             const bool keep = inside && (mu * mask[(long)bb * N + (inside ? k : 0)] >= 0.5f);
-            kmul[k] = keep ? 1.f : 0.f;
             kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
         }
-        __syncthreads();
-        // ---- phase 1: K_h, V_h of every position of the row (zeros beyond N) ----
+        // ---- phase 1: K_h, V_h of every position of the row (zeros beyond N); q/g of the own block ----
+        float qg[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) qg[i] = 0.f;
         for (int vb = wave; vb < nvb; vb += NW) {
             const int v = vb * 32 + r;
             const bool valid = v < N;
             const int vv = valid ? v : 0;
             const long pos = ending ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
-            float x[KH];
-            load_row_cll<P>(pair + pos * P, hi, valid, x);
-            ln_cll<KH>(x);
-            f32x16 acc[1];
-            zero_acc(acc);
-            rowgemm<P, 1>(Wkv, x, acc, r, hi);
+            f32x16 kv;
+            if (fused && vb == wave) {
+                f32x16 acc[2];
+                ta_project<P, 2>(pair, pos, valid, Wl, acc, r, hi);
+                kv = acc[0];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qg[i] = acc[1][i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {            // gate pre-activation incl. bias of this lane's channels
+                    qg[8 + e] = acc[1][8 + e] + bg[h * C + 4 * hi + e];
+                    qg[12 + e] = acc[1][12 + e] + bg[h * C + 8 + 4 * hi + e];
+                }
+            } else {
+                f32x16 acc[1];
+                ta_project<P, 1>(pair, pos, valid, Wl, acc, r, hi);
+                kv = acc[0];
+            }
             // D rows 0-15 = k channels {4hi+e, 8+4hi+e}; rows 16-31 = v channels likewise
-            *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-            *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+            *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = make_float4(kv[0], kv[1], kv[2], kv[3]);
+            *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = make_float4(kv[4], kv[5], kv[6], kv[7]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                Vt[(4 * hi + e) * (npad + 4) + v] = acc[0][8 + e];
-                Vt[(8 + 4 * hi + e) * (npad + 4) + v] = acc[0][12 + e];
+                Vt[(4 * hi + e) * (npad + 4) + v] = kv[8 + e];
+                Vt[(8 + 4 * hi + e) * (npad + 4) + v] = kv[12 + e];
             }
         }
         __syncthreads();
         // ---- phase 2: queries in blocks of 32 per wave ----
-        const int ql = lane & 15, g4 = lane >> 4;
         for (int qb = wave; qb < nqb; qb += NW) {
-            float gate[8];                                   // this lane's 8 gate channels of query r
-            {
+            if (!fused) {                                   // long rows: re-project this block's q / gate
                 const int v = qb * 32 + r;
                 const bool valid = v < N;
                 const int vv = valid ? v : 0;
                 const long pos = ending ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
-                float x[KH];
-                load_row_cll<P>(pair + pos * P, hi, valid, x);
-                ln_cll<KH>(x);
                 f32x16 acc[1];
-                zero_acc(acc);
-                rowgemm<P, 1>(Wqg, x, acc, r, hi);
-                const float sc = 0.25f * LOG2E;            // 1/sqrt(c) (modules.py:176,216) in the exp2 domain
-                *reinterpret_cast<float4*>(Qs + r * KP + 4 * hi) = make_float4(sc * acc[0][0], sc * acc[0][1], sc * acc[0][2], sc * acc[0][3]);
-                *reinterpret_cast<float4*>(Qs + r * KP + 8 + 4 * hi) = make_float4(sc * acc[0][4], sc * acc[0][5], sc * acc[0][6], sc * acc[0][7]);
-                const float* bgh = bg + h * C;
+                ta_project<P, 1>(pair, pos, valid, Wl + 2 * C * (P + 4), acc, r, hi);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qg[i] = acc[0][i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    gate[e] = sigmoidf_(acc[0][8 + e] + bgh[4 * hi + e]);
-                    gate[4 + e] = sigmoidf_(acc[0][12 + e] + bgh[8 + 4 * hi + e]);
+                    qg[8 + e] = acc[0][8 + e] + bg[h * C + 4 * hi + e];
+                    qg[12 + e] = acc[0][12 + e] + bg[h * C + 8 + 4 * hi + e];
                 }
             }
-            wave_lds_fence();
-            float4 qf[2];
-            qf[0] = *reinterpret_cast<const float4*>(Qs + ql * KP + 4 * g4);
-            qf[1] = *reinterpret_cast<const float4*>(Qs + (16 + ql) * KP + 4 * g4);
-            wave_lds_fence();
-            // the gate goes through the same scratch into the (query = ql, channels 4*g4..) layout of O^T
-            *reinterpret_cast<float4*>(Qs + r * KP + 4 * hi) = make_float4(gate[0], gate[1], gate[2], gate[3]);
-            *reinterpret_cast<float4*>(Qs + r * KP + 8 + 4 * hi) = make_float4(gate[4], gate[5], gate[6], gate[7]);
+            // lane (r, hi) holds q channels {4hi+e} in qg[0..3], {8+4hi+e} in qg[4..7], gate likewise in qg[8..15].
+            // Lane (ql, g4) of query tile t needs channels 4*g4+e of position 16t+ql: they sit in lane
+            // 16t + ql + 32*(g4&1), register half (g4>>1)  -> wave shuffles, no LDS scratch.
+            float4 qf[2], gf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int src = 16 * t + ql + 32 * (g4 & 1);
+                float lo[4], up[4], glo[4], gup[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __shfl(qg[e], src);
+                    up[e] = __shfl(qg[4 + e], src);
+                    glo[e] = __shfl(qg[8 + e], src);
+                    gup[e] = __shfl(qg[12 + e], src);
+                }
+                const bool hiq = (g4 >> 1) != 0;
+                qf[t] = make_float4(sc * (hiq ? up[0] : lo[0]), sc * (hiq ? up[1] : lo[1]), sc * (hiq ? up[2] : lo[2]), sc * (hiq ? up[3] : lo[3]));
+                gf[t] = make_float4(sigmoidf_(hiq ? gup[0] : glo[0]), sigmoidf_(hiq ? gup[1] : glo[1]),
+                                    sigmoidf_(hiq ? gup[2] : glo[2]), sigmoidf_(hiq ? gup[3] : glo[3]));
+            }
             float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
             f32x4 o[2];
             o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             o[1] = o[0];                                    // O^T[c = 4*g4 + e][q = ql] of the two query tiles
-            for (int key0 = 0; key0 < npad; key0 += 64) {
-                float4 kf[4], vf[4], mm[4], ma[4];
+            for (int key0 = 0; key0 < npad; key0 += 16 * JT) {
+                float4 kf[JT], ma[JT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < JT; ++j) {
                     kf[j] = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
-                    vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
-                    mm[j] = *reinterpret_cast<const float4*>(kmul + key0 + 16 * j + 4 * g4);
                     ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
                 }
-                f32x4 s[2][4];
+                f32x4 s[2][JT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < JT; ++j)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -252,15 +276,20 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                         z4 = mfma16(kf[j].w, qf[t].w, z4);
                         s[t][j] = z4;
                     }
+                __builtin_amdgcn_sched_barrier(0);          // V^T is fetched behind the QK^T MFMAs, not before them
+                float4 vf[JT];
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+                    vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float tmax = -INFINITY;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        s[t][j][0] = fmaf(s[t][j][0], mm[j].x, ma[j].x);
-                        s[t][j][1] = fmaf(s[t][j][1], mm[j].y, ma[j].y);
-                        s[t][j][2] = fmaf(s[t][j][2], mm[j].z, ma[j].z);
-                        s[t][j][3] = fmaf(s[t][j][3], mm[j].w, ma[j].w);
+                    for (int j = 0; j < JT; ++j) {
+                        s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x;
+                        s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y;
+                        s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z;
+                        s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w;
                         tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][j][0], s[t][j][1]), fmaxf(s[t][j][2], s[t][j][3])));
                     }
                     tmax = rows4_max(tmax);
@@ -269,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                     m_run[t] = m_new;
                     float psum = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < JT; ++j)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float pe = __builtin_amdgcn_exp2f(s[t][j][e] - m_new);
@@ -281,7 +310,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                     for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < JT; ++j)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         o[t] = mfma16(vf[j].x, s[t][j][0], o[t]);    // O^T += V^T[c = ql][key] * P^T[key][q]
@@ -290,20 +319,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                         o[t] = mfma16(vf[j].w, s[t][j][3], o[t]);
                     }
             }
-            wave_lds_fence();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float l_tot = rows4_sum(l_run[t]);
-                const int qrow = 16 * t + ql;
-                const int v = qb * 32 + qrow;
+                const int v = qb * 32 + 16 * t + ql;
                 if (v < N) {
-                    const float4 gf = *reinterpret_cast<const float4*>(Qs + qrow * KP + 4 * g4);
                     const long pos = ending ? (((long)bb * N + v) * N + u) : (bu * N + v);
                     *reinterpret_cast<float4*>(og + pos * HC + h * C + 4 * g4) =
-                        make_float4(gf.x * (o[t][0] / l_tot), gf.y * (o[t][1] / l_tot), gf.z * (o[t][2] / l_tot), gf.w * (o[t][3] / l_tot));
+                        make_float4(gf[t].x * (o[t][0] / l_tot), gf[t].y * (o[t][1] / l_tot),
+                                    gf[t].z * (o[t][2] / l_tot), gf[t].w * (o[t][3] / l_tot));
                 }
             }
-            wave_lds_fence();
         }
     }
 }
@@ -416,22 +442,26 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
-    const size_t lds_fixed = (size_t)2 * 32 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + 2 * npad;
-    // waves per workgroup: the candidate that wastes the fewest 32-query slots (ties -> more waves),
-    // among those whose per-wave scratch still fits the 160 KiB LDS next to the row's K/V
+    const size_t lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    // waves per workgroup: the candidate that wastes the fewest 32-query slots (first one wins ties)
     static const int cand[4] = {10, 8, 5, 4};          // (13 / 16 waves would cap the kernel at 128 VGPRs and spill)
-    int nw = 0;
+    int nw = 4;
     long best = -1;
     for (int i = 0; i < 4; ++i) {
-        const size_t need = (lds_fixed + (size_t)cand[i] * 32 * KP) * sizeof(float);
-        if (need > 160 * 1024) continue;
         const long slots = (long)prd_ceil_div(nqb, cand[i]) * cand[i];
         if (best < 0 || slots < best) { best = slots; nw = cand[i]; }
     }
-    if (nw == 0) return PRD_ERR_UNSUPPORTED;
-    const size_t lds = (lds_fixed + (size_t)nw * 32 * KP) * sizeof(float);
-    const long ntask = (long)b * N * H;
-    const int grid = grid_for(ntask, 1, 8192);
+    // persistent workgroups (weights staged once per workgroup): per head the SMALLEST workgroup count that
+    // reaches the minimum number of row rounds within the residency cap (one 10/8-wave or two 4/5-wave
+    // workgroups per CU at 144 VGPRs), so every workgroup walks the same number of rows
+    const long rows_total = (long)b * N;
+    const long cap = (nw > 6 ? 256 : 512) / H;
+    long per_head = cap < rows_total ? cap : rows_total;
+    if (per_head < 1) per_head = 1;
+    const long rounds = (rows_total + per_head - 1) / per_head;
+    per_head = (rows_total + rounds - 1) / rounds;
+    const int grid = (int)(per_head * H);
 #define PRD_TA_LAUNCH(PP, NW)                                                                                          \
     do {                                                                                                               \
         PRD_SET_LDS((tri_attn_core_kernel<PP, NW>), lds);                                                              \
