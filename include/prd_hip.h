@@ -98,7 +98,10 @@ int prd_pair_init(float* pair, const float* static_pair, const float* z, const f
                   const float* centers, const float* w_dist, const float* ebeta,
                   int b, int N, int P, int dist_dim, hipStream_t stream);
 
-/* ---- trunk operators ------------------------------------------------------------------------------ */
+/* ---- trunk operators ------------------------------------------------------------------------------
+ * `queue` (where present): device pointer to 256 int32 (one counter per XCD, 128 B apart), zero before the first use, owned by the
+ * caller and shared only by stream-ordered launches; the persistent waves pull 32-row tasks from it and
+ * the last fetch of each resets it to zero.  NULL selects a static round-robin instead (same results). */
 /* pair[b,N,N,P] -> bias[b,H,N,N] = Linear(LN(pair)) permuted (modules.py:300-304 with bias, no LN affine;
  * models/AF2_modules.py:406-411,454-459 with LN affine gamma/beta and no bias). */
 int prd_pair_bias(float* bias_out, const float* pair, const float* gamma, const float* beta,
@@ -111,27 +114,27 @@ int prd_opm_pair(float* out, const float* pair, const float* ab, const float* ma
 /* OuterLinear (modules.py:283-287): out[i,j,:] = (residual ? pair : 0) + W1 (x_i * x_j) + u_i - u_j + bias,
  * x = LN(single), u = x W2^T [b,N,P] (computed by prd_gemm), w = [W1 | W2] of shape [P, 2S]. */
 int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
-                     const float* bias, int residual, int b, int N, int P, int S, hipStream_t stream);
+                     const float* bias, int residual, int b, int N, int P, int S, int* queue, hipStream_t stream);
 /* TriangleMultiplication (modules.py:262-274): out = (residual ? pair : 0) + update(pair).
  * ws: 3 * b * P * N * round_up(N,32) floats. */
 int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w_proj, const float* b_proj,
                 const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
                 const float* w_ogate, const float* b_ogate, int incoming, int residual,
-                int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream);
+                int b, int N, int P, float* ws, size_t ws_bytes, int* queue, hipStream_t stream);
 /* TriangleAttention (modules.py:236-243 -> 185-225): out = (residual ? pair : 0) + update(pair).
  * ws: b * N * N * 64 floats. */
 int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
                  const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
-                 int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, hipStream_t stream);
+                 int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, hipStream_t stream);
 /* the two launches of prd_tri_attn, exposed separately (og = gated per-head output [b,N,N,64]) */
 int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                       const float* wv, const float* wg, const float* bg, int ending,
                       int b, int N, int P, int H, int c, hipStream_t stream);
 int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
-                     int residual, int b, int N, int P, hipStream_t stream);
+                     int residual, int b, int N, int P, int* queue, hipStream_t stream);
 /* pair transition (modules.py:321-326): out = (residual ? pair : 0) + W2 relu(W1 LN(pair) + b1) + b2, hidden = 4P */
 int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
-                        const float* b2, int residual, int b, int N, int P, hipStream_t stream);
+                        const float* b2, int residual, int b, int N, int P, int* queue, hipStream_t stream);
 /* coordinate head (modules.py:403 + model.py:364-372): symmetrise, LN -> Linear -> ReLU -> Linear(1),
  * eps_raw[b,N,3] = sum_j m_i m_j w_ij (z_i - z_j) rsqrt(|z_i - z_j|^2 + 1e-4)  (mean not yet removed) */
 int prd_coord_head(float* eps_raw, const float* pair, const float* z, const float* mask,

@@ -44,15 +44,15 @@ SIGNATURES = {
     "prd_pair_init": [vp] * 7 + [ci] * 4 + [vp],
     "prd_pair_bias": [vp] * 6 + [ci] * 4 + [vp],
     "prd_opm_pair": [vp] * 6 + [ci] * 5 + [vp],
-    "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp],
-    "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp],
-    "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp],
-    "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp],
+    "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp, vp],
+    "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, vp],
+    "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, vp],
+    "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, vp],
     "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 6 + [vp],
-    "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp],
+    "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
 }
 

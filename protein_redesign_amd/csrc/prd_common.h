@@ -167,5 +167,43 @@ PRD_DEV void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- task distribution over persistent waves ----------------------------------------------------
+// The row kernels run as ~one persistent workgroup per CU (weights staged into LDS once).  With a
+// static round-robin the 3200 32-row tasks of an N=320 complex over 2048..3072 resident waves finish in
+// ceil() rounds; a device-side queue lets every wave pull its next task instead.  `queue` points to 256
+// zero-initialised ints (one counter per XCD, 128 B apart) owned by the caller; every wave performs exactly one failing fetch, so the wave
+// that draws ticket ntask + nwaves - 1 is the last user and resets the counter for the next launch
+// (launches sharing a counter must be stream-ordered).  queue == nullptr -> static round-robin.
+struct WaveTasks {
+    int* q;
+    long ntask, cur, stride;
+    int shard, nshard, count, last;
+    PRD_DEV WaveTasks(int* queue, long ntask_, int waves_per_wg) : q(queue), ntask(ntask_) {
+        stride = (long)gridDim.x * waves_per_wg;
+        cur = (long)blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+        // one counter per XCD (workgroup b is observed to run on XCD b % 8; only speed depends on it):
+        // a single word saturates near 90 dequeues/us, far below what 3000 waves ask for
+        nshard = gridDim.x < 8 ? (int)gridDim.x : 8;
+        shard = (int)(blockIdx.x % nshard);
+        count = (int)((ntask - shard + nshard - 1) / nshard);                       // tasks shard, shard+nshard, ...
+        const int wgs = (int)((gridDim.x - shard + nshard - 1) / nshard);           // workgroups feeding on this shard
+        last = count + wgs * waves_per_wg - 1;                                       // ticket of the final (failing) fetch
+    }
+    PRD_DEV long next() {                       // task id, or -1 when the work is exhausted
+        if (!q) {
+            const long t = cur;
+            cur += stride;
+            return t < ntask ? t : -1;
+        }
+        int t = 0;
+        if ((threadIdx.x & 63) == 0) {
+            t = atomicAdd(q + 32 * shard, 1);              // counters 128 B apart: one L2 line / channel each
+            if (t == last) atomicExch(q + 32 * shard, 0);
+        }
+        t = __builtin_amdgcn_readfirstlane(t);
+        return t < count ? (long)t * nshard + shard : -1;
+    }
+};
+
 static inline int prd_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int prd_round_up(int a, int b) { return prd_ceil_div(a, b) * b; }

@@ -328,54 +328,108 @@ __global__ __launch_bounds__(WG) void outer_linear_kernel(float* out, const floa
     }
 }
 
+// outer-linear, resident-weight variant: all of W1 [P][S] stays in LDS (132 KB at S=512, P=64) for the
+// lifetime of a persistent workgroup, so the task loop has no workgroup barrier and every wave pulls
+// (i, j-block) tasks from the device queue on its own.
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, float* out, const float* pair,
+                                                                   const float* __restrict__ x, const float* __restrict__ u,
+                                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                                   int b, int N, int S, int residual) {
+    constexpr int NB = P / 32, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                      // [P][S+4]
+    float* bl = smem + P * (S + 4);        // [P] CLL
+    stage_weight_plain(Wl, w, P, S, 2 * S, 0, threadIdx.x, NW * 64);
+    stage_vec_cll(bl, bias, P, threadIdx.x, NW * 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int nvb = (N + 31) / 32;
+    const long ntask = (long)b * N * nvb;
+    const int kb = hi * (S / 2);
+    WaveTasks tasks(queue, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        const int vb = (int)(task % nvb);
+        const long bi = task / nvb;
+        const int bb = (int)(bi / N);
+        const int j = vb * 32 + r;
+        const bool valid = j < N;
+        const int jj = valid ? j : 0;
+        const float* xi = x + bi * S + kb;
+        const float* xj = x + ((long)bb * N + jj) * S + kb;
+        const float* wl = Wl + r * (S + 4) + kb;
+        f32x16 acc[NB];
+        zero_acc(acc);
+#pragma unroll 2
+        for (int m = 0; m < S / 8; ++m) {
+            const float4 a4 = *reinterpret_cast<const float4*>(xi + 4 * m);
+            const float4 b4 = *reinterpret_cast<const float4*>(xj + 4 * m);
+            const float f0 = a4.x * b4.x, f1 = a4.y * b4.y, f2 = a4.z * b4.z, f3 = a4.w * b4.w;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float4 wv = *reinterpret_cast<const float4*>(wl + nb * 32 * (S + 4) + 4 * m);
+                acc[nb] = mfma32(wv.x, f0, acc[nb]);
+                acc[nb] = mfma32(wv.y, f1, acc[nb]);
+                acc[nb] = mfma32(wv.z, f2, acc[nb]);
+                acc[nb] = mfma32(wv.w, f3, acc[nb]);
+            }
+        }
+        float ui[KH], uj[KH], pr[KH];
+        load_row_cll<P>(u + bi * P, hi, true, ui);
+        load_row_cll<P>(u + ((long)bb * N + jj) * P, hi, true, uj);
+        const long off = (bi * N + jj) * P;
+        load_row_cll<P>(pair + off, hi, valid && residual, pr);
+#pragma unroll
+        for (int s = 0; s < KH; ++s) pr[s] = pr[s] + (((acc[s >> 4][s & 15] + ui[s]) - uj[s]) + bl[hi * KH + s]);
+        store_row_cll<P>(out + off, hi, valid, pr);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pair transition: pair += W2 relu(W1 LN(pair) + b1) + b2  (hidden 4P kept in registers)
 // ------------------------------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(WG) void pair_transition_kernel(float* out, const float* pair, const float* __restrict__ w1,
-                                                              const float* __restrict__ b1, const float* __restrict__ w2,
-                                                              const float* __restrict__ b2, long rows, int residual) {
-    constexpr int KH = P / 2, HID = 4 * P, HB = HID / 32, HH = HID / 2, NB = P / 32;
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void pair_transition_kernel(int* queue, float* out, const float* pair, const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                  const float* __restrict__ b2, long rows, int residual) {
+    constexpr int KH = P / 2, HID = 4 * P, HH = HID / 2, NB = P / 32;
+    constexpr int PASSES = 4, HBP = HID / 32 / PASSES, HHP = HH / PASSES;     // hidden units handled per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W1l = smem;                         // [HID][P+4]
     float* W2l = W1l + HID * (P + 4);          // [P][HID+4]
     float* b1l = W2l + P * (HID + 4);          // [HID] CLL
     float* b2l = b1l + HID;                    // [P] CLL
-    stage_weight_cll<P>(W1l, w1, HID, P, threadIdx.x, WG);
-    stage_weight_cll<HID>(W2l, w2, P, HID, threadIdx.x, WG);
-    stage_vec_cll(b1l, b1, HID, threadIdx.x, WG);
-    stage_vec_cll(b2l, b2, P, threadIdx.x, WG);
+    stage_weight_cll<P>(W1l, w1, HID, P, threadIdx.x, NW * 64);
+    stage_weight_cll<HID>(W2l, w2, P, HID, threadIdx.x, NW * 64);
+    stage_vec_cll(b1l, b1, HID, threadIdx.x, NW * 64);
+    stage_vec_cll(b2l, b2, P, threadIdx.x, NW * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const long ntask = (rows + 31) / 32;
-    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+    WaveTasks tasks(queue, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
         const long pos = task * 32 + r;
         const bool valid = pos < rows;
         float x[KH];
         load_row_cll<P>(pair + pos * P, hi, valid, x);
         ln_cll<KH>(x);
-        // hidden units in two halves of 2P (CLL elements [0,HH/2) and [HH/2,HH)) to bound live registers
+        // the 4P hidden units are produced and consumed a quarter at a time (CLL elements [q*HHP, (q+1)*HHP)),
+        // which keeps the live registers low enough for three waves per SIMD
         f32x16 acc2[NB];
         zero_acc(acc2);
-        {
-            float h[HH / 2];
-            f32x16 acc[HB / 2];
-            zero_acc(acc);
-            rowgemm<P, HB / 2>(W1l, x, acc, r, hi);
-#pragma unroll
-            for (int s = 0; s < HH / 2; ++s) h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + s], 0.f);
-            rowgemm_part<HID, NB, 0, HID / 16>(W2l, h, acc2, r, hi);
+#define PRD_PT_PASS(Q)                                                                                              \
+        {                                                                                                           \
+            float h[HHP];                                                                                           \
+            f32x16 acc[HBP];                                                                                        \
+            zero_acc(acc);                                                                                          \
+            rowgemm<P, HBP>(W1l + (Q) * HBP * 32 * (P + 4), x, acc, r, hi);                                         \
+            _Pragma("unroll") for (int s = 0; s < HHP; ++s)                                                         \
+                h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s], 0.f);                             \
+            rowgemm_part<HID, NB, (Q) * HHP / 4, ((Q) + 1) * HHP / 4>(W2l, h, acc2, r, hi);                         \
         }
-        {
-            float h[HH / 2];
-            f32x16 acc[HB / 2];
-            zero_acc(acc);
-            rowgemm<P, HB / 2>(W1l + (HID / 2) * (P + 4), x, acc, r, hi);
-#pragma unroll
-            for (int s = 0; s < HH / 2; ++s) h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + HH / 2 + s], 0.f);
-            rowgemm_part<HID, NB, HID / 16, HID / 8>(W2l, h, acc2, r, hi);
-        }
-        load_row_cll<P>(pair + pos * P, hi, valid && residual, x);      // raw row again (L2 hit) for the residual
+        PRD_PT_PASS(0) PRD_PT_PASS(1) PRD_PT_PASS(2) PRD_PT_PASS(3)
+#undef PRD_PT_PASS
+        load_row_cll<P>(pair + pos * P, hi, valid && residual, x);      // raw row again (cache hit) for the residual
 #pragma unroll
         for (int s = 0; s < KH; ++s) x[s] = x[s] + (acc2[s >> 4][s & 15] + b2l[hi * KH + s]);
         store_row_cll<P>(out + pos * P, hi, valid, x);
@@ -623,30 +677,44 @@ extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, cons
 }
 
 extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
-                                const float* bias, int residual, int b, int N, int P, int S, hipStream_t stream) {
+                                const float* bias, int residual, int b, int N, int P, int S, int* queue, hipStream_t stream) {
     if (!out || !pair || !x || !u || !w || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
-    const int grid = grid_for(ntask, 4, 1024);
+    const size_t lds = ((size_t)P * (S + 4) + P) * sizeof(float);
+    if (lds <= 150 * 1024) {                 // W1 resident in LDS: persistent 8-wave workgroups, queue-fed
+        constexpr int NWL = 8;
+        const int grid = grid_for(ntask, NWL, 256);
+        if (P == 64) {
+            PRD_SET_LDS((outer_linear_res_kernel<64, NWL>), lds);
+            hipLaunchKernelGGL((outer_linear_res_kernel<64, NWL>), dim3(grid), dim3(NWL * 64), lds, stream, queue, out, pair, x, u, w, bias, b, N, S, residual);
+        } else {
+            PRD_SET_LDS((outer_linear_res_kernel<32, NWL>), lds);
+            hipLaunchKernelGGL((outer_linear_res_kernel<32, NWL>), dim3(grid), dim3(NWL * 64), lds, stream, queue, out, pair, x, u, w, bias, b, N, S, residual);
+        }
+        return (int)hipGetLastError();
+    }
+    const int grid = grid_for(ntask, 4, 1024);       // very wide single track: stream W1 through LDS in K chunks
     if (P == 64) hipLaunchKernelGGL(outer_linear_kernel<64>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual);
     else hipLaunchKernelGGL(outer_linear_kernel<32>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual);
     return (int)hipGetLastError();
 }
 
 extern "C" int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
-                                   const float* b2, int residual, int b, int N, int P, hipStream_t stream) {
+                                   const float* b2, int residual, int b, int N, int P, int* queue, hipStream_t stream) {
     if (!out || !pair || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
+    constexpr int NWT = 12;                    // one persistent 12-wave workgroup per CU (weights: 137 KB of LDS at P=64)
     const long rows = (long)b * N * N;
     const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + 5 * P) * sizeof(float);
-    const int grid = grid_for((rows + 31) / 32, 4, 256);
+    const int grid = grid_for((rows + 31) / 32, NWT, 256);
     if (P == 64) {
-        PRD_SET_LDS(pair_transition_kernel<64>, lds);
-        hipLaunchKernelGGL(pair_transition_kernel<64>, dim3(grid), dim3(WG), lds, stream, out, pair, w1, b1, w2, b2, rows, residual);
+        PRD_SET_LDS((pair_transition_kernel<64, NWT>), lds);
+        hipLaunchKernelGGL((pair_transition_kernel<64, NWT>), dim3(grid), dim3(NWT * 64), lds, stream, queue, out, pair, w1, b1, w2, b2, rows, residual);
     } else {
-        PRD_SET_LDS(pair_transition_kernel<32>, lds);
-        hipLaunchKernelGGL(pair_transition_kernel<32>, dim3(grid), dim3(WG), lds, stream, out, pair, w1, b1, w2, b2, rows, residual);
+        PRD_SET_LDS((pair_transition_kernel<32, NWT>), lds);
+        hipLaunchKernelGGL((pair_transition_kernel<32, NWT>), dim3(grid), dim3(NWT * 64), lds, stream, queue, out, pair, w1, b1, w2, b2, rows, residual);
     }
     return (int)hipGetLastError();
 }

@@ -22,8 +22,8 @@ namespace {
 constexpr int WG = 256;
 
 // ---------------------------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(WG) void tri_mul_proj_kernel(float* __restrict__ AB, const float* __restrict__ pair,
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float* __restrict__ AB, const float* __restrict__ pair,
                                                           const float* __restrict__ mask,
                                                           const float* __restrict__ wp, const float* __restrict__ bp,
                                                           const float* __restrict__ wg, const float* __restrict__ bg,
@@ -34,15 +34,16 @@ __global__ __launch_bounds__(WG) void tri_mul_proj_kernel(float* __restrict__ AB
     float* Wgl = Wpl + OUT * (P + 4);
     float* bpl = Wgl + OUT * (P + 4);        // [2P] CLL
     float* bgl = bpl + OUT;
-    stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, WG);
-    stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, WG);
-    stage_vec_cll(bpl, bp, OUT, threadIdx.x, WG);
-    stage_vec_cll(bgl, bg, OUT, threadIdx.x, WG);
+    stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NW * 64);
+    stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NW * 64);
+    stage_vec_cll(bpl, bp, OUT, threadIdx.x, NW * 64);
+    stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const int nvb = ldn / 32;
     const long ntask = (long)b * N * nvb;
-    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+    WaveTasks tasks(queue, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
         const int vb = (int)(task % nvb);
         const long bu = task / nvb;                 // bb*N + u
         const int bb = (int)(bu / N), u = (int)(bu - (long)bb * N);
@@ -73,25 +74,26 @@ __global__ __launch_bounds__(WG) void tri_mul_proj_kernel(float* __restrict__ AB
     }
 }
 
-template <int P>
-__global__ __launch_bounds__(WG) void tri_mul_out_kernel(float* out, const float* pair, const float* __restrict__ O,
-                                                         const float* __restrict__ wo, const float* __restrict__ bo,
-                                                         const float* __restrict__ wog, const float* __restrict__ bog,
-                                                         int b, int N, int ldn, int residual) {
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float* out, const float* pair, const float* __restrict__ O,
+                                                              const float* __restrict__ wo, const float* __restrict__ bo,
+                                                              const float* __restrict__ wog, const float* __restrict__ bog,
+                                                              int b, int N, int ldn, int residual) {
     constexpr int KH = P / 2, NB = P / 32;
     __shared__ __attribute__((aligned(16))) float Wol[P * (P + 4)];
     __shared__ __attribute__((aligned(16))) float Wgl[P * (P + 4)];
     __shared__ __attribute__((aligned(16))) float bol[P];
     __shared__ __attribute__((aligned(16))) float bgl[P];
-    stage_weight_cll<P>(Wol, wo, P, P, threadIdx.x, WG);
-    stage_weight_cll<P>(Wgl, wog, P, P, threadIdx.x, WG);
-    stage_vec_cll(bol, bo, P, threadIdx.x, WG);
-    stage_vec_cll(bgl, bog, P, threadIdx.x, WG);
+    stage_weight_cll<P>(Wol, wo, P, P, threadIdx.x, NW * 64);
+    stage_weight_cll<P>(Wgl, wog, P, P, threadIdx.x, NW * 64);
+    stage_vec_cll(bol, bo, P, threadIdx.x, NW * 64);
+    stage_vec_cll(bgl, bog, P, threadIdx.x, NW * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const int nvb = (N + 31) / 32;
     const long ntask = (long)b * N * nvb;
-    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+    WaveTasks tasks(queue, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
         const int vb = (int)(task % nvb);
         const long bi = task / nvb;
         const int bb = (int)(bi / N), i = (int)(bi - (long)bb * N);
@@ -99,14 +101,18 @@ __global__ __launch_bounds__(WG) void tri_mul_out_kernel(float* out, const float
         const bool valid = j < N;
         const int jj = valid ? j : 0;
         const long off = (bi * N + jj) * P;
-        float raw[KH], x[KH];
-        load_row_cll<P>(pair + off, hi, valid, raw);
+        float gate[KH];
+        {
+            float x[KH];
+            load_row_cll<P>(pair + off, hi, valid, x);
+            ln_cll<KH>(x);
+            f32x16 ag[NB];
+            zero_acc(ag);
+            rowgemm<P, NB>(Wgl, x, ag, r, hi);
 #pragma unroll
-        for (int s = 0; s < KH; ++s) x[s] = raw[s];
-        ln_cll<KH>(x);
-        f32x16 ag[NB];
-        zero_acc(ag);
-        rowgemm<P, NB>(Wgl, x, ag, r, hi);
+            for (int s = 0; s < KH; ++s) gate[s] = sigmoidf_(ag[s >> 4][s & 15] + bgl[hi * KH + s]);
+        }
+        float x[KH];
         // contraction output of this (i,j) for the lane's channels (coalesced over j per channel)
 #pragma unroll
         for (int s = 0; s < KH; ++s)
@@ -115,10 +121,10 @@ __global__ __launch_bounds__(WG) void tri_mul_out_kernel(float* out, const float
         f32x16 ao[NB];
         zero_acc(ao);
         rowgemm<P, NB>(Wol, x, ao, r, hi);
+        load_row_cll<P>(pair + off, hi, valid && residual, x);       // raw row again (cache hit) for the residual
 #pragma unroll
-        for (int s = 0; s < KH; ++s)
-            raw[s] = (residual ? raw[s] : 0.f) + sigmoidf_(ag[s >> 4][s & 15] + bgl[hi * KH + s]) * (ao[s >> 4][s & 15] + bol[hi * KH + s]);
-        store_row_cll<P>(out + off, hi, valid, raw);
+        for (int s = 0; s < KH; ++s) x[s] = x[s] + gate[s] * (ao[s >> 4][s & 15] + bol[hi * KH + s]);
+        store_row_cll<P>(out + off, hi, valid, x);
     }
 }
 
@@ -334,18 +340,19 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     }
 }
 
-template <int P>
-__global__ __launch_bounds__(WG) void tri_attn_out_kernel(float* out, const float* pair, const float* __restrict__ og,
-                                                          const float* __restrict__ wo, const float* __restrict__ bo, long rows, int residual) {
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float* out, const float* pair, const float* __restrict__ og,
+                                                               const float* __restrict__ wo, const float* __restrict__ bo, long rows, int residual) {
     constexpr int KH = P / 2, NB = P / 32, HC = 64;
     __shared__ __attribute__((aligned(16))) float Wl[P * (HC + 4)];
     __shared__ __attribute__((aligned(16))) float bl[P];
-    stage_weight_cll<HC>(Wl, wo, P, HC, threadIdx.x, WG);
-    stage_vec_cll(bl, bo, P, threadIdx.x, WG);
+    stage_weight_cll<HC>(Wl, wo, P, HC, threadIdx.x, NW * 64);
+    stage_vec_cll(bl, bo, P, threadIdx.x, NW * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const long ntask = (rows + 31) / 32;
-    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+    WaveTasks tasks(queue, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
         const long pos = task * 32 + r;
         const bool valid = pos < rows;
         float x[HC / 2];
@@ -391,7 +398,7 @@ extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P
 extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w_proj, const float* b_proj,
                            const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
                            const float* w_ogate, const float* b_ogate, int incoming, int residual,
-                           int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream) {
+                           int b, int N, int P, float* ws, size_t ws_bytes, int* queue, hipStream_t stream) {
     if (!out || !pair || !mask || !w_proj || !b_proj || !w_gate || !b_gate || !w_out || !b_out || !w_ogate || !b_ogate || !ws ||
         b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
@@ -400,15 +407,16 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     float* AB = ws;                                   // [b][2P][N][ldn]
     float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
     {
+        constexpr int NWP = 12;                      // one persistent 12-wave workgroup per CU (3 waves / SIMD)
         const size_t lds = ((size_t)2 * 2 * P * (P + 4) + 4 * P) * sizeof(float);
         const long ntask = (long)b * N * (ldn / 32);
-        const int grid = grid_for(ntask, 4, 1024);
+        const int grid = grid_for(ntask, NWP, 256);
         if (P == 64) {
-            PRD_SET_LDS(tri_mul_proj_kernel<64>, lds);
-            hipLaunchKernelGGL(tri_mul_proj_kernel<64>, dim3(grid), dim3(WG), lds, stream, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
+            PRD_SET_LDS((tri_mul_proj_kernel<64, NWP>), lds);
+            hipLaunchKernelGGL((tri_mul_proj_kernel<64, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, queue, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
         } else {
-            PRD_SET_LDS(tri_mul_proj_kernel<32>, lds);
-            hipLaunchKernelGGL(tri_mul_proj_kernel<32>, dim3(grid), dim3(WG), lds, stream, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
+            PRD_SET_LDS((tri_mul_proj_kernel<32, NWP>), lds);
+            hipLaunchKernelGGL((tri_mul_proj_kernel<32, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, queue, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
         }
         int e = (int)hipGetLastError();
         if (e) return e;
@@ -427,10 +435,11 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
         if (e) return e;
     }
     {
+        constexpr int NWO = 8;
         const long ntask = (long)b * N * prd_ceil_div(N, 32);
-        const int grid = grid_for(ntask, 4, 2048);
-        if (P == 64) hipLaunchKernelGGL(tri_mul_out_kernel<64>, dim3(grid), dim3(WG), 0, stream, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
-        else hipLaunchKernelGGL(tri_mul_out_kernel<32>, dim3(grid), dim3(WG), 0, stream, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
+        const int grid = grid_for(ntask, NWO, 256);
+        if (P == 64) hipLaunchKernelGGL((tri_mul_out_kernel<64, NWO>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
+        else hipLaunchKernelGGL((tri_mul_out_kernel<32, NWO>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
     }
     return (int)hipGetLastError();
 }
@@ -481,22 +490,23 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
 }
 
 extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
-                                int residual, int b, int N, int P, hipStream_t stream) {
+                                int residual, int b, int N, int P, int* queue, hipStream_t stream) {
     if (!out || !pair || !og || !wo || !bo || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
+    constexpr int NWA = 12;
     const long rows = (long)b * N * N;
-    const int grid2 = grid_for((rows + 31) / 32, 4, 2048);
-    if (P == 64) hipLaunchKernelGGL(tri_attn_out_kernel<64>, dim3(grid2), dim3(WG), 0, stream, out, pair, og, wo, bo, rows, residual);
-    else hipLaunchKernelGGL(tri_attn_out_kernel<32>, dim3(grid2), dim3(WG), 0, stream, out, pair, og, wo, bo, rows, residual);
+    const int grid2 = grid_for((rows + 31) / 32, NWA, 256);
+    if (P == 64) hipLaunchKernelGGL((tri_attn_out_kernel<64, NWA>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual);
+    else hipLaunchKernelGGL((tri_attn_out_kernel<32, NWA>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual);
     return (int)hipGetLastError();
 }
 
 extern "C" int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
                             const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
-                            int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, hipStream_t stream) {
+                            int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, hipStream_t stream) {
     if (!ws) return PRD_ERR_ARG;
     if (ws_bytes < prd_workspace_bytes("tri_attn", b, N, 0, P)) return PRD_ERR_WORKSPACE;
     int e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
     if (e) return e;
-    return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, stream);
+    return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, queue, stream);
 }

@@ -16,6 +16,21 @@ from ._lib import PrdGemm, check, dptr, lib, stream
 F32 = torch.float32
 
 
+_QUEUES = {}
+
+
+def task_queue(device) -> int:
+    """Device pointer of the per-device task-queue counters (zero-initialised int32s, see prd_hip.h)."""
+    import os
+    if os.environ.get("PRD_NO_QUEUE"):
+        return 0
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    q = _QUEUES.get(key)
+    if q is None:
+        q = _QUEUES[key] = torch.zeros(256, dtype=torch.int32, device=f"cuda:{key}")
+    return q.data_ptr()
+
+
 def _off(t: torch.Tensor, elem_offset: int = 0) -> int:
     return dptr(t) + 4 * elem_offset
 
@@ -160,7 +175,7 @@ def outer_linear_pair(pair, x, u, w, bias, *, residual: bool, out=None) -> torch
     if out is None:
         out = torch.empty_like(pair)
     check(lib().prd_outer_linear(dptr(out), dptr(pair), dptr(x), dptr(u), dptr(w), dptr(bias), int(residual),
-                                 b, N, P, x.shape[-1], stream()), "prd_outer_linear")
+                                 b, N, P, x.shape[-1], task_queue(pair.device), stream()), "prd_outer_linear")
     return out
 
 
@@ -177,7 +192,7 @@ def tri_mul(pair, mask, wts, *, incoming: bool, residual: bool, out=None, ws=Non
     if ws is None:
         ws = torch.empty(nbytes // 4, device=pair.device, dtype=F32)
     check(lib().prd_tri_mul(dptr(out), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(incoming), int(residual),
-                            b, N, P, dptr(ws), ws.numel() * 4, stream()), "prd_tri_mul")
+                            b, N, P, dptr(ws), ws.numel() * 4, task_queue(pair.device), stream()), "prd_tri_mul")
     return out
 
 
@@ -190,7 +205,7 @@ def tri_attn(pair, mask, wts, H: int, c: int, *, ending: bool, residual: bool, o
     if ws is None:
         ws = torch.empty(nbytes // 4, device=pair.device, dtype=F32)
     check(lib().prd_tri_attn(dptr(out), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending), int(residual),
-                             b, N, P, H, c, dptr(ws), ws.numel() * 4, stream()), "prd_tri_attn")
+                             b, N, P, H, c, dptr(ws), ws.numel() * 4, task_queue(pair.device), stream()), "prd_tri_attn")
     return out
 
 
@@ -199,7 +214,7 @@ def pair_transition(pair, w1, b1, w2, b2, *, residual: bool, out=None) -> torch.
     if out is None:
         out = torch.empty_like(pair)
     check(lib().prd_pair_transition(dptr(out), dptr(pair), dptr(w1), dptr(b1), dptr(w2), dptr(b2), int(residual),
-                                    b, N, P, stream()), "prd_pair_transition")
+                                    b, N, P, task_queue(pair.device), stream()), "prd_pair_transition")
     return out
 
 
