@@ -29,6 +29,9 @@ PRD_DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma
 PRD_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 PRD_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gate sigmoid on the hardware transcendentals (v_exp_f32 + v_rcp_f32, ~1 ulp each): the gates multiply
+// O(1) values, so their 1e-7 relative error is far inside the 1e-5 operator tolerance
+PRD_DEV float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 // row index inside a 32x32 MFMA D fragment held in register q by a lane of half hi
 PRD_DEV int drow32(int q, int hi) { return (q & 3) + 8 * (q >> 2) + 4 * hi; }

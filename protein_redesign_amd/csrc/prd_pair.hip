@@ -360,19 +360,39 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, f
         const float* wl = Wl + r * (S + 4) + kb;
         f32x16 acc[NB];
         zero_acc(acc);
-#pragma unroll 2
-        for (int m = 0; m < S / 8; ++m) {
-            const float4 a4 = *reinterpret_cast<const float4*>(xi + 4 * m);
-            const float4 b4 = *reinterpret_cast<const float4*>(xj + 4 * m);
-            const float f0 = a4.x * b4.x, f1 = a4.y * b4.y, f2 = a4.z * b4.z, f3 = a4.w * b4.w;
+        // software pipeline: the x_i / x_j operands of K group g+1 (4 x 16 B per lane and operand) are in
+        // flight while the 16*NB MFMAs of group g execute (2048+ cycles >> L2 latency)
+        constexpr int G = 4;                               // 16-byte steps per group
+        float4 ca[G], cb[G], na[G], nb4[G];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const float4 wv = *reinterpret_cast<const float4*>(wl + nb * 32 * (S + 4) + 4 * m);
-                acc[nb] = mfma32(wv.x, f0, acc[nb]);
-                acc[nb] = mfma32(wv.y, f1, acc[nb]);
-                acc[nb] = mfma32(wv.z, f2, acc[nb]);
-                acc[nb] = mfma32(wv.w, f3, acc[nb]);
+        for (int t = 0; t < G; ++t) {
+            ca[t] = *reinterpret_cast<const float4*>(xi + 4 * t);
+            cb[t] = *reinterpret_cast<const float4*>(xj + 4 * t);
+        }
+        const int ngroups = S / (8 * G);                   // S is a multiple of 64 on this path
+        for (int g = 0; g < ngroups; ++g) {
+            if (g + 1 < ngroups) {
+#pragma unroll
+                for (int t = 0; t < G; ++t) {
+                    na[t] = *reinterpret_cast<const float4*>(xi + 4 * (G * (g + 1) + t));
+                    nb4[t] = *reinterpret_cast<const float4*>(xj + 4 * (G * (g + 1) + t));
+                }
             }
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const float f0 = ca[t].x * cb[t].x, f1 = ca[t].y * cb[t].y, f2 = ca[t].z * cb[t].z, f3 = ca[t].w * cb[t].w;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wl + nb * 32 * (S + 4) + 4 * (G * g + t));
+                    acc[nb] = mfma32(wv.x, f0, acc[nb]);
+                    acc[nb] = mfma32(wv.y, f1, acc[nb]);
+                    acc[nb] = mfma32(wv.z, f2, acc[nb]);
+                    acc[nb] = mfma32(wv.w, f3, acc[nb]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < G; ++t) { ca[t] = na[t]; cb[t] = nb4[t]; }
         }
         float ui[KH], uj[KH], pr[KH];
         load_row_cll<P>(u + bi * P, hi, true, ui);
@@ -683,7 +703,7 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
     if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const size_t lds = ((size_t)P * (S + 4) + P) * sizeof(float);
-    if (lds <= 150 * 1024) {                 // W1 resident in LDS: persistent 8-wave workgroups, queue-fed
+    if (lds <= 150 * 1024 && (S % 64) == 0) {   // W1 resident in LDS: persistent 8-wave workgroups, queue-fed
         constexpr int NWL = 8;
         const int grid = grid_for(ntask, NWL, 256);
         if (P == 64) {

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
             for (int q = 0; q < 16; ++q) {
                 const int s = ob * 16 + q;                       // CLL element of the 2P-wide output
                 const int c = 32 * ob + drow32(q, hi);           // output channel
-                const float val = m2 * sigmoidf_(ag[0][q] + bgl[hi * P + s]) * (ap[0][q] + bpl[hi * P + s]);
+                const float val = m2 * sigmoid_fast(ag[0][q] + bgl[hi * P + s]) * (ap[0][q] + bpl[hi * P + s]);
                 AB[(((long)bb * OUT + c) * N + u) * ldn + v] = valid ? val : 0.f;
             }
         }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
             zero_acc(ag);
             rowgemm<P, NB>(Wgl, x, ag, r, hi);
 #pragma unroll
-            for (int s = 0; s < KH; ++s) gate[s] = sigmoidf_(ag[s >> 4][s & 15] + bgl[hi * KH + s]);
+            for (int s = 0; s < KH; ++s) gate[s] = sigmoid_fast(ag[s >> 4][s & 15] + bgl[hi * KH + s]);
         }
         float x[KH];
         // contraction output of this (i,j) for the lane's channels (coalesced over j per channel)
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 }
                 const bool hiq = (g4 >> 1) != 0;
                 qf[t] = make_float4(sc * (hiq ? up[0] : lo[0]), sc * (hiq ? up[1] : lo[1]), sc * (hiq ? up[2] : lo[2]), sc * (hiq ? up[3] : lo[3]));
-                gf[t] = make_float4(sigmoidf_(hiq ? gup[0] : glo[0]), sigmoidf_(hiq ? gup[1] : glo[1]),
-                                    sigmoidf_(hiq ? gup[2] : glo[2]), sigmoidf_(hiq ? gup[3] : glo[3]));
+                gf[t] = make_float4(sigmoid_fast(hiq ? gup[0] : glo[0]), sigmoid_fast(hiq ? gup[1] : glo[1]),
+                                    sigmoid_fast(hiq ? gup[2] : glo[2]), sigmoid_fast(hiq ? gup[3] : glo[3]));
             }
             float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
             f32x4 o[2];
@@ -431,6 +431,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
         g.sb1 = g.sa1; g.sb2 = g.sa2;
         g.sc1 = (long long)P * N * ldn; g.sc2 = (long long)N * ldn;
         g.alpha = 1.f;
+        g.tile_hint = 64;
         int e = prd_gemm(&g, stream);
         if (e) return e;
     }
