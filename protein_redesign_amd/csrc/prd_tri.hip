@@ -141,44 +141,137 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
 constexpr int KP = 20;          // LDS pitch (floats) of the [*, 16] K / Q / G tiles
 constexpr float LOG2E = 1.4426950408889634f;
 
-// One 32-position block of the row: load, LayerNorm, project.  NB = 1: [k_h; v_h] only; NB = 2: also [q_h; g_h].
-template <int P, int NB>
-PRD_DEV void ta_project(const float* __restrict__ pair, long pos, bool valid, const float* W, f32x16 (&acc)[NB], int r, int hi) {
-    float x[P / 2];
-    load_row_cll<P>(pair + pos * P, hi, valid, x);
-    ln_cll<P / 2>(x);
-    zero_acc(acc);
-    rowgemm<P, NB>(W, x, acc, r, hi);
+// The key loop of one wave for NTQ (1 or 2) 16-query tiles: S^T = K Q^T, online softmax in the exp2
+// domain over blocks of 16*JT keys, O^T += V^T P^T.  Returns O^T[c = 4*g4 + e][q = ql] / l per tile.
+template <int NTQ>
+PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ Vt, const float* __restrict__ kadd,
+                        const float4 (&qf)[NTQ], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
+    constexpr int JT = 2;                      // 16-key tiles per online-softmax update (32 keys): register budget
+    float m_run[NTQ], l_run[NTQ];
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        m_run[t] = -1e30f;
+        l_run[t] = 0.f;
+        o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int key0 = 0; key0 < npad; key0 += 16 * JT) {
+        float4 kf[JT], ma[JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            kf[j] = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
+            ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
+        }
+        f32x4 s[NTQ][JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) {
+                f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                z4 = mfma16(kf[j].x, qf[t].x, z4);          // S^T[key = key0+16j+4*g4+e][q]
+                z4 = mfma16(kf[j].y, qf[t].y, z4);
+                z4 = mfma16(kf[j].z, qf[t].z, z4);
+                z4 = mfma16(kf[j].w, qf[t].w, z4);
+                s[t][j] = z4;
+            }
+        __builtin_amdgcn_sched_barrier(0);                  // V^T is fetched behind the QK^T MFMAs, not before them
+        float4 vf[JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+            vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x;
+                s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y;
+                s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z;
+                s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w;
+                tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][j][0], s[t][j][1]), fmaxf(s[t][j][2], s[t][j][3])));
+            }
+            tmax = rows4_max(tmax);
+            const float m_new = fmaxf(m_run[t], tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+            m_run[t] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(s[t][j][e] - m_new);
+                    s[t][j][e] = pe;
+                    psum += pe;
+                }
+            l_run[t] = l_run[t] * alpha + psum;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
+        }
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) {
+                o[t] = mfma16(vf[j].x, s[t][j][0], o[t]);    // O^T += V^T[c = ql][key] * P^T[key][q]
+                o[t] = mfma16(vf[j].y, s[t][j][1], o[t]);
+                o[t] = mfma16(vf[j].z, s[t][j][2], o[t]);
+                o[t] = mfma16(vf[j].w, s[t][j][3], o[t]);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) l_tot[t] = rows4_sum(l_run[t]);
 }
 
+// One workgroup (NW waves, persistent) serves head h = blockIdx % H for a strided set of pair rows.
+//   phase 1: each wave LayerNorms 32-position blocks of the row and projects [k_h; v_h; q_h; g_h] (64 outputs)
+//            on v_mfma_f32_32x32x2_f32; K, V^T, Q (pre-scaled by log2(e)/sqrt(c)) and the gate go to LDS in the
+//            operand layouts of the 16x16x4 MFMAs.  The next row's block is already in registers (prefetch).
+//   phase 2: the ceil(N/16) query tiles are dealt round-robin to the waves (SIMD-balanced: waves w and w+4
+//            share a SIMD), two tiles at a time through ta_keyloop.
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
-    constexpr int C = 16, HC = 64, NT = NW * 64;
-    constexpr int JT = 2;                      // 16-key tiles per online-softmax update (32 keys): register budget
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                          // [64][P+4]: rows 0-15 k_h, 16-31 v_h, 32-47 q_h, 48-63 g_h
     float* Kl = Wl + 64 * (P + 4);             // [npad][KP]           (npad = round_up(N, 64))
     float* Vt = Kl + npad * KP;                // [16][npad+4]
     float* kadd = Vt + C * (npad + 4);         // [npad]: 0 = keep the logit, else the value that replaces it
+    float* Ql = kadd + npad;                   // [npad][KP]
+    float* Gl = Ql + npad * KP;                // [npad][KP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const int ql = lane & 15, g4 = lane >> 4;
     const int nvb = npad / 32;
     const int nqb = (N + 31) / 32;
-    const bool fused = nqb <= NW;              // every wave owns at most one query block: q/g stay in registers
-    // persistent workgroups: workgroup w serves head w % H for rows w / H, w / H + gridDim/H, ...
+    const int ntile = (N + 15) / 16;
     const int h = blockIdx.x % H;
     const int rstride = gridDim.x / H;
     stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
     stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
     stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT);
     stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
+    float bgl[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bgl[e] = bg[h * C + 4 * hi + e]; bgl[4 + e] = bg[h * C + 8 + 4 * hi + e]; }
     const float sc = 0.25f * LOG2E;            // 1/sqrt(c) (modules.py:176,216) in the exp2 domain
-    for (long bu = blockIdx.x / H; bu < (long)b * N; bu += rstride) {
-        const int bb = (int)(bu / N), u = (int)(bu - (long)bb * N);
+    const long nrows = (long)b * N;
+
+    auto row_pos = [&](long bu, int v) -> long {          // pair position of sequence element v of row bu
+        const long bb = bu / N;
+        const long u = bu - bb * N;
+        return ending ? ((bb * N + v) * N + u) : (bu * N + v);
+    };
+    // prefetch of this wave's first block of the first row
+    float xnext[KH];
+    {
+        const long bu0 = blockIdx.x / H;
+        const int v = wave * 32 + r;
+        const bool ok = bu0 < nrows && wave < nqb && v < N;
+        load_row_cll<P>(pair + row_pos(ok ? bu0 : 0, ok ? v : 0) * P, hi, ok, xnext);
+    }
+    for (long bu = blockIdx.x / H; bu < nrows; bu += rstride) {
+        const int bb = (int)(bu / N);
         __syncthreads();                        // previous row's LDS fully consumed (and weights staged)
         const float mu = mask[bu];
         for (int k = tid; k < npad; k += NT) {
@@ -186,51 +279,163 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
             const bool keep = inside && (mu * mask[(long)bb * N + (inside ? k : 0)] >= 0.5f);
             kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
         }
-        // ---- phase 1: K_h, V_h of every position of the row (zeros beyond N); q/g of the own block ----
-        float qg[16];
+        // ---- phase 1 ----
+        for (int vb = wave; vb < nvb; vb += NW) {
+            const int v = vb * 32 + r;
+            float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, q0 = k0, q1 = k0, g0 = k0, g1 = k0;
+            float vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (vb < nqb) {                                   // blocks past the sequence end are all zeros
+                float x[KH];
+                if (vb == wave) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) qg[i] = 0.f;
+                    for (int s = 0; s < KH; ++s) x[s] = xnext[s];
+                } else {
+                    const bool valid = v < N;
+                    load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
+                }
+                ln_cll<KH>(x);
+                f32x16 acc[2];
+                zero_acc(acc);
+                rowgemm<P, 2>(Wl, x, acc, r, hi);
+                k0 = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                k1 = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = acc[0][8 + e];
+                q0 = make_float4(sc * acc[1][0], sc * acc[1][1], sc * acc[1][2], sc * acc[1][3]);
+                q1 = make_float4(sc * acc[1][4], sc * acc[1][5], sc * acc[1][6], sc * acc[1][7]);
+                g0 = make_float4(sigmoid_fast(acc[1][8] + bgl[0]), sigmoid_fast(acc[1][9] + bgl[1]),
+                                 sigmoid_fast(acc[1][10] + bgl[2]), sigmoid_fast(acc[1][11] + bgl[3]));
+                g1 = make_float4(sigmoid_fast(acc[1][12] + bgl[4]), sigmoid_fast(acc[1][13] + bgl[5]),
+                                 sigmoid_fast(acc[1][14] + bgl[6]), sigmoid_fast(acc[1][15] + bgl[7]));
+            }
+            // D rows of a block: channels {4hi+e} in registers 0-3 and {8+4hi+e} in 4-7 of each 16-row group
+            *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = k0;
+            *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = k1;
+            *reinterpret_cast<float4*>(Ql + v * KP + 4 * hi) = q0;
+            *reinterpret_cast<float4*>(Ql + v * KP + 8 + 4 * hi) = q1;
+            *reinterpret_cast<float4*>(Gl + v * KP + 4 * hi) = g0;
+            *reinterpret_cast<float4*>(Gl + v * KP + 8 + 4 * hi) = g1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Vt[(4 * hi + e) * (npad + 4) + v] = vv[e];
+                Vt[(8 + 4 * hi + e) * (npad + 4) + v] = vv[4 + e];
+            }
+        }
+        __syncthreads();
+        // next row's first block: in flight during the whole key loop
+        {
+            const long bun = bu + rstride;
+            const int v = wave * 32 + r;
+            const bool ok = bun < nrows && wave < nqb && v < N;
+            load_row_cll<P>(pair + row_pos(ok ? bun : 0, ok ? v : 0) * P, hi, ok, xnext);
+        }
+        // ---- phase 2 ----
+        for (int t0 = wave; t0 < ntile; t0 += 2 * NW) {
+            const int t1 = t0 + NW;
+            if (t1 < ntile) {
+                float4 qf[2];
+                qf[0] = *reinterpret_cast<const float4*>(Ql + (16 * t0 + ql) * KP + 4 * g4);
+                qf[1] = *reinterpret_cast<const float4*>(Ql + (16 * t1 + ql) * KP + 4 * g4);
+                f32x4 o[2];
+                float l_tot[2];
+                ta_keyloop<2>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int v = 16 * (t == 0 ? t0 : t1) + ql;
+                    if (v < N) {
+                        const float4 gf = *reinterpret_cast<const float4*>(Gl + v * KP + 4 * g4);
+                        *reinterpret_cast<float4*>(og + row_pos(bu, v) * HC + h * C + 4 * g4) =
+                            make_float4(gf.x * (o[t][0] / l_tot[t]), gf.y * (o[t][1] / l_tot[t]),
+                                        gf.z * (o[t][2] / l_tot[t]), gf.w * (o[t][3] / l_tot[t]));
+                    }
+                }
+            } else {
+                float4 qf[1];
+                qf[0] = *reinterpret_cast<const float4*>(Ql + (16 * t0 + ql) * KP + 4 * g4);
+                f32x4 o[1];
+                float l_tot[1];
+                ta_keyloop<1>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
+                const int v = 16 * t0 + ql;
+                if (v < N) {
+                    const float4 gf = *reinterpret_cast<const float4*>(Gl + v * KP + 4 * g4);
+                    *reinterpret_cast<float4*>(og + row_pos(bu, v) * HC + h * C + 4 * g4) =
+                        make_float4(gf.x * (o[0][0] / l_tot[0]), gf.y * (o[0][1] / l_tot[0]),
+                                    gf.z * (o[0][2] / l_tot[0]), gf.w * (o[0][3] / l_tot[0]));
+                }
+            }
+        }
+    }
+}
+
+// Long-row variant (K/V of the row fill the LDS, no room for Q / gate tiles): queries are re-projected per
+// 32-query block in phase 2 and reach the MFMA operand layout through wave shuffles instead of LDS.
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_core_long_kernel(
+    float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                          // [64][P+4]: rows 0-15 k_h, 16-31 v_h, 32-47 q_h, 48-63 g_h
+    float* Kl = Wl + 64 * (P + 4);             // [npad][KP]
+    float* Vt = Kl + npad * KP;                // [16][npad+4]
+    float* kadd = Vt + C * (npad + 4);         // [npad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int ql = lane & 15, g4 = lane >> 4;
+    const int nvb = npad / 32;
+    const int nqb = (N + 31) / 32;
+    const int h = blockIdx.x % H;
+    const int rstride = gridDim.x / H;
+    stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
+    const float sc = 0.25f * LOG2E;
+    for (long bu = blockIdx.x / H; bu < (long)b * N; bu += rstride) {
+        const int bb = (int)(bu / N), u = (int)(bu - (long)bb * N);
+        __syncthreads();
+        const float mu = mask[bu];
+        for (int k = tid; k < npad; k += NT) {
+            const bool inside = k < N;
+            const bool keep = inside && (mu * mask[(long)bb * N + (inside ? k : 0)] >= 0.5f);
+            kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
+        }
         for (int vb = wave; vb < nvb; vb += NW) {
             const int v = vb * 32 + r;
             const bool valid = v < N;
             const int vv = valid ? v : 0;
             const long pos = ending ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
-            f32x16 kv;
-            if (fused && vb == wave) {
-                f32x16 acc[2];
-                ta_project<P, 2>(pair, pos, valid, Wl, acc, r, hi);
-                kv = acc[0];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) qg[i] = acc[1][i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {            // gate pre-activation incl. bias of this lane's channels
-                    qg[8 + e] = acc[1][8 + e] + bg[h * C + 4 * hi + e];
-                    qg[12 + e] = acc[1][12 + e] + bg[h * C + 8 + 4 * hi + e];
-                }
-            } else {
-                f32x16 acc[1];
-                ta_project<P, 1>(pair, pos, valid, Wl, acc, r, hi);
-                kv = acc[0];
+            f32x16 kv[1];
+            zero_acc(kv);
+            if (vb < nqb) {
+                float x[KH];
+                load_row_cll<P>(pair + pos * P, hi, valid, x);
+                ln_cll<KH>(x);
+                rowgemm<P, 1>(Wl, x, kv, r, hi);
             }
-            // D rows 0-15 = k channels {4hi+e, 8+4hi+e}; rows 16-31 = v channels likewise
-            *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = make_float4(kv[0], kv[1], kv[2], kv[3]);
-            *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = make_float4(kv[4], kv[5], kv[6], kv[7]);
+            *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = make_float4(kv[0][0], kv[0][1], kv[0][2], kv[0][3]);
+            *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = make_float4(kv[0][4], kv[0][5], kv[0][6], kv[0][7]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                Vt[(4 * hi + e) * (npad + 4) + v] = kv[8 + e];
-                Vt[(8 + 4 * hi + e) * (npad + 4) + v] = kv[12 + e];
+                Vt[(4 * hi + e) * (npad + 4) + v] = kv[0][8 + e];
+                Vt[(8 + 4 * hi + e) * (npad + 4) + v] = kv[0][12 + e];
             }
         }
         __syncthreads();
-        // ---- phase 2: queries in blocks of 32 per wave ----
         for (int qb = wave; qb < nqb; qb += NW) {
-            if (!fused) {                                   // long rows: re-project this block's q / gate
+            float qg[16];
+            {
                 const int v = qb * 32 + r;
                 const bool valid = v < N;
                 const int vv = valid ? v : 0;
                 const long pos = ending ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
+                float x[KH];
+                load_row_cll<P>(pair + pos * P, hi, valid, x);
+                ln_cll<KH>(x);
                 f32x16 acc[1];
-                ta_project<P, 1>(pair, pos, valid, Wl + 2 * C * (P + 4), acc, r, hi);
+                zero_acc(acc);
+                rowgemm<P, 1>(Wl + 2 * C * (P + 4), x, acc, r, hi);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) qg[i] = acc[0][i];
 #pragma unroll
@@ -239,9 +444,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                     qg[12 + e] = acc[0][12 + e] + bg[h * C + 8 + 4 * hi + e];
                 }
             }
-            // lane (r, hi) holds q channels {4hi+e} in qg[0..3], {8+4hi+e} in qg[4..7], gate likewise in qg[8..15].
-            // Lane (ql, g4) of query tile t needs channels 4*g4+e of position 16t+ql: they sit in lane
-            // 16t + ql + 32*(g4&1), register half (g4>>1)  -> wave shuffles, no LDS scratch.
+            // lane (r, hi) holds q channels {4hi+e} in qg[0..3], {8+4hi+e} in qg[4..7], gate likewise in qg[8..15];
+            // lane (ql, g4) of query tile t needs channels 4*g4+e of position 16t+ql = lane 16t+ql+32*(g4&1), half g4>>1
             float4 qf[2], gf[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -259,81 +463,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 gf[t] = make_float4(sigmoid_fast(hiq ? gup[0] : glo[0]), sigmoid_fast(hiq ? gup[1] : glo[1]),
                                     sigmoid_fast(hiq ? gup[2] : glo[2]), sigmoid_fast(hiq ? gup[3] : glo[3]));
             }
-            float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
             f32x4 o[2];
-            o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            o[1] = o[0];                                    // O^T[c = 4*g4 + e][q = ql] of the two query tiles
-            for (int key0 = 0; key0 < npad; key0 += 16 * JT) {
-                float4 kf[JT], ma[JT];
-#pragma unroll
-                for (int j = 0; j < JT; ++j) {
-                    kf[j] = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
-                    ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
-                }
-                f32x4 s[2][JT];
-#pragma unroll
-                for (int j = 0; j < JT; ++j)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                        z4 = mfma16(kf[j].x, qf[t].x, z4);          // S^T[key = key0+16j+4*g4+e][q]
-                        z4 = mfma16(kf[j].y, qf[t].y, z4);
-                        z4 = mfma16(kf[j].z, qf[t].z, z4);
-                        z4 = mfma16(kf[j].w, qf[t].w, z4);
-                        s[t][j] = z4;
-                    }
-                __builtin_amdgcn_sched_barrier(0);          // V^T is fetched behind the QK^T MFMAs, not before them
-                float4 vf[JT];
-#pragma unroll
-                for (int j = 0; j < JT; ++j)
-                    vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float tmax = -INFINITY;
-#pragma unroll
-                    for (int j = 0; j < JT; ++j) {
-                        s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x;
-                        s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y;
-                        s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z;
-                        s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w;
-                        tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][j][0], s[t][j][1]), fmaxf(s[t][j][2], s[t][j][3])));
-                    }
-                    tmax = rows4_max(tmax);
-                    const float m_new = fmaxf(m_run[t], tmax);
-                    const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
-                    m_run[t] = m_new;
-                    float psum = 0.f;
-#pragma unroll
-                    for (int j = 0; j < JT; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float pe = __builtin_amdgcn_exp2f(s[t][j][e] - m_new);
-                            s[t][j][e] = pe;
-                            psum += pe;
-                        }
-                    l_run[t] = l_run[t] * alpha + psum;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
-                }
-#pragma unroll
-                for (int j = 0; j < JT; ++j)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        o[t] = mfma16(vf[j].x, s[t][j][0], o[t]);    // O^T += V^T[c = ql][key] * P^T[key][q]
-                        o[t] = mfma16(vf[j].y, s[t][j][1], o[t]);
-                        o[t] = mfma16(vf[j].z, s[t][j][2], o[t]);
-                        o[t] = mfma16(vf[j].w, s[t][j][3], o[t]);
-                    }
-            }
+            float l_tot[2];
+            ta_keyloop<2>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const float l_tot = rows4_sum(l_run[t]);
                 const int v = qb * 32 + 16 * t + ql;
                 if (v < N) {
                     const long pos = ending ? (((long)bb * N + v) * N + u) : (bu * N + v);
                     *reinterpret_cast<float4*>(og + pos * HC + h * C + 4 * g4) =
-                        make_float4(gf[t].x * (o[t][0] / l_tot), gf[t].y * (o[t][1] / l_tot),
-                                    gf[t].z * (o[t][2] / l_tot), gf[t].w * (o[t][3] / l_tot));
+                        make_float4(gf[t].x * (o[t][0] / l_tot[t]), gf[t].y * (o[t][1] / l_tot[t]),
+                                    gf[t].z * (o[t][2] / l_tot[t]), gf[t].w * (o[t][3] / l_tot[t]));
                 }
             }
         }
@@ -452,40 +592,28 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
-    const size_t lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    size_t lds = ((size_t)64 * (P + 4) + (size_t)3 * npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    const bool long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
+    if (long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
-    // waves per workgroup: the candidate that wastes the fewest 32-query slots (first one wins ties)
-    static const int cand[4] = {10, 8, 5, 4};          // (13 / 16 waves would cap the kernel at 128 VGPRs and spill)
-    int nw = 4;
-    long best = -1;
-    for (int i = 0; i < 4; ++i) {
-        const long slots = (long)prd_ceil_div(nqb, cand[i]) * cand[i];
-        if (best < 0 || slots < best) { best = slots; nw = cand[i]; }
-    }
-    // persistent workgroups (weights staged once per workgroup): per head the SMALLEST workgroup count that
-    // reaches the minimum number of row rounds within the residency cap (one 10/8-wave or two 4/5-wave
-    // workgroups per CU at 144 VGPRs), so every workgroup walks the same number of rows
+    const int nw = 8;                                   // 2 waves / SIMD: room for the next-row prefetch registers
+    // persistent workgroups (weights staged once per workgroup), one per CU: per head the SMALLEST workgroup
+    // count that reaches the minimum number of row rounds, so every workgroup walks the same number of rows
     const long rows_total = (long)b * N;
-    const long cap = (nw > 6 ? 256 : 512) / H;
+    const long cap = 256 / H;
     long per_head = cap < rows_total ? cap : rows_total;
     if (per_head < 1) per_head = 1;
     const long rounds = (rows_total + per_head - 1) / per_head;
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
-#define PRD_TA_LAUNCH(PP, NW)                                                                                          \
+#define PRD_TA_LAUNCH(KERNEL, PP)                                                                                      \
     do {                                                                                                               \
-        PRD_SET_LDS((tri_attn_core_kernel<PP, NW>), lds);                                                              \
-        hipLaunchKernelGGL((tri_attn_core_kernel<PP, NW>), dim3(grid), dim3(NW * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
+        PRD_SET_LDS((KERNEL<PP, 8>), lds);                                                                             \
+        hipLaunchKernelGGL((KERNEL<PP, 8>), dim3(grid), dim3(8 * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
     } while (0)
-#define PRD_TA_SWITCH(PP)                                                                                              \
-    switch (nw) {                                                                                                      \
-        case 10: PRD_TA_LAUNCH(PP, 10); break;                                                                         \
-        case 8: PRD_TA_LAUNCH(PP, 8); break;                                                                           \
-        case 5: PRD_TA_LAUNCH(PP, 5); break;                                                                           \
-        default: PRD_TA_LAUNCH(PP, 4); break;                                                                          \
-    }
-    if (P == 64) { PRD_TA_SWITCH(64) } else { PRD_TA_SWITCH(32) }
-#undef PRD_TA_SWITCH
+    (void)nqb; (void)nw;
+    if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 64); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 32); }
+    else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 64); else PRD_TA_LAUNCH(tri_attn_core_kernel, 32); }
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();
 }
