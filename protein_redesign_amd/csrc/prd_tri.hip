@@ -274,14 +274,14 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         const int bb = (int)(bu / N);
         __syncthreads();                        // previous row's LDS fully consumed (and weights staged)
         const float mu = mask[bu];
-        for (int k = tid; k < npad; k += NT) {
-            const bool inside = k < N;
-            const bool keep = inside && (mu * mask[(long)bb * N + (inside ? k : 0)] >= 0.5f);
-            kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
-        }
         // ---- phase 1 ----
         for (int vb = wave; vb < nvb; vb += NW) {
             const int v = vb * 32 + r;
+            if (hi == 0) {                                    // per-key logit override of this row (see header comment)
+                const bool inside = v < N;
+                const bool keep = inside && (mu * mask[(long)bb * N + (inside ? v : 0)] >= 0.5f);
+                kadd[v] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
+            }
             float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, q0 = k0, q1 = k0, g0 = k0, g1 = k0;
             float vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (vb < nqb) {                                   // blocks past the sequence end are all zeros
@@ -606,14 +606,15 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     const long rounds = (rows_total + per_head - 1) / per_head;
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
-#define PRD_TA_LAUNCH(KERNEL, PP)                                                                                      \
+#define PRD_TA_LAUNCH(KERNEL, PP, NW)                                                                                  \
     do {                                                                                                               \
-        PRD_SET_LDS((KERNEL<PP, 8>), lds);                                                                             \
-        hipLaunchKernelGGL((KERNEL<PP, 8>), dim3(grid), dim3(8 * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
+        PRD_SET_LDS((KERNEL<PP, NW>), lds);                                                                            \
+        hipLaunchKernelGGL((KERNEL<PP, NW>), dim3(grid), dim3(NW * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
     } while (0)
     (void)nqb; (void)nw;
-    if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 64); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 32); }
-    else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 64); else PRD_TA_LAUNCH(tri_attn_core_kernel, 32); }
+    // 12 waves (3 per SIMD): the ceil(N/16) query tiles dealt in pairs land 5 per SIMD at N = 320, all concurrent
+    if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 32, 8); }
+    else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 64, 12); else PRD_TA_LAUNCH(tri_attn_core_kernel, 32, 12); }
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();
 }
