@@ -245,8 +245,18 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     const int nvb = npad / 32;
     const int nqb = (N + 31) / 32;
     const int ntile = (N + 15) / 16;
-    const int h = blockIdx.x % H;
-    const int rstride = gridDim.x / H;
+    // workgroup -> (head, row slot).  Workgroup w is observed to run on XCD w % 8; the H heads of one row
+    // are given to workgroups of the SAME XCD so that the row is fetched into one L2 only (speed only).
+    const int rstride = gridDim.x / H;          // row slots
+    int h, slot;
+    if ((rstride & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        h = idx % H;
+        slot = (idx / H) * 8 + xcd;
+    } else {
+        h = blockIdx.x % H;
+        slot = blockIdx.x / H;
+    }
     stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
     stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
     stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT);
@@ -265,12 +275,12 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     // prefetch of this wave's first block of the first row
     float xnext[KH];
     {
-        const long bu0 = blockIdx.x / H;
+        const long bu0 = slot;
         const int v = wave * 32 + r;
         const bool ok = bu0 < nrows && wave < nqb && v < N;
         load_row_cll<P>(pair + row_pos(ok ? bu0 : 0, ok ? v : 0) * P, hi, ok, xnext);
     }
-    for (long bu = blockIdx.x / H; bu < nrows; bu += rstride) {
+    for (long bu = slot; bu < nrows; bu += rstride) {
         const int bb = (int)(bu / N);
         __syncthreads();                        // previous row's LDS fully consumed (and weights staged)
         const float mu = mask[bu];
