@@ -74,6 +74,96 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
     }
 }
 
+// Triangle-multiplication contraction (reference modules.py:272, "ikd,jkd->ijd" / "kid,kjd->ijd" after the
+// operand transposition done by tri_mul_proj): nch = b*P independent K-contiguous GEMMs
+//   O[ch][i][j] = sum_k A[ch][i][k] * B[ch][j][k],   A/B/O rows of pitch ldn (zero padded to a multiple of 32).
+// 64x64 output tile per workgroup (exact for N = 320), 2x2 waves of 32x32 on v_mfma_f32_32x32x2_f32, K in
+// chunks of 32 through DOUBLE-BUFFERED LDS: the global loads of chunk c+1 are in flight while chunk c is
+// multiplied, one barrier per chunk.  Workgroups of one channel are placed on one XCD (they share A/B in L2).
+template <int KCH, int NBUF>
+__global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict__ O, const float* __restrict__ AB,
+                                                               int N, int ldn, int P, int nbatch, int tiles) {
+    constexpr int LDP = KCH + 4, F = KCH / 4, RPT = 64 * F / 256;   // RPT = 16-byte groups per thread and operand
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                    // [NBUF][64][LDP]
+    float* Bs = smem + NBUF * 64 * LDP;                  // [NBUF][64][LDP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    // (channel, tile) of this workgroup
+    const int nch = nbatch * P;
+    const int t2 = tiles * tiles;
+    int ch, tile;
+    if ((nch & 7) == 0) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        ch = xcd + 8 * (k / t2);
+        tile = k % t2;
+    } else {
+        ch = blockIdx.x / t2;
+        tile = blockIdx.x % t2;
+    }
+    const int bb = ch / P, d = ch - bb * P;
+    const int m0 = (tile / tiles) * 64, n0 = (tile % tiles) * 64;
+    const float* __restrict__ A = AB + ((size_t)bb * 2 * P + d) * N * ldn;
+    const float* __restrict__ B = AB + ((size_t)bb * 2 * P + P + d) * N * ldn;
+    // staging: 64 rows x F groups of 16 B per operand and chunk = RPT groups per thread and operand
+    constexpr int RSTEP = 256 / F;                       // rows covered by one pass of the workgroup
+    const int srow = tid / F, sf = tid % F;              // rows srow + RSTEP*i
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int nchunk = (ldn + KCH - 1) / KCH;            // columns >= N hold zeros; columns >= ldn are not read
+    float4 ra[RPT], rb[RPT];
+    auto fetch = [&](int c) {
+        const int k = c * KCH + 4 * sf;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int ma = m0 + srow + RSTEP * i, nb = n0 + srow + RSTEP * i;
+            ra[i] = (ma < N && k < ldn) ? *reinterpret_cast<const float4*>(A + (size_t)ma * ldn + k) : zero4;
+            rb[i] = (nb < N && k < ldn) ? *reinterpret_cast<const float4*>(B + (size_t)nb * ldn + k) : zero4;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            *reinterpret_cast<float4*>(As + (buf * 64 + srow + RSTEP * i) * LDP + 4 * sf) = ra[i];
+            *reinterpret_cast<float4*>(Bs + (buf * 64 + srow + RSTEP * i) * LDP + 4 * sf) = rb[i];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = (NBUF == 2) ? (c & 1) : 0;
+        const bool more = c + 1 < nchunk;
+        if (more) fetch(c + 1);                           // global loads of the next chunk fly over the MFMAs
+        const float* as = As + (cur * 64 + wm0 + r) * LDP + hi * (KCH / 2);
+        const float* bs = Bs + (cur * 64 + wn0 + r) * LDP + hi * (KCH / 2);
+#pragma unroll
+        for (int t = 0; t < F / 2; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(as + 4 * t);
+            const float4 bq = *reinterpret_cast<const float4*>(bs + 4 * t);
+            acc = mfma32(a.x, bq.x, acc);
+            acc = mfma32(a.y, bq.y, acc);
+            acc = mfma32(a.z, bq.z, acc);
+            acc = mfma32(a.w, bq.w, acc);
+        }
+        if (NBUF == 1) __syncthreads();                   // single buffer: everyone done reading before the overwrite
+        if (more) stash((NBUF == 2) ? (cur ^ 1) : 0);
+        __syncthreads();
+    }
+    float* __restrict__ Oc = O + (size_t)ch * N * ldn;
+    const int n = n0 + wn0 + r;
+    if (n < N) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + wm0 + drow32(q, hi);
+            if (m < N) Oc[(size_t)m * ldn + n] = acc[q];
+        }
+    }
+}
+
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float* out, const float* pair, const float* __restrict__ O,
                                                               const float* __restrict__ wo, const float* __restrict__ bo,
@@ -572,17 +662,11 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
         if (e) return e;
     }
     {
-        PrdGemm g = {};
-        g.A = AB; g.B = AB + (size_t)P * N * ldn; g.C = O;
-        g.M = N; g.N = N; g.K = N;
-        g.lda = ldn; g.ldb = ldn; g.ldc = ldn;
-        g.G1 = b; g.G2 = P;
-        g.sa1 = (long long)2 * P * N * ldn; g.sa2 = (long long)N * ldn;
-        g.sb1 = g.sa1; g.sb2 = g.sa2;
-        g.sc1 = (long long)P * N * ldn; g.sc2 = (long long)N * ldn;
-        g.alpha = 1.f;
-        g.tile_hint = 64;
-        int e = prd_gemm(&g, stream);
+        const int tiles = prd_ceil_div(N, 64);
+        constexpr int CK = 32, CB = 2;                   // measured at N=320: (32,2) 51 us, (32,1) 83 us, (64,2) 119 us
+        const size_t clds = (size_t)2 * CB * 64 * (CK + 4) * sizeof(float);
+        hipLaunchKernelGGL((tri_mul_contract_kernel<CK, CB>), dim3(b * P * tiles * tiles), dim3(256), clds, stream, O, AB, N, ldn, P, b, tiles);
+        int e = (int)hipGetLastError();
         if (e) return e;
     }
     {
