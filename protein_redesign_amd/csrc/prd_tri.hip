@@ -80,13 +80,13 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
 // 64x64 output tile per workgroup (exact for N = 320), 2x2 waves of 32x32 on v_mfma_f32_32x32x2_f32, K in
 // chunks of 32 through DOUBLE-BUFFERED LDS: the global loads of chunk c+1 are in flight while chunk c is
 // multiplied, one barrier per chunk.  Workgroups of one channel are placed on one XCD (they share A/B in L2).
-template <int KCH, int NBUF>
 __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict__ O, const float* __restrict__ AB,
                                                                int N, int ldn, int P, int nbatch, int tiles) {
-    constexpr int LDP = KCH + 4, F = KCH / 4, RPT = 64 * F / 256;   // RPT = 16-byte groups per thread and operand
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                    // [NBUF][64][LDP]
-    float* Bs = smem + NBUF * 64 * LDP;                  // [NBUF][64][LDP]
+    // Measured alternatives at N = 320 (b = 1): this form (32-wide K chunks, two LDS buffers, 4 workgroups / CU) 51 us;
+    // one LDS buffer + register prefetch 83 us; 64-wide chunks (2 workgroups / CU) 119 us; generic prd_gemm 55 us.
+    constexpr int KCH = 32, LDP = KCH + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][64 * LDP];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64 * LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
@@ -106,42 +106,49 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
     const int m0 = (tile / tiles) * 64, n0 = (tile % tiles) * 64;
     const float* __restrict__ A = AB + ((size_t)bb * 2 * P + d) * N * ldn;
     const float* __restrict__ B = AB + ((size_t)bb * 2 * P + P + d) * N * ldn;
-    // staging: 64 rows x F groups of 16 B per operand and chunk = RPT groups per thread and operand
-    constexpr int RSTEP = 256 / F;                       // rows covered by one pass of the workgroup
-    const int srow = tid / F, sf = tid % F;              // rows srow + RSTEP*i
+    // staging assignment: thread -> (row = tid>>3 (+32), 16-byte group f = tid&7); explicit scalars, no arrays
+    const int srow = tid >> 3, sf = tid & 7;
+    const bool a0 = (m0 + srow) < N, a1 = (m0 + srow + 32) < N, b0 = (n0 + srow) < N, b1 = (n0 + srow + 32) < N;
+    const float* pa0 = A + (size_t)(a0 ? m0 + srow : 0) * ldn + 4 * sf;
+    const float* pa1 = A + (size_t)(a1 ? m0 + srow + 32 : 0) * ldn + 4 * sf;
+    const float* pb0 = B + (size_t)(b0 ? n0 + srow : 0) * ldn + 4 * sf;
+    const float* pb1 = B + (size_t)(b1 ? n0 + srow + 32 : 0) * ldn + 4 * sf;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    const int nchunk = (ldn + KCH - 1) / KCH;            // columns >= N hold zeros; columns >= ldn are not read
-    float4 ra[RPT], rb[RPT];
-    auto fetch = [&](int c) {
-        const int k = c * KCH + 4 * sf;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int ma = m0 + srow + RSTEP * i, nb = n0 + srow + RSTEP * i;
-            ra[i] = (ma < N && k < ldn) ? *reinterpret_cast<const float4*>(A + (size_t)ma * ldn + k) : zero4;
-            rb[i] = (nb < N && k < ldn) ? *reinterpret_cast<const float4*>(B + (size_t)nb * ldn + k) : zero4;
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            *reinterpret_cast<float4*>(As + (buf * 64 + srow + RSTEP * i) * LDP + 4 * sf) = ra[i];
-            *reinterpret_cast<float4*>(Bs + (buf * 64 + srow + RSTEP * i) * LDP + 4 * sf) = rb[i];
-        }
-    };
-    fetch(0);
-    stash(0);
+    const int nchunk = ldn / KCH;                        // ldn is a multiple of 32; columns >= N hold zeros
+    // rows past the edge are loaded from row 0 (always valid) and zeroed in registers: a select between a load and
+    // a constant would be lowered to a load from a stack slot (scratch memory) instead
+    float4 ra0 = *reinterpret_cast<const float4*>(pa0), ra1 = *reinterpret_cast<const float4*>(pa1);
+    float4 rb0 = *reinterpret_cast<const float4*>(pb0), rb1 = *reinterpret_cast<const float4*>(pb1);
+    if (!a0) ra0 = zero4;
+    if (!a1) ra1 = zero4;
+    if (!b0) rb0 = zero4;
+    if (!b1) rb1 = zero4;
+    *reinterpret_cast<float4*>(&As[0][srow * LDP + 4 * sf]) = ra0;
+    *reinterpret_cast<float4*>(&As[0][(srow + 32) * LDP + 4 * sf]) = ra1;
+    *reinterpret_cast<float4*>(&Bs[0][srow * LDP + 4 * sf]) = rb0;
+    *reinterpret_cast<float4*>(&Bs[0][(srow + 32) * LDP + 4 * sf]) = rb1;
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
-        const int cur = (NBUF == 2) ? (c & 1) : 0;
+        const int cur = c & 1;
         const bool more = c + 1 < nchunk;
-        if (more) fetch(c + 1);                           // global loads of the next chunk fly over the MFMAs
-        const float* as = As + (cur * 64 + wm0 + r) * LDP + hi * (KCH / 2);
-        const float* bs = Bs + (cur * 64 + wn0 + r) * LDP + hi * (KCH / 2);
+        if (more) {                                       // next chunk's global loads fly over this chunk's MFMAs
+            const int ko = (c + 1) * KCH;
+            ra0 = *reinterpret_cast<const float4*>(pa0 + ko);
+            ra1 = *reinterpret_cast<const float4*>(pa1 + ko);
+            rb0 = *reinterpret_cast<const float4*>(pb0 + ko);
+            rb1 = *reinterpret_cast<const float4*>(pb1 + ko);
+            if (!a0) ra0 = zero4;
+            if (!a1) ra1 = zero4;
+            if (!b0) rb0 = zero4;
+            if (!b1) rb1 = zero4;
+        }
+        const float* as = &As[cur][(wm0 + r) * LDP + hi * 16];
+        const float* bs = &Bs[cur][(wn0 + r) * LDP + hi * 16];
 #pragma unroll
-        for (int t = 0; t < F / 2; ++t) {
+        for (int t = 0; t < 4; ++t) {
             const float4 a = *reinterpret_cast<const float4*>(as + 4 * t);
             const float4 bq = *reinterpret_cast<const float4*>(bs + 4 * t);
             acc = mfma32(a.x, bq.x, acc);
@@ -149,8 +156,12 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
             acc = mfma32(a.z, bq.z, acc);
             acc = mfma32(a.w, bq.w, acc);
         }
-        if (NBUF == 1) __syncthreads();                   // single buffer: everyone done reading before the overwrite
-        if (more) stash((NBUF == 2) ? (cur ^ 1) : 0);
+        if (more) {
+            *reinterpret_cast<float4*>(&As[cur ^ 1][srow * LDP + 4 * sf]) = ra0;
+            *reinterpret_cast<float4*>(&As[cur ^ 1][(srow + 32) * LDP + 4 * sf]) = ra1;
+            *reinterpret_cast<float4*>(&Bs[cur ^ 1][srow * LDP + 4 * sf]) = rb0;
+            *reinterpret_cast<float4*>(&Bs[cur ^ 1][(srow + 32) * LDP + 4 * sf]) = rb1;
+        }
         __syncthreads();
     }
     float* __restrict__ Oc = O + (size_t)ch * N * ldn;
@@ -663,9 +674,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     }
     {
         const int tiles = prd_ceil_div(N, 64);
-        constexpr int CK = 32, CB = 2;                   // measured at N=320: (32,2) 51 us, (32,1) 83 us, (64,2) 119 us
-        const size_t clds = (size_t)2 * CB * 64 * (CK + 4) * sizeof(float);
-        hipLaunchKernelGGL((tri_mul_contract_kernel<CK, CB>), dim3(b * P * tiles * tiles), dim3(256), clds, stream, O, AB, N, ldn, P, b, tiles);
+        hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(b * P * tiles * tiles), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
         int e = (int)hipGetLastError();
         if (e) return e;
     }
