@@ -135,6 +135,12 @@ int prd_tri_attn_out(float* out, const float* pair, const float* og, const float
 /* pair transition (modules.py:321-326): out = (residual ? pair : 0) + W2 relu(W1 LN(pair) + b1) + b2, hidden = 4P */
 int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
                         const float* b2, int residual, int b, int N, int P, int* queue, hipStream_t stream);
+/* fused tail of a folding block, in place on `pair`: output projection of the ENDING triangle attention
+ * (og from prd_tri_attn_core; modules.py:341), pair transition (modules.py:342), and optionally the next block's
+ * attention bias Linear(LN(pair)) -> bias_out[b,H,N,N] (modules.py:300-304; bias_out NULL = skip). */
+int prd_block_tail(float* pair, const float* og, const float* wo, const float* bo, const float* w1, const float* b1,
+                   const float* w2, const float* b2, const float* bias_w, const float* bias_b, float* bias_out,
+                   int b, int N, int P, int H, int* queue, hipStream_t stream);
 /* coordinate head (modules.py:403 + model.py:364-372): symmetrise, LN -> Linear -> ReLU -> Linear(1),
  * eps_raw[b,N,3] = sum_j m_i m_j w_ij (z_i - z_j) rsqrt(|z_i - z_j|^2 + 1e-4)  (mean not yet removed) */
 int prd_coord_head(float* eps_raw, const float* pair, const float* z, const float* mask,

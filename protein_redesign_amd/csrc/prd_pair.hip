@@ -457,6 +457,94 @@ __global__ __launch_bounds__(NW * 64) void pair_transition_kernel(int* queue, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused tail of a folding block (reference modules.py:341-342 and the next block's :300-304):
+//   pair += W_o og + b_o                     (output projection of the ending triangle attention)
+//   pair += W_2 relu(W_1 LN(pair) + b_1) + b_2                                  (pair transition)
+//   bias_out[b,h,i,j] = Linear_h(LN(pair))   (attention bias of the NEXT block's single attention; optional)
+// All three are row-local, so one pass reads og + pair and writes pair (+ the H-channel bias) instead of three
+// kernels reading / writing the pair tensor three times.
+// ------------------------------------------------------------------------------------------------
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void block_tail_kernel(int* queue, float* pair, const float* __restrict__ og,
+                                                             const float* __restrict__ wo, const float* __restrict__ bo,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             const float* __restrict__ wb, const float* __restrict__ bb_,
+                                                             float* __restrict__ bias_out, int H, long rows, long nn) {
+    constexpr int KH = P / 2, HID = 4 * P, HH = HID / 2, NB = P / 32, HC = 64;
+    constexpr int PASSES = 4, HBP = HID / 32 / PASSES, HHP = HH / PASSES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W1l = smem;                         // [HID][P+4]
+    float* W2l = W1l + HID * (P + 4);          // [P][HID+4]
+    float* Wol = W2l + P * (HID + 4);          // [P][HC+4]
+    float* b1l = Wol + P * (HC + 4);           // [HID] CLL
+    float* b2l = b1l + HID;                    // [P] CLL
+    float* bol = b2l + P;                      // [P] CLL
+    float* wbl = bol + P;                      // [8][P] CLL (bias head)
+    const int NT = NW * 64;
+    stage_weight_cll<P>(W1l, w1, HID, P, threadIdx.x, NT);
+    stage_weight_cll<HID>(W2l, w2, P, HID, threadIdx.x, NT);
+    stage_weight_cll<HC>(Wol, wo, P, HC, threadIdx.x, NT);
+    stage_vec_cll(b1l, b1, HID, threadIdx.x, NT);
+    stage_vec_cll(b2l, b2, P, threadIdx.x, NT);
+    stage_vec_cll(bol, bo, P, threadIdx.x, NT);
+    if (bias_out)
+        for (int h = 0; h < H; ++h) stage_vec_cll(wbl + h * P, wb + h * P, P, threadIdx.x, NT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long ntask = (rows + 31) / 32;
+    WaveTasks tasks(queue, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        const long pos = task * 32 + r;
+        const bool valid = pos < rows;
+        float raw[KH];
+        {
+            float xo[HC / 2];
+            load_row_cll<HC>(og + pos * HC, hi, valid, xo);
+            f32x16 acc[NB];
+            zero_acc(acc);
+            rowgemm<HC, NB>(Wol, xo, acc, r, hi);
+            load_row_cll<P>(pair + pos * P, hi, valid, raw);
+#pragma unroll
+            for (int s = 0; s < KH; ++s) raw[s] = raw[s] + (acc[s >> 4][s & 15] + bol[hi * KH + s]);
+        }
+        float x[KH];
+#pragma unroll
+        for (int s = 0; s < KH; ++s) x[s] = raw[s];
+        ln_cll<KH>(x);
+        f32x16 acc2[NB];
+        zero_acc(acc2);
+#define PRD_PT_PASS(Q)                                                                                              \
+        {                                                                                                           \
+            float h[HHP];                                                                                           \
+            f32x16 acc[HBP];                                                                                        \
+            zero_acc(acc);                                                                                          \
+            rowgemm<P, HBP>(W1l + (Q) * HBP * 32 * (P + 4), x, acc, r, hi);                                         \
+            _Pragma("unroll") for (int s = 0; s < HHP; ++s)                                                         \
+                h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s], 0.f);                             \
+            rowgemm_part<HID, NB, (Q) * HHP / 4, ((Q) + 1) * HHP / 4>(W2l, h, acc2, r, hi);                         \
+        }
+        PRD_PT_PASS(0) PRD_PT_PASS(1) PRD_PT_PASS(2) PRD_PT_PASS(3)
+#undef PRD_PT_PASS
+#pragma unroll
+        for (int s = 0; s < KH; ++s) raw[s] = raw[s] + (acc2[s >> 4][s & 15] + b2l[hi * KH + s]);
+        store_row_cll<P>(pair + pos * P, hi, valid, raw);
+        if (bias_out) {
+            ln_cll<KH>(raw);
+            const long bb = pos / nn, rem = pos - bb * nn;
+            for (int h = 0; h < H; ++h) {
+                float a = 0.f;
+#pragma unroll
+                for (int s = 0; s < KH; ++s) a += raw[s] * wbl[h * P + hi * KH + s];
+                a = xhalf_sum(a);
+                if (bb_) a += bb_[h];
+                if (valid && hi == 0) bias_out[(bb * H + h) * nn + rem] = a;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // coordinate head: one workgroup per (b,i); 4 waves split the j blocks; fixed-order reduction
 // ------------------------------------------------------------------------------------------------
 template <int P>
@@ -735,6 +823,27 @@ extern "C" int prd_pair_transition(float* out, const float* pair, const float* w
     } else {
         PRD_SET_LDS((pair_transition_kernel<32, NWT>), lds);
         hipLaunchKernelGGL((pair_transition_kernel<32, NWT>), dim3(grid), dim3(NWT * 64), lds, stream, queue, out, pair, w1, b1, w2, b2, rows, residual);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_block_tail(float* pair, const float* og, const float* wo, const float* bo, const float* w1, const float* b1,
+                              const float* w2, const float* b2, const float* bias_w, const float* bias_b, float* bias_out,
+                              int b, int N, int P, int H, int* queue, hipStream_t stream) {
+    if (!pair || !og || !wo || !bo || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (bias_out && (!bias_w || H <= 0 || H > 8)) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    constexpr int NWT = 8;
+    const long rows = (long)b * N * N;
+    const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + (size_t)P * 68 + 6 * P + 8 * P) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    const int grid = grid_for((rows + 31) / 32, NWT, 256);
+    if (P == 64) {
+        PRD_SET_LDS((block_tail_kernel<64, NWT>), lds);
+        hipLaunchKernelGGL((block_tail_kernel<64, NWT>), dim3(grid), dim3(NWT * 64), lds, stream, queue, pair, og, wo, bo, w1, b1, w2, b2, bias_w, bias_b, bias_out, H, rows, (long)N * N);
+    } else {
+        PRD_SET_LDS((block_tail_kernel<32, NWT>), lds);
+        hipLaunchKernelGGL((block_tail_kernel<32, NWT>), dim3(grid), dim3(NWT * 64), lds, stream, queue, pair, og, wo, bo, w1, b1, w2, b2, bias_w, bias_b, bias_out, H, rows, (long)N * N);
     }
     return (int)hipGetLastError();
 }

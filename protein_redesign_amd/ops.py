@@ -218,6 +218,21 @@ def pair_transition(pair, w1, b1, w2, b2, *, residual: bool, out=None) -> torch.
     return out
 
 
+def block_tail_(pair, og, wo, bo, w1, b1, w2, b2, bias_w=None, bias_b=None) -> Optional[torch.Tensor]:
+    """In place: pair += W_o og + b_o; pair += transition(pair); returns the next block's attention bias
+    [b,H,N,N] = Linear(LN(pair)) when ``bias_w`` is given (else None)."""
+    b, N, _, P = pair.shape
+    bias_out = None
+    H = 0
+    if bias_w is not None:
+        H = bias_w.shape[0]
+        bias_out = torch.empty(b, H, N, N, device=pair.device, dtype=F32)
+    check(lib().prd_block_tail(dptr(pair), dptr(og), dptr(wo), dptr(bo), dptr(w1), dptr(b1), dptr(w2), dptr(b2),
+                               dptr(bias_w), dptr(bias_b), dptr(bias_out), b, N, P, H, task_queue(pair.device), stream()),
+          "prd_block_tail")
+    return bias_out
+
+
 def coord_head(pair, z, mask, w1, b1, w2) -> torch.Tensor:
     b, N, _, P = pair.shape
     out = torch.empty(b, N, 3, device=pair.device, dtype=F32)

@@ -211,10 +211,18 @@ class FoldingBlock(nn.Module):
             Linear(pair_dim * transition_factor, pair_dim, init="final"),
         )
 
-    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """In-place on ``pair``; returns the new single and the same pair tensor."""
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, bias=None, next_block=None):
+        """In place on ``pair``.  ``bias``: this block's attention bias if the previous block's fused tail
+        already produced it; ``next_block``: the following FoldingBlock, whose attention bias is then computed
+        by this block's fused tail.  Returns (single, pair, next_bias or None)."""
         sa = self.single_attn
-        bias = ops.pair_bias(pair, self.attn_bias[1].weight, self.attn_bias[1].bias)
+        b, N = mask.shape
+        if ws is None:
+            ws = torch.empty(max(ops.workspace_bytes("tri_mul", b, N, 0, pair.shape[-1]),
+                                 ops.workspace_bytes("tri_attn", b, N, 0, pair.shape[-1])) // 4,
+                             device=pair.device, dtype=torch.float32)
+        if bias is None:
+            bias = ops.pair_bias(pair, self.attn_bias[1].weight, self.attn_bias[1].bias)
         xn = ops.layer_norm(single)
         single = sa.run_single(xn, mask, bias, single)
         fc = self.single_fc
@@ -223,13 +231,21 @@ class FoldingBlock(nn.Module):
         self.pair_mul_outgoing.run(pair, mask, residual=True, out=pair, ws=ws)
         self.pair_mul_incoming.run(pair, mask, residual=True, out=pair, ws=ws)
         self.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)
-        self.pair_attn_ending.run(pair, mask, residual=True, out=pair, ws=ws)
+        # ending triangle attention: core kernel, then ONE fused row pass = its output projection + the pair
+        # transition + (if there is a next block) that block's attention bias
+        ta = self.pair_attn_ending.attn
+        og = ops.tri_attn_core(pair, mask, ta.weights()[:5], ta.num_heads, ta.head_dim, ending=True,
+                               og=ws[: b * N * N * 64].view(b, N, N, 64))
         pf = self.pair_fc
-        ops.pair_transition(pair, pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias, residual=True, out=pair)
-        return single, pair
+        nb_w = next_block.attn_bias[1].weight if next_block is not None else None
+        nb_b = next_block.attn_bias[1].bias if next_block is not None else None
+        next_bias = ops.block_tail_(pair, og, ta.out_proj.weight, ta.out_proj.bias, pf[1].weight, pf[1].bias,
+                                    pf[3].weight, pf[3].bias, nb_w, nb_b)
+        return single, pair, next_bias
 
     def forward(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        return self.run_(single.contiguous(), pair.contiguous().clone(), mask.contiguous())
+        single, pair, _ = self.run_(single.contiguous(), pair.contiguous().clone(), mask.contiguous())
+        return single, pair
 
 
 class Denoiser(nn.Module):
@@ -262,8 +278,11 @@ class Denoiser(nn.Module):
             ws = torch.empty(self.ws_floats(b, N), device=pair.device, dtype=torch.float32)
         self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair)
         single = self.SPAAttnBlock(single, pair, mask)
-        for block in self.folding_blocks:
-            single, pair = block.run_(single, pair, mask, ws=ws)
+        bias = None
+        blocks = list(self.folding_blocks)
+        for i, block in enumerate(blocks):
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            single, pair, bias = block.run_(single, pair, mask, ws=ws, bias=bias, next_block=nxt)
         return single, pair
 
     def forward(self, batch, z, t, single, pair, cache):
