@@ -327,7 +327,7 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
 //            operand layouts of the 16x16x4 MFMAs.  The next row's block is already in registers (prefetch).
 //   phase 2: the ceil(N/16) query tiles are dealt round-robin to the waves (SIMD-balanced: waves w and w+4
 //            share a SIMD), two tiles at a time through ta_keyloop.
-template <int P, int NW>
+template <int P, int NW, bool PREFETCH>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     };
     // prefetch of this wave's first block of the first row
     float xnext[KH];
-    {
+    if (PREFETCH) {
         const long bu0 = slot;
         const int v = wave * 32 + r;
         const bool ok = bu0 < nrows && wave < nqb && v < N;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
             float vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (vb < nqb) {                                   // blocks past the sequence end are all zeros
                 float x[KH];
-                if (vb == wave) {
+                if (PREFETCH && vb == wave) {
 #pragma unroll
                     for (int s = 0; s < KH; ++s) x[s] = xnext[s];
                 } else {
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         }
         __syncthreads();
         // next row's first block: in flight during the whole key loop
-        {
+        if (PREFETCH) {
             const long bun = bu + rstride;
             const int v = wave * 32 + r;
             const bool ok = bun < nrows && wave < nqb && v < N;
@@ -709,15 +709,16 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     const long rounds = (rows_total + per_head - 1) / per_head;
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
-#define PRD_TA_LAUNCH(KERNEL, PP, NW)                                                                                  \
+#define PRD_TA_LAUNCH(KERNEL, NWV, ...)                                                                                \
     do {                                                                                                               \
-        PRD_SET_LDS((KERNEL<PP, NW>), lds);                                                                            \
-        hipLaunchKernelGGL((KERNEL<PP, NW>), dim3(grid), dim3(NW * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
+        PRD_SET_LDS((KERNEL<__VA_ARGS__>), lds);                                                                       \
+        hipLaunchKernelGGL((KERNEL<__VA_ARGS__>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending); \
     } while (0)
     (void)nqb; (void)nw;
-    // 12 waves (3 per SIMD): the ceil(N/16) query tiles dealt in pairs land 5 per SIMD at N = 320, all concurrent
-    if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 32, 8); }
-    else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 64, 12); else PRD_TA_LAUNCH(tri_attn_core_kernel, 32, 12); }
+    // 12 waves (3 per SIMD) + next-row prefetch: the ceil(N/16) query tiles dealt in pairs land 5 per SIMD at N = 320
+    // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
+    if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
+    else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true); }
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();
 }
