@@ -132,6 +132,10 @@ int prd_tri_attn_core(float* og, const float* pair, const float* mask, const flo
                       int b, int N, int P, int H, int c, hipStream_t stream);
 int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
                      int residual, int b, int N, int P, int* queue, hipStream_t stream);
+/* single-track gated attention core for heads of width 16 (modules.py:216-223): qkvg = [q/sqrt(c) | k | v | sigmoid(gate)]
+ * of shape [b,N,4*H*c] (one packed prd_gemm), bias [b,H,N,N], mask [b,N] or NULL -> o[b,N,H*c] = gate * softmax(qk + bias) v */
+int prd_single_attn_core(float* o, const float* qkvg, const float* bias, const float* mask,
+                         int b, int N, int H, int c, hipStream_t stream);
 /* pair transition (modules.py:321-326): out = (residual ? pair : 0) + W2 relu(W1 LN(pair) + b1) + b2, hidden = 4P */
 int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
                         const float* b2, int residual, int b, int N, int P, int* queue, hipStream_t stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, vp],
+    "prd_single_attn_core": [vp] * 4 + [ci] * 4 + [vp],
     "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],

@@ -321,6 +321,112 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
     for (int t = 0; t < NTQ; ++t) l_tot[t] = rows4_sum(l_run[t]);
 }
 
+// Single-track gated attention core (reference modules.py:216-223 with the pair bias of :300-304), heads of width 16:
+// o[b,q,h*16+c] = gate * softmax_k(q.k + bias[b,h,q,k], keys with mask < 0.5 filled with -2^15) v.  One workgroup per
+// (b, h, 64 queries): K_h / V_h^T of all N nodes are staged in LDS, each wave streams the keys for one 16-query tile
+// with the same swapped 16x16x4 MFMA scheme as the triangle attention.  Replaces three launches (logits GEMM, row
+// softmax, P*V GEMM) and the [b,H,N,N] logits round trip.
+__global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict__ o_out, const float* __restrict__ qkvg,
+                                                               const float* __restrict__ bias, const float* __restrict__ mask,
+                                                               int b, int N, int npad, int H) {
+    constexpr int C = 16, HC = 64, L = 4 * HC;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Kl = smem;                          // [npad][KP]
+    float* Vt = Kl + npad * KP;                // [16][npad+4]
+    float* kadd = Vt + C * (npad + 4);         // [npad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 15, g4 = lane >> 4;
+    const int qblocks = (N + 63) / 64;
+    const int qb = blockIdx.x % qblocks;
+    const int bh = blockIdx.x / qblocks;
+    const int h = bh % H, bb = bh / H;
+    const float* base = qkvg + (size_t)bb * N * L;
+    for (int idx = tid; idx < npad * 4; idx += 256) {          // K rows: 4 groups of 16 B per node
+        const int j = idx >> 2, f = idx & 3;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (j < N) {
+            kv = *reinterpret_cast<const float4*>(base + (size_t)j * L + HC + h * C + 4 * f);
+            vv = *reinterpret_cast<const float4*>(base + (size_t)j * L + 2 * HC + h * C + 4 * f);
+        }
+        *reinterpret_cast<float4*>(Kl + j * KP + 4 * f) = kv;
+        Vt[(4 * f + 0) * (npad + 4) + j] = vv.x;
+        Vt[(4 * f + 1) * (npad + 4) + j] = vv.y;
+        Vt[(4 * f + 2) * (npad + 4) + j] = vv.z;
+        Vt[(4 * f + 3) * (npad + 4) + j] = vv.w;
+    }
+    for (int k = tid; k < npad; k += 256) {
+        const bool inside = k < N;
+        const bool keep = inside && (!mask || mask[(size_t)bb * N + (inside ? k : 0)] >= 0.5f);
+        kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
+    }
+    __syncthreads();
+    const int q = qb * 64 + wave * 16 + ql;
+    const bool qok = q < N;
+    const int qq = qok ? q : 0;
+    const float4 qf = *reinterpret_cast<const float4*>(base + (size_t)qq * L + h * C + 4 * g4);   // already scaled by 1/sqrt(c)
+    const float* brow = bias + (((size_t)bb * H + h) * N + qq) * N;
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int key0 = 0; key0 < npad; key0 += 32) {
+        f32x4 s[2];
+        float4 ma[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 kf = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
+            ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
+            f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            z4 = mfma16(kf.x, qf.x, z4);
+            z4 = mfma16(kf.y, qf.y, z4);
+            z4 = mfma16(kf.z, qf.z, z4);
+            z4 = mfma16(kf.w, qf.w, z4);
+            s[j] = z4;
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float mav[4] = {ma[j].x, ma[j].y, ma[j].z, ma[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = key0 + 16 * j + 4 * g4 + e;
+                const float bv = (key < N) ? brow[key] : 0.f;
+                const float v = (s[j][e] + bv) * LOG2E;                   // logits + bias, exp2 domain
+                s[j][e] = (mav[e] == 0.f) ? v : mav[e];
+                tmax = fmaxf(tmax, s[j][e]);
+            }
+        }
+        tmax = rows4_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(s[j][e] - m_new);
+                s[j][e] = pe;
+                psum += pe;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 vf = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
+            o = mfma16(vf.x, s[j][0], o);
+            o = mfma16(vf.y, s[j][1], o);
+            o = mfma16(vf.z, s[j][2], o);
+            o = mfma16(vf.w, s[j][3], o);
+        }
+    }
+    const float l_tot = rows4_sum(l_run);
+    if (qok) {
+        const float4 gf = *reinterpret_cast<const float4*>(base + (size_t)q * L + 3 * HC + h * C + 4 * g4);
+        *reinterpret_cast<float4*>(o_out + ((size_t)bb * N + q) * HC + h * C + 4 * g4) =
+            make_float4(gf.x * (o[0] / l_tot), gf.y * (o[1] / l_tot), gf.z * (o[2] / l_tot), gf.w * (o[3] / l_tot));
+    }
+}
+
 // One workgroup (NW waves, persistent) serves head h = blockIdx % H for a strided set of pair rows.
 //   phase 1: each wave LayerNorms 32-position blocks of the row and projects [k_h; v_h; q_h; g_h] (64 outputs)
 //            on v_mfma_f32_32x32x2_f32; K, V^T, Q (pre-scaled by log2(e)/sqrt(c)) and the gate go to LDS in the
@@ -720,6 +826,18 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
     else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true); }
 #undef PRD_TA_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_single_attn_core(float* o, const float* qkvg, const float* bias, const float* mask,
+                                    int b, int N, int H, int c, hipStream_t stream) {
+    if (!o || !qkvg || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
+    const int npad = prd_round_up(N, 32);
+    const size_t lds = ((size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    PRD_SET_LDS(single_attn_core_kernel, lds);
+    hipLaunchKernelGGL(single_attn_core_kernel, dim3(b * H * prd_ceil_div(N, 64)), dim3(256), lds, stream, o, qkvg, bias, mask, b, N, npad, H);
     return (int)hipGetLastError();
 }
 

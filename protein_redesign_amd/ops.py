@@ -304,13 +304,18 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     L = 4 * HC
     qkvg = torch.empty(b, N, L, device=x_normed.device, dtype=F32)
     gemm(x_normed, w, qkvg, b * N, L, S, S, S, L, bias=pbias, colscale=colscale, act=2, act_from=3 * HC)
+    o = torch.empty(b, N, HC, device=x_normed.device, dtype=F32)
+    if c == 16 and HC == 64:
+        # heads of width 16 (FoldingBlock.single_attn): fused logits + bias + mask + softmax + PV + gate
+        check(lib().prd_single_attn_core(dptr(o), dptr(qkvg), dptr(bias), dptr(mask) if key_mask else None,
+                                         b, N, H, c, stream()), "prd_single_attn_core")
+        return linear(o, wo, bo, resid=resid)
     ldp = round_up(N, 4)
     logits = torch.empty(b, H, N, ldp, device=x_normed.device, dtype=F32)
     gemm(qkvg, qkvg, logits, N, N, c, L, L, ldp, b_off=HC, G1=b, G2=H, sa=(N * L, c), sb=(N * L, c),
          sc=(H * N * ldp, N * ldp), addmat=bias, sad=(H * N * N, N * N), ldadd=N,
          colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15))
     softmax_rows_(logits, N)
-    o = torch.empty(b, N, HC, device=x_normed.device, dtype=F32)
     gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
          sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L)
     return linear(o, wo, bo, resid=resid)
