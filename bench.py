@@ -131,8 +131,12 @@ def main():
         kus = e0.elapsed_time(e1) * 1e3 / reps
         kfl = tri_attn_core_flops(bpg, N, P)
         ach = kfl / (kus * 1e-6) / 1e12
+        traffic = None          # HBM-side bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and bpg == 1 and N == 320:
+            traffic = json.load(open(tpath))["tri_attn_core_kernel"]["traffic_bytes_per_launch"]
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "kernel": "tri_attn_core_kernel", "launches_per_step": 2 * NB,
                     "flops_per_launch": kfl, "avg_launch_us": round(kus, 2)}
 
