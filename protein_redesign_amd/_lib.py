@@ -8,7 +8,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libprd_hip.so")
+LIB_PATH = os.environ.get("PRD_LIB", os.path.join(HERE, "libprd_hip.so"))   # PRD_LIB: experiment builds
 
 vp, ci, cf, cz, cll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 

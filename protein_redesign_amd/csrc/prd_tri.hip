@@ -244,7 +244,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 // The key loop of one wave for NTQ (1 or 2) 16-query tiles: S^T = K Q^T, online softmax in the exp2
 // domain over blocks of 16*JT keys, O^T += V^T P^T.  Returns O^T[c = 4*g4 + e][q = ql] / l per tile.
-template <int NTQ>
+template <int NTQ, bool MASKED>
 PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ Vt, const float* __restrict__ kadd,
                         const float4 (&qf)[NTQ], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
     constexpr int JT = 2;                      // 16-key tiles per online-softmax update (32 keys): register budget
@@ -260,7 +260,7 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             kf[j] = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
-            ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
+            if (MASKED) ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
         }
         f32x4 s[NTQ][JT];
 #pragma unroll
@@ -275,6 +275,16 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
                 s[t][j] = z4;
             }
         __builtin_amdgcn_sched_barrier(0);                  // V^T is fetched behind the QK^T MFMAs, not before them
+#if defined(PRD_ABLATE) && PRD_ABLATE == 1
+        {   // ablation: no softmax arithmetic (keeps every MFMA and LDS read)
+            float4 vf0[JT];
+            _Pragma("unroll") for (int j = 0; j < JT; ++j) vf0[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
+            _Pragma("unroll") for (int j = 0; j < JT; ++j) _Pragma("unroll") for (int t = 0; t < NTQ; ++t) {
+                o[t] = mfma16(vf0[j].x, s[t][j][0] + ma[j].x, o[t]); o[t] = mfma16(vf0[j].y, s[t][j][1], o[t]);
+                o[t] = mfma16(vf0[j].z, s[t][j][2], o[t]); o[t] = mfma16(vf0[j].w, s[t][j][3], o[t]); }
+            continue;
+        }
+#endif
         float4 vf[JT];
 #pragma unroll
         for (int j = 0; j < JT; ++j)
@@ -284,10 +294,12 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
             float tmax = -INFINITY;
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x;
-                s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y;
-                s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z;
-                s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w;
+                if (MASKED) {
+                    s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x;
+                    s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y;
+                    s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z;
+                    s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w;
+                }
                 tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][j][0], s[t][j][1]), fmaxf(s[t][j][2], s[t][j][3])));
             }
             tmax = rows4_max(tmax);
@@ -547,6 +559,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
             load_row_cll<P>(pair + row_pos(ok ? bun : 0, ok ? v : 0) * P, hi, ok, xnext);
         }
         // ---- phase 2 ----
+        // rows without masked or padded keys (the common case) take a key loop without the per-key override
+        bool row_masked = false;
+        for (int k = lane; k < npad; k += 64) row_masked |= (kadd[k] != 0.f);
+        row_masked = __any(row_masked);
         for (int t0 = wave; t0 < ntile; t0 += 2 * NW) {
             const int t1 = t0 + NW;
             if (t1 < ntile) {
@@ -555,7 +571,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 qf[1] = *reinterpret_cast<const float4*>(Ql + (16 * t1 + ql) * KP + 4 * g4);
                 f32x4 o[2];
                 float l_tot[2];
-                ta_keyloop<2>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
+                if (row_masked) ta_keyloop<2, true>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
+                else ta_keyloop<2, false>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int v = 16 * (t == 0 ? t0 : t1) + ql;
@@ -571,7 +588,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 qf[0] = *reinterpret_cast<const float4*>(Ql + (16 * t0 + ql) * KP + 4 * g4);
                 f32x4 o[1];
                 float l_tot[1];
-                ta_keyloop<1>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
+                if (row_masked) ta_keyloop<1, true>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
+                else ta_keyloop<1, false>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
                 const int v = 16 * t0 + ql;
                 if (v < N) {
                     const float4 gf = *reinterpret_cast<const float4*>(Gl + v * KP + 4 * g4);
@@ -682,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_long_kernel(
             }
             f32x4 o[2];
             float l_tot[2];
-            ta_keyloop<2>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
+            ta_keyloop<2, true>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int v = qb * 32 + 16 * t + ql;
