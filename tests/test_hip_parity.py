@@ -167,6 +167,31 @@ def test_pair_transition(setup):
     assert rel_l2(got.cpu(), O.transition(s["params"], "Denoiser.folding_blocks.0.pair_fc", s["pair"])) < OP_TOL
 
 
+def test_block_tail_fusion_and_queue_reset(setup):
+    """Fused tail (ending tri-attn output projection + pair transition + next block's bias) == the three separate
+    oracle ops; and every persistent-kernel task queue counter is back at zero afterwards."""
+    s = setup
+    m, p, args = s["model"], s["params"], s["args"]
+    blk, nxt = m.Denoiser.folding_blocks[0], m.Denoiser.folding_blocks[1]
+    H, c = args["num_heads"], args["head_dim"]
+    m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
+    with torch.inference_mode():
+        want = s["pair"] + O.triangle_attention(p, "Denoiser.folding_blocks.0.pair_attn_ending", s["pair"], m2, H, c, True)
+        want = want + O.transition(p, "Denoiser.folding_blocks.0.pair_fc", want)
+        want_bias = O.pair_bias(p, "Denoiser.folding_blocks.1.attn_bias", want)
+    pair = cu(s["pair"]).clone()
+    ta = blk.pair_attn_ending.attn
+    og = ops.tri_attn_core(pair, cu(s["mask"]), ta.weights()[:5], H, c, ending=True)
+    pf = blk.pair_fc
+    bias = ops.block_tail_(pair, og, ta.out_proj.weight, ta.out_proj.bias, pf[1].weight, pf[1].bias, pf[3].weight,
+                           pf[3].bias, nxt.attn_bias[1].weight, nxt.attn_bias[1].bias)
+    assert rel_l2(pair.cpu(), want) < BLOCK_TOL
+    assert rel_l2(bias.cpu(), want_bias) < BLOCK_TOL
+    torch.cuda.synchronize()
+    for q in ops._QUEUES.values():
+        assert int(q.abs().sum()) == 0
+
+
 def test_outer_product_update(setup):
     s = setup
     got = s["model"].Denoiser.opm(cu(s["single"]), cu(s["mask"]))
