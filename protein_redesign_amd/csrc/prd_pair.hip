@@ -330,7 +330,9 @@ __global__ __launch_bounds__(WG) void outer_linear_kernel(float* out, const floa
 
 // outer-linear, resident-weight variant: all of W1 [P][S] stays in LDS (132 KB at S=512, P=64) for the
 // lifetime of a persistent workgroup, so the task loop has no workgroup barrier and every wave pulls
-// (i, j-block) tasks from the device queue on its own.
+// tasks from the device queue on its own.
+// The product term W1 (x_i * x_j) is SYMMETRIC in (i, j): a task (i, 32-block of j >= block of i) computes it once and
+// writes both out[i,j] = S + u_i - u_j + b and out[j,i] = S + u_j - u_i + b  (55 % of the MFMAs of the full square).
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, float* out, const float* pair,
                                                                    const float* __restrict__ x, const float* __restrict__ u,
@@ -345,14 +347,22 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, f
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const int nvb = (N + 31) / 32;
-    const long ntask = (long)b * N * nvb;
+    const int npairs = nvb * (nvb + 1) / 2;                // block pairs (ib <= jb)
+    const long ntask = (long)b * npairs * 32;              // 32 rows i per block pair
     const int kb = hi * (S / 2);
     WaveTasks tasks(queue, ntask, NW);
     for (long task = tasks.next(); task >= 0; task = tasks.next()) {
-        const int vb = (int)(task % nvb);
-        const long bi = task / nvb;
-        const int bb = (int)(bi / N);
-        const int j = vb * 32 + r;
+        const int ii = (int)(task & 31);
+        const long t2 = task >> 5;
+        const int bb = (int)(t2 / npairs);
+        int pidx = (int)(t2 - (long)bb * npairs);
+        int ib = 0;
+        while (pidx >= nvb - ib) { pidx -= nvb - ib; ++ib; }
+        const int jb = ib + pidx;
+        const int i = ib * 32 + ii;
+        if (i >= N) continue;                              // wave-uniform
+        const long bi = (long)bb * N + i;
+        const int j = jb * 32 + r;
         const bool valid = j < N;
         const int jj = valid ? j : 0;
         const float* xi = x + bi * S + kb;
@@ -394,14 +404,22 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, f
 #pragma unroll
             for (int t = 0; t < G; ++t) { ca[t] = na[t]; cb[t] = nb4[t]; }
         }
+        // epilogue: (i,j) for j >= i ... and the mirrored (j,i) for j > i; positions j < i of the diagonal block belong
+        // to the task of row j (which has i in ITS block, i > j)
         float ui[KH], uj[KH], pr[KH];
         load_row_cll<P>(u + bi * P, hi, true, ui);
         load_row_cll<P>(u + ((long)bb * N + jj) * P, hi, true, uj);
+        const bool upper = valid && j >= i, mirror = valid && j > i;
         const long off = (bi * N + jj) * P;
-        load_row_cll<P>(pair + off, hi, valid && residual, pr);
+        load_row_cll<P>(pair + off, hi, upper && residual, pr);
 #pragma unroll
         for (int s = 0; s < KH; ++s) pr[s] = pr[s] + (((acc[s >> 4][s & 15] + ui[s]) - uj[s]) + bl[hi * KH + s]);
-        store_row_cll<P>(out + off, hi, valid, pr);
+        store_row_cll<P>(out + off, hi, upper, pr);
+        const long offm = (((long)bb * N + jj) * N + i) * P;
+        load_row_cll<P>(pair + offm, hi, mirror && residual, pr);
+#pragma unroll
+        for (int s = 0; s < KH; ++s) pr[s] = pr[s] + (((acc[s >> 4][s & 15] + uj[s]) - ui[s]) + bl[hi * KH + s]);
+        store_row_cll<P>(out + offm, hi, mirror, pr);
     }
 }
 
@@ -793,7 +811,9 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
     const size_t lds = ((size_t)P * (S + 4) + P) * sizeof(float);
     if (lds <= 150 * 1024 && (S % 64) == 0) {   // W1 resident in LDS: persistent 8-wave workgroups, queue-fed
         constexpr int NWL = 8;
-        const int grid = grid_for(ntask, NWL, 256);
+        const int nvb = prd_ceil_div(N, 32);
+        const long nsym = (long)b * (nvb * (nvb + 1) / 2) * 32;      // symmetric half: (i, j-block >= i-block) tasks
+        const int grid = grid_for(nsym, NWL, 256);
         if (P == 64) {
             PRD_SET_LDS((outer_linear_res_kernel<64, NWL>), lds);
             hipLaunchKernelGGL((outer_linear_res_kernel<64, NWL>), dim3(grid), dim3(NWL * 64), lds, stream, queue, out, pair, x, u, w, bias, b, N, S, residual);
