@@ -381,12 +381,13 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, f
         }
         const int ngroups = S / (8 * G);                   // S is a multiple of 64 on this path
         for (int g = 0; g < ngroups; ++g) {
-            if (g + 1 < ngroups) {
+            // UNCONDITIONAL prefetch (the last iteration re-reads its own group): with the loads under an `if`
+            // hipcc merges the two paths into `s_waitcnt vmcnt(0)` in front of the MFMAs and the prefetch is lost
+            const int gn = (g + 1 < ngroups) ? g + 1 : g;
 #pragma unroll
-                for (int t = 0; t < G; ++t) {
-                    na[t] = *reinterpret_cast<const float4*>(xi + 4 * (G * (g + 1) + t));
-                    nb4[t] = *reinterpret_cast<const float4*>(xj + 4 * (G * (g + 1) + t));
-                }
+            for (int t = 0; t < G; ++t) {
+                na[t] = *reinterpret_cast<const float4*>(xi + 4 * (G * gn + t));
+                nb4[t] = *reinterpret_cast<const float4*>(xj + 4 * (G * gn + t));
             }
 #pragma unroll
             for (int t = 0; t < G; ++t) {

@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
     for (int c = 0; c < nchunk; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < nchunk;
-        if (more) {                                       // next chunk's global loads fly over this chunk's MFMAs
-            const int ko = (c + 1) * KCH;
+        {   // next chunk's global loads fly over this chunk's MFMAs.  UNCONDITIONAL (the last iteration re-reads its own
+            // chunk): loads under an `if` make hipcc emit `s_waitcnt vmcnt(0)` in front of the MFMAs
+            const int ko = (more ? c + 1 : c) * KCH;
             ra0 = *reinterpret_cast<const float4*>(pa0 + ko);
             ra1 = *reinterpret_cast<const float4*>(pa1 + ko);
             rb0 = *reinterpret_cast<const float4*>(pb0 + ko);
