@@ -172,14 +172,41 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(PrdGemm g) {
         const float* brow = B + (size_t)(nv ? n0 + r : 0) * g.ldb;
         if (k4) {
             const float am = mv ? 1.f : 0.f, bm = nv ? 1.f : 0.f;     // rows past the edge contribute zeros
-#pragma unroll 4
-            for (int k = kbeg + 4 * hi; k < kend; k += 8) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + k);
-                const float4 b = *reinterpret_cast<const float4*>(brow + k);
-                acc = mfma32(a.x * am, b.x * bm, acc);
-                acc = mfma32(a.y * am, b.y * bm, acc);
-                acc = mfma32(a.z * am, b.z * bm, acc);
-                acc = mfma32(a.w * am, b.w * bm, acc);
+            // software pipeline over batches of BT k-groups: the 2*BT loads of batch t+1 are in flight while the 4*BT
+            // MFMAs of batch t execute.  The prefetch is UNCONDITIONAL (clamped indices; groups past the end are
+            // multiplied by zero): loads under an `if` would be waited for with vmcnt(0) in front of the MFMAs.
+            constexpr int BT = 4;
+            float4 ca[BT], cb[BT], na[BT], nb[BT];
+            const int k0 = kbeg + 4 * hi;
+            const int nk = (kend > k0) ? (kend - k0 + 7) / 8 : 0;      // k-groups of this lane's half (k4: all complete)
+            const int nkw = (kend > kbeg) ? (kend - kbeg + 7) / 8 : 0; // k-groups of the wave (uniform trip count)
+            const int nbatch = (nkw + BT - 1) / BT;
+            const int ksafe = (k0 < g.K) ? k0 : 0;
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                const int k = (t < nk) ? k0 + 8 * t : ksafe;
+                ca[t] = *reinterpret_cast<const float4*>(arow + k);
+                cb[t] = *reinterpret_cast<const float4*>(brow + k);
+            }
+            for (int bt = 0; bt < nbatch; ++bt) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t) {
+                    const int gi = (bt + 1) * BT + t;
+                    const int k = (gi < nk) ? k0 + 8 * gi : ksafe;
+                    na[t] = *reinterpret_cast<const float4*>(arow + k);
+                    nb[t] = *reinterpret_cast<const float4*>(brow + k);
+                }
+#pragma unroll
+                for (int t = 0; t < BT; ++t) {
+                    const float z = (bt * BT + t < nk) ? am : 0.f;     // groups past this lane's range add nothing
+                    acc = mfma32(ca[t].x * z, cb[t].x * bm, acc);
+                    acc = mfma32(ca[t].y * z, cb[t].y * bm, acc);
+                    acc = mfma32(ca[t].z * z, cb[t].z * bm, acc);
+                    acc = mfma32(ca[t].w * z, cb[t].w * bm, acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < BT; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
             }
         } else {
             for (int k = kbeg + 4 * hi; k < kend; k += 8) {
