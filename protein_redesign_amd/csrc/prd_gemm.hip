@@ -146,8 +146,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(PrdGemm g) {
 // single-track linears (M = b*N rows) the generic kernel above launches fewer workgroups than there
 // are CUs and is latency bound on its K loop; this one launches (M/32)*(N/32) workgroups and cuts the
 // dependent K chain by 4. ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(PrdGemm g) {
-    __shared__ float red[4][16][64];
+template <int NWK>                          // waves per workgroup = K splits
+__global__ __launch_bounds__(NWK * 64) void gemm_skinny_kernel(PrdGemm g) {
+    __shared__ float red[NWK][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const int tiles_n = (g.N + 31) / 32;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(PrdGemm g) {
     const float* __restrict__ B = g.B + g1 * g.sb1 + g2 * g.sb2;
     // K range of this wave, in groups of 8
     const int groups = (g.K + 7) / 8;
-    const int gper = (groups + 3) / 4;
+    const int gper = (groups + NWK - 1) / NWK;
     const int kbeg = wave * gper * 8;
     int kend = kbeg + gper * 8;
     if (kend > g.K) kend = g.K;
@@ -235,13 +236,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(PrdGemm g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) red[wave][q][lane] = acc[q];
     __syncthreads();
-    // thread (wave w, lane) finishes registers q = 4w .. 4w+3 of the tile: fixed summation order
+    // wave w finishes registers q = (16/NWK)*w ... of the tile: fixed summation order over the K splits
     float* __restrict__ C = g.C + g1 * g.sc1 + g2 * g.sc2;
     const int n = n0 + r;
+    constexpr int QPW = 16 / NWK;
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-        const int q = 4 * wave + qq;
-        const float v = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
+    for (int qq = 0; qq < QPW; ++qq) {
+        const int q = QPW * wave + qq;
+        float v = red[0][q][lane];
+#pragma unroll
+        for (int w = 1; w < NWK; ++w) v += red[w][q][lane];
         const int m = m0 + drow32(q, hi);
         if (m < g.M && n < g.N) epilogue_store(g, g1, g2, m, n, v, C);
     }
@@ -298,7 +302,9 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     if (tile == 0) tile = (tiles64 < 512) ? 32 : ((tiles64 <= 1024 || g.M <= 64 || g.N <= 64) ? 64 : 128);
     if (tile == 32) {          // fewer 64x64 tiles than two per CU: skinny kernel, 32x32 tiles + in-workgroup split-K
         dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
-        hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(256), 0, stream, g);
+        // long K and few tiles: 8 K-splits (twice the waves per CU to cover the L2 latency of the operand stream)
+        if (g.K >= 1024 && (long)grid.x * grid.y <= 512) hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, stream, g);
     } else if (tile == 64) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
         hipLaunchKernelGGL((gemm_kernel<32, 32>), grid, dim3(256), 0, stream, g);

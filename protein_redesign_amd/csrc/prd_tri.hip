@@ -52,10 +52,12 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
         const int vv = valid ? v : 0;
         // outgoing: operand row u, contraction index v <-> pair[u, v]; incoming: pair[v, u]
         const long pos = incoming ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
+        // mask loads are issued together with the row (their latency hides behind the row's), not after the LayerNorm
+        const float mu = mask[bu], mv = mask[(long)bb * N + vv];
         float x[KH];
         load_row_cll<P>(pair + pos * P, hi, valid, x);
+        const float m2 = valid ? mu * mv : 0.f;
         ln_cll<KH>(x);
-        const float m2 = valid ? mask[bu] * mask[(long)bb * N + vv] : 0.f;
 #pragma unroll 1
         for (int ob = 0; ob < OB; ++ob) {
             f32x16 ap[1], ag[1];
