@@ -119,13 +119,13 @@ def main():
         ta = model.Denoiser.folding_blocks[0].pair_attn_starting.attn
         wts = ta.weights()[:5]
         og = torch.empty(bpg, N, N, 64, device=dev)
-        for _ in range(3):
-            ops.tri_attn_core(pair, loop.mask, wts, 4, 16, ending=False, og=og)
+        for i in range(4):
+            ops.tri_attn_core(pair, loop.mask, wts, 4, 16, ending=bool(i & 1), og=og)
         reps = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
-            ops.tri_attn_core(pair, loop.mask, wts, 4, 16, ending=False, og=og)
+        for i in range(reps):                      # starting / ending modes alternate, as inside a step
+            ops.tri_attn_core(pair, loop.mask, wts, 4, 16, ending=bool(i & 1), og=og)
         e1.record()
         torch.cuda.synchronize()
         kus = e0.elapsed_time(e1) * 1e3 / reps
