@@ -170,10 +170,52 @@ class _FixedPerm:
         raise RuntimeError("prepare_batch must not draw normals")
 
 
+def run_host_case():
+    """Callers / data formats around the hot path: reference collate_fn, PDB text, sequence decoding."""
+    import dataclasses
+
+    import generate as ref_generate                     # /root/reference/generate.py (stubs make it importable)
+    import ProteinReDiff.data as ref_data
+    import ProteinReDiff.protein as ref_protein
+    from protein_redesign_amd.synthetic import synthetic_sample
+    out = {}
+    samples = [synthetic_sample(4, 9, esm_dim=8, seed=31), synthetic_sample(6, 5, esm_dim=8, seed=32)]
+    batch = ref_data.collate_fn(samples)
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            out["collate_" + k] = v.numpy()
+    g = torch.Generator().manual_seed(33)
+    nres = 7
+    prot = ref_protein.Protein(
+        chain_index=np.array([0, 0, 0, 1, 1, 1, 1]), residue_index=np.array([3, 4, 5, 1, 2, 3, 12]),
+        aatype=torch.randint(0, 20, (nres,), generator=g).numpy(),
+        atom_pos=(30 * torch.randn(nres, 37, 3, generator=g)).numpy().astype(np.float32),
+        atom_mask=(torch.rand(nres, 37, generator=g) < 0.3).float().numpy())
+    out.update(pdb_chain_index=prot.chain_index, pdb_residue_index=prot.residue_index, pdb_aatype=prot.aatype,
+               pdb_atom_pos=prot.atom_pos, pdb_atom_mask=prot.atom_mask,
+               pdb_text=np.array(ref_protein.protein_to_pdb_string(prot)))
+    logits = torch.randn(12, 21, generator=g)
+    logits[:2, 0] += 10.0                                  # leading X's are stripped
+    logits[-1, 0] += 10.0
+    logits[2:-1, 0] -= 10.0
+    out["seq_logits"] = logits.numpy()
+    out["seq_pred"] = np.array("".join(ref_generate.predict_seq(logits.numpy())))
+    seq_prot = ref_generate.update_seq(ref_protein.protein_from_sequence("A" * 9), logits.numpy())
+    out["seq_aatype"] = seq_prot.aatype
+    fs = ref_protein.protein_from_sequence("ACDXW")
+    out.update(fromseq_aatype=fs.aatype, fromseq_mask=fs.atom_mask)
+    return out
+
+
 def main():
     ref_model, _ = import_reference()
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or list(CASES) + ["host"]
+    if "host" in names:
+        names = [n for n in names if n != "host"]
+        path = os.path.join(ROOT, "tests", "golden", "host.npz")
+        np.savez_compressed(path, **run_host_case())
+        print("host ->", path, f"{os.path.getsize(path) / 1024:.1f} KiB")
     for name in names:
         torch.manual_seed(0)
         res = run_case(name, CASES[name], ref_model)

@@ -1,0 +1,214 @@
+"""Callers and data formats on either side of the hot path (SURVEY.md §8f "next" #2 and #3), host-side Python.
+
+* batch assembly: ``collate_fn`` / ``RepeatDataset`` / ``PDBDataset`` with the contract of the reference's
+  ProteinReDiff/data.py:80-185 (atoms first, residues after, ``residue_type + 1``, padded to the longest complex);
+* output handling of ``generate.py``: sequence decoding (generate.py:75-91), CA placement (:65-74), multi-model PDB
+  text (protein.py:124-174);
+* ``generate_samples``: the ``Trainer.predict`` loop of generate.py:138-159 without Lightning.
+
+rdkit / Biopython / TM-align are not needed: ligands are handled as coordinate arrays, proteins as plain arrays.
+Nothing here is on the arithmetic path; the model call goes to the HIP path through ``ProteinReDiffModel``.
+"""
+from __future__ import annotations
+
+import dataclasses
+from pathlib import Path
+from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .constants import NUM_RESIDUE_ATOMS, RESIDUE_TYPES
+
+RESIDUE_NAMES = ["ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE",
+                 "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL"]
+RESIDUE_ATOMS = ["N", "CA", "C", "CB", "O", "CG", "CG1", "CG2", "OG", "OG1", "SG", "CD", "CD1", "CD2", "ND1", "ND2",
+                 "OD1", "OD2", "SD", "CE", "CE1", "CE2", "CE3", "NE", "NE1", "NE2", "OE1", "OE2", "CH2", "NH1", "NH2",
+                 "OH", "CZ", "CZ2", "CZ3", "NZ", "OXT"]
+PDB_CHAIN_IDS = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"
+assert len(RESIDUE_ATOMS) == NUM_RESIDUE_ATOMS
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch assembly (data.py:80-185)
+# ---------------------------------------------------------------------------------------------------
+
+def collate_fn(data_list: Sequence[Mapping[str, Any]]) -> Dict[str, Any]:
+    """Pad and stack per-complex dicts.  Key families decide the placement, as in data.py:80-142:
+    ``atom_*`` -> rows [0, na); ``bond_*`` -> the [0, na)^2 corner; ``residue_*`` -> rows [na, na+nr)
+    (and ``residue_type`` shifted by +1 so that 0 means pad / atom slot); ``*_mol`` -> python lists."""
+    n_max = max(d["num_atoms"] + d["num_residues"] for d in data_list)
+    out: Dict[str, Any] = {}
+    for key, first in data_list[0].items():
+        if key.startswith("atom_"):
+            tail = (0, 0) * (first.dim() - 1)
+            out[key] = torch.stack([F.pad(d[key], tail + (0, n_max - d["num_atoms"])) for d in data_list])
+        elif key.startswith("bond_"):
+            tail = (0, 0) * (first.dim() - 2)
+            out[key] = torch.stack([F.pad(d[key], tail + (0, n_max - d["num_atoms"]) * 2) for d in data_list])
+        elif key.startswith("residue_"):
+            tail = (0, 0) * (first.dim() - 1)
+            shift = 1 if key.endswith("_type") else 0
+            out[key] = torch.stack([
+                F.pad(d[key] + shift, tail + (d["num_atoms"], n_max - d["num_atoms"] - d["num_residues"]))
+                for d in data_list])
+        elif key.endswith("_mol"):
+            out[key] = [d[key] for d in data_list]
+        elif torch.is_tensor(first):
+            out[key] = torch.stack([d[key] for d in data_list])
+        elif isinstance(first, (int, float)):
+            out[key] = torch.tensor([d[key] for d in data_list])
+        else:
+            out[key] = [d[key] for d in data_list]
+    return out
+
+
+class RepeatDataset(torch.utils.data.Dataset):
+    """data.py:145-155: the same complex ``repeat`` times (one entry per requested sample)."""
+
+    def __init__(self, data: Mapping[str, Any], repeat: int):
+        self.data, self.repeat = data, repeat
+
+    def __len__(self):
+        return self.repeat
+
+    def __getitem__(self, index: int):
+        return self.data
+
+
+class PDBDataset(torch.utils.data.Dataset):
+    """data.py:170-185: ``root/<pdb_id>/{ligand,protein}_data.pt`` as written by preprocess_pdbbind.py:79-83."""
+
+    def __init__(self, root_dir: Union[str, Path], pdb_ids: Sequence[str]):
+        self.root_dir, self.pdb_ids = Path(root_dir), list(pdb_ids)
+
+    def __len__(self):
+        return len(self.pdb_ids)
+
+    def __getitem__(self, index: int):
+        pdb_id = self.pdb_ids[index]
+        ligand = torch.load(self.root_dir / pdb_id / "ligand_data.pt", weights_only=False)
+        protein = torch.load(self.root_dir / pdb_id / "protein_data.pt", weights_only=False)
+        return {"pdb_id": pdb_id, **ligand, **protein}
+
+
+# ---------------------------------------------------------------------------------------------------
+# proteins and output handling (protein.py:50-202, generate.py:65-91)
+# ---------------------------------------------------------------------------------------------------
+
+@dataclasses.dataclass(frozen=True)
+class Protein:
+    chain_index: np.ndarray
+    residue_index: np.ndarray
+    aatype: np.ndarray
+    atom_pos: np.ndarray
+    atom_mask: np.ndarray
+
+
+def protein_from_sequence(sequence: str) -> Protein:
+    """protein.py:177-191: CA-only placeholder protein for a sequence ('X' -> -1)."""
+    idx = {name: i for i, name in enumerate(RESIDUE_TYPES)}
+    idx["X"] = -1
+    aatype = np.array([idx[s] for s in sequence], dtype=np.int64)
+    n = len(aatype)
+    mask = np.zeros((n, NUM_RESIDUE_ATOMS), dtype=np.float32)
+    mask[:, 1] = 1.0
+    return Protein(np.zeros((n,), np.int64), np.arange(n, dtype=np.int64), aatype,
+                   np.zeros((n, NUM_RESIDUE_ATOMS, 3), np.float32), mask)
+
+
+def protein_to_data(prot: Protein, **extra) -> Dict[str, Any]:
+    """data.py:59-77 without the rdkit CA molecule."""
+    return {"num_residues": len(prot.aatype), "residue_type": torch.from_numpy(prot.aatype),
+            "residue_mask": torch.ones(len(prot.aatype)), "residue_chain_index": torch.from_numpy(prot.chain_index),
+            "residue_index": torch.from_numpy(prot.residue_index), "residue_atom_pos": torch.from_numpy(prot.atom_pos),
+            "residue_atom_mask": torch.from_numpy(prot.atom_mask), **extra}
+
+
+def protein_to_pdb_string(prot: Protein) -> str:
+    """Fixed-column ATOM records, one per present atom (protein.py:124-156)."""
+    lines, serial = [], 1
+    for i in range(prot.chain_index.shape[0]):
+        chain, resi, resn = PDB_CHAIN_IDS[prot.chain_index[i]], prot.residue_index[i], RESIDUE_NAMES[prot.aatype[i]]
+        for xyz, present, name in zip(prot.atom_pos[i], prot.atom_mask[i], RESIDUE_ATOMS):
+            if present < 0.5:
+                continue
+            field = name if len(name) >= 4 else " " + name.ljust(3)
+            lines.append(f"{'ATOM':<6}{serial:>5} {field}{'':>1}{resn:>3} {chain:>1}{resi:>4}{'':>1}   "
+                         f"{xyz[0]:>8.3f}{xyz[1]:>8.3f}{xyz[2]:>8.3f}{1.0:>6.2f}{0.0:>6.2f}          {name[0]:>2}{'':>2}".ljust(80))
+            serial += 1
+    return "\n".join(lines) + "\n"
+
+
+def proteins_to_pdb_file(proteins: Iterable[Protein], pdb_path: Union[str, Path]) -> None:
+    """Multi-model PDB (protein.py:165-174)."""
+    text = ""
+    for model_id, prot in enumerate(proteins, 1):
+        text += f"MODEL      {model_id:>3}".ljust(80) + "\n" + protein_to_pdb_string(prot) + "ENDMDL".ljust(80) + "\n"
+    Path(pdb_path).write_text(text)
+
+
+def predict_seq(logits) -> List[str]:
+    """generate.py:75-80: argmax over the 21 classes with alphabet ["X"] + RESIDUE_TYPES."""
+    tokens = torch.argmax(torch.softmax(torch.as_tensor(logits), dim=-1), dim=-1)
+    alphabet = ["X"] + RESIDUE_TYPES
+    return [alphabet[int(i)] for i in tokens]
+
+
+def update_seq(protein: Protein, logits) -> Protein:
+    """generate.py:82-91: decoded sequence with leading / trailing X stripped becomes the new aatype."""
+    sequence = "".join(predict_seq(logits)).lstrip("X").rstrip("X")
+    return dataclasses.replace(protein, aatype=np.array([RESIDUE_TYPES.index(s) for s in sequence], dtype=np.int64))
+
+
+def update_pos(protein: Protein, num_ligand_atoms: int, pos: np.ndarray) -> Tuple[Protein, np.ndarray]:
+    """generate.py:65-74: rows [na:] are the CA trace, rows [:na] the ligand atoms (returned as an array)."""
+    atom_pos = np.zeros_like(protein.atom_pos)
+    atom_pos[:, 1] = pos[num_ligand_atoms: num_ligand_atoms + atom_pos.shape[0]]
+    atom_mask = np.zeros_like(protein.atom_mask)
+    atom_mask[:, 1] = 1.0
+    return dataclasses.replace(protein, atom_pos=atom_pos, atom_mask=atom_mask), np.asarray(pos[:num_ligand_atoms])
+
+
+# ---------------------------------------------------------------------------------------------------
+# generate.py:138-195 without Lightning / rdkit / TM-align
+# ---------------------------------------------------------------------------------------------------
+
+@torch.inference_mode()
+def generate_samples(model, data: Mapping[str, Any], num_samples: int, batch_size: int = 1, seed: int = 0,
+                     output_dir: Optional[Union[str, Path]] = None):
+    """Draw ``num_samples`` samples of one featurised complex ``data`` (the dict of ligand_to_data ∪ protein_to_data).
+
+    Returns (positions [S,N,3] in Angstrom, logits [S,N,21], proteins, ligand_positions).  With ``output_dir`` the CA
+    models go to ``sample_protein.pdb`` and the ligand coordinates to ``sample_ligand_pos.npy`` (the reference writes an
+    SDF through rdkit and aligns every sample with TM-align first -- both out of scope here)."""
+    from .synthetic import NoiseSource, batch_to
+    device = model.device
+    positions, logits = [], []
+    for start in range(0, num_samples, batch_size):
+        idx = list(range(start, min(start + batch_size, num_samples)))
+        batch = collate_fn([data] * len(idx))
+        batch = batch_to({k: v for k, v in batch.items() if torch.is_tensor(v)}, device)
+        pos, lg = model.sample(batch, sources=[NoiseSource(seed, k) for k in idx])
+        positions.append(pos.cpu())
+        logits.append(lg.cpu())
+    positions, logits = torch.cat(positions).numpy(), torch.cat(logits).numpy()
+    na, nr = int(data["num_atoms"]), int(data["num_residues"])
+    template = Protein(np.asarray(data["residue_chain_index"]), np.asarray(data["residue_index"]),
+                       np.asarray(data["residue_type"]), np.asarray(data["residue_atom_pos"], dtype=np.float32),
+                       np.asarray(data["residue_atom_mask"], dtype=np.float32))
+    proteins, ligands = [], []
+    for pos, lg in zip(positions, logits):
+        prot, lig = update_pos(template, na, pos)
+        seq = "".join(predict_seq(lg[na: na + nr]))
+        if "X" not in seq:                      # a fully decoded design replaces the residue types
+            prot = dataclasses.replace(prot, aatype=np.array([RESIDUE_TYPES.index(s) for s in seq], dtype=np.int64))
+        proteins.append(prot)
+        ligands.append(lig)
+    if output_dir is not None:
+        out = Path(output_dir)
+        out.mkdir(parents=True, exist_ok=True)
+        proteins_to_pdb_file(proteins, out / "sample_protein.pdb")
+        np.save(out / "sample_ligand_pos.npy", np.stack(ligands))
+    return positions, logits, proteins, ligands

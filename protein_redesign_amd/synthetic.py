@@ -78,6 +78,26 @@ def synthetic_batch(sizes: Sequence[Tuple[int, int]], esm_dim: int = 1280,
     return batch
 
 
+def synthetic_sample(na: int, nr: int, esm_dim: int = 1280, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """One UN-collated complex: the union of the reference's ``ligand_to_data`` and ``protein_to_data`` dicts
+    (data.py:28-77) without the rdkit molecule objects; ``residue_type`` is the raw aatype (collate adds 1)."""
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.stack([torch.randint(0, c, (na,), generator=g) for c in ATOM_FEATURE_CARDS], dim=-1)
+    upper = (torch.rand(na, na, generator=g) < 0.05).float().triu(1)
+    bmask = upper + upper.T
+    bfeats = torch.stack([torch.randint(0, c, (na, na), generator=g).triu(1) for c in BOND_FEATURE_CARDS], dim=-1)
+    bfeats = (bfeats + bfeats.transpose(0, 1)) * bmask.long().unsqueeze(-1)
+    bd = torch.randint(0, 12, (na, na), generator=g).triu(1)
+    return {
+        "num_atoms": na, "atom_feats": feats, "atom_mask": torch.ones(na), "atom_pos": 5.0 * torch.randn(na, 3, generator=g),
+        "bond_feats": bfeats, "bond_mask": bmask, "bond_distance": bd + bd.T,
+        "num_residues": nr, "residue_type": torch.randint(0, NUM_RESIDUE_CLASSES - 1, (nr,), generator=g),
+        "residue_mask": torch.ones(nr), "residue_chain_index": (torch.arange(nr) >= (nr + 1) // 2).long(),
+        "residue_index": torch.arange(nr), "residue_atom_pos": 10.0 * torch.randn(nr, NUM_RESIDUE_ATOMS, 3, generator=g),
+        "residue_atom_mask": torch.ones(nr, NUM_RESIDUE_ATOMS), "residue_esm": torch.randn(nr, esm_dim, generator=g),
+    }
+
+
 def clone_batch(batch: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
 
