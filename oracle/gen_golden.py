@@ -117,6 +117,13 @@ def run_case(name, case, ref_model):
                step_noise_pred=eps.numpy(), step_seq_pred=logits.numpy(),
                prep_extra_mask=pb["residue_extra_mask"].numpy(), prep_x=pb["x"].numpy())
 
+    # ---- diffusion loss (validation / training forward value), injected noise ----
+    nz = O_remove_mean(torch.randn(b, N, 3, generator=g), mask)
+    ns = O_remove_mean(torch.randn(b, N, 21, generator=g), pb["residue_mask"])
+    with _Sequence([nz, ns]):
+        out["loss_value"] = model.diffusion_loss(pb, pb["x"], mask, t).numpy()
+    out.update(loss_noise_z=nz.numpy(), loss_noise_seq=ns.numpy())
+
     # ---- schedule tables ----
     for T, sched in ((10, "linear"), (64, "linear"), (1000, "linear"), (64, "cosine")):
         model.num_steps, model.diffusion_schedule = T, sched
@@ -156,6 +163,28 @@ def run_case(name, case, ref_model):
         pos, logits = model.sample(clone_batch(one))
     out.update(traj_pos=pos.numpy(), traj_logits=logits.numpy())
     return out
+
+
+def O_remove_mean(x, mask):
+    m = mask.unsqueeze(-1).expand_as(x)
+    return x - m * (m * x).sum(1, keepdim=True) / m.sum(1, keepdim=True)
+
+
+class _Sequence:
+    """torch.randn_like returns the given tensors in order (their mean is already removed, and remove_mean is
+    idempotent up to round-off, so the reference's remove_mean(randn_like(.)) reproduces them)."""
+
+    def __init__(self, tensors):
+        self.tensors = list(tensors)
+
+    def __enter__(self):
+        self._randn_like = torch.randn_like
+        it = iter(self.tensors)
+        torch.randn_like = lambda x, **kw: next(it).to(x.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._randn_like
 
 
 class _FixedPerm:

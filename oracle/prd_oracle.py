@@ -293,6 +293,40 @@ def schedule_tables(num_steps: int, schedule: str = "linear") -> Dict[str, torch
     }
 
 
+def q_sample(sch: Mapping[str, torch.Tensor], batch: Mapping[str, torch.Tensor], x, seq, t, noise_z, noise_seq):
+    """model.py:471-488: forward noising of structure and sequence at step t, and the sequence at t-1."""
+    ac, om = sch["sqrt_alphas_cumprod"], sch["sqrt_one_minus_alphas_cumprod"]
+    extra, inv = batch["residue_extra_mask"], batch["residue_inv_extra_mask"]
+    z_t = ac[t][:, None, None] * x + om[t][:, None, None] * noise_z
+    seq_t = ac[t][:, None, None] * seq + om[t][:, None, None] * noise_seq
+    seq_t = extra.unsqueeze(-1) * seq + inv.unsqueeze(-1) * seq_t
+    t1 = (t - 1).clamp(min=0)
+    seq_t1 = ac[t1][:, None, None] * seq + om[t1][:, None, None] * noise_seq
+    return z_t, seq_t, seq_t1, t1
+
+
+def diffusion_loss(p: Params, cfg: Mapping, batch: Mapping[str, torch.Tensor], t: torch.Tensor,
+                   noise_z: torch.Tensor, noise_seq: torch.Tensor, network=None) -> torch.Tensor:
+    """model.py:490-526 with injected noise (already mean-free, :495-496): squared error on the predicted noise,
+    KL between the re-noised predicted and true sequence at t-1 (summed over the WHOLE batch, as the reference does),
+    and cross-entropy of (logits+1)/2 against residue_type with ignore_index 0, times the node mask."""
+    sch = schedule_tables(cfg["num_steps"], cfg.get("diffusion_schedule", "linear"))
+    x, mask, rm = batch["x"], batch["residue_and_atom_mask"], batch["residue_mask"]
+    seq = batch["residue_one_hot"]
+    z_t, seq_t, seq_t1, t1 = q_sample(sch, batch, x, seq, t, noise_z, noise_seq)
+    net = network or (lambda z, s, m, tt: network_step(p, cfg, batch, z, s, m, tt))
+    noise_pred, seq_pred = net(z_t, seq_t, mask, t)
+    ac, om = sch["sqrt_alphas_cumprod"], sch["sqrt_one_minus_alphas_cumprod"]
+    seq_pred_t1 = ac[t1][:, None, None] * seq_pred + om[t1][:, None, None] * noise_seq
+    loss = (mask.unsqueeze(-1) * torch.square(noise_pred - noise_z)).sum(dim=(1, 2))
+    loss = loss + F.kl_div(torch.log_softmax(seq_pred_t1, dim=-1) * rm.unsqueeze(-1),
+                           torch.softmax(seq_t1, dim=-1) * rm.unsqueeze(-1), reduction="none").sum()
+    ce = F.cross_entropy(((seq_pred + 1) / 2).view(-1, seq_pred.shape[-1]), batch["residue_type"].view(-1),
+                         reduction="none", ignore_index=0)
+    loss = loss + (ce * mask.view(-1)).sum()
+    return loss
+
+
 def redesign_mask(residue_mask: torch.Tensor, mask_prob: float, perms: Sequence[torch.Tensor]):
     """RandomMaskingModule.forward(stochastic=False) (mask_utils.py:77-102), applied per sample:
     ``int(n_res * mask_prob)`` residues, chosen by ``perms[k]`` (a permutation of range(n_res_k)),

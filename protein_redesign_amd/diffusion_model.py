@@ -245,11 +245,56 @@ class ProteinReDiffModel(_Base):
             super().optimizer_step(*args, **kwargs)
         self.ema.update(self.parameters())
 
-    def training_step(self, batch, batch_idx):
-        raise NotImplementedError("training (backward of the HIP kernels) is SURVEY.md §8f 'next #1'; "
-                                  "this build covers inference / sampling")
+    # ------------------------------------------------------------------ loss path (model.py:471-549), forward only
+    def q(self, x, seq, t, noise_z, noise_seq, batch):
+        """Forward noising of structure / sequence at step t and of the sequence at t-1 (model.py:471-488)."""
+        ac, om = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        extra, inv = batch["residue_extra_mask"], batch["residue_inv_extra_mask"]
+        z_t = ac[t][:, None, None] * x + om[t][:, None, None] * noise_z
+        seq_t = ac[t][:, None, None] * seq + om[t][:, None, None] * noise_seq
+        seq_t = extra.unsqueeze(-1) * seq + inv.unsqueeze(-1) * seq_t
+        t1 = (t - 1).clamp(min=0)
+        seq_t1 = ac[t1][:, None, None] * seq + om[t1][:, None, None] * noise_seq
+        return z_t, seq_t, seq_t1, t1
 
-    validation_step = training_step
+    def diffusion_loss(self, batch, x, mask, t, noise_z=None, noise_seq=None):
+        """model.py:490-526.  The network forward runs on the HIP path; the O(N) loss reductions are torch ops.
+        ``noise_z`` / ``noise_seq`` (mean-free) may be injected; otherwise they are drawn on the device."""
+        seq, rm = batch["residue_one_hot"], batch["residue_mask"]
+        if noise_z is None:
+            noise_z = ops.remove_mean(torch.randn_like(x), mask.contiguous())
+        if noise_seq is None:
+            noise_seq = ops.remove_mean(torch.randn_like(seq), rm.contiguous())
+        z_t, seq_t, seq_t1, t1 = self.q(x, seq, t, noise_z, noise_seq, batch)
+        noise_pred, seq_pred = self(batch, z_t, seq_t, mask, t)
+        ac, om = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        seq_pred_t1 = ac[t1][:, None, None] * seq_pred + om[t1][:, None, None] * noise_seq
+        loss = (mask.unsqueeze(-1) * torch.square(noise_pred - noise_z)).sum(dim=(1, 2))
+        loss = loss + F.kl_div(torch.log_softmax(seq_pred_t1, dim=-1) * rm.unsqueeze(-1),
+                               torch.softmax(seq_t1, dim=-1) * rm.unsqueeze(-1), reduction="none").sum()
+        ce = F.cross_entropy(((seq_pred + 1) / 2).view(-1, NUM_RESIDUE_CLASSES), batch["residue_type"].view(-1),
+                             reduction="none", ignore_index=0)
+        return loss + (ce * mask.view(-1)).sum()
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """model.py:226-247: loss under the EMA weights, logged as ``val_loss``."""
+        if not self.setup_schedule:
+            self.run_setup_schedule()
+            self.setup_schedule = True
+        batch = self.prepare_batch(batch, batch_idx)
+        x, mask = batch["x"], batch["residue_and_atom_mask"]
+        num_nodes = (mask > 0.5).sum(-1)
+        t = torch.randint(0, self.num_steps, size=(x.size(0),), device=x.device)
+        with self.ema.average_parameters(self.parameters()):
+            diff_loss = self.diffusion_loss(batch, x, mask, t)
+        loss = torch.mean(diff_loss / num_nodes)
+        self.log("val_loss", loss, on_epoch=True, sync_dist=True, batch_size=x.size(0))
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("the optimisation step needs the backward of the HIP kernels (SURVEY.md §8f 'next #1'); "
+                                  "forward / loss evaluation is available through validation_step / diffusion_loss")
 
     def predict_step(self, batch, batch_idx):
         with self.ema.average_parameters(self.parameters()):

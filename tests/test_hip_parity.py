@@ -287,6 +287,22 @@ def test_trajectory_vs_reference_golden(golden, name):
     assert rel_l2(logits.cpu(), z["traj_logits"]) < TRAJ_TOL
 
 
+@pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
+def test_diffusion_loss_vs_reference_golden(golden, name):
+    """validation / training forward value: q-noising + HIP network + loss (model.py:471-526) vs the reference."""
+    case, z, args, model, params = golden_case(golden, name)
+    sizes = [tuple(s) for s in case["sizes"]]
+    batch = synthetic_batch(sizes, esm_dim=args["esm_dim"], seed=case["batch_seed"], n_total=case["n_total"])
+    perms = [NoiseSource(NOISE_SEED, 100 + k).randperm(n) for k, (_, n) in enumerate(sizes)]
+    pb = batch_to(O.prepare_batch(batch, args["mask_prob"], perms), DEV)
+    model.run_setup_schedule()
+    model.setup_schedule = True
+    with torch.inference_mode():
+        loss = model.diffusion_loss(pb, pb["x"], pb["residue_and_atom_mask"], cu(torch.from_numpy(z["step_t"])),
+                                    cu(torch.from_numpy(z["loss_noise_z"])), cu(torch.from_numpy(z["loss_noise_seq"])))
+    assert rel_l2(loss.cpu(), z["loss_value"]) < 1e-4
+
+
 def test_batched_sampling_equals_single_samples(golden):
     """Shard / batch invariance on the GPU: samples k = 0, 1 drawn together equal the same samples drawn alone."""
     case, z, args, model, params = golden_case(golden, "small64")
