@@ -55,9 +55,15 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
         // mask loads are issued together with the row (their latency hides behind the row's), not after the LayerNorm
         const float mu = mask[bu], mv = mask[(long)bb * N + vv];
         float x[KH];
+#if defined(PRD_ABLATE) && PRD_ABLATE == 11
+        for (int s = 0; s < KH; ++s) x[s] = 0.01f * (s + r);       // ablation: no row load
+#else
         load_row_cll<P>(pair + pos * P, hi, valid, x);
+#endif
         const float m2 = valid ? mu * mv : 0.f;
+#if !(defined(PRD_ABLATE) && PRD_ABLATE == 12)
         ln_cll<KH>(x);
+#endif
 #pragma unroll 1
         for (int ob = 0; ob < OB; ++ob) {
             f32x16 ap[1], ag[1];
@@ -70,7 +76,11 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
                 const int s = ob * 16 + q;                       // CLL element of the 2P-wide output
                 const int c = 32 * ob + drow32(q, hi);           // output channel
                 const float val = m2 * sigmoid_fast(ag[0][q] + bgl[hi * P + s]) * (ap[0][q] + bpl[hi * P + s]);
+#if defined(PRD_ABLATE) && PRD_ABLATE == 13
+                if (val == 123.456f) AB[0] = val;                  // ablation: no stores
+#else
                 AB[(((long)bb * OUT + c) * N + u) * ldn + v] = valid ? val : 0.f;
+#endif
             }
         }
     }
