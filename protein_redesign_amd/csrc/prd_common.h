@@ -22,6 +22,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));      // operand of the packed fp32 VALU ops (v_pk_add/mul/fma_f32)
 
 #define PRD_DEV __device__ __forceinline__
 
@@ -32,6 +33,30 @@ PRD_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // gate sigmoid on the hardware transcendentals (v_exp_f32 + v_rcp_f32, ~1 ulp each): the gates multiply
 // O(1) values, so their 1e-7 relative error is far inside the 1e-5 operator tolerance
 PRD_DEV float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+
+// Gates whose weights and bias were staged with the factor -log2(e) (stage_*_cll(..., NEG_LOG2E)): the MFMA result is
+// y = -log2(e) * logit and sigmoid(logit) = 1 / (1 + 2^y) -- v_exp_f32, v_add_f32, v_rcp_f32, nothing else.
+constexpr float NEG_LOG2E = -1.4426950408889634f;
+PRD_DEV float gate_from_scaled(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
+
+// Buffer addressing: base in a scalar resource descriptor, per-lane byte offset in ONE VGPR that never changes,
+// per-access byte offset in an SGPR -- strided stores / loads without a single VALU address instruction.
+// The descriptor covers 2 GiB from `p`; callers re-base it (scalar work) to stay inside.
+typedef __amdgpu_buffer_rsrc_t prd_rsrc;
+PRD_DEV prd_rsrc make_rsrc(const void* p) {
+    // the base must be wave-uniform; readfirstlane states it (a no-op when hipcc already knows) -- a base it believes
+    // divergent turns every access into a waterfall loop
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+PRD_DEV void buf_store(float v, prd_rsrc rs, unsigned lane_bytes, unsigned uniform_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, lane_bytes, uniform_bytes, 0);
+}
+PRD_DEV float buf_load(prd_rsrc rs, unsigned lane_bytes, unsigned uniform_bytes) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_bytes, uniform_bytes, 0));
+}
+constexpr unsigned BUF_OOB = 0x80000000u;       // lane offset outside every descriptor: loads return 0, stores are dropped
 
 // row index inside a 32x32 MFMA D fragment held in register q by a lane of half hi
 PRD_DEV int drow32(int q, int hi) { return (q & 3) + 8 * (q >> 2) + 4 * hi; }
@@ -51,6 +76,19 @@ PRD_DEV void load_row_cll(const float* __restrict__ row, int hi, bool valid, flo
     }
 }
 
+// Same through a buffer descriptor: `lane_bytes` = byte offset of the lane's row (+ 16*hi) from the descriptor base, or
+// BUF_OOB for a lane without a row (returns zeros) -- unconditional loads (exact vmcnt accounting, so that a prefetch
+// can stay in flight), no 64-bit VALU address arithmetic and no per-element select.
+template <int C>
+PRD_DEV void load_row_cll_buf(prd_rsrc rs, unsigned lane_bytes, float (&x)[C / 2]) {
+#pragma unroll
+    for (int m = 0; m < C / 8; ++m) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, 32 * m, 0);
+        x[4 * m + 0] = __uint_as_float(v[0]); x[4 * m + 1] = __uint_as_float(v[1]);
+        x[4 * m + 2] = __uint_as_float(v[2]); x[4 * m + 3] = __uint_as_float(v[3]);
+    }
+}
+
 template <int C>
 PRD_DEV void store_row_cll(float* __restrict__ row, int hi, bool valid, const float (&x)[C / 2]) {
     if (!valid) return;
@@ -59,33 +97,45 @@ PRD_DEV void store_row_cll(float* __restrict__ row, int hi, bool valid, const fl
         *reinterpret_cast<float4*>(row + 8 * m + 4 * hi) = make_float4(x[4 * m], x[4 * m + 1], x[4 * m + 2], x[4 * m + 3]);
 }
 
-// LayerNorm without affine over a CLL row (eps = 1e-5, biased variance; nn.LayerNorm semantics)
+// LayerNorm without affine over a CLL row (eps = 1e-5, biased variance; nn.LayerNorm semantics).
+// fp32 MFMA and VALU instructions share a SIMD's issue time on gfx950, so every VALU instruction saved is MFMA
+// time gained: the sums run on the packed fp32 ops (two elements per instruction, two partial sums).
 template <int KH>
 PRD_DEV void ln_cll(float (&x)[KH]) {
-    float s = 0.f;
+    f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < KH; ++k) s += x[k];
-    s = xhalf_sum(s);
-    const float mean = s * (1.0f / (2 * KH));
-    float v = 0.f;
+    for (int k = 0; k < KH; k += 2) s2 += f32x2{x[k], x[k + 1]};
+    const float mean = xhalf_sum(s2.x + s2.y) * (1.0f / (2 * KH));
+    const f32x2 m2 = {mean, mean};
+    f32x2 v2 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < KH; ++k) { const float d = x[k] - mean; v += d * d; }
-    v = xhalf_sum(v);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / (2 * KH)) + 1e-5f);
+    for (int k = 0; k < KH; k += 2) {
+        const f32x2 d = f32x2{x[k], x[k + 1]} - m2;
+        x[k] = d.x;
+        x[k + 1] = d.y;
+        v2 = __builtin_elementwise_fma(d, d, v2);
+    }
+    const float rstd = 1.0f / sqrtf(xhalf_sum(v2.x + v2.y) * (1.0f / (2 * KH)) + 1e-5f);
+    const f32x2 r2 = {rstd, rstd};
 #pragma unroll
-    for (int k = 0; k < KH; ++k) x[k] = (x[k] - mean) * rstd;
+    for (int k = 0; k < KH; k += 2) {
+        const f32x2 y = f32x2{x[k], x[k + 1]} * r2;
+        x[k] = y.x;
+        x[k + 1] = y.y;
+    }
 }
 
 // ---- LDS staging ------------------------------------------------------------------------------
 // W: global [nout][K] (row pitch ldw floats, 16-byte aligned rows) -> Wl: LDS, row pitch K+4,
 // K axis permuted to CLL order: 16-byte group f of a row goes to slot (f&1)*(K/8) + (f>>1).
 template <int K>
-PRD_DEV void stage_weight_cll(float* Wl, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads) {
+PRD_DEV void stage_weight_cll(float* Wl, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads, float scale = 1.0f) {
     constexpr int F = K / 4;
     for (int idx = tid; idx < nout * F; idx += nthreads) {
         const int o = idx / F, f = idx - o * F;
         const float4 v = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 4 * f);
-        *reinterpret_cast<float4*>(Wl + o * (K + 4) + (f & 1) * (K / 2) + (f >> 1) * 4) = v;
+        *reinterpret_cast<float4*>(Wl + o * (K + 4) + (f & 1) * (K / 2) + (f >> 1) * 4) =
+            make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
     }
 }
 // same, but K axis kept in plain order split in two contiguous halves (for generated B operands)
@@ -98,10 +148,10 @@ PRD_DEV void stage_weight_plain(float* Wl, const float* __restrict__ W, int nout
     }
 }
 // per-channel vector (bias, LN affine, 1-row weight) in CLL order: vl[hi*(C/2) + s] = v[ch(s,hi)]
-PRD_DEV void stage_vec_cll(float* vl, const float* __restrict__ v, int C, int tid, int nthreads) {
+PRD_DEV void stage_vec_cll(float* vl, const float* __restrict__ v, int C, int tid, int nthreads, float scale = 1.0f) {
     for (int c = tid; c < C; c += nthreads) {
         const int f = c >> 2, e = c & 3;
-        vl[(f & 1) * (C / 2) + (f >> 1) * 4 + e] = v ? v[c] : 0.f;
+        vl[(f & 1) * (C / 2) + (f >> 1) * 4 + e] = v ? scale * v[c] : 0.f;
     }
 }
 
@@ -138,6 +188,19 @@ PRD_DEV void rowgemm_part(const float* Wl, const float (&x)[4 * (M1 - M0)], f32x
 template <int K, int NB>
 PRD_DEV void rowgemm(const float* Wl, const float (&x)[K / 2], f32x16 (&acc)[NB], int r, int hi) {
     rowgemm_part<K, NB, 0, K / 8>(Wl, x, acc, r, hi);
+}
+
+// accumulators preloaded with a CLL-staged bias vector (16 consecutive floats per output block and lane half): the
+// bias add of the epilogue becomes part of the MFMA chain; vl points at the lane's first element (vl + hi * C/2 + 16 * nb0)
+template <int NB>
+PRD_DEV void bias_acc(f32x16 (&acc)[NB], const float* vl) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(vl + 16 * nb + 4 * g);
+            acc[nb][4 * g] = v.x; acc[nb][4 * g + 1] = v.y; acc[nb][4 * g + 2] = v.z; acc[nb][4 * g + 3] = v.w;
+        }
 }
 
 template <int NB>
@@ -183,7 +246,9 @@ struct WaveTasks {
     int shard, nshard, count, last;
     PRD_DEV WaveTasks(int* queue, long ntask_, int waves_per_wg) : q(queue), ntask(ntask_) {
         stride = (long)gridDim.x * waves_per_wg;
-        cur = (long)blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+        // static order is WAVE-major (slot = wave * #workgroups + workgroup): the tasks of a partial last round land
+        // on as many different CUs as possible instead of filling the first few workgroups
+        cur = (long)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
         // one counter per XCD (workgroup b is observed to run on XCD b % 8; only speed depends on it):
         // a single word saturates near 90 dequeues/us, far below what 3000 waves ask for
         nshard = gridDim.x < 8 ? (int)gridDim.x : 8;
@@ -194,7 +259,10 @@ struct WaveTasks {
     }
     PRD_DEV long next() {                       // task id, or -1 when the work is exhausted
         if (!q) {
-            const long t = cur;
+            // readfirstlane: the id is the same in all 64 lanes, but only an SGPR value lets hipcc do the
+            // task -> (row, block) index arithmetic on the scalar unit.  fp32 MFMA and VALU instructions share
+            // the SIMD's issue time on gfx950 (tools/ubench/coissue_bench.hip), so VALU address math is not free.
+            const long t = (long)__builtin_amdgcn_readfirstlane((int)cur);
             cur += stride;
             return t < ntask ? t : -1;
         }

@@ -17,11 +17,115 @@
 #include "prd_common.h"
 #include "../../include/prd_hip.h"
 
+#ifdef PRD_TIMING     // diagnostic builds only (tools/ta_timing.py, tools/phase_timing.py): in-kernel cycle stamps
+__device__ unsigned long long prd_dbg[256 * 16 * 8 * 4];
+extern "C" int prd_debug_read(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(prd_dbg), sizeof(prd_dbg)); }
+// tri_attn_core: [wg][12 waves][8 iterations][4 stamps]
+#define PRD_STAMP(k) do { if (lane == 0 && it < 8) prd_dbg[((blockIdx.x * 12 + wave) * 8 + it) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+// row kernels: cycles per phase summed over the tasks of a wave, [wg][16 waves][8 phases]
+struct PhaseTimer {
+    unsigned long long t, acc[8];
+    __device__ PhaseTimer() { for (int k = 0; k < 8; ++k) acc[k] = 0; t = __builtin_readcyclecounter(); }
+    __device__ void mark(int k) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long n = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        acc[k] += n - t;
+        t = n;
+    }
+    __device__ void flush() {
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) prd_dbg[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k] = acc[k];
+    }
+};
+#else
+#define PRD_STAMP(k)
+struct PhaseTimer {
+    __device__ void mark(int) {}
+    __device__ void flush() {}
+};
+#endif
+
 namespace {
 
 constexpr int WG = 256;
 
 // ---------------------------------------------------------------------------------------------
+// position of a tri_mul_proj task; every field is wave-uniform (scalar registers, scalar index arithmetic; 32-bit on
+// purpose: a 64-bit division expands to ~130 instructions)
+struct ProjTask {
+    int ob, vb, bb, u, bu;
+    bool ok;
+};
+template <int OB>
+PRD_DEV ProjTask proj_decode(long task, int nrb, int nvb, int N) {
+    ProjTask t;
+    const int ti = task < 0 ? 0 : (int)task;
+    const int grp = ti / (8 * OB), within = ti % (8 * OB);
+    t.ob = within >> 3;
+    int rb = grp * 8 + (within & 7);
+    t.ok = task >= 0 && rb < nrb;               // false: past the end, or padding of the last group of 8 row blocks
+    if (!t.ok) rb = 0;                          // such tasks still prefetch (a valid row) but do not compute
+    t.vb = rb % nvb;
+    t.bu = rb / nvb;                            // bb*N + u
+    t.bb = t.bu / N;
+    t.u = t.bu - t.bb * N;
+    return t;
+}
+// row + mask loads of a task: issued one task ahead, so that they are OLDER than the stores of the task computed
+// meanwhile -- vmcnt retires in order, a load issued after those stores would wait for all of them (measured: 57 % of
+// the wave's time in tri_mul_proj before this prefetch)
+template <int P>
+PRD_DEV void proj_fetch(const ProjTask& t, const float* __restrict__ pair, const float* __restrict__ mask, int N, int incoming,
+                        int r, int hi, float (&x)[P / 2], float& mu, float& mv) {
+    const int v = t.vb * 32 + r;
+    const bool valid = v < N;
+    const int vv = valid ? v : 0;
+    mu = mask[t.bu];
+    mv = mask[t.bb * N + vv];
+    // outgoing: operand row u, contraction index v <-> pair[u, v]; incoming: pair[v, u].  Descriptor base = pair of batch
+    // element bb (uniform); lane offset = the row's position inside it
+    const prd_rsrc rs = make_rsrc(pair + (long)t.bb * N * N * P);
+    const unsigned rowi = incoming ? (unsigned)vv * N + t.u : (unsigned)t.u * N + vv;
+    load_row_cll_buf<P>(rs, valid ? (rowi * P + 4 * hi) * 4u : BUF_OOB, x);
+}
+
+template <int P>
+PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float mv, float* __restrict__ AB,
+                          const float* Wpl, const float* Wgl, const float* bpl, const float* bgl,
+                          int N, int ldn, long cstride, unsigned lane_off, int r, int hi, PhaseTimer& pt) {
+    constexpr int KH = P / 2, OUT = 2 * P;
+    const bool valid = t.vb * 32 + r < N;
+    pt.mark(0);                                     // 0: task fetch / decode, prefetch issue
+    const float m2 = valid ? mu * mv : 0.f;
+    const bool plain = __all(m2 == 1.0f);           // every row of the block valid and unmasked (the common case)
+    pt.mark(1);                                     // 1: wait for this task's row + masks
+    ln_cll<KH>(x);
+    pt.mark(2);                                     // 2: LayerNorm
+    f32x16 ap[1], ag[1];
+    bias_acc(ap, bpl + hi * P + 16 * t.ob);         // biases ride in the accumulators
+    bias_acc(ag, bgl + hi * P + 16 * t.ob);
+    rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
+    rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
+    pt.mark(3);                                     // 3: MFMAs
+    // output channel of register q: 32*ob + (q&3) + 8*(q>>2) + 4*hi; the hi part sits in lane_off
+    const prd_rsrc cb = make_rsrc(AB + ((((long)t.bb * OUT) + 32 * t.ob) * N + t.u) * ldn + t.vb * 32);
+    const unsigned cbytes = (unsigned)cstride * 4u;
+    if (plain) {
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const f32x2 den = f32x2{__builtin_amdgcn_exp2f(ag[0][q]), __builtin_amdgcn_exp2f(ag[0][q + 1])} + 1.0f;
+            const f32x2 val = f32x2{ap[0][q], ap[0][q + 1]} * f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            buf_store(val.x, cb, lane_off, ((q & 3) + 8 * (q >> 2)) * cbytes);
+            buf_store(val.y, cb, lane_off, (((q + 1) & 3) + 8 * ((q + 1) >> 2)) * cbytes);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            buf_store(m2 * (gate_from_scaled(ag[0][q]) * ap[0][q]), cb, lane_off, ((q & 3) + 8 * (q >> 2)) * cbytes);
+    }
+    pt.mark(4);                                     // 4: epilogue + store issue
+}
+
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float* __restrict__ AB, const float* __restrict__ pair,
                                                           const float* __restrict__ mask,
@@ -30,60 +134,45 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
                                                           int b, int N, int ldn, int incoming) {
     constexpr int KH = P / 2, OUT = 2 * P, OB = OUT / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    PhaseTimer pt;
     float* Wpl = smem;                       // [2P][P+4]
     float* Wgl = Wpl + OUT * (P + 4);
     float* bpl = Wgl + OUT * (P + 4);        // [2P] CLL
     float* bgl = bpl + OUT;
     stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NW * 64);
-    stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NW * 64);
+    stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E);
     stage_vec_cll(bpl, bp, OUT, threadIdx.x, NW * 64);
-    stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64);
-    __syncthreads();
+    stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64, NEG_LOG2E);
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const int nvb = ldn / 32;
-    const long ntask = (long)b * N * nvb;
+    const int nrb = b * N * nvb;                        // 32-row blocks
+    // A task is one 32-output block `ob` of one 32-row block: at N = 320 there are only 3.1 row blocks per SIMD, and
+    // whole-block tasks leave the SIMDs that draw a 4th one running alone (28 % of the launch).  The row is re-read
+    // (L2) and re-normalised per task; the four tasks of a row block sit 8 task ids apart = same XCD, different CUs.
+    const long ntask = (long)((nrb + 7) / 8 * 8) * OB;
+    const long cstride = (long)N * ldn;                 // channel stride of AB
+    const unsigned lane_off = (hi * 4 * (unsigned)cstride + r) * 4u;   // lane part (bytes) of every store address: channel 4*hi, column r
     WaveTasks tasks(queue, ntask, NW);
-    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
-        const int vb = (int)(task % nvb);
-        const long bu = task / nvb;                 // bb*N + u
-        const int bb = (int)(bu / N), u = (int)(bu - (long)bb * N);
-        const int v = vb * 32 + r;
-        const bool valid = v < N;
-        const int vv = valid ? v : 0;
-        // outgoing: operand row u, contraction index v <-> pair[u, v]; incoming: pair[v, u]
-        const long pos = incoming ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
-        // mask loads are issued together with the row (their latency hides behind the row's), not after the LayerNorm
-        const float mu = mask[bu], mv = mask[(long)bb * N + vv];
-        float x[KH];
-#if defined(PRD_ABLATE) && PRD_ABLATE == 11
-        for (int s = 0; s < KH; ++s) x[s] = 0.01f * (s + r);       // ablation: no row load
-#else
-        load_row_cll<P>(pair + pos * P, hi, valid, x);
-#endif
-        const float m2 = valid ? mu * mv : 0.f;
-#if !(defined(PRD_ABLATE) && PRD_ABLATE == 12)
-        ln_cll<KH>(x);
-#endif
-#pragma unroll 1
-        for (int ob = 0; ob < OB; ++ob) {
-            f32x16 ap[1], ag[1];
-            zero_acc(ap);
-            zero_acc(ag);
-            rowgemm<P, 1>(Wpl + ob * 32 * (P + 4), x, ap, r, hi);
-            rowgemm<P, 1>(Wgl + ob * 32 * (P + 4), x, ag, r, hi);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int s = ob * 16 + q;                       // CLL element of the 2P-wide output
-                const int c = 32 * ob + drow32(q, hi);           // output channel
-                const float val = m2 * sigmoid_fast(ag[0][q] + bgl[hi * P + s]) * (ap[0][q] + bpl[hi * P + s]);
-#if defined(PRD_ABLATE) && PRD_ABLATE == 13
-                if (val == 123.456f) AB[0] = val;                  // ablation: no stores
-#else
-                AB[(((long)bb * OUT + c) * N + u) * ldn + v] = valid ? val : 0.f;
-#endif
-            }
-        }
+    // two row buffers, used alternately: the row of the NEXT task is in flight while the current one is computed
+    float xa[KH], xb[KH], mua, mva, mub, mvb;
+    long t = tasks.next();
+    ProjTask ta = proj_decode<OB>(t, nrb, nvb, N), tb;
+    proj_fetch<P>(ta, pair, mask, N, incoming, r, hi, xa, mua, mva);        // overlaps the weight staging
+    __syncthreads();
+    pt.mark(6);                                     // 6: prologue (weight staging, first fetch, barrier)
+    while (t >= 0) {
+        const long tn = tasks.next();
+        tb = proj_decode<OB>(tn, nrb, nvb, N);
+        proj_fetch<P>(tb, pair, mask, N, incoming, r, hi, xb, mub, mvb);
+        if (ta.ok) proj_compute<P>(ta, xa, mua, mva, AB, Wpl, Wgl, bpl, bgl, N, ldn, cstride, lane_off, r, hi, pt);
+        if (tn < 0) break;
+        t = tasks.next();
+        ta = proj_decode<OB>(t, nrb, nvb, N);
+        proj_fetch<P>(ta, pair, mask, N, incoming, r, hi, xa, mua, mva);
+        if (tb.ok) proj_compute<P>(tb, xb, mub, mvb, AB, Wpl, Wgl, bpl, bgl, N, ldn, cstride, lane_off, r, hi, pt);
     }
+    pt.mark(5);
+    pt.flush();
 }
 
 // Triangle-multiplication contraction (reference modules.py:272, "ikd,jkd->ijd" / "kid,kjd->ijd" after the
@@ -512,9 +601,11 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         const bool ok = bu0 < nrows && wave < nqb && v < N;
         load_row_cll<P>(pair + row_pos(ok ? bu0 : 0, ok ? v : 0) * P, hi, ok, xnext);
     }
-    for (long bu = slot; bu < nrows; bu += rstride) {
+    int it = 0;
+    for (long bu = slot; bu < nrows; bu += rstride, ++it) {
         const int bb = (int)(bu / N);
         __syncthreads();                        // previous row's LDS fully consumed (and weights staged)
+        PRD_STAMP(0);
         const float mu = mask[bu];
         // ---- phase 1 ----
         for (int vb = wave; vb < nvb; vb += NW) {
@@ -563,7 +654,23 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 Vt[(8 + 4 * hi + e) * (npad + 4) + v] = vv[4 + e];
             }
         }
+        PRD_STAMP(1);
         __syncthreads();
+        PRD_STAMP(2);
+#if defined(PRD_TA_PRIO)
+        {   // experiment: static priorities against the age-ordered arbitration of the matrix pipe
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+#if PRD_TA_PRIO == 1
+            if (wv >= 8) __builtin_amdgcn_s_setprio(1);
+#elif PRD_TA_PRIO == 2
+            if (wv >= 8) __builtin_amdgcn_s_setprio(2); else if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#elif PRD_TA_PRIO == 3
+            if (wv >= 4 && wv < 8) __builtin_amdgcn_s_setprio(1);
+#elif PRD_TA_PRIO == 4
+            if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+        }
+#endif
         // next row's first block: in flight during the whole key loop
         if (PREFETCH) {
             const long bun = bu + rstride;
@@ -612,6 +719,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 }
             }
         }
+#if defined(PRD_TA_PRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        PRD_STAMP(3);
     }
 }
 
@@ -797,7 +908,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     {
         constexpr int NWP = 12;                      // one persistent 12-wave workgroup per CU (3 waves / SIMD)
         const size_t lds = ((size_t)2 * 2 * P * (P + 4) + 4 * P) * sizeof(float);
-        const long ntask = (long)b * N * (ldn / 32);
+        const long ntask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);     // (row block, output block) tasks
         const int grid = grid_for(ntask, NWP, 256);
         if (P == 64) {
             PRD_SET_LDS((tri_mul_proj_kernel<64, NWP>), lds);

@@ -167,10 +167,16 @@ def test_pair_transition(setup):
     assert rel_l2(got.cpu(), O.transition(s["params"], "Denoiser.folding_blocks.0.pair_fc", s["pair"])) < OP_TOL
 
 
-def test_block_tail_fusion_and_queue_reset(setup):
+@pytest.mark.parametrize("use_queue", [False, True])
+def test_block_tail_fusion_and_queue_reset(setup, monkeypatch, use_queue):
     """Fused tail (ending tri-attn output projection + pair transition + next block's bias) == the three separate
-    oracle ops; and every persistent-kernel task queue counter is back at zero afterwards."""
+    oracle ops, with the static task order and with the opt-in device task queue; every queue counter is back at
+    zero afterwards."""
     s = setup
+    if use_queue:
+        monkeypatch.setenv("PRD_TASK_QUEUE", "1")
+    else:
+        monkeypatch.delenv("PRD_TASK_QUEUE", raising=False)
     m, p, args = s["model"], s["params"], s["args"]
     blk, nxt = m.Denoiser.folding_blocks[0], m.Denoiser.folding_blocks[1]
     H, c = args["num_heads"], args["head_dim"]
@@ -188,6 +194,7 @@ def test_block_tail_fusion_and_queue_reset(setup):
     assert rel_l2(pair.cpu(), want) < BLOCK_TOL
     assert rel_l2(bias.cpu(), want_bias) < BLOCK_TOL
     torch.cuda.synchronize()
+    assert bool(ops._QUEUES) or not use_queue
     for q in ops._QUEUES.values():
         assert int(q.abs().sum()) == 0
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Per-phase cycle totals of a row kernel from in-kernel stamps (library built with -DPRD_TIMING, PRD_LIB=...).
+usage: phase_timing.py tri_mul_proj [N]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from protein_redesign_amd import _lib, ops  # noqa: E402
+from protein_redesign_amd.constants import make_args  # noqa: E402
+from protein_redesign_amd.diffusion_model import ProteinReDiffModel  # noqa: E402
+from protein_redesign_amd.synthetic import deterministic_state_dict  # noqa: E402
+from protein_redesign_amd.weights import spec_tensors  # noqa: E402
+
+PHASES = {"tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"]}
+
+
+def main():
+    which = sys.argv[1]
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+    args = make_args(single_dim=512, pair_dim=64, num_blocks=2, num_steps=1000)
+    m = ProteinReDiffModel(args)
+    m.load_state_dict(deterministic_state_dict(spec_tensors(args), seed=1))
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(0)
+    pair = torch.randn(1, N, N, 64, generator=g).cuda()
+    mask = torch.ones(1, N).cuda()
+    blk = m.Denoiser.folding_blocks[0]
+    ws = torch.empty(m.Denoiser.ws_floats(1, N), device="cuda")
+    L = _lib.lib()
+    L.prd_debug_read.argtypes = [ctypes.c_void_p]
+    with torch.inference_mode():
+        for _ in range(3):
+            blk.pair_mul_outgoing.run(pair, mask, residual=True, out=pair.clone(), ws=ws)
+        torch.cuda.synchronize()
+    buf = np.zeros(256 * 16 * 8 * 4, dtype=np.uint64)
+    assert L.prd_debug_read(buf.ctypes.data) == 0
+    t = buf[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64)
+    nw = int((t.sum(axis=(0, 2)) > 0).sum())
+    t = t[:, :nw]
+    tot = t.sum(axis=2)
+    print(f"{which}: N={N}, {nw} waves/WG; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
+    for k, name in enumerate(PHASES[which]):
+        print(f"  {name:20s} mean {t[:, :, k].mean():9.0f}  ({100 * t[:, :, k].mean() / tot.mean():5.1f} %)   max over waves {t[:, :, k].max():9.0f}")
+
+
+if __name__ == "__main__":
+    main()
