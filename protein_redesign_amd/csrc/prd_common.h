@@ -211,13 +211,26 @@ PRD_DEV void zero_acc(f32x16 (&acc)[NB]) {
         for (int q = 0; q < 16; ++q) acc[nb][q] = 0.f;
 }
 
+// plain v_max3_f32 / v_max_f32: fmaxf() adds a canonicalising v_max per operand that comes out of an MFMA, and on
+// gfx950 every VALU instruction costs matrix-pipe time (fp32 MFMA and VALU share the SIMD's issue cycles)
+PRD_DEV float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+PRD_DEV float max2f(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // cross-lane reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the
 // gfx950 half/row swap instructions: VALU only, no LDS round trip (ds_bpermute)
 PRD_DEV float rows4_max(float v) {
     auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    v = max2f(__uint_as_float(a[0]), __uint_as_float(a[1]));
     auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    return max2f(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 PRD_DEV float rows4_sum(float v) {
     auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);

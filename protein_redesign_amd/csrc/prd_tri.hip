@@ -345,11 +345,16 @@ constexpr int KP = 20;          // LDS pitch (floats) of the [*, 16] K / Q / G t
 constexpr float LOG2E = 1.4426950408889634f;
 
 // The key loop of one wave for NTQ (1 or 2) 16-query tiles: S^T = K Q^T, online softmax in the exp2
-// domain over blocks of 16*JT keys, O^T += V^T P^T.  Returns O^T[c = 4*g4 + e][q = ql] / l per tile.
+// domain over blocks of 16*JT keys, O^T += V^T P^T.  Returns O^T[c = 4*g4 + e][q = ql] and l per tile.
+//
+// fp32 MFMA and VALU instructions share the SIMD's issue time on gfx950 (tools/ubench/coissue_bench.hip: the cycles
+// add, for any number of waves), so the softmax arithmetic is kept as short as it gets: 64 keys per running-max update,
+// v_max3 without canonicalisation, packed fp32 subtract / add (two logits per instruction); what is left is the one
+// v_exp_f32 per logit.
 template <int NTQ, bool MASKED>
 PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ Vt, const float* __restrict__ kadd,
                         const float4 (&qf)[NTQ], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
-    constexpr int JT = 2;                      // 16-key tiles per online-softmax update (32 keys): register budget
+    constexpr int JT = 4;                      // 16-key tiles per online-softmax update (64 keys; npad is a multiple of 64)
     float m_run[NTQ], l_run[NTQ];
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) {
@@ -358,6 +363,15 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
         o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int key0 = 0; key0 < npad; key0 += 16 * JT) {
+        {   // Priority = fraction of the wave's own key loop still to do.  The waves of a SIMD are arbitrated strictly
+            // oldest-first: without this the youngest wave is starved until the others are done and then runs alone,
+            // latency-bound (measured at N = 320: phase 2 of a row 42.4k -> 39.4k cycles, all waves end together).
+            const int rem = npad - key0;
+            if (4 * rem > 3 * npad) __builtin_amdgcn_s_setprio(3);
+            else if (2 * rem > npad) __builtin_amdgcn_s_setprio(2);
+            else if (4 * rem > npad) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         float4 kf[JT], ma[JT];
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
@@ -393,31 +407,39 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
             vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
-            float tmax = -INFINITY;
+            if (MASKED) {
 #pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                if (MASKED) {
+                for (int j = 0; j < JT; ++j) {
                     s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x;
                     s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y;
                     s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z;
                     s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w;
                 }
-                tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][j][0], s[t][j][1]), fmaxf(s[t][j][2], s[t][j][3])));
+            }
+            float tmax = max3f(s[t][0][0], s[t][0][1], s[t][0][2]);
+            tmax = max3f(tmax, s[t][0][3], s[t][1][0]);
+#pragma unroll
+            for (int j = 1; j < JT; ++j) {
+                tmax = max3f(tmax, s[t][j][1], s[t][j][2]);
+                if (j + 1 < JT) tmax = max3f(tmax, s[t][j][3], s[t][j + 1][0]);
+                else tmax = max2f(tmax, s[t][j][3]);
             }
             tmax = rows4_max(tmax);
-            const float m_new = fmaxf(m_run[t], tmax);
+            const float m_new = max2f(m_run[t], tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             m_run[t] = m_new;
-            float psum = 0.f;
+            const f32x2 mm = {m_new, m_new};
+            f32x2 ps = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < JT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(s[t][j][e] - m_new);
-                    s[t][j][e] = pe;
-                    psum += pe;
-                }
-            l_run[t] = l_run[t] * alpha + psum;
+            for (int j = 0; j < JT; ++j) {
+                const f32x2 d0 = f32x2{s[t][j][0], s[t][j][1]} - mm, d1 = f32x2{s[t][j][2], s[t][j][3]} - mm;
+                const f32x2 e0 = {__builtin_amdgcn_exp2f(d0.x), __builtin_amdgcn_exp2f(d0.y)};
+                const f32x2 e1 = {__builtin_amdgcn_exp2f(d1.x), __builtin_amdgcn_exp2f(d1.y)};
+                s[t][j][0] = e0.x; s[t][j][1] = e0.y; s[t][j][2] = e1.x; s[t][j][3] = e1.y;
+                ps += e0;
+                ps += e1;
+            }
+            l_run[t] = l_run[t] * alpha + (ps.x + ps.y);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
         }
@@ -657,20 +679,6 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         PRD_STAMP(1);
         __syncthreads();
         PRD_STAMP(2);
-#if defined(PRD_TA_PRIO)
-        {   // experiment: static priorities against the age-ordered arbitration of the matrix pipe
-            const int wv = __builtin_amdgcn_readfirstlane(wave);
-#if PRD_TA_PRIO == 1
-            if (wv >= 8) __builtin_amdgcn_s_setprio(1);
-#elif PRD_TA_PRIO == 2
-            if (wv >= 8) __builtin_amdgcn_s_setprio(2); else if (wv >= 4) __builtin_amdgcn_s_setprio(1);
-#elif PRD_TA_PRIO == 3
-            if (wv >= 4 && wv < 8) __builtin_amdgcn_s_setprio(1);
-#elif PRD_TA_PRIO == 4
-            if (wv >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-        }
-#endif
         // next row's first block: in flight during the whole key loop
         if (PREFETCH) {
             const long bun = bu + rstride;
@@ -719,9 +727,6 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 }
             }
         }
-#if defined(PRD_TA_PRIO)
-        __builtin_amdgcn_s_setprio(0);
-#endif
         PRD_STAMP(3);
     }
 }

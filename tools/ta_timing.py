@@ -22,11 +22,11 @@ for ending in (False, True):
     for _ in range(3):
         ops.tri_attn_core(pair, mask, wts, 4, 16, ending=ending, og=og)
     torch.cuda.synchronize()
-    buf = np.zeros(256 * 12 * 8 * 4, dtype=np.uint64)
+    buf = np.zeros(256 * 16 * 8 * 4, dtype=np.uint64)      # sizeof(prd_dbg)
     L = _lib.lib()
     L.prd_debug_read.argtypes = [ctypes.c_void_p]
     assert L.prd_debug_read(buf.ctypes.data) == 0
-    t = buf.reshape(256, 12, 8, 4).astype(np.int64)
+    t = buf[: 256 * 12 * 8 * 4].reshape(256, 12, 8, 4).astype(np.int64)
     nit = int((t[0, 0, :, 0] > 0).sum())
     t = t[:, :, :nit]
     t0 = t[..., 0].min()
