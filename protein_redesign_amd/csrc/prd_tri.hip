@@ -582,10 +582,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     float* kadd = Vt + C * (npad + 4);         // [npad]: 0 = keep the logit, else the value that replaces it
     float* Ql = kadd + npad;                   // [npad][KP]
     float* Gl = Ql + npad * KP;                // [npad][KP]
+    float* bqg = Gl + npad * KP;               // [2][16]: accumulator preload of the [q; g] half (0 | -log2e * gate bias)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const int ql = lane & 15, g4 = lane >> 4;
-    const int nvb = npad / 32;
     const int nqb = (N + 31) / 32;
     const int ntile = (N + 15) / 16;
     // workgroup -> (head, row slot).  Workgroup w is observed to run on XCD w % 8; the H heads of one row
@@ -600,14 +600,16 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         h = blockIdx.x % H;
         slot = blockIdx.x / H;
     }
+    const float sc = 0.25f * LOG2E;            // 1/sqrt(c) (modules.py:176,216) in the exp2 domain, folded into Wq
     stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
     stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
-    stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT);
-    stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
-    float bgl[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { bgl[e] = bg[h * C + 4 * hi + e]; bgl[4 + e] = bg[h * C + 8 + 4 * hi + e]; }
-    const float sc = 0.25f * LOG2E;            // 1/sqrt(c) (modules.py:176,216) in the exp2 domain
+    stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT, sc);
+    stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E);   // gate_from_scaled
+    // accumulator preload of the [q; g] half: lane half hi owns D rows q{4hi+e}, q{8+4hi+e}, g{4hi+e}, g{8+4hi+e}
+    if (tid < 32) {
+        const int hh = tid >> 4, e = tid & 15;
+        bqg[tid] = e < 8 ? 0.f : NEG_LOG2E * bg[h * C + (e < 12 ? 4 * hh + (e - 8) : 8 + 4 * hh + (e - 12))];
+    }
     const long nrows = (long)b * N;
 
     auto row_pos = [&](long bu, int v) -> long {          // pair position of sequence element v of row bu
@@ -615,12 +617,30 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         const long u = bu - bb * N;
         return ending ? ((bb * N + v) * N + u) : (bu * N + v);
     };
+    // ---- phase-1 work of this wave: (block, halves) units.  Half 0 = [k; v], half 1 = [q; gate] (32 MFMAs each).
+    // Whole rounds of NW blocks go one block per wave; of the R blocks left, as many as needed are split in halves
+    // over two waves so that the SIMDs (waves w, w+4, w+8 share one) end together: N = 320 -> waves 0-7 a block each,
+    // waves 8-11 half a block each = 5 half units per SIMD instead of 6 / 6 / 4 / 4.
+    const int full_rounds = nqb / NW, R = nqb - full_rounds * NW;
+    const int S = 2 * R <= NW ? R : NW - R;               // blocks of the last round that are split
+    const int F = R - S;                                   // blocks of the last round done whole by waves 0..F-1
+    int last_blk = -1, last_halves = 0;
+    if (wave < F) { last_blk = full_rounds * NW + wave; last_halves = 3; }
+    else if (wave - F < 2 * S) { last_blk = full_rounds * NW + F + (wave - F) % S; last_halves = 1 << ((wave - F) / S); }
+    const int nunits = full_rounds + (last_blk >= 0 ? 1 : 0);
+    const int first_blk = full_rounds > 0 ? wave : last_blk;
+    // positions past the last real block never change: K = V = Q = 0, logit override -inf
+    for (int v = nqb * 32 + tid; v < npad; v += NT) {
+#pragma unroll
+        for (int e = 0; e < C; ++e) { Kl[v * KP + e] = 0.f; Ql[v * KP + e] = 0.f; Gl[v * KP + e] = 0.f; Vt[e * (npad + 4) + v] = 0.f; }
+        kadd[v] = -INFINITY;
+    }
     // prefetch of this wave's first block of the first row
     float xnext[KH];
     if (PREFETCH) {
         const long bu0 = slot;
-        const int v = wave * 32 + r;
-        const bool ok = bu0 < nrows && wave < nqb && v < N;
+        const int v = first_blk * 32 + r;
+        const bool ok = bu0 < nrows && first_blk >= 0 && v < N;
         load_row_cll<P>(pair + row_pos(ok ? bu0 : 0, ok ? v : 0) * P, hi, ok, xnext);
     }
     int it = 0;
@@ -630,50 +650,46 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         PRD_STAMP(0);
         const float mu = mask[bu];
         // ---- phase 1 ----
-        for (int vb = wave; vb < nvb; vb += NW) {
+        for (int un = 0; un < nunits; ++un) {
+            const int vb = un < full_rounds ? un * NW + wave : last_blk;
+            const int halves = un < full_rounds ? 3 : last_halves;
             const int v = vb * 32 + r;
-            if (hi == 0) {                                    // per-key logit override of this row (see header comment)
-                const bool inside = v < N;
-                const bool keep = inside && (mu * mask[(long)bb * N + (inside ? v : 0)] >= 0.5f);
-                kadd[v] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
-            }
-            float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, q0 = k0, q1 = k0, g0 = k0, g1 = k0;
-            float vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (vb < nqb) {                                   // blocks past the sequence end are all zeros
-                float x[KH];
-                if (PREFETCH && vb == wave) {
+            const bool valid = v < N;
+            float x[KH];
+            if (PREFETCH && un == 0) {
 #pragma unroll
-                    for (int s = 0; s < KH; ++s) x[s] = xnext[s];
-                } else {
-                    const bool valid = v < N;
-                    load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
+                for (int s = 0; s < KH; ++s) x[s] = xnext[s];
+            } else {
+                load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
+            }
+            ln_cll<KH>(x);
+            if (halves & 1) {
+                if (hi == 0) {                                // per-key logit override of this row (see header comment)
+                    const bool keep = valid && (mu * mask[(long)bb * N + (valid ? v : 0)] >= 0.5f);
+                    kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E : -INFINITY);
                 }
-                ln_cll<KH>(x);
-                f32x16 acc[2];
+                f32x16 acc[1];
                 zero_acc(acc);
-                rowgemm<P, 2>(Wl, x, acc, r, hi);
-                k0 = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-                k1 = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+                rowgemm<P, 1>(Wl, x, acc, r, hi);
+                // D rows of a block: channels {4hi+e} in registers 0-3 and {8+4hi+e} in 4-7 of each 16-row group
+                *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] = acc[0][8 + e];
-                q0 = make_float4(sc * acc[1][0], sc * acc[1][1], sc * acc[1][2], sc * acc[1][3]);
-                q1 = make_float4(sc * acc[1][4], sc * acc[1][5], sc * acc[1][6], sc * acc[1][7]);
-                g0 = make_float4(sigmoid_fast(acc[1][8] + bgl[0]), sigmoid_fast(acc[1][9] + bgl[1]),
-                                 sigmoid_fast(acc[1][10] + bgl[2]), sigmoid_fast(acc[1][11] + bgl[3]));
-                g1 = make_float4(sigmoid_fast(acc[1][12] + bgl[4]), sigmoid_fast(acc[1][13] + bgl[5]),
-                                 sigmoid_fast(acc[1][14] + bgl[6]), sigmoid_fast(acc[1][15] + bgl[7]));
+                for (int e = 0; e < 4; ++e) {
+                    Vt[(4 * hi + e) * (npad + 4) + v] = acc[0][8 + e];
+                    Vt[(8 + 4 * hi + e) * (npad + 4) + v] = acc[0][12 + e];
+                }
             }
-            // D rows of a block: channels {4hi+e} in registers 0-3 and {8+4hi+e} in 4-7 of each 16-row group
-            *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = k0;
-            *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = k1;
-            *reinterpret_cast<float4*>(Ql + v * KP + 4 * hi) = q0;
-            *reinterpret_cast<float4*>(Ql + v * KP + 8 + 4 * hi) = q1;
-            *reinterpret_cast<float4*>(Gl + v * KP + 4 * hi) = g0;
-            *reinterpret_cast<float4*>(Gl + v * KP + 8 + 4 * hi) = g1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Vt[(4 * hi + e) * (npad + 4) + v] = vv[e];
-                Vt[(8 + 4 * hi + e) * (npad + 4) + v] = vv[4 + e];
+            if (halves & 2) {
+                f32x16 acc[1];
+                bias_acc(acc, bqg + 16 * hi);
+                rowgemm<P, 1>(Wl + 2 * C * (P + 4), x, acc, r, hi);
+                *reinterpret_cast<float4*>(Ql + v * KP + 4 * hi) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                *reinterpret_cast<float4*>(Ql + v * KP + 8 + 4 * hi) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+                *reinterpret_cast<float4*>(Gl + v * KP + 4 * hi) = make_float4(gate_from_scaled(acc[0][8]), gate_from_scaled(acc[0][9]),
+                                                                                gate_from_scaled(acc[0][10]), gate_from_scaled(acc[0][11]));
+                *reinterpret_cast<float4*>(Gl + v * KP + 8 + 4 * hi) = make_float4(gate_from_scaled(acc[0][12]), gate_from_scaled(acc[0][13]),
+                                                                                    gate_from_scaled(acc[0][14]), gate_from_scaled(acc[0][15]));
             }
         }
         PRD_STAMP(1);
@@ -682,8 +698,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         // next row's first block: in flight during the whole key loop
         if (PREFETCH) {
             const long bun = bu + rstride;
-            const int v = wave * 32 + r;
-            const bool ok = bun < nrows && wave < nqb && v < N;
+            const int v = first_blk * 32 + r;
+            const bool ok = bun < nrows && first_blk >= 0 && v < N;
             load_row_cll<P>(pair + row_pos(ok ? bun : 0, ok ? v : 0) * P, hi, ok, xnext);
         }
         // ---- phase 2 ----
@@ -948,7 +964,7 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
-    size_t lds = ((size_t)64 * (P + 4) + (size_t)3 * npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    size_t lds = ((size_t)64 * (P + 4) + (size_t)3 * npad * KP + 16 * (npad + 4) + npad + 32) * sizeof(float);
     const bool long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
     if (long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
