@@ -183,25 +183,32 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
 // multiplied, one barrier per chunk.  Workgroups of one channel are placed on one XCD (they share A/B in L2).
 __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict__ O, const float* __restrict__ AB,
                                                                int N, int ldn, int P, int nbatch, int tiles) {
-    // Measured alternatives at N = 320 (b = 1): this form (32-wide K chunks, two LDS buffers, 4 workgroups / CU) 51 us;
-    // one LDS buffer + register prefetch 83 us; 64-wide chunks (2 workgroups / CU) 119 us; generic prd_gemm 55 us.
+    // Measured alternatives at N = 320 (b = 1): this form (32-wide K chunks, two LDS buffers, 4 workgroups / CU, global
+    // loads two chunks ahead) 51 us; loads one chunk ahead 54 us; one LDS buffer + register prefetch 83 us; 64-wide chunks
+    // (2 workgroups / CU) 119 us; generic prd_gemm 55 us.  In-kernel stamps: the first 1024 workgroups keep the matrix pipe
+    // ~100 % busy for 17 us; the launch as a whole is cold-start + a 1.56-round tail (1600 tiles on 1024 slots).
     constexpr int KCH = 32, LDP = KCH + 4;
     __shared__ __attribute__((aligned(16))) float As[2][64 * LDP];
     __shared__ __attribute__((aligned(16))) float Bs[2][64 * LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    // (channel, tile) of this workgroup
+    // Persistent workgroups (4 per CU): virtual block vb = blockIdx.x, blockIdx.x + gridDim.x, ...  One workgroup per tile
+    // leaves the dispatcher to refill whichever CUs finish first (1600 tiles on 1024 slots at N = 320: a second full round
+    // on a subset of the CUs, 47 us); consecutive workgroup ids sit on different CUs, so the strided loop gives every CU
+    // 6 or 7 tiles.
     const int nch = nbatch * P;
     const int t2 = tiles * tiles;
+    for (int vblk = blockIdx.x; vblk < nch * t2; vblk += gridDim.x) {
+    // (channel, tile) of this virtual block: the tiles of one channel stay on one XCD (they share A / B in L2)
     int ch, tile;
-    if ((nch & 7) == 0) {
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    if ((nch & 7) == 0 && (gridDim.x & 7) == 0) {
+        const int xcd = vblk & 7, k = vblk >> 3;
         ch = xcd + 8 * (k / t2);
         tile = k % t2;
     } else {
-        ch = blockIdx.x / t2;
-        tile = blockIdx.x % t2;
+        ch = vblk / t2;
+        tile = vblk % t2;
     }
     const int bb = ch / P, d = ch - bb * P;
     const int m0 = (tile / tiles) * 64, n0 = (tile % tiles) * 64;
@@ -221,51 +228,57 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
     const int nchunk = ldn / KCH;                        // ldn is a multiple of 32; columns >= N hold zeros
     // rows past the edge are loaded from row 0 (always valid) and zeroed in registers: a select between a load and
     // a constant would be lowered to a load from a stack slot (scratch memory) instead
-    float4 ra0 = *reinterpret_cast<const float4*>(pa0), ra1 = *reinterpret_cast<const float4*>(pa1);
-    float4 rb0 = *reinterpret_cast<const float4*>(pb0), rb1 = *reinterpret_cast<const float4*>(pb1);
-    if (!a0) ra0 = zero4;
-    if (!a1) ra1 = zero4;
-    if (!b0) rb0 = zero4;
-    if (!b1) rb1 = zero4;
-    *reinterpret_cast<float4*>(&As[0][srow * LDP + 4 * sf]) = ra0;
-    *reinterpret_cast<float4*>(&As[0][(srow + 32) * LDP + 4 * sf]) = ra1;
-    *reinterpret_cast<float4*>(&Bs[0][srow * LDP + 4 * sf]) = rb0;
-    *reinterpret_cast<float4*>(&Bs[0][(srow + 32) * LDP + 4 * sf]) = rb1;
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int cur = c & 1;
-        const bool more = c + 1 < nchunk;
-        {   // next chunk's global loads fly over this chunk's MFMAs.  UNCONDITIONAL (the last iteration re-reads its own
-            // chunk): loads under an `if` make hipcc emit `s_waitcnt vmcnt(0)` in front of the MFMAs
-            const int ko = (more ? c + 1 : c) * KCH;
-            ra0 = *reinterpret_cast<const float4*>(pa0 + ko);
-            ra1 = *reinterpret_cast<const float4*>(pa1 + ko);
-            rb0 = *reinterpret_cast<const float4*>(pb0 + ko);
-            rb1 = *reinterpret_cast<const float4*>(pb1 + ko);
-            if (!a0) ra0 = zero4;
-            if (!a1) ra1 = zero4;
-            if (!b0) rb0 = zero4;
-            if (!b1) rb1 = zero4;
-        }
-        const float* as = &As[cur][(wm0 + r) * LDP + hi * 16];
-        const float* bs = &Bs[cur][(wn0 + r) * LDP + hi * 16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 a = *reinterpret_cast<const float4*>(as + 4 * t);
-            const float4 bq = *reinterpret_cast<const float4*>(bs + 4 * t);
-            acc = mfma32(a.x, bq.x, acc);
-            acc = mfma32(a.y, bq.y, acc);
-            acc = mfma32(a.z, bq.z, acc);
-            acc = mfma32(a.w, bq.w, acc);
-        }
-        if (more) {
-            *reinterpret_cast<float4*>(&As[cur ^ 1][srow * LDP + 4 * sf]) = ra0;
-            *reinterpret_cast<float4*>(&As[cur ^ 1][(srow + 32) * LDP + 4 * sf]) = ra1;
-            *reinterpret_cast<float4*>(&Bs[cur ^ 1][srow * LDP + 4 * sf]) = rb0;
-            *reinterpret_cast<float4*>(&Bs[cur ^ 1][(srow + 32) * LDP + 4 * sf]) = rb1;
-        }
-        __syncthreads();
+#define PRD_TMC_LOAD(R, KO)                                                       \
+    R##a0 = *reinterpret_cast<const float4*>(pa0 + (KO));                         \
+    R##a1 = *reinterpret_cast<const float4*>(pa1 + (KO));                         \
+    R##b0 = *reinterpret_cast<const float4*>(pb0 + (KO));                         \
+    R##b1 = *reinterpret_cast<const float4*>(pb1 + (KO));
+    // (the edge rows are zeroed when they are STAGED: touching the registers earlier would wait for the loads at once)
+#define PRD_TMC_STAGE(R, BUF)                                                     \
+    if (!a0) R##a0 = zero4;                                                       \
+    if (!a1) R##a1 = zero4;                                                       \
+    if (!b0) R##b0 = zero4;                                                       \
+    if (!b1) R##b1 = zero4;                                                       \
+    *reinterpret_cast<float4*>(&As[BUF][srow * LDP + 4 * sf]) = R##a0;            \
+    *reinterpret_cast<float4*>(&As[BUF][(srow + 32) * LDP + 4 * sf]) = R##a1;     \
+    *reinterpret_cast<float4*>(&Bs[BUF][srow * LDP + 4 * sf]) = R##b0;            \
+    *reinterpret_cast<float4*>(&Bs[BUF][(srow + 32) * LDP + 4 * sf]) = R##b1;
+    // One chunk: the global loads of chunk c+2 are issued into register set N (measured: one chunk of distance leaves the
+    // wave waiting ~2000 cycles per chunk for them), chunk c is multiplied out of LDS buffer CUR, then register set R
+    // (chunk c+1, loaded during chunk c-1) goes to the other buffer.  Loads are UNCONDITIONAL with a clamped chunk index
+    // (loads under an `if` make hipcc emit `s_waitcnt vmcnt(0)` in front of the MFMAs).
+#define PRD_TMC_CHUNK(C, CUR, R, N)                                               \
+    {                                                                             \
+        const int c2 = (C) + 2 < nchunk ? (C) + 2 : nchunk - 1;                   \
+        PRD_TMC_LOAD(N, c2 * KCH)                                                 \
+        const float* as = &As[CUR][(wm0 + r) * LDP + hi * 16];                    \
+        const float* bs = &Bs[CUR][(wn0 + r) * LDP + hi * 16];                    \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                           \
+            const float4 a = *reinterpret_cast<const float4*>(as + 4 * t);        \
+            const float4 bq = *reinterpret_cast<const float4*>(bs + 4 * t);       \
+            acc = mfma32(a.x, bq.x, acc);                                         \
+            acc = mfma32(a.y, bq.y, acc);                                         \
+            acc = mfma32(a.z, bq.z, acc);                                         \
+            acc = mfma32(a.w, bq.w, acc);                                         \
+        }                                                                         \
+        if ((C) + 1 < nchunk) { PRD_TMC_STAGE(R, (CUR) ^ 1) }                     \
+        __syncthreads();                                                          \
     }
+    float4 ua0, ua1, ub0, ub1, va0, va1, vb0, vb1;
+    PRD_TMC_LOAD(u, 0)
+    PRD_TMC_STAGE(u, 0)
+    {
+        const int c1 = 1 < nchunk ? 1 : 0;
+        PRD_TMC_LOAD(u, c1 * KCH)                       // chunk 1 -> set u (staged at the end of chunk 0)
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; c += 2) {
+        PRD_TMC_CHUNK(c, 0, u, v)
+        if (c + 1 < nchunk) PRD_TMC_CHUNK(c + 1, 1, v, u)
+    }
+#undef PRD_TMC_LOAD
+#undef PRD_TMC_STAGE
+#undef PRD_TMC_CHUNK
     float* __restrict__ Oc = O + (size_t)ch * N * ldn;
     const int n = n0 + wn0 + r;
     if (n < N) {
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
             if (m < N) Oc[(size_t)m * ldn + n] = acc[q];
         }
     }
+    }   // virtual blocks
 }
 
 template <int P, int NW>
@@ -943,7 +957,8 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     }
     {
         const int tiles = prd_ceil_div(N, 64);
-        hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(b * P * tiles * tiles), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
+        const int vblocks = b * P * tiles * tiles;
+        hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
         int e = (int)hipGetLastError();
         if (e) return e;
     }

@@ -15,7 +15,8 @@ from protein_redesign_amd.diffusion_model import ProteinReDiffModel  # noqa: E40
 from protein_redesign_amd.synthetic import deterministic_state_dict  # noqa: E402
 from protein_redesign_amd.weights import spec_tensors  # noqa: E402
 
-PHASES = {"tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"]}
+PHASES = {"tri_mul_contract": ["loads issue + LDS reads + MFMA", "vmcnt wait + LDS writes", "barrier"],
+          "tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"]}
 
 
 def main():
@@ -39,8 +40,10 @@ def main():
     buf = np.zeros(256 * 16 * 8 * 4, dtype=np.uint64)
     assert L.prd_debug_read(buf.ctypes.data) == 0
     t = buf[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64)
-    nw = int((t.sum(axis=(0, 2)) > 0).sum())
-    t = t[:, :nw]
+    if which == "tri_mul_contract":
+        t = buf[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64)
+    nw = 4 if which == "tri_mul_contract" else int((t.sum(axis=(0, 2)) > 0).sum())
+    t = t[:, :nw, : len(PHASES[which])]
     tot = t.sum(axis=2)
     print(f"{which}: N={N}, {nw} waves/WG; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
     for k, name in enumerate(PHASES[which]):

@@ -69,15 +69,26 @@ void run(int grid, int threads, size_t lds, int spin) {
 }
 
 int main() {
-    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
-    printf("CUs %d\n", p.multiProcessorCount);
-    run(256, 768, 100 * 1024, 2000);
-    run(256, 512, 140 * 1024, 2000);
-    run(256, 256, 36 * 1024, 2000);
-    run(256, 1024, 100 * 1024, 2000);
-    run(512, 384, 70 * 1024, 2000);
-    run(1024, 256, 36 * 1024, 2000);
-    run(3072, 64, 8 * 1024, 2000);
-    run(256, 64, 100 * 1024, 2000);
+    // which workgroups share a CU?  1024 WGs x 256 threads, 36 KB LDS (4 per CU)
+    const int grid = 1024, threads = 256; const size_t lds = 36 * 1024;
+    long long* rec; float* out;
+    hipMalloc(&rec, grid * 4 * sizeof(long long));
+    hipMalloc(&out, grid * threads * sizeof(float));
+    hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe, dim3(grid), dim3(threads), lds, 0, rec, 20000, out);
+    hipDeviceSynchronize();
+    std::vector<long long> h(grid * 4);
+    hipMemcpy(h.data(), rec, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    std::map<long long, std::vector<int>> per_cu;
+    for (int i = 0; i < grid; ++i) {
+        const unsigned hw = (unsigned)h[4 * i + 2];
+        const long long cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7, xcc = h[4 * i + 3] & 0xf;
+        per_cu[((xcc * 8 + se) * 2 + sh) * 16 + cu].push_back(i);
+    }
+    int shown = 0;
+    for (auto& kv : per_cu) { if (shown++ >= 12) break; printf("cu key %lld:", kv.first); for (int w : kv.second) printf(" %d", w); printf("\n"); }
+    // how many of the WGs < 576 per CU
+    int mx = 0, mn = 99; for (auto& kv : per_cu) { int c = 0; for (int w : kv.second) c += w < 576; mx = std::max(mx, c); mn = std::min(mn, c); }
+    printf("WGs with id < 576 per CU: min %d max %d (CUs %zu)\n", mn, mx, per_cu.size());
     return 0;
 }
