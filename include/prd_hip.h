@@ -65,6 +65,9 @@ typedef struct PrdGemm {
     const float* mulmat; long long smu1, smu2; int ldmul;
     const float* resid; long long sr1, sr2; int ldr;
     int tile_hint;                  /* 0 = automatic; 32 / 64 / 128 force the workgroup tile */
+    int a_ln;                       /* 1: A rows are LayerNorm-ed over K on the fly (no affine, eps 1e-5, biased variance) --
+                                       nn.LayerNorm(K, elementwise_affine=False) fused into the linear that follows it
+                                       (reference modules.py:296,306).  Needs !b_kn, K % 4 == 0, K <= 512; uses the 32x32 K-split tile. */
 } PrdGemm;
 int prd_gemm(const PrdGemm* args, hipStream_t stream);
 

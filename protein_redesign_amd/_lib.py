@@ -28,6 +28,7 @@ class PrdGemm(C.Structure):
         ("mulmat", vp), ("smu1", cll), ("smu2", cll), ("ldmul", ci),
         ("resid", vp), ("sr1", cll), ("sr2", cll), ("ldr", ci),
         ("tile_hint", ci),
+        ("a_ln", ci),
     ]
 
 

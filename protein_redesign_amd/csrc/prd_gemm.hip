@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(PrdGemm g) {
 // single-track linears (M = b*N rows) the generic kernel above launches fewer workgroups than there
 // are CUs and is latency bound on its K loop; this one launches (M/32)*(N/32) workgroups and cuts the
 // dependent K chain by 4. ----------------------------------------------------------------------------
-template <int NWK>                          // waves per workgroup = K splits
-__global__ __launch_bounds__(NWK * 64) void gemm_skinny_kernel(PrdGemm g) {
+template <int NWK, bool LN>                 // waves per workgroup = K splits; LN: fused LayerNorm of the A rows (own
+__global__ __launch_bounds__(NWK * 64) void gemm_skinny_kernel(PrdGemm g) {   // instantiation: it holds the K slice in registers)
     __shared__ float red[NWK][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
@@ -169,7 +169,74 @@ __global__ __launch_bounds__(NWK * 64) void gemm_skinny_kernel(PrdGemm g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     const bool k4 = (g.K & 3) == 0;                      // every 16-byte group inside K is complete
-    if (!g.b_kn) {
+    if (LN) {
+        // Fused LayerNorm of the A rows over K (no affine): the lane's K slice (<= LNG 16-byte groups) is loaded ONCE and
+        // stays in registers; per-wave (sum, M2 about the wave mean) go through LDS, are merged with the parallel-variance
+        // formula (as accurate as the two-pass form) and the MFMA operand is (a - mean) * rstd.  One barrier, no second
+        // read of A -- the separate LayerNorm launch costs ~6 us for a 320 x 512 activation, all of it launch latency.
+        constexpr int LNG = 16, BT = 4;
+        const float* brow = B + (size_t)(nv ? n0 + r : 0) * g.ldb;
+        const float am = mv ? 1.f : 0.f, bm = nv ? 1.f : 0.f;
+        const int k0 = kbeg + 4 * hi;
+        const int nk = (kend > k0) ? (kend - k0 + 7) / 8 : 0;
+        const int ksafe = (k0 < g.K) ? k0 : 0;
+        float4 av[LNG], cb[BT], nb[BT];
+#pragma unroll
+        for (int t = 0; t < LNG; ++t) av[t] = *reinterpret_cast<const float4*>(arow + ((t < nk) ? k0 + 8 * t : ksafe));
+#pragma unroll
+        for (int t = 0; t < BT; ++t) cb[t] = *reinterpret_cast<const float4*>(brow + ((t < nk) ? k0 + 8 * t : ksafe));
+        float s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < LNG; ++t) s1 += (t < nk) ? (av[t].x + av[t].y) + (av[t].z + av[t].w) : 0.f;
+        s1 += __shfl_xor(s1, 32);
+        const float nw = (float)((kend > kbeg) ? kend - kbeg : 0);      // values of this wave's slice (uniform)
+        const float mw = nw > 0.f ? s1 / nw : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < LNG; ++t) {
+            const float d0 = av[t].x - mw, d1 = av[t].y - mw, d2 = av[t].z - mw, d3 = av[t].w - mw;
+            m2 += (t < nk) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+        }
+        m2 += __shfl_xor(m2, 32);
+        red[wave][0][lane] = s1;
+        red[wave][1][lane] = m2;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWK; ++w) tot += red[w][0][lane];
+        const float mean = tot / (float)g.K;
+        float var = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWK; ++w) {
+            int ke = (w + 1) * gper * 8;
+            if (ke > g.K) ke = g.K;
+            const float n = (float)((ke > w * gper * 8) ? ke - w * gper * 8 : 0);
+            const float dm = (n > 0.f ? red[w][0][lane] / n : mean) - mean;
+            var += red[w][1][lane] + n * dm * dm;
+        }
+        const float rz = am / sqrtf(var / (float)g.K + 1e-5f);
+        __syncthreads();                                  // red[] is reused by the K-split reduction below
+#pragma unroll
+        for (int bt = 0; bt < LNG / BT; ++bt) {
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                const int gi = (bt + 1) * BT + t;
+                nb[t] = *reinterpret_cast<const float4*>(brow + ((gi < nk) ? k0 + 8 * gi : ksafe));
+            }
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                const float z = (bt * BT + t < nk) ? rz : 0.f;
+                const float4 a = av[bt * BT + t];
+                acc = mfma32((a.x - mean) * z, cb[t].x * bm, acc);
+                acc = mfma32((a.y - mean) * z, cb[t].y * bm, acc);
+                acc = mfma32((a.z - mean) * z, cb[t].z * bm, acc);
+                acc = mfma32((a.w - mean) * z, cb[t].w * bm, acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < BT; ++t) cb[t] = nb[t];
+        }
+    } else if (!g.b_kn) {
         const float* brow = B + (size_t)(nv ? n0 + r : 0) * g.ldb;
         if (k4) {
             const float am = mv ? 1.f : 0.f, bm = nv ? 1.f : 0.f;     // rows past the edge contribute zeros
@@ -299,12 +366,18 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     const int batches = g.G1 * g.G2;
     const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
     int tile = g.tile_hint;
+    if (g.a_ln) {                                   // fused LayerNorm lives in the K-split kernel only; the K slice of a lane
+        // (K / splits / 2 values) has to fit its 16 register groups: K <= 512 with 4 splits
+        if (g.b_kn || (g.K & 3) || g.K > 512 || (tile != 0 && tile != 32)) return PRD_ERR_UNSUPPORTED;
+        tile = 32;
+    }
     if (tile == 0) tile = (tiles64 < 512) ? 32 : ((tiles64 <= 1024 || g.M <= 64 || g.N <= 64) ? 64 : 128);
     if (tile == 32) {          // fewer 64x64 tiles than two per CU: skinny kernel, 32x32 tiles + in-workgroup split-K
         dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
         // long K and few tiles: 8 K-splits (twice the waves per CU to cover the L2 latency of the operand stream)
-        if (g.K >= 1024 && (long)grid.x * grid.y <= 512) hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, dim3(512), 0, stream, g);
-        else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, stream, g);
+        if (g.a_ln) hipLaunchKernelGGL((gemm_skinny_kernel<4, true>), grid, dim3(256), 0, stream, g);
+        else if (g.K >= 1024 && (long)grid.x * grid.y <= 512) hipLaunchKernelGGL((gemm_skinny_kernel<8, false>), grid, dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<4, false>), grid, dim3(256), 0, stream, g);
     } else if (tile == 64) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
         hipLaunchKernelGGL((gemm_kernel<32, 32>), grid, dim3(256), 0, stream, g);

@@ -372,7 +372,7 @@ class ProteinReDiffModel(_Base):
         eps_raw = ops.coord_head(pair, z, mask, wr[1].weight, wr[1].bias, wr[3].weight)
         noise_pred = ops.remove_mean(eps_raw, mask)
         sm = self.seq_mlp
-        h = ops.linear(ops.layer_norm(single), sm[1].weight, sm[1].bias, act=1)
+        h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)        # LayerNorm (no affine) fused into the linear
         seq_pred = ops.linear(h, sm[3].weight)
         return noise_pred, seq_pred
 

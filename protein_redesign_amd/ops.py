@@ -45,7 +45,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), b_kn=False, alpha=1.0, bias=None, act=0, act_from=0,
          addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
          mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0,
-         colscale=None, tile_hint=0):
+         colscale=None, tile_hint=0, a_ln=False):
     """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h)."""
     g = PrdGemm()
     g.A, g.B, g.C = _off(A, a_off), _off(B, b_off), _off(Cout, c_off)
@@ -61,6 +61,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.resid = (_off(resid, res_off) if resid is not None else None)
     g.sr1, g.sr2, g.ldr = sr[0], sr[1], ldr
     g.colscale, g.tile_hint = dptr(colscale), tile_hint
+    g.a_ln = 1 if a_ln else 0
     import ctypes
     check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
     return Cout
@@ -68,16 +69,24 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = 0,
            alpha: float = 1.0, resid: Optional[torch.Tensor] = None, rowmask: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = act(alpha * x W^T + bias) [* rowmask] [+ resid] for x [..., K], W [N, K]."""
+           out: Optional[torch.Tensor] = None, ln_a: bool = False) -> torch.Tensor:
+    """y = act(alpha * x W^T + bias) [* rowmask] [+ resid] for x [..., K], W [N, K]; ``ln_a``: x is LayerNorm-ed
+    (no affine) inside the GEMM instead of by a separate launch."""
     K = x.shape[-1]
     M = x.numel() // K
     N = w.shape[0]
+    if ln_a and not ln_fusable(K):
+        x, ln_a = layer_norm(x.contiguous()), False
     if out is None:
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
     gemm(x, w, out, M, N, K, K, w.stride(0), N, alpha=alpha, bias=bias, act=act,
-         rowmask=rowmask, resid=resid, ldr=N)
+         rowmask=rowmask, resid=resid, ldr=N, a_ln=ln_a)
     return out
+
+
+def ln_fusable(K: int) -> bool:
+    """PrdGemm.a_ln keeps a lane's K slice in registers: K <= 512 and a multiple of 4 (prd_hip.h)."""
+    return K <= 512 and K % 4 == 0
 
 
 def layer_norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -294,18 +303,21 @@ def pack_attention(wq, wk, wv, wg, bg, q_scale: float):
 
 
 def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int, *,
-                           key_mask: bool, resid: Optional[torch.Tensor]) -> torch.Tensor:
+                           key_mask: bool, resid: Optional[torch.Tensor], ln_a: bool = False) -> torch.Tensor:
     """Multi-head gated attention over the node axis with an additive [b,H,N,N] bias.
 
     Covers reference modules.py:185-225 (c = head_dim, key mask filled with -2**15, q pre-scaled by
     1/sqrt(c)) and models/AF2_modules.py:251-293,613-628 (c = single_dim, no mask).  ``packed`` comes
-    from ``pack_attention``.  Returns ``resid + out_proj(...)`` (or the bare update when ``resid`` is None)."""
+    from ``pack_attention``.  Returns ``resid + out_proj(...)`` (or the bare update when ``resid`` is None).
+    ``ln_a``: ``x_normed`` is the raw input and its (affine-free) LayerNorm is fused into the q|k|v|g projection."""
     b, N, S = x_normed.shape
     HC = H * c
     w, pbias, colscale = packed
     L = 4 * HC
+    if ln_a and not ln_fusable(S):
+        x_normed, ln_a = layer_norm(x_normed.contiguous()), False
     qkvg = torch.empty(b, N, L, device=x_normed.device, dtype=F32)
-    gemm(x_normed, w, qkvg, b * N, L, S, S, S, L, bias=pbias, colscale=colscale, act=2, act_from=3 * HC)
+    gemm(x_normed, w, qkvg, b * N, L, S, S, S, L, bias=pbias, colscale=colscale, act=2, act_from=3 * HC, a_ln=ln_a)
     o = torch.empty(b, N, HC, device=x_normed.device, dtype=F32)
     if c == 16 and HC == 64:
         # heads of width 16 (FoldingBlock.single_attn): fused logits + bias + mask + softmax + PV + gate
@@ -324,6 +336,5 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
 
 
 def transition_single(single, w1, b1, w2, b2, *, residual: bool) -> torch.Tensor:
-    x = layer_norm(single)
-    h = linear(x, w1, b1, act=1)
+    h = linear(single, w1, b1, act=1, ln_a=True)        # LayerNorm (no affine) fused into the first linear
     return linear(h, w2, b2, resid=single if residual else None)

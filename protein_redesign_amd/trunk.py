@@ -93,9 +93,10 @@ class Attention(nn.Module):
         ws = self.weights()[:5]
         return ops.cached_pack(self, "qkvg", ws, lambda: ops.pack_attention(*ws, self.scale))
 
-    def run_single(self, xn, mask, attn_bias, resid):
-        return ops.gated_attention_single(xn, mask, attn_bias, self.packed(), self.out_proj.weight, self.out_proj.bias,
-                                          self.num_heads, self.head_dim, key_mask=True, resid=resid)
+    def run_single(self, x, mask, attn_bias, resid, ln_a=False):
+        """``x`` is the LayerNorm-ed input, or with ``ln_a`` the raw one (the norm is then fused into the projection)."""
+        return ops.gated_attention_single(x, mask, attn_bias, self.packed(), self.out_proj.weight, self.out_proj.bias,
+                                          self.num_heads, self.head_dim, key_mask=True, resid=resid, ln_a=ln_a)
 
     def forward(self, x: torch.Tensor, mask: torch.Tensor, attn_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         if x.dim() != 3:
@@ -103,8 +104,7 @@ class Attention(nn.Module):
         b, N, _ = x.shape
         if attn_bias is None:
             attn_bias = torch.zeros(b, self.num_heads, N, N, device=x.device, dtype=torch.float32)
-        xn = ops.layer_norm(x.contiguous())
-        return self.run_single(xn, mask.contiguous(), attn_bias.contiguous(), None)
+        return self.run_single(x.contiguous(), mask.contiguous(), attn_bias.contiguous(), None, ln_a=True)
 
 
 class TriangleAttention(nn.Module):
@@ -223,8 +223,7 @@ class FoldingBlock(nn.Module):
                              device=pair.device, dtype=torch.float32)
         if bias is None:
             bias = ops.pair_bias(pair, self.attn_bias[1].weight, self.attn_bias[1].bias)
-        xn = ops.layer_norm(single)
-        single = sa.run_single(xn, mask, bias, single)
+        single = sa.run_single(single, mask, bias, single, ln_a=True)
         fc = self.single_fc
         single = ops.transition_single(single, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=True)
         self.outer_linear.run(single, pair, residual=True, out=pair)

@@ -105,6 +105,25 @@ def test_layer_norm_and_softmax():
     assert torch.all(got[:, 141:] == 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(320, 256, 512), (45, 2048, 512), (33, 70, 2048), (7, 5, 64)])
+def test_linear_with_fused_layer_norm(M, N, K):
+    """PrdGemm.a_ln: y = relu(LN(x) W^T + b) with the (affine-free) LayerNorm computed inside the GEMM == the oracle's
+    LayerNorm followed by the linear; rows with |mean| >> spread included.  K = 2048 exceeds the fused kernel's register
+    slice: the wrapper falls back to a separate LayerNorm launch, the C ABI itself refuses."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 2.0
+    x[::3] = x[::3] * 0.25 + 4.0                        # |mean| several times the spread
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    want = torch.relu(O.ln(x).double() @ w.double().t() + b.double())
+    got = ops.linear(cu(x), cu(w), cu(b), act=1, ln_a=True)
+    assert rel_l2(got.cpu(), want) < 5e-6
+    sep = ops.linear(ops.layer_norm(cu(x)), cu(w), cu(b), act=1)
+    assert rel_l2(got.cpu(), sep.cpu()) < 5e-6
+    if not ops.ln_fusable(K):
+        with pytest.raises(RuntimeError):
+            ops.gemm(cu(x), cu(w), torch.empty(M, N, device=DEV), M, N, K, K, K, N, a_ln=True)
+
+
 # ---------------------------------------------------------------------------------------------------
 # operators vs the oracle (module-level API of the mirror classes)
 # ---------------------------------------------------------------------------------------------------
