@@ -655,23 +655,31 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
                                                              const float* __restrict__ seq_pred, const float* __restrict__ noise,
                                                              const float* __restrict__ mask, const float* __restrict__ coef,
                                                              int N, int ncls, int num_steps) {
-    __shared__ float red[256];
+    __shared__ float red[4][4];
     __shared__ float mean[4];
     const int bb = blockIdx.x;
     const long tt = t[bb];
     const float wn = coef[tt * 4 + 0], isa = coef[tt * 4 + 1], sb = coef[tt * 4 + 2];
     // noise table [T-1][b][N][3]: row (T-1-t) is the draw consumed at step t (t > 0)
     const float* nz = noise + ((long)(tt > 0 ? num_steps - 1 - tt : 0) * gridDim.x + bb) * N * 3;
-    if (tt > 0) {
-        for (int d = 0; d < 4; ++d) {
-            float s = 0.f;
-            for (int i = threadIdx.x; i < N; i += 256) s += mask[bb * N + i] * (d < 3 ? nz[i * 3 + d] : 1.f);
-            red[threadIdx.x] = s;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-            if (threadIdx.x == 0) mean[d] = red[0];
-            __syncthreads();
+    if (tt > 0) {       // masked sums of the three noise coordinates and the node count: one pass, wave shuffles, one barrier
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = threadIdx.x; i < N; i += 256) {
+            const float m = mask[bb * N + i];
+            s[0] += m * nz[i * 3];
+            s[1] += m * nz[i * 3 + 1];
+            s[2] += m * nz[i * 3 + 2];
+            s[3] += m;
         }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s[d] += __shfl_xor(s[d], o);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = s[d];
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) mean[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        __syncthreads();
     }
     for (int idx = threadIdx.x; idx < N * 3; idx += 256) {
         const int i = idx / 3, d = idx - i * 3;
@@ -686,8 +694,9 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
         float m = -INFINITY;
         for (int c = 0; c < ncls; ++c) m = fmaxf(m, lp[c]);
         float s = 0.f;
-        for (int c = 0; c < ncls; ++c) s += expf(lp[c] - m);
-        for (int c = 0; c < ncls; ++c) seq_t[((long)bb * N + i) * ncls + c] = expf(lp[c] - m) / s * 2.f - 1.f;
+        float* sp = seq_t + ((long)bb * N + i) * ncls;
+        for (int c = 0; c < ncls; ++c) { const float e = expf(lp[c] - m); sp[c] = e; s += e; }
+        for (int c = 0; c < ncls; ++c) sp[c] = sp[c] / s * 2.f - 1.f;
     }
     __syncthreads();
     if (threadIdx.x == 0) t[bb] = tt - 1;
