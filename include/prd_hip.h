@@ -104,7 +104,8 @@ int prd_pair_init(float* pair, const float* static_pair, const float* z, const f
 /* ---- trunk operators ------------------------------------------------------------------------------
  * `queue` (where present): device pointer to 256 int32 (one counter per XCD, 128 B apart), zero before the first use, owned by the
  * caller and shared only by stream-ordered launches; the persistent waves pull 32-row tasks from it and
- * the last fetch of each resets it to zero.  NULL selects a static round-robin instead (same results). */
+ * the last fetch of each resets it to zero.  NULL selects the static wave-major task order instead (same results;
+ * measured faster on MI355X for every kernel, the Python host passes NULL unless PRD_TASK_QUEUE=1). */
 /* pair[b,N,N,P] -> bias[b,H,N,N] = Linear(LN(pair)) permuted (modules.py:300-304 with bias, no LN affine;
  * models/AF2_modules.py:406-411,454-459 with LN affine gamma/beta and no bias). */
 int prd_pair_bias(float* bias_out, const float* pair, const float* gamma, const float* beta,
