@@ -517,7 +517,25 @@ __global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict
     const float* brow = bias + (((size_t)bb * H + h) * N + qq) * N;
     float m_run = -1e30f, l_run = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    // the pair bias of the NEXT 32-key block is fetched while the current one is processed (unconditional loads with a
+    // clamped key: a load issued where it is needed costs one L2 round trip per block -- 10 of them were most of the
+    // kernel's 18 us at N = 320)
+    float bcur[2][4], bnxt[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * j + 4 * g4 + e;
+            bcur[j][e] = brow[key < N ? key : N - 1];
+        }
     for (int key0 = 0; key0 < npad; key0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = key0 + 32 + 16 * j + 4 * g4 + e;
+                bnxt[j][e] = brow[key < N ? key : N - 1];
+            }
         f32x4 s[2];
         float4 ma[2];
 #pragma unroll
@@ -537,9 +555,7 @@ __global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict
             const float mav[4] = {ma[j].x, ma[j].y, ma[j].z, ma[j].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int key = key0 + 16 * j + 4 * g4 + e;
-                const float bv = (key < N) ? brow[key] : 0.f;
-                const float v = (s[j][e] + bv) * LOG2E;                   // logits + bias, exp2 domain
+                const float v = (s[j][e] + bcur[j][e]) * LOG2E;           // logits + bias, exp2 domain (keys >= N: overridden below)
                 s[j][e] = (mav[e] == 0.f) ? v : mav[e];
                 tmax = fmaxf(tmax, s[j][e]);
             }
@@ -568,6 +584,10 @@ __global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict
             o = mfma16(vf.z, s[j][2], o);
             o = mfma16(vf.w, s[j][3], o);
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bcur[j][e] = bnxt[j][e];
     }
     const float l_tot = rows4_sum(l_run);
     if (qok) {
