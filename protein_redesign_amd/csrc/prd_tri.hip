@@ -365,71 +365,65 @@ constexpr float LOG2E = 1.4426950408889634f;
 // add, for any number of waves), so the softmax arithmetic is kept as short as it gets: 64 keys per running-max update,
 // v_max3 without canonicalisation, packed fp32 subtract / add (two logits per instruction); what is left is the one
 // v_exp_f32 per logit.
-template <int NTQ, bool MASKED>
-PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ Vt, const float* __restrict__ kadd,
-                        const float4 (&qf)[NTQ], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
-    constexpr int JT = 4;                      // 16-key tiles per online-softmax update (64 keys; npad is a multiple of 64)
-    float m_run[NTQ], l_run[NTQ];
+PRD_DEV void ta_prio(int rem, int npad) {
+    // Priority = fraction of the wave's own key loop still to do.  The waves of a SIMD are arbitrated strictly
+    // oldest-first: without this the youngest wave is starved until the others are done and then runs alone,
+    // latency-bound (measured at N = 320: phase 2 of a row 42.4k -> 39.4k cycles, all waves end together).
+    if (4 * rem > 3 * npad) __builtin_amdgcn_s_setprio(3);
+    else if (2 * rem > npad) __builtin_amdgcn_s_setprio(2);
+    else if (4 * rem > npad) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+// One 64-key block (JT = 4 tiles of 16 keys) of the key loop.
+//   ONLINE: running maximum, rescale of o / l (the classic online softmax).
+//   !ONLINE: the reference maximum m_run stays frozen; the logits come out of the MFMA already relative to it (the
+//            accumulator is preloaded with -m_run), so a block costs one v_exp_f32 per logit and the sum -- no max, no
+//            cross-lane reduction, no subtract, no rescale (-45 % VALU instructions, which on gfx950 are matrix-pipe time).
+template <int NTQ, bool MASKED, bool ONLINE>
+PRD_DEV void ta_block(const float* __restrict__ Kl, const float* __restrict__ Vt, const float* __restrict__ kadd,
+                      const float4 (&qf)[NTQ], int npad, int key0, int ql, int g4,
+                      float (&m_run)[NTQ], float (&l_run)[NTQ], f32x4 (&o)[NTQ]) {
+    constexpr int JT = 4;                      // 16-key tiles per block (64 keys; npad is a multiple of 64)
+    ta_prio(npad - key0, npad);
+    float4 kf[JT], ma[JT];
 #pragma unroll
-    for (int t = 0; t < NTQ; ++t) {
-        m_run[t] = -1e30f;
-        l_run[t] = 0.f;
-        o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JT; ++j) {
+        kf[j] = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
+        if (MASKED) ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
     }
-    for (int key0 = 0; key0 < npad; key0 += 16 * JT) {
-        {   // Priority = fraction of the wave's own key loop still to do.  The waves of a SIMD are arbitrated strictly
-            // oldest-first: without this the youngest wave is starved until the others are done and then runs alone,
-            // latency-bound (measured at N = 320: phase 2 of a row 42.4k -> 39.4k cycles, all waves end together).
-            const int rem = npad - key0;
-            if (4 * rem > 3 * npad) __builtin_amdgcn_s_setprio(3);
-            else if (2 * rem > npad) __builtin_amdgcn_s_setprio(2);
-            else if (4 * rem > npad) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        float4 kf[JT], ma[JT];
+    f32x4 s[NTQ][JT];
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            kf[j] = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
-            if (MASKED) ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
-        }
-        f32x4 s[NTQ][JT];
-#pragma unroll
-        for (int j = 0; j < JT; ++j)
-#pragma unroll
-            for (int t = 0; t < NTQ; ++t) {
-                f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                z4 = mfma16(kf[j].x, qf[t].x, z4);          // S^T[key = key0+16j+4*g4+e][q]
-                z4 = mfma16(kf[j].y, qf[t].y, z4);
-                z4 = mfma16(kf[j].z, qf[t].z, z4);
-                z4 = mfma16(kf[j].w, qf[t].w, z4);
-                s[t][j] = z4;
-            }
-        __builtin_amdgcn_sched_barrier(0);                  // V^T is fetched behind the QK^T MFMAs, not before them
-#if defined(PRD_ABLATE) && PRD_ABLATE == 1
-        {   // ablation: no softmax arithmetic (keeps every MFMA and LDS read)
-            float4 vf0[JT];
-            _Pragma("unroll") for (int j = 0; j < JT; ++j) vf0[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
-            _Pragma("unroll") for (int j = 0; j < JT; ++j) _Pragma("unroll") for (int t = 0; t < NTQ; ++t) {
-                o[t] = mfma16(vf0[j].x, s[t][j][0] + ma[j].x, o[t]); o[t] = mfma16(vf0[j].y, s[t][j][1], o[t]);
-                o[t] = mfma16(vf0[j].z, s[t][j][2], o[t]); o[t] = mfma16(vf0[j].w, s[t][j][3], o[t]); }
-            continue;
-        }
-#endif
-        float4 vf[JT];
-#pragma unroll
-        for (int j = 0; j < JT; ++j)
-            vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
-            if (MASKED) {
+            const float c0 = ONLINE ? 0.f : -m_run[t];
+            f32x4 z4 = {c0, c0, c0, c0};
+            z4 = mfma16(kf[j].x, qf[t].x, z4);          // S^T[key = key0+16j+4*g4+e][q]  (- m_run when !ONLINE)
+            z4 = mfma16(kf[j].y, qf[t].y, z4);
+            z4 = mfma16(kf[j].z, qf[t].z, z4);
+            z4 = mfma16(kf[j].w, qf[t].w, z4);
+            s[t][j] = z4;
+        }
+    __builtin_amdgcn_sched_barrier(0);                  // V^T is fetched behind the QK^T MFMAs, not before them
+    float4 vf[JT];
 #pragma unroll
-                for (int j = 0; j < JT; ++j) {
-                    s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x;
-                    s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y;
-                    s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z;
-                    s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w;
-                }
+    for (int j = 0; j < JT; ++j)
+        vf[j] = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        if (MASKED) {
+            const float mr = ONLINE ? 0.f : m_run[t];   // override values are absolute logits
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x - mr;
+                s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y - mr;
+                s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z - mr;
+                s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w - mr;
             }
+        }
+        f32x2 ps = {0.f, 0.f};
+        if (ONLINE) {
             float tmax = max3f(s[t][0][0], s[t][0][1], s[t][0][2]);
             tmax = max3f(tmax, s[t][0][3], s[t][1][0]);
 #pragma unroll
@@ -443,7 +437,6 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             m_run[t] = m_new;
             const f32x2 mm = {m_new, m_new};
-            f32x2 ps = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
                 const f32x2 d0 = f32x2{s[t][j][0], s[t][j][1]} - mm, d1 = f32x2{s[t][j][2], s[t][j][3]} - mm;
@@ -456,19 +449,63 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
             l_run[t] = l_run[t] * alpha + (ps.x + ps.y);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
-        }
+        } else {
 #pragma unroll
-        for (int j = 0; j < JT; ++j)
-#pragma unroll
-            for (int t = 0; t < NTQ; ++t) {
-                o[t] = mfma16(vf[j].x, s[t][j][0], o[t]);    // O^T += V^T[c = ql][key] * P^T[key][q]
-                o[t] = mfma16(vf[j].y, s[t][j][1], o[t]);
-                o[t] = mfma16(vf[j].z, s[t][j][2], o[t]);
-                o[t] = mfma16(vf[j].w, s[t][j][3], o[t]);
+            for (int j = 0; j < JT; ++j) {
+                const f32x2 e0 = {__builtin_amdgcn_exp2f(s[t][j][0]), __builtin_amdgcn_exp2f(s[t][j][1])};
+                const f32x2 e1 = {__builtin_amdgcn_exp2f(s[t][j][2]), __builtin_amdgcn_exp2f(s[t][j][3])};
+                s[t][j][0] = e0.x; s[t][j][1] = e0.y; s[t][j][2] = e1.x; s[t][j][3] = e1.y;
+                ps += e0;
+                ps += e1;
             }
+            l_run[t] += ps.x + ps.y;
+        }
     }
 #pragma unroll
-    for (int t = 0; t < NTQ; ++t) l_tot[t] = rows4_sum(l_run[t]);
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            o[t] = mfma16(vf[j].x, s[t][j][0], o[t]);    // O^T += V^T[c = ql][key] * P^T[key][q]
+            o[t] = mfma16(vf[j].y, s[t][j][1], o[t]);
+            o[t] = mfma16(vf[j].z, s[t][j][2], o[t]);
+            o[t] = mfma16(vf[j].w, s[t][j][3], o[t]);
+        }
+}
+
+// The key loop of one wave for NTQ (1 or 2) 16-query tiles: S^T = K Q^T, softmax in the exp2 domain over blocks of 64
+// keys, O^T += V^T P^T.  Returns O^T[c = 4*g4 + e][q = ql] and l per tile.
+//
+// fp32 MFMA and VALU instructions share the SIMD's issue time on gfx950 (tools/ubench/coissue_bench.hip: the cycles
+// add, for any number of waves), so the softmax arithmetic is kept as short as it gets: the first block runs the online
+// update and fixes the reference maximum, the others use it unchanged (softmax is shift invariant; a later logit above the
+// reference only makes p > 1).  Should a logit exceed the reference by more than the fp32 exponent range the sum
+// overflows to inf -- then, and only then, the wave redoes its tiles with the online update in every block.
+template <int NTQ, bool MASKED>
+PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ Vt, const float* __restrict__ kadd,
+                        const float4 (&qf)[NTQ], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
+    float m_run[NTQ], l_run[NTQ];
+    bool online_all = false;                     // second pass only: online update in every block
+    while (true) {
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            m_run[t] = -1e30f;
+            l_run[t] = 0.f;
+            o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int key0 = 0; key0 < npad; key0 += 64) {
+            if (key0 == 0 || online_all) ta_block<NTQ, MASKED, true>(Kl, Vt, kadd, qf, npad, key0, ql, g4, m_run, l_run, o);
+            else ta_block<NTQ, MASKED, false>(Kl, Vt, kadd, qf, npad, key0, ql, g4, m_run, l_run, o);
+        }
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            l_tot[t] = rows4_sum(l_run[t]);
+            bad |= !(l_tot[t] < 3.0e38f);        // inf or NaN
+        }
+        if (online_all || !__any(bad)) break;    // the second pass is never needed for logit spreads below 2^127
+        online_all = true;
+    }
 }
 
 // Single-track gated attention core (reference modules.py:216-223 with the pair bias of :300-304), heads of width 16:

@@ -186,6 +186,26 @@ def test_pair_transition(setup):
     assert rel_l2(got.cpu(), O.transition(s["params"], "Denoiser.folding_blocks.0.pair_fc", s["pair"])) < OP_TOL
 
 
+@pytest.mark.parametrize("scale", [30.0, 400.0])
+def test_triangle_attention_large_logit_spread(setup, scale):
+    """Key loop with a frozen reference maximum: logits that rise far above those of the first 64-key block.  scale = 30:
+    p > 1 inside the fast path; scale = 400: the spread passes the fp32 exponent range, the sum overflows and the wave
+    must redo its tiles with the online update (the oracle's softmax is stable either way)."""
+    s = setup
+    pfx = "Denoiser.folding_blocks.0.pair_attn_starting"
+    params = dict(s["params"])
+    params[pfx + ".attn.q_proj.weight"] = s["params"][pfx + ".attn.q_proj.weight"] * scale
+    m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
+    want = O.triangle_attention(params, pfx, s["pair"], m2, s["args"]["num_heads"], s["args"]["head_dim"], False)
+    mod = s["model"].Denoiser.folding_blocks[0].pair_attn_starting
+    w = [t.clone() for t in mod.attn.weights()]
+    w[0] = w[0] * scale                                   # weights(): q, k, v, gate weight, gate bias, out weight, out bias
+    got = ops.tri_attn(cu(s["pair"]), cu(s["mask"]), w, s["args"]["num_heads"], s["args"]["head_dim"], ending=False,
+                       residual=False)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got.cpu(), want) < 5 * OP_TOL
+
+
 @pytest.mark.parametrize("use_queue", [False, True])
 def test_block_tail_fusion_and_queue_reset(setup, monkeypatch, use_queue):
     """Fused tail (ending tri-attn output projection + pair transition + next block's bias) == the three separate
