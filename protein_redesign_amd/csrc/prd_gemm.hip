@@ -53,36 +53,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(PrdGemm g) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
 
-    for (int k0 = 0; k0 < g.K; k0 += KC) {
-        // ---- stage A tile: TM rows x 32 floats, 8 threads per row, 16 B each ----
+    // Operand staging: thread -> (row = tid>>3 (+32 per rep), 16-byte group f = tid&7).  For B given as [N][K] the global
+    // loads of chunk k0+KC are issued right after chunk k0 went to LDS and fly over its MFMAs (unconditional loads from
+    // clamped addresses; rows / columns past the edge are zeroed when they are written to LDS).
+    constexpr int RA = TM / 32, RB = TN / 32;
+    const int srow = tid >> 3, sf = tid & 7;
+    float4 pa[RA], pb[RB];
+    auto fetch = [&](int k0) {
+        const int k = k0 + 4 * sf;
+        const int kc = k < g.K ? k : 0;                     // lda / ldb are multiples of 4: a 16-byte load at k < K stays in the row
 #pragma unroll
-        for (int rep = 0; rep < TM / 32; ++rep) {
-            const int row = (tid >> 3) + 32 * rep, f = tid & 7;
-            const int m = m0 + row, k = k0 + 4 * f;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < g.M && k < g.K) {
-                v = *reinterpret_cast<const float4*>(A + (size_t)m * g.lda + k);
-                if (k + 1 >= g.K) v.y = 0.f;
-                if (k + 2 >= g.K) v.z = 0.f;
-                if (k + 3 >= g.K) v.w = 0.f;
-            }
-            *reinterpret_cast<float4*>(&As[row * LDT + 4 * f]) = v;
+        for (int rep = 0; rep < RA; ++rep) {
+            const int m = m0 + srow + 32 * rep;
+            pa[rep] = *reinterpret_cast<const float4*>(A + (size_t)(m < g.M ? m : 0) * g.lda + kc);
         }
         if (!g.b_kn) {
 #pragma unroll
-            for (int rep = 0; rep < TN / 32; ++rep) {
-                const int row = (tid >> 3) + 32 * rep, f = tid & 7;
-                const int n = n0 + row, k = k0 + 4 * f;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < g.N && k < g.K) {
-                    v = *reinterpret_cast<const float4*>(B + (size_t)n * g.ldb + k);
-                    if (k + 1 >= g.K) v.y = 0.f;
-                    if (k + 2 >= g.K) v.z = 0.f;
-                    if (k + 3 >= g.K) v.w = 0.f;
-                }
-                *reinterpret_cast<float4*>(&Bs[row * LDT + 4 * f]) = v;
+            for (int rep = 0; rep < RB; ++rep) {
+                const int n = n0 + srow + 32 * rep;
+                pb[rep] = *reinterpret_cast<const float4*>(B + (size_t)(n < g.N ? n : 0) * g.ldb + kc);
             }
-        } else {
+        }
+    };
+    auto edge = [&](float4 v, bool row_ok, int k) {
+        if (!row_ok || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + 1 >= g.K) v.y = 0.f;
+        if (k + 2 >= g.K) v.z = 0.f;
+        if (k + 3 >= g.K) v.w = 0.f;
+        return v;
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += KC) {
+        {
+            const int k = k0 + 4 * sf;
+#pragma unroll
+            for (int rep = 0; rep < RA; ++rep)
+                *reinterpret_cast<float4*>(&As[(srow + 32 * rep) * LDT + 4 * sf]) = edge(pa[rep], m0 + srow + 32 * rep < g.M, k);
+            if (!g.b_kn) {
+#pragma unroll
+                for (int rep = 0; rep < RB; ++rep)
+                    *reinterpret_cast<float4*>(&Bs[(srow + 32 * rep) * LDT + 4 * sf]) = edge(pb[rep], n0 + srow + 32 * rep < g.N, k);
+            }
+        }
+        if (g.b_kn) {
             // B is [K][N]: read 16 B along n, scatter transposed into Bs[n][k]
             constexpr int F = TN / 4;                 // float4 per k row of the tile
             for (int idx = tid; idx < KC * F; idx += 256) {
@@ -101,6 +114,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PrdGemm g) {
                 Bs[(4 * f + 3) * LDT + kk] = v.w;
             }
         }
+        fetch(k0 + KC < g.K ? k0 + KC : k0);                // next chunk (the last iteration re-reads its own)
         __syncthreads();
         // ---- 16 k-steps of 2: lane (r,hi) feeds k = hi*16 + 4t + e for both operands ----
 #pragma unroll

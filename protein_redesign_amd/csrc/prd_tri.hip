@@ -998,7 +998,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     float* AB = ws;                                   // [b][2P][N][ldn]
     float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
     {
-        constexpr int NWP = 12;                      // one persistent 12-wave workgroup per CU (3 waves / SIMD)
+        constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
         const size_t lds = ((size_t)2 * 2 * P * (P + 4) + 4 * P) * sizeof(float);
         const long ntask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);     // (row block, output block) tasks
         const int grid = grid_for(ntask, NWP, 256);
