@@ -840,7 +840,7 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
         constexpr int NWL = 8;
         const int nvb = prd_ceil_div(N, 32);
         const long nsym = (long)b * (nvb * (nvb + 1) / 2) * 32;      // symmetric half: (i, j-block >= i-block) tasks
-        const int grid = grid_for(nsym, NWL, 256);
+        const int grid = grid_for(nsym, 4, 256);
         // fewer tasks than resident waves (symmetric half): the static assignment beats the queue (56 vs 74 us at N = 320)
         int* oq = (nsym > (long)grid * NWL) ? queue : nullptr;
         if (P == 64) {
@@ -865,7 +865,7 @@ extern "C" int prd_pair_transition(float* out, const float* pair, const float* w
     constexpr int NWT = 12;                    // one persistent 12-wave workgroup per CU (weights: 137 KB of LDS at P=64)
     const long rows = (long)b * N * N;
     const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + 5 * P) * sizeof(float);
-    const int grid = grid_for((rows + 31) / 32, NWT, 256);
+    const int grid = grid_for((rows + 31) / 32, 4, 256);
     if (P == 64) {
         PRD_SET_LDS((pair_transition_kernel<64, NWT>), lds);
         hipLaunchKernelGGL((pair_transition_kernel<64, NWT>), dim3(grid), dim3(NWT * 64), lds, stream, queue, out, pair, w1, b1, w2, b2, rows, residual);
@@ -886,7 +886,7 @@ extern "C" int prd_block_tail(float* pair, const float* og, const float* wo, con
     const long rows = (long)b * N * N;
     const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + (size_t)P * 68 + 6 * P + 8 * P) * sizeof(float);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
-    const int grid = grid_for((rows + 31) / 32, NWT, 256);
+    const int grid = grid_for((rows + 31) / 32, 4, 256);
     // measured at N = 320: static round-robin 87 us, queue 93 us (8-wave workgroups, < 2 tasks per wave); queue beyond that
     int* bq = ((rows + 31) / 32 > (long)2 * grid * NWT) ? queue : nullptr;
     if (P == 64) {

@@ -1001,7 +1001,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
         constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
         const size_t lds = ((size_t)2 * 2 * P * (P + 4) + 4 * P) * sizeof(float);
         const long ntask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);     // (row block, output block) tasks
-        const int grid = grid_for(ntask, NWP, 256);
+        const int grid = grid_for(ntask, 4, 256);
         if (P == 64) {
             PRD_SET_LDS((tri_mul_proj_kernel<64, NWP>), lds);
             hipLaunchKernelGGL((tri_mul_proj_kernel<64, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, queue, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
@@ -1022,7 +1022,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     {
         constexpr int NWO = 8;
         const long ntask = (long)b * N * prd_ceil_div(N, 32);
-        const int grid = grid_for(ntask, NWO, 256);
+        const int grid = grid_for(ntask, 4, 256);
         if (P == 64) hipLaunchKernelGGL((tri_mul_out_kernel<64, NWO>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
         else hipLaunchKernelGGL((tri_mul_out_kernel<32, NWO>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
     }
@@ -1082,7 +1082,7 @@ extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, 
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     constexpr int NWA = 12;
     const long rows = (long)b * N * N;
-    const int grid2 = grid_for((rows + 31) / 32, NWA, 256);
+    const int grid2 = grid_for((rows + 31) / 32, 4, 256);
     if (P == 64) hipLaunchKernelGGL((tri_attn_out_kernel<64, NWA>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual);
     else hipLaunchKernelGGL((tri_attn_out_kernel<32, NWA>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual);
     return (int)hipGetLastError();
