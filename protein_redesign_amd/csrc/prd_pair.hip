@@ -527,41 +527,25 @@ __global__ __launch_bounds__(NW * 64) void block_tail_kernel(int* queue, float* 
     if (bias_out)
         for (int h = 0; h < H; ++h) stage_vec_cll(wbl + h * P, wb + h * P, P, threadIdx.x, NT);
     __syncthreads();
-    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5, wave = threadIdx.x >> 6;
     const long ntask = (rows + 31) / 32;
-    WaveTasks tasks(queue, ntask, NW);
-    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
-        const long pos = task * 32 + r;
-        const bool valid = pos < rows;
-        float raw[KH];
-        {
-            float xo[HC / 2];
-            load_row_cll<HC>(og + pos * HC, hi, valid, xo);
-            f32x16 acc[NB];
-            zero_acc(acc);
-            rowgemm<HC, NB>(Wol, xo, acc, r, hi);
-            load_row_cll<P>(pair + pos * P, hi, valid, raw);
+
+    // raw = pair + Wo og + bo for the 32 rows of a task; x = LN(raw)
+    auto head = [&](long pos, bool valid, float (&raw)[KH], float (&x)[KH]) {
+        float xo[HC / 2];
+        load_row_cll<HC>(og + pos * HC, hi, valid, xo);
+        f32x16 acc[NB];
+        zero_acc(acc);
+        rowgemm<HC, NB>(Wol, xo, acc, r, hi);
+        load_row_cll<P>(pair + pos * P, hi, valid, raw);
 #pragma unroll
-            for (int s = 0; s < KH; ++s) raw[s] = raw[s] + (acc[s >> 4][s & 15] + bol[hi * KH + s]);
-        }
-        float x[KH];
+        for (int s = 0; s < KH; ++s) raw[s] = raw[s] + (acc[s >> 4][s & 15] + bol[hi * KH + s]);
 #pragma unroll
         for (int s = 0; s < KH; ++s) x[s] = raw[s];
         ln_cll<KH>(x);
-        f32x16 acc2[NB];
-        zero_acc(acc2);
-#define PRD_PT_PASS(Q)                                                                                              \
-        {                                                                                                           \
-            float h[HHP];                                                                                           \
-            f32x16 acc[HBP];                                                                                        \
-            zero_acc(acc);                                                                                          \
-            rowgemm<P, HBP>(W1l + (Q) * HBP * 32 * (P + 4), x, acc, r, hi);                                         \
-            _Pragma("unroll") for (int s = 0; s < HHP; ++s)                                                         \
-                h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s], 0.f);                             \
-            rowgemm_part<HID, NB, (Q) * HHP / 4, ((Q) + 1) * HHP / 4>(W2l, h, acc2, r, hi);                         \
-        }
-        PRD_PT_PASS(0) PRD_PT_PASS(1) PRD_PT_PASS(2) PRD_PT_PASS(3)
-#undef PRD_PT_PASS
+    };
+    // pair row out (raw + transition) and, if asked for, the next block's attention bias from its LayerNorm
+    auto tail = [&](long pos, bool valid, float (&raw)[KH], const f32x16 (&acc2)[NB]) {
 #pragma unroll
         for (int s = 0; s < KH; ++s) raw[s] = raw[s] + (acc2[s >> 4][s & 15] + b2l[hi * KH + s]);
         store_row_cll<P>(pair + pos * P, hi, valid, raw);
@@ -577,7 +561,91 @@ __global__ __launch_bounds__(NW * 64) void block_tail_kernel(int* queue, float* 
                 if (valid && hi == 0) bias_out[(bb * H + h) * nn + rem] = a;
             }
         }
+    };
+    // hidden units [Q*HID/PASSES, (Q+1)*HID/PASSES): acc2 += W2[:, q] relu(W1[q, :] x + b1[q])
+#define PRD_PT_PASS(Q)                                                                                              \
+    {                                                                                                               \
+        float h[HHP];                                                                                               \
+        f32x16 acc[HBP];                                                                                            \
+        zero_acc(acc);                                                                                              \
+        rowgemm<P, HBP>(W1l + (Q) * HBP * 32 * (P + 4), x, acc, r, hi);                                             \
+        _Pragma("unroll") for (int s = 0; s < HHP; ++s)                                                             \
+            h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s], 0.f);                                 \
+        rowgemm_part<HID, NB, (Q) * HHP / 4, ((Q) + 1) * HHP / 4>(W2l, h, acc2, r, hi);                             \
     }
+
+    // Static schedule per SIMD (waves w and w+4 share SIMD w): whole 32-row tasks in rounds of 4*gridDim.x, alternating
+    // between the two waves of a SIMD.  What is left after the whole rounds -- at N = 320: 128 of 3200 tasks, which used
+    // to keep one SIMD of 128 CUs busy for a full task (15.7 us) while everything else idled -- is computed by the four
+    // SIMDs of a workgroup TOGETHER: each of waves 0-3 does the head redundantly and one quarter of the hidden units
+    // (192 of the task's 576 MFMAs); the partial outputs meet in LDS (over the W1 image, no longer needed) and wave 0
+    // finishes the rows.  Chosen only when it is cheaper than one more whole round (leftover <= 2 tasks per workgroup).
+    const long slots = (long)gridDim.x * 4;
+    const long nfull = ntask / slots;
+    const long left = ntask - nfull * slots;
+    const bool coop = queue == nullptr && left > 0 && left <= 2 * (long)gridDim.x && NW == 8;
+    const long nwhole = coop ? nfull * slots : ntask;
+    {
+        WaveTasks tasks(queue, ntask, NW);                      // used with a queue only
+        const int simd = wave & 3, par = wave >> 2;             // static: rounds 0, 2, .. to wave simd, rounds 1, 3, .. to wave simd + 4
+        long rnd = par;
+        while (true) {
+            long task;
+            if (queue) {
+                task = tasks.next();
+            } else {
+                task = rnd * slots < nwhole ? (long)__builtin_amdgcn_readfirstlane((int)(rnd * slots + (long)simd * gridDim.x + blockIdx.x)) : -1;
+                if (task >= nwhole) task = -1;
+                rnd += NW / 4;
+            }
+            if (task < 0) break;
+            const long pos = task * 32 + r;
+            const bool valid = pos < rows;
+            float raw[KH], x[KH];
+            head(pos, valid, raw, x);
+            f32x16 acc2[NB];
+            zero_acc(acc2);
+            PRD_PT_PASS(0) PRD_PT_PASS(1) PRD_PT_PASS(2) PRD_PT_PASS(3)
+            tail(pos, valid, raw, acc2);
+        }
+    }
+    if (coop) {
+        float* part = W1l;                                      // [4 waves][64 lanes][KH + 1]
+        for (long task = nwhole + blockIdx.x; task < ntask; task += gridDim.x) {     // uniform over the workgroup
+            const long pos = task * 32 + r;
+            const bool valid = pos < rows;
+            float raw[KH], x[KH];
+            f32x16 acc2[NB];
+            zero_acc(acc2);
+            if (wave < 4) {
+                head(pos, valid, raw, x);
+                if (wave == 0) PRD_PT_PASS(0)
+                else if (wave == 1) PRD_PT_PASS(1)
+                else if (wave == 2) PRD_PT_PASS(2)
+                else PRD_PT_PASS(3)
+            }
+            __syncthreads();                                    // every wave is done with W1 (whole tasks and this quarter)
+            if (wave >= 1 && wave < 4) {
+#pragma unroll
+                for (int s = 0; s < KH; ++s) part[((wave - 1) * 64 + lane) * (KH + 1) + s] = acc2[s >> 4][s & 15];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+#pragma unroll
+                    for (int s = 0; s < KH; ++s) acc2[s >> 4][s & 15] += part[(w * 64 + lane) * (KH + 1) + s];
+                tail(pos, valid, raw, acc2);
+            }
+            __syncthreads();                                    // partials consumed before the next cooperative task
+            // W1 is overwritten: restore the quarter images for a following cooperative task
+            if (task + gridDim.x < ntask) {
+                stage_weight_cll<P>(W1l, w1, HID, P, threadIdx.x, NT);
+                __syncthreads();
+            }
+        }
+    }
+#undef PRD_PT_PASS
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -238,6 +238,36 @@ def test_block_tail_fusion_and_queue_reset(setup, monkeypatch, use_queue):
         assert int(q.abs().sum()) == 0
 
 
+def test_block_tail_cooperative_leftover(setup, monkeypatch):
+    """N = 192: 1152 row tasks on 256 persistent workgroups = one whole round per SIMD + 128 leftover tasks, which the four
+    SIMDs of a workgroup compute together (hidden units split four ways, partial sums merged in LDS).  Must agree with the
+    queue-fed path, which always computes whole tasks."""
+    s = setup
+    m = s["model"]
+    blk, nxt = m.Denoiser.folding_blocks[0], m.Denoiser.folding_blocks[1]
+    N, P = 192, s["P"]
+    g = torch.Generator().manual_seed(11)
+    pair0 = torch.randn(1, N, N, P, generator=g)
+    og = torch.randn(1, N, N, 64, generator=g)
+    ta, pf = blk.pair_attn_ending.attn, blk.pair_fc
+    outs = []
+    for use_queue in (False, True):
+        if use_queue:
+            monkeypatch.setenv("PRD_TASK_QUEUE", "1")
+        else:
+            monkeypatch.delenv("PRD_TASK_QUEUE", raising=False)
+        pair = cu(pair0).clone()
+        bias = ops.block_tail_(pair, cu(og), ta.out_proj.weight, ta.out_proj.bias, pf[1].weight, pf[1].bias, pf[3].weight,
+                               pf[3].bias, nxt.attn_bias[1].weight, nxt.attn_bias[1].bias)
+        outs.append((pair.cpu(), bias.cpu()))
+    assert rel_l2(outs[0][0], outs[1][0]) < 2e-6
+    assert rel_l2(outs[0][1], outs[1][1]) < 2e-6
+    with torch.inference_mode():                     # and against the oracle's out-projection + transition
+        x = pair0 + O.lin(s["params"], "Denoiser.folding_blocks.0.pair_attn_ending.attn.out_proj", og)
+        want = x + O.transition(s["params"], "Denoiser.folding_blocks.0.pair_fc", x)
+    assert rel_l2(outs[0][0], want) < BLOCK_TOL
+
+
 def test_outer_product_update(setup):
     s = setup
     got = s["model"].Denoiser.opm(cu(s["single"]), cu(s["mask"]))
