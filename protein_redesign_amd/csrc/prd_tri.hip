@@ -306,10 +306,17 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
     stage_vec_cll(bol, bo, P, threadIdx.x, NW * 64);
     stage_vec_cll(bgl, bog, P, threadIdx.x, NW * 64);
     __syncthreads();
-    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5, wave = threadIdx.x >> 6;
     const int nvb = (N + 31) / 32;
     const long ntask = (long)b * N * nvb;
-    WaveTasks tasks(queue, ntask, NW);
+    // What is left after the whole rounds of 4 * gridDim.x tasks (one per SIMD) is computed by the four SIMDs of a
+    // workgroup together, like in block_tail: waves 0 / 1 the gate for output channels 0-31 / 32-63, waves 2 / 3 the
+    // projection of LN(O) for the same halves (32 MFMAs each instead of 128 in one wave); the halves meet in LDS.
+    const long slots = (long)gridDim.x * 4;
+    const long left = ntask % slots;
+    const bool coop = queue == nullptr && NB == 2 && NW >= 4 && left > 0 && left <= 2 * (long)gridDim.x;
+    const long nwhole = coop ? ntask - left : ntask;
+    WaveTasks tasks(queue, nwhole, NW);
     for (long task = tasks.next(); task >= 0; task = tasks.next()) {
         const int vb = (int)(task % nvb);
         const long bi = task / nvb;
@@ -342,6 +349,55 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
 #pragma unroll
         for (int s = 0; s < KH; ++s) x[s] = x[s] + gate[s] * (ao[s >> 4][s & 15] + bol[hi * KH + s]);
         store_row_cll<P>(out + off, hi, valid, x);
+    }
+    if (coop) {
+        __shared__ float part[2][64][17];                     // LN(O) projections of waves 2 / 3, per lane 16 values
+        for (long task = nwhole + blockIdx.x; task < ntask; task += gridDim.x) {     // uniform over the workgroup
+            const int vb = (int)(task % nvb);
+            const long bi = task / nvb;
+            const int bb = (int)(bi / N), i = (int)(bi - (long)bb * N);
+            const int j = vb * 32 + r;
+            const bool valid = j < N;
+            const int jj = valid ? j : 0;
+            const long off = (bi * N + jj) * P;
+            const int nb = wave & 1;                           // output channels [32 nb, 32 nb + 32)
+            f32x16 acc[1];
+            zero_acc(acc);
+            float x[KH];
+            if (wave < 2) {
+                load_row_cll<P>(pair + off, hi, valid, x);
+                ln_cll<KH>(x);
+                rowgemm<P, 1>(Wgl + nb * 32 * (P + 4), x, acc, r, hi);
+            } else if (wave < 4) {
+#pragma unroll
+                for (int s = 0; s < KH; ++s)
+                    x[s] = valid ? O[(((long)bb * P + cll_ch(s, hi)) * N + i) * ldn + jj] : 0.f;
+                ln_cll<KH>(x);
+                rowgemm<P, 1>(Wol + nb * 32 * (P + 4), x, acc, r, hi);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) part[nb][lane][q] = acc[0][q];
+            }
+            __syncthreads();
+            if (wave < 2) {
+                // CLL elements 16 nb .. 16 nb + 15 = channels 32 nb + 8 g + 4 hi + e: four 16-byte groups of the row
+                float* orow = out + off + 32 * nb + 4 * hi;
+                const float* prow = pair + off + 32 * nb + 4 * hi;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid && residual) pv = *reinterpret_cast<const float4*>(prow + 8 * gq);
+                    float o4[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = 4 * gq + e, sidx = 16 * nb + q;
+                        const float gt = sigmoid_fast(acc[0][q] + bgl[hi * KH + sidx]);
+                        o4[e] = o4[e] + gt * (part[nb][lane][q] + bol[hi * KH + sidx]);
+                    }
+                    if (valid) *reinterpret_cast<float4*>(orow + 8 * gq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                }
+            }
+            __syncthreads();                                   // part[] consumed before the next cooperative task
+        }
     }
 }
 

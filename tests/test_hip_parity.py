@@ -268,6 +268,31 @@ def test_block_tail_cooperative_leftover(setup, monkeypatch):
     assert rel_l2(outs[0][0], want) < BLOCK_TOL
 
 
+@pytest.mark.parametrize("mode", ["outgoing", "incoming"])
+def test_triangle_multiplication_cooperative_leftover(setup, monkeypatch, mode):
+    """N = 192: 1152 tasks per row kernel = one whole round per SIMD + 128 leftover tasks, which tri_mul_out computes with
+    the four SIMDs of a workgroup together.  Static (cooperative) order vs the queue-fed whole tasks vs the oracle."""
+    s = setup
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_mul_{mode}")
+    N, P = 192, s["P"]
+    g = torch.Generator().manual_seed(12)
+    pair = torch.randn(1, N, N, P, generator=g)
+    mask = torch.ones(1, N)
+    mask[0, -7:] = 0
+    outs = []
+    for use_queue in (False, True):
+        if use_queue:
+            monkeypatch.setenv("PRD_TASK_QUEUE", "1")
+        else:
+            monkeypatch.delenv("PRD_TASK_QUEUE", raising=False)
+        outs.append(mod.run(cu(pair), cu(mask), residual=False).cpu())
+    assert rel_l2(outs[0], outs[1]) < 2e-6
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    with torch.inference_mode():
+        want = O.triangle_multiplication(s["params"], f"Denoiser.folding_blocks.0.pair_mul_{mode}", pair, m2, mode == "incoming")
+    assert rel_l2(outs[0], want) < OP_TOL
+
+
 def test_outer_product_update(setup):
     s = setup
     got = s["model"].Denoiser.opm(cu(s["single"]), cu(s["mask"]))
