@@ -172,7 +172,10 @@ def main():
             "config": {"workload": f"configs[1]: synthetic {a.residues}-residue + {a.atoms}-atom ligand (N={N}), "
                                    f"single_dim={S} pair_dim={P} num_blocks={NB} num_steps={T}, "
                                    f"{bpg} complex/GPU, sharded by sample index (no data-path collective)",
-                       "samples_per_gpu": bpg, "hip_graph": not a.no_graph, "outputs_finite": finite},
+                       "samples_per_gpu": bpg, "hip_graph": not a.no_graph, "outputs_finite": finite,
+                       # default: fp32 MFMA everywhere.  PRD_BF16X3=1 opts in to the experimental split-bf16 row GEMMs
+                       # (fp32-accurate); such a run says so here and is not the headline number
+                       "row_gemm": "bf16x3-split (opt-in, experimental)" if os.environ.get("PRD_BF16X3") else "fp32-mfma"},
             "step_gflop": round(flops / 1e9, 1),
             "step_tflops": round(flops * bpg / (dt / a.steps) / 1e12, 2),
             "roofline": roofline, "cpu_baseline": cpu,

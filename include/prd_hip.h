@@ -40,6 +40,13 @@ typedef struct ihipStream_t* hipStream_t;
 
 int prd_version(void);
 
+/* Arithmetic of the row GEMMs inside the pair-track operators (process-wide, set before launching):
+ *   0 (default)  fp32 MFMA (v_mfma_f32_32x32x2_f32) -- what every reported number and parity claim uses;
+ *   1 (opt-in, experimental)  both operands split exactly into three bf16 parts, six products on the bf16 matrix pipe with
+ *     fp32 accumulation: fp32-accurate (~1e-7 relative, tools/ubench/bf16x3_bench.hip), 2.1-2.4x the rate.  Round 1:
+ *     implemented in prd_tri_mul's projection kernel only. */
+int prd_set_gemm_mode(int mode);
+
 /* ---- generic batched GEMM:  C[g] = epilogue(A[g] * B[g]^T)  (b_kn = 1: A[g] * B[g]) -------------
  * Replaces aten::linear / bmm / matmul on the single track (modules.py:185-225, 306-311;
  * models/AF2_modules.py:251-293, 613-628) and the triangle-multiplication einsum (modules.py:272).

@@ -35,6 +35,7 @@ class PrdGemm(C.Structure):
 # name -> argtypes (every entry point of include/prd_hip.h; tests check the export list against the header)
 SIGNATURES = {
     "prd_version": [],
+    "prd_set_gemm_mode": [ci],
     "prd_gemm": [C.POINTER(PrdGemm), vp],
     "prd_ln_rows": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "prd_softmax_rows": [vp, ci, ci, ci, vp],
@@ -75,6 +76,8 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes
             fn.restype = cz if name == "prd_workspace_bytes" else ci
+        if os.environ.get("PRD_BF16X3"):         # opt-in experimental row-GEMM arithmetic (prd_hip.h: prd_set_gemm_mode)
+            _lib.prd_set_gemm_mode(1)
     return _lib
 
 

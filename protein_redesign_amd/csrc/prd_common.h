@@ -234,6 +234,104 @@ PRD_DEV void bias_acc(f32x16 (&acc)[NB], const float* vl) {
         }
 }
 
+// ---- experimental: the row GEMM on the bf16 matrix pipe, operands split three ways ---------------------------------
+// x = hi + mid + lo, each part a bf16 obtained by TRUNCATION (exact for an fp32 value: 3 x 8 = 24 mantissa bits); the six
+// products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 with fp32 accumulation reproduce the
+// fp32 GEMM to ~1e-7 (tools/ubench/bf16x3_bench.hip: 1.16e-7 vs 1.39e-7 for the fp32 MFMA) at 2.1-2.4x its rate.  OPT-IN
+// (prd_set_gemm_mode(1)): the default path and the reported numbers are plain fp32 MFMA arithmetic.
+// One MFMA consumes 16 channels: lane (r, hi) supplies its CLL elements 8*step .. 8*step+7 (two 16-byte groups of the row).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+PRD_DEV unsigned pack_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
+PRD_DEV void split3(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+    const float ah = __uint_as_float(__float_as_uint(a) & 0xffff0000u), bh = __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+    const float ar = a - ah, br = b - bh;
+    const float am = __uint_as_float(__float_as_uint(ar) & 0xffff0000u), bm = __uint_as_float(__float_as_uint(br) & 0xffff0000u);
+    ph = pack_hi16(ah, bh);
+    pm = pack_hi16(am, bm);
+    pl = pack_hi16(ar - am, br - bm);
+}
+// the lane's K/2 channels -> 3 planes x K/16 steps x 8 bf16
+template <int K>
+PRD_DEV void split3_cll(const float (&x)[K / 2], u32x4 (&p)[3][K / 16]) {
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned ph, pm, pl;
+            split3(x[8 * s + 2 * q], x[8 * s + 2 * q + 1], ph, pm, pl);
+            p[0][s][q] = ph;
+            p[1][s][q] = pm;
+            p[2][s][q] = pl;
+        }
+}
+// W: global [nout][K] fp32 -> LDS image [3 planes][nout rows of (2*K/16 + 1) x 16 bytes] (the +1 pads the row pitch so that
+// the b128 A-operand reads are bank-conflict free); returns nothing, rows_total = nout is the plane stride in rows
+template <int K>
+PRD_DEV void stage_weight_b3(u32x4* Wb, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads, float scale = 1.0f) {
+    constexpr int S = K / 16, PITCH = 2 * S + 1;
+    for (int idx = tid; idx < nout * S * 2; idx += nthreads) {
+        const int o = idx / (2 * S), rem = idx - o * (2 * S), st = rem >> 1, h = rem & 1;
+        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 4 * h);        // CLL elements 8st .. 8st+3
+        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 8 + 4 * h);    // 8st+4 .. 8st+7
+        const float v[8] = {scale * g0.x, scale * g0.y, scale * g0.z, scale * g0.w, scale * g1.x, scale * g1.y, scale * g1.z, scale * g1.w};
+        u32x4 pk[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned ph, pm, pl;
+            split3(v[2 * q], v[2 * q + 1], ph, pm, pl);
+            pk[0][q] = ph;
+            pk[1][q] = pm;
+            pk[2][q] = pl;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) Wb[((size_t)pl * nout + o) * PITCH + 2 * st + h] = pk[pl];
+    }
+}
+// same, for `nrows` rows of W placed at rows row0.. of an image whose planes are `nout` rows apart
+template <int K>
+PRD_DEV void stage_weight_b3_rows(u32x4* Wb, int nout, int row0, const float* __restrict__ W, int nrows, int ldw, int tid, int nthreads,
+                                  float scale) {
+    constexpr int S = K / 16, PITCH = 2 * S + 1;
+    for (int idx = tid; idx < nrows * S * 2; idx += nthreads) {
+        const int o = idx / (2 * S), rem = idx - o * (2 * S), st = rem >> 1, h = rem & 1;
+        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 4 * h);
+        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 8 + 4 * h);
+        const float v[8] = {scale * g0.x, scale * g0.y, scale * g0.z, scale * g0.w, scale * g1.x, scale * g1.y, scale * g1.z, scale * g1.w};
+        u32x4 pk[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned ph, pm, pl;
+            split3(v[2 * q], v[2 * q + 1], ph, pm, pl);
+            pk[0][q] = ph;
+            pk[1][q] = pm;
+            pk[2][q] = pl;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) Wb[((size_t)pl * nout + row0 + o) * PITCH + 2 * st + h] = pk[pl];
+    }
+}
+// acc[nb] += W[row0 + 32*nb .. +31][:] * x for the split row p; Wb / nout as staged by stage_weight_b3
+template <int K, int NB>
+PRD_DEV void rowgemm_b3(const u32x4* Wb, int nout, int row0, const u32x4 (&p)[3][K / 16], f32x16 (&acc)[NB], int r, int hi) {
+    constexpr int S = K / 16, PITCH = 2 * S + 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            u32x4 w[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[pl] = Wb[((size_t)pl * nout + row0 + nb * 32 + r) * PITCH + 2 * s + hi];
+            const int wp[6] = {0, 0, 1, 0, 2, 1}, xp[6] = {0, 1, 0, 2, 0, 1};     // (weight plane, row plane) of the 6 products
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[wp[t]]), __builtin_bit_cast(bf16x8, p[xp[t]][s]),
+                                                                   acc[nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // keeps hipcc from hoisting every LDS read of the unrolled loops (spills)
+        }
+}
+
 template <int NB>
 PRD_DEV void zero_acc(f32x16 (&acc)[NB]) {
 #pragma unroll

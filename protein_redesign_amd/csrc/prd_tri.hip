@@ -89,7 +89,7 @@ PRD_DEV void proj_fetch(const ProjTask& t, const float* __restrict__ pair, const
     load_row_cll_buf<P>(rs, valid ? (rowi * P + 4 * hi) * 4u : BUF_OOB, x);
 }
 
-template <int P>
+template <int P, bool B3>
 PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float mv, float* __restrict__ AB,
                           const float* Wpl, const float* Wgl, const float* bpl, const float* bgl,
                           int N, int ldn, long cstride, unsigned lane_off, int r, int hi, PhaseTimer& pt) {
@@ -104,8 +104,15 @@ PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float 
     f32x16 ap[1], ag[1];
     bias_acc(ap, bpl + hi * P + 16 * t.ob);         // biases ride in the accumulators
     bias_acc(ag, bgl + hi * P + 16 * t.ob);
-    rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
-    rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
+    if (B3) {                                       // opt-in bf16 x 3 form (prd_common.h): same results to ~1e-7
+        u32x4 xs[3][P / 16];
+        split3_cll<P>(x, xs);
+        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, t.ob * 32, xs, ap, r, hi);
+        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, t.ob * 32, xs, ag, r, hi);
+    } else {
+        rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
+        rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
+    }
     pt.mark(3);                                     // 3: MFMAs
     // output channel of register q: 32*ob + (q&3) + 8*(q>>2) + 4*hi; the hi part sits in lane_off
     const prd_rsrc cb = make_rsrc(AB + ((((long)t.bb * OUT) + 32 * t.ob) * N + t.u) * ldn + t.vb * 32);
@@ -126,7 +133,7 @@ PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float 
     pt.mark(4);                                     // 4: epilogue + store issue
 }
 
-template <int P, int NW>
+template <int P, int NW, bool B3>
 __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float* __restrict__ AB, const float* __restrict__ pair,
                                                           const float* __restrict__ mask,
                                                           const float* __restrict__ wp, const float* __restrict__ bp,
@@ -135,12 +142,18 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
     constexpr int KH = P / 2, OUT = 2 * P, OB = OUT / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     PhaseTimer pt;
-    float* Wpl = smem;                       // [2P][P+4]
-    float* Wgl = Wpl + OUT * (P + 4);
-    float* bpl = Wgl + OUT * (P + 4);        // [2P] CLL
+    constexpr int WSZ = B3 ? 3 * OUT * (2 * (P / 16) + 1) * 4 : OUT * (P + 4);    // floats per staged weight matrix
+    float* Wpl = smem;                       // fp32: [2P][P+4]; bf16 x 3: 3 planes of [2P] rows (prd_common.h)
+    float* Wgl = Wpl + WSZ;
+    float* bpl = Wgl + WSZ;                  // [2P] CLL
     float* bgl = bpl + OUT;
-    stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NW * 64);
-    stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E);
+    if (B3) {
+        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wpl), wp, OUT, P, threadIdx.x, NW * 64);
+        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wgl), wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E);
+    } else {
+        stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NW * 64);
+        stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E);
+    }
     stage_vec_cll(bpl, bp, OUT, threadIdx.x, NW * 64);
     stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64, NEG_LOG2E);
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
@@ -164,12 +177,12 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
         const long tn = tasks.next();
         tb = proj_decode<OB>(tn, nrb, nvb, N);
         proj_fetch<P>(tb, pair, mask, N, incoming, r, hi, xb, mub, mvb);
-        if (ta.ok) proj_compute<P>(ta, xa, mua, mva, AB, Wpl, Wgl, bpl, bgl, N, ldn, cstride, lane_off, r, hi, pt);
+        if (ta.ok) proj_compute<P, B3>(ta, xa, mua, mva, AB, Wpl, Wgl, bpl, bgl, N, ldn, cstride, lane_off, r, hi, pt);
         if (tn < 0) break;
         t = tasks.next();
         ta = proj_decode<OB>(t, nrb, nvb, N);
         proj_fetch<P>(ta, pair, mask, N, incoming, r, hi, xa, mua, mva);
-        if (tb.ok) proj_compute<P>(tb, xb, mub, mvb, AB, Wpl, Wgl, bpl, bgl, N, ldn, cstride, lane_off, r, hi, pt);
+        if (tb.ok) proj_compute<P, B3>(tb, xb, mub, mvb, AB, Wpl, Wgl, bpl, bgl, N, ldn, cstride, lane_off, r, hi, pt);
     }
     pt.mark(5);
     pt.flush();
@@ -291,18 +304,24 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
     }   // virtual blocks
 }
 
-template <int P, int NW>
+template <int P, int NW, bool B3>
 __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float* out, const float* pair, const float* __restrict__ O,
                                                               const float* __restrict__ wo, const float* __restrict__ bo,
                                                               const float* __restrict__ wog, const float* __restrict__ bog,
                                                               int b, int N, int ldn, int residual) {
     constexpr int KH = P / 2, NB = P / 32;
-    __shared__ __attribute__((aligned(16))) float Wol[P * (P + 4)];
-    __shared__ __attribute__((aligned(16))) float Wgl[P * (P + 4)];
+    constexpr int WSZ = B3 ? 3 * P * (2 * (P / 16) + 1) * 4 : P * (P + 4);        // B3: opt-in bf16 x 3 row GEMMs (prd_common.h)
+    __shared__ __attribute__((aligned(16))) float Wol[WSZ];
+    __shared__ __attribute__((aligned(16))) float Wgl[WSZ];
     __shared__ __attribute__((aligned(16))) float bol[P];
     __shared__ __attribute__((aligned(16))) float bgl[P];
-    stage_weight_cll<P>(Wol, wo, P, P, threadIdx.x, NW * 64);
-    stage_weight_cll<P>(Wgl, wog, P, P, threadIdx.x, NW * 64);
+    if (B3) {
+        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wol), wo, P, P, threadIdx.x, NW * 64);
+        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wgl), wog, P, P, threadIdx.x, NW * 64);
+    } else {
+        stage_weight_cll<P>(Wol, wo, P, P, threadIdx.x, NW * 64);
+        stage_weight_cll<P>(Wgl, wog, P, P, threadIdx.x, NW * 64);
+    }
     stage_vec_cll(bol, bo, P, threadIdx.x, NW * 64);
     stage_vec_cll(bgl, bog, P, threadIdx.x, NW * 64);
     __syncthreads();
@@ -332,7 +351,13 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
             ln_cll<KH>(x);
             f32x16 ag[NB];
             zero_acc(ag);
-            rowgemm<P, NB>(Wgl, x, ag, r, hi);
+            if (B3) {
+                u32x4 xs[3][P / 16];
+                split3_cll<P>(x, xs);
+                rowgemm_b3<P, NB>(reinterpret_cast<const u32x4*>(Wgl), P, 0, xs, ag, r, hi);
+            } else {
+                rowgemm<P, NB>(Wgl, x, ag, r, hi);
+            }
 #pragma unroll
             for (int s = 0; s < KH; ++s) gate[s] = sigmoid_fast(ag[s >> 4][s & 15] + bgl[hi * KH + s]);
         }
@@ -344,7 +369,13 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
         ln_cll<KH>(x);
         f32x16 ao[NB];
         zero_acc(ao);
-        rowgemm<P, NB>(Wol, x, ao, r, hi);
+        if (B3) {
+            u32x4 xs[3][P / 16];
+            split3_cll<P>(x, xs);
+            rowgemm_b3<P, NB>(reinterpret_cast<const u32x4*>(Wol), P, 0, xs, ao, r, hi);
+        } else {
+            rowgemm<P, NB>(Wol, x, ao, r, hi);
+        }
         load_row_cll<P>(pair + off, hi, valid && residual, x);       // raw row again (cache hit) for the residual
 #pragma unroll
         for (int s = 0; s < KH; ++s) x[s] = x[s] + gate[s] * (ao[s >> 4][s & 15] + bol[hi * KH + s]);
@@ -367,13 +398,25 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
             if (wave < 2) {
                 load_row_cll<P>(pair + off, hi, valid, x);
                 ln_cll<KH>(x);
-                rowgemm<P, 1>(Wgl + nb * 32 * (P + 4), x, acc, r, hi);
+                if (B3) {
+                    u32x4 xs[3][P / 16];
+                    split3_cll<P>(x, xs);
+                    rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wgl), P, nb * 32, xs, acc, r, hi);
+                } else {
+                    rowgemm<P, 1>(Wgl + nb * 32 * (P + 4), x, acc, r, hi);
+                }
             } else if (wave < 4) {
 #pragma unroll
                 for (int s = 0; s < KH; ++s)
                     x[s] = valid ? O[(((long)bb * P + cll_ch(s, hi)) * N + i) * ldn + jj] : 0.f;
                 ln_cll<KH>(x);
-                rowgemm<P, 1>(Wol + nb * 32 * (P + 4), x, acc, r, hi);
+                if (B3) {
+                    u32x4 xs[3][P / 16];
+                    split3_cll<P>(x, xs);
+                    rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wol), P, nb * 32, xs, acc, r, hi);
+                } else {
+                    rowgemm<P, 1>(Wol + nb * 32 * (P + 4), x, acc, r, hi);
+                }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) part[nb][lane][q] = acc[0][q];
             }
@@ -696,15 +739,16 @@ __global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict
 //            operand layouts of the 16x16x4 MFMAs.  The next row's block is already in registers (prefetch).
 //   phase 2: the ceil(N/16) query tiles are dealt round-robin to the waves (SIMD-balanced: waves w and w+4
 //            share a SIMD), two tiles at a time through ta_keyloop.
-template <int P, int NW, bool PREFETCH>
+template <int P, int NW, bool PREFETCH, bool B3>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WSZ = B3 ? 3 * 64 * (2 * (P / 16) + 1) * 4 : 64 * (P + 4);   // B3: opt-in bf16 x 3 projections (prd_common.h)
     float* Wl = smem;                          // [64][P+4]: rows 0-15 k_h, 16-31 v_h, 32-47 q_h, 48-63 g_h
-    float* Kl = Wl + 64 * (P + 4);             // [npad][KP]           (npad = round_up(N, 64))
+    float* Kl = Wl + WSZ;                      // [npad][KP]           (npad = round_up(N, 64))
     float* Vt = Kl + npad * KP;                // [16][npad+4]
     float* kadd = Vt + C * (npad + 4);         // [npad]: 0 = keep the logit, else the value that replaces it
     float* Ql = kadd + npad;                   // [npad][KP]
@@ -728,10 +772,20 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
         slot = blockIdx.x / H;
     }
     const float sc = 0.25f * LOG2E;            // 1/sqrt(c) (modules.py:176,216) in the exp2 domain, folded into Wq
-    stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
-    stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
-    stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT, sc);
-    stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E);   // gate_from_scaled
+    if (B3) {       // one image of 64 rows; stage_weight_b3 takes (first row pointer, rows staged, plane stride in rows)
+        u32x4* Wb = reinterpret_cast<u32x4*>(Wl);
+        constexpr int PITCH = 2 * (P / 16) + 1;
+        stage_weight_b3_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, 1.0f);
+        stage_weight_b3_rows<P>(Wb, 64, C, wv + (long)h * C * P, C, P, tid, NT, 1.0f);
+        stage_weight_b3_rows<P>(Wb, 64, 2 * C, wq + (long)h * C * P, C, P, tid, NT, sc);
+        stage_weight_b3_rows<P>(Wb, 64, 3 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E);
+        (void)PITCH;
+    } else {
+        stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
+        stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
+        stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT, sc);
+        stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E);   // gate_from_scaled
+    }
     // accumulator preload of the [q; g] half: lane half hi owns D rows q{4hi+e}, q{8+4hi+e}, g{4hi+e}, g{8+4hi+e}
     if (tid < 32) {
         const int hh = tid >> 4, e = tid & 15;
@@ -790,6 +844,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
             }
             ln_cll<KH>(x);
+            u32x4 xs[3][P / 16];
+            if (B3) split3_cll<P>(x, xs);
             if (halves & 1) {
                 if (hi == 0) {                                // per-key logit override of this row (see header comment)
                     const bool keep = valid && (mu * mask[(long)bb * N + (valid ? v : 0)] >= 0.5f);
@@ -797,7 +853,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
                 }
                 f32x16 acc[1];
                 zero_acc(acc);
-                rowgemm<P, 1>(Wl, x, acc, r, hi);
+                if (B3) rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wl), 64, 0, xs, acc, r, hi);
+                else rowgemm<P, 1>(Wl, x, acc, r, hi);
                 // D rows of a block: channels {4hi+e} in registers 0-3 and {8+4hi+e} in 4-7 of each 16-row group
                 *reinterpret_cast<float4*>(Kl + v * KP + 4 * hi) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
                 *reinterpret_cast<float4*>(Kl + v * KP + 8 + 4 * hi) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
@@ -810,7 +867,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
             if (halves & 2) {
                 f32x16 acc[1];
                 bias_acc(acc, bqg + 16 * hi);
-                rowgemm<P, 1>(Wl + 2 * C * (P + 4), x, acc, r, hi);
+                if (B3) rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wl), 64, 32, xs, acc, r, hi);
+                else rowgemm<P, 1>(Wl + 2 * C * (P + 4), x, acc, r, hi);
                 *reinterpret_cast<float4*>(Ql + v * KP + 4 * hi) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
                 *reinterpret_cast<float4*>(Ql + v * KP + 8 + 4 * hi) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
                 *reinterpret_cast<float4*>(Gl + v * KP + 4 * hi) = make_float4(gate_from_scaled(acc[0][8]), gate_from_scaled(acc[0][9]),
@@ -1015,6 +1073,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float
     }
 }
 
+int g_gemm_mode = 0;            // 0: fp32 MFMA (default, what every reported number uses); 1: bf16 x 3 split (experimental)
+
 int grid_for(long tasks, int per_wg, int cap) {
     long g = (tasks + per_wg - 1) / per_wg;
     if (g > cap) g = cap;
@@ -1032,6 +1092,12 @@ int grid_for(long tasks, int per_wg, int cap) {
             prd_lds_set = (size_t)(bytes);                                                                      \
         }                                                                                                       \
     } while (0)
+
+extern "C" int prd_set_gemm_mode(int mode) {
+    if (mode != 0 && mode != 1) return PRD_ERR_ARG;
+    g_gemm_mode = mode;
+    return 0;
+}
 
 extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P) {
     (void)S;
@@ -1055,16 +1121,21 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
     {
         constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
-        const size_t lds = ((size_t)2 * 2 * P * (P + 4) + 4 * P) * sizeof(float);
+        const bool b3 = g_gemm_mode == 1;            // opt-in bf16 x 3 row GEMM (prd_set_gemm_mode)
+        const size_t wsz = b3 ? (size_t)3 * 2 * P * (2 * (P / 16) + 1) * 4 : (size_t)2 * P * (P + 4);
+        const size_t lds = (2 * wsz + 4 * P) * sizeof(float);
         const long ntask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);     // (row block, output block) tasks
         const int grid = grid_for(ntask, 4, 256);
-        if (P == 64) {
-            PRD_SET_LDS((tri_mul_proj_kernel<64, NWP>), lds);
-            hipLaunchKernelGGL((tri_mul_proj_kernel<64, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, queue, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
-        } else {
-            PRD_SET_LDS((tri_mul_proj_kernel<32, NWP>), lds);
-            hipLaunchKernelGGL((tri_mul_proj_kernel<32, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, queue, AB, pair, mask, w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);
-        }
+#define PRD_PROJ_LAUNCH(PP, BB, NWV)                                                                                 \
+        do {                                                                                                         \
+            PRD_SET_LDS((tri_mul_proj_kernel<PP, NWV, BB>), lds);                                                    \
+            hipLaunchKernelGGL((tri_mul_proj_kernel<PP, NWV, BB>), dim3(grid), dim3(NWV * 64), lds, stream, queue, AB, pair, mask, \
+                               w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);                                 \
+        } while (0)
+        // (the split operands of the bf16 x 3 form need the registers of a 12-wave workgroup)
+        if (P == 64) { if (b3) PRD_PROJ_LAUNCH(64, true, 12); else PRD_PROJ_LAUNCH(64, false, NWP); }
+        else { if (b3) PRD_PROJ_LAUNCH(32, true, 12); else PRD_PROJ_LAUNCH(32, false, NWP); }
+#undef PRD_PROJ_LAUNCH
         int e = (int)hipGetLastError();
         if (e) return e;
     }
@@ -1079,8 +1150,12 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
         constexpr int NWO = 8;
         const long ntask = (long)b * N * prd_ceil_div(N, 32);
         const int grid = grid_for(ntask, 4, 256);
-        if (P == 64) hipLaunchKernelGGL((tri_mul_out_kernel<64, NWO>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
-        else hipLaunchKernelGGL((tri_mul_out_kernel<32, NWO>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, b_out, w_ogate, b_ogate, b, N, ldn, residual);
+#define PRD_OUT_LAUNCH(PP, BB)                                                                                         \
+        hipLaunchKernelGGL((tri_mul_out_kernel<PP, NWO, BB>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, \
+                           b_out, w_ogate, b_ogate, b, N, ldn, residual)
+        if (P == 64) { if (g_gemm_mode == 1) PRD_OUT_LAUNCH(64, true); else PRD_OUT_LAUNCH(64, false); }
+        else { if (g_gemm_mode == 1) PRD_OUT_LAUNCH(32, true); else PRD_OUT_LAUNCH(32, false); }
+#undef PRD_OUT_LAUNCH
     }
     return (int)hipGetLastError();
 }
@@ -1092,7 +1167,9 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
-    size_t lds = ((size_t)64 * (P + 4) + (size_t)3 * npad * KP + 16 * (npad + 4) + npad + 32) * sizeof(float);
+    const bool b3 = g_gemm_mode == 1;                    // opt-in bf16 x 3 projections (short-row kernel only)
+    const size_t wsz = b3 ? (size_t)3 * 64 * (2 * (P / 16) + 1) * 4 : (size_t)64 * (P + 4);
+    size_t lds = (wsz + (size_t)3 * npad * KP + 16 * (npad + 4) + npad + 32) * sizeof(float);
     const bool long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
     if (long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
@@ -1115,7 +1192,8 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     // 12 waves (3 per SIMD) + next-row prefetch: the ceil(N/16) query tiles dealt in pairs land 5 per SIMD at N = 320
     // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
     if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
-    else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true); }
+    else if (b3) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true, true); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true, true); }
+    else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true, false); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true, false); }
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();
 }

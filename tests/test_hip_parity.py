@@ -293,6 +293,27 @@ def test_triangle_multiplication_cooperative_leftover(setup, monkeypatch, mode):
     assert rel_l2(outs[0], want) < OP_TOL
 
 
+def test_bf16x3_gemm_mode_is_fp32_accurate(setup):
+    """Opt-in row-GEMM arithmetic (prd_set_gemm_mode(1): operands split exactly into three bf16 parts, six products on the bf16
+    matrix pipe, fp32 accumulate): a whole folding block must meet the same tolerances as the default fp32 MFMA path, and stay
+    within 1e-6 of it."""
+    from protein_redesign_amd import _lib
+    s = setup
+    with torch.inference_mode():
+        ws, wp = O.folding_block(s["params"], "Denoiser.folding_blocks.0", s["single"], s["pair"], s["mask"],
+                                 s["args"]["num_heads"], s["args"]["head_dim"])
+    blk = s["model"].Denoiser.folding_blocks[0]
+    gs0, gp0 = blk(cu(s["single"]), cu(s["pair"]), cu(s["mask"]))
+    assert _lib.lib().prd_set_gemm_mode(1) == 0
+    try:
+        gs1, gp1 = blk(cu(s["single"]), cu(s["pair"]), cu(s["mask"]))
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(0) == 0
+    assert rel_l2(gs1.cpu(), ws) < BLOCK_TOL and rel_l2(gp1.cpu(), wp) < BLOCK_TOL
+    assert rel_l2(gp1.cpu(), gp0.cpu()) < 1e-6 and rel_l2(gs1.cpu(), gs0.cpu()) < 1e-6
+    assert _lib.lib().prd_set_gemm_mode(7) != 0
+
+
 def test_outer_product_update(setup):
     s = setup
     got = s["model"].Denoiser.opm(cu(s["single"]), cu(s["mask"]))

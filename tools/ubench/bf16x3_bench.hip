@@ -30,7 +30,7 @@ __device__ __forceinline__ void rowgemm_f32(const float* Wl, const float (&x)[K 
     }
 }
 
-// ---- bf16 x 3 form.  LDS image: Wb[plane 3][out 32*NBLK][step K/16][half 2] x 16 bytes (8 bf16) ----
+// ---- bf16 x 3 form.  LDS image: Wb[plane 3][out 32*NBLK] rows of (K/16 steps x 2 halves + 1 pad) x 16 bytes (8 bf16) ----
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) {          // (a, b) truncated to bf16, a in the low half
     return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
 }
@@ -58,7 +58,7 @@ __device__ __forceinline__ void rowgemm_bf16x3(const u32x4* Wb, const u32x4 (&p)
         for (int s = 0; s < S; ++s) {
             u32x4 w[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) w[pl] = Wb[((pl * 32 * NBLK + nb * 32 + r) * S + s) * 2 + hi];
+            for (int pl = 0; pl < 3; ++pl) w[pl] = Wb[(pl * 32 * NBLK + nb * 32 + r) * (2 * S + 1) + 2 * s + hi];   // pitch 2S+1: conflict-free b128 reads
             // (weight plane, row plane): (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)
             const int wp[6] = {0, 0, 1, 0, 2, 1}, xp[6] = {0, 1, 0, 2, 0, 1};
 #pragma unroll
@@ -71,7 +71,7 @@ __device__ __forceinline__ void rowgemm_bf16x3(const u32x4* Wb, const u32x4 (&p)
 template <int MODE, int NW>       // 0: fp32, 1: bf16x3 (split inside the loop), 2: bf16x3 MFMAs only (row split hoisted)
 __global__ __launch_bounds__(NW * 64) void bench(float* out, int reps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    for (int i = threadIdx.x; i < 3 * 32 * NBLK * (K / 16) * 2 * 4; i += NW * 64) smem[i] = 0.001f * (i % 977);
+    for (int i = threadIdx.x; i < 3 * 32 * NBLK * (2 * (K / 16) + 1) * 4; i += NW * 64) smem[i] = 0.001f * (i % 977);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     float x[K / 2];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void accuracy(const float* W, const float* X, f
                     }
                     pk[0][q] = pack_hi16(hh[0], hh[1]); pk[1][q] = pack_hi16(mm[0], mm[1]); pk[2][q] = pack_hi16(ll[0], ll[1]);
                 }
-                for (int pl = 0; pl < 3; ++pl) Wb[((pl * 64 + o) * (K / 16) + st) * 2 + h] = u32x4{pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]};
+                for (int pl = 0; pl < 3; ++pl) Wb[(pl * 64 + o) * (2 * (K / 16) + 1) + 2 * st + h] = u32x4{pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]};
             }
     __syncthreads();
     float x[K / 2];
@@ -154,7 +154,7 @@ void check_accuracy() {
     float *dW, *dX, *d32, *d16;
     hipMalloc(&dW, W.size() * 4); hipMalloc(&dX, X.size() * 4); hipMalloc(&d32, o32.size() * 4); hipMalloc(&d16, o16.size() * 4);
     hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice);
-    const size_t lds = 64 * (K + 4) * 4 + 3 * 64 * (K / 16) * 2 * 16;
+    const size_t lds = 64 * (K + 4) * 4 + 3 * 64 * (2 * (K / 16) + 1) * 16;
     hipLaunchKernelGGL(accuracy, dim3(1), dim3(64), lds, 0, dW, dX, d32, d16);
     hipMemcpy(o32.data(), d32, o32.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(o16.data(), d16, o16.size() * 4, hipMemcpyDeviceToHost);
     double e32 = 0, e16 = 0, nrm = 0;
@@ -174,7 +174,7 @@ void run(const char* name, int reps) {
     float* out;
     const int grid = 256;
     hipMalloc(&out, grid * NW * 64 * sizeof(float));
-    const size_t lds = 3 * 32 * NBLK * (K / 16) * 2 * 16 + 1024;
+    const size_t lds = 3 * 32 * NBLK * (2 * (K / 16) + 1) * 16 + 1024;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL((bench<MODE, NW>), dim3(grid), dim3(NW * 64), lds, 0, out, 10);
