@@ -47,8 +47,6 @@ struct PhaseTimer {
 
 namespace {
 
-constexpr int WG = 256;
-
 // ---------------------------------------------------------------------------------------------
 // position of a tri_mul_proj task; every field is wave-uniform (scalar registers, scalar index arithmetic; 32-bit on
 // purpose: a 64-bit division expands to ~130 instructions)
