@@ -206,6 +206,24 @@ def test_triangle_attention_large_logit_spread(setup, scale):
     assert rel_l2(got.cpu(), want) < 5 * OP_TOL
 
 
+def test_triangle_attention_row_longer_than_one_round(setup):
+    """N = 400: 13 key blocks on a 12-wave workgroup = one whole round of projection blocks + one block split in halves over
+    two waves; 25 query tiles dealt two per wave; still the short-row kernel (K / V / Q / gate of a row fit the LDS)."""
+    s = setup
+    N, P = 400, s["P"]
+    g = torch.Generator().manual_seed(13)
+    pair = torch.randn(1, N, N, P, generator=g)
+    mask = torch.ones(1, N)
+    mask[0, 391:] = 0
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    with torch.inference_mode():
+        want = O.triangle_attention(s["params"], "Denoiser.folding_blocks.0.pair_attn_ending", pair, m2, s["args"]["num_heads"],
+                                    s["args"]["head_dim"], True)
+    mod = s["model"].Denoiser.folding_blocks[0].pair_attn_ending
+    got = mod.run(cu(pair), cu(mask), residual=False)
+    assert rel_l2(got.cpu(), want) < OP_TOL
+
+
 @pytest.mark.parametrize("use_queue", [False, True])
 def test_block_tail_fusion_and_queue_reset(setup, monkeypatch, use_queue):
     """Fused tail (ending tri-attn output projection + pair transition + next block's bias) == the three separate
