@@ -228,28 +228,24 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
     // staging assignment: thread -> (row = tid>>3 (+32), 16-byte group f = tid&7); explicit scalars, no arrays
     const int srow = tid >> 3, sf = tid & 7;
     const bool a0 = (m0 + srow) < N, a1 = (m0 + srow + 32) < N, b0 = (n0 + srow) < N, b1 = (n0 + srow + 32) < N;
-    const float* pa0 = A + (size_t)(a0 ? m0 + srow : 0) * ldn + 4 * sf;
-    const float* pa1 = A + (size_t)(a1 ? m0 + srow + 32 : 0) * ldn + 4 * sf;
-    const float* pb0 = B + (size_t)(b0 ? n0 + srow : 0) * ldn + 4 * sf;
-    const float* pb1 = B + (size_t)(b1 ? n0 + srow + 32 : 0) * ldn + 4 * sf;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // buffer addressing: descriptor base = the tile's first operand row (uniform), lane offset = (row, 16-byte group) fixed
+    // for the whole kernel (BUF_OOB for rows past the edge: they load zeros), per-chunk offset in an SGPR -- the chunk loop
+    // carries no VALU address arithmetic and no edge selects (fp32 MFMA and VALU share the SIMD's issue time)
+    const prd_rsrc ra = make_rsrc(A + (size_t)m0 * ldn), rb = make_rsrc(B + (size_t)n0 * ldn);
+    const unsigned oa0 = a0 ? ((unsigned)srow * ldn + 4 * sf) * 4u : BUF_OOB, oa1 = a1 ? ((unsigned)(srow + 32) * ldn + 4 * sf) * 4u : BUF_OOB;
+    const unsigned ob0 = b0 ? ((unsigned)srow * ldn + 4 * sf) * 4u : BUF_OOB, ob1 = b1 ? ((unsigned)(srow + 32) * ldn + 4 * sf) * 4u : BUF_OOB;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     const int nchunk = ldn / KCH;                        // ldn is a multiple of 32; columns >= N hold zeros
-    // rows past the edge are loaded from row 0 (always valid) and zeroed in registers: a select between a load and
-    // a constant would be lowered to a load from a stack slot (scratch memory) instead
+#define PRD_TMC_LD1(RS, OFF, KO) [&] { const auto v_ = __builtin_amdgcn_raw_buffer_load_b128(RS, OFF, (KO) * 4, 0);      \
+        return make_float4(__uint_as_float(v_[0]), __uint_as_float(v_[1]), __uint_as_float(v_[2]), __uint_as_float(v_[3])); }()
 #define PRD_TMC_LOAD(R, KO)                                                       \
-    R##a0 = *reinterpret_cast<const float4*>(pa0 + (KO));                         \
-    R##a1 = *reinterpret_cast<const float4*>(pa1 + (KO));                         \
-    R##b0 = *reinterpret_cast<const float4*>(pb0 + (KO));                         \
-    R##b1 = *reinterpret_cast<const float4*>(pb1 + (KO));
-    // (the edge rows are zeroed when they are STAGED: touching the registers earlier would wait for the loads at once)
+    R##a0 = PRD_TMC_LD1(ra, oa0, KO);                                             \
+    R##a1 = PRD_TMC_LD1(ra, oa1, KO);                                             \
+    R##b0 = PRD_TMC_LD1(rb, ob0, KO);                                             \
+    R##b1 = PRD_TMC_LD1(rb, ob1, KO);
 #define PRD_TMC_STAGE(R, BUF)                                                     \
-    if (!a0) R##a0 = zero4;                                                       \
-    if (!a1) R##a1 = zero4;                                                       \
-    if (!b0) R##b0 = zero4;                                                       \
-    if (!b1) R##b1 = zero4;                                                       \
     *reinterpret_cast<float4*>(&As[BUF][srow * LDP + 4 * sf]) = R##a0;            \
     *reinterpret_cast<float4*>(&As[BUF][(srow + 32) * LDP + 4 * sf]) = R##a1;     \
     *reinterpret_cast<float4*>(&Bs[BUF][srow * LDP + 4 * sf]) = R##b0;            \
@@ -288,6 +284,7 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
         if (c + 1 < nchunk) PRD_TMC_CHUNK(c + 1, 1, v, u)
     }
 #undef PRD_TMC_LOAD
+#undef PRD_TMC_LD1
 #undef PRD_TMC_STAGE
 #undef PRD_TMC_CHUNK
     float* __restrict__ Oc = O + (size_t)ch * N * ldn;
