@@ -3,28 +3,37 @@
 BASELINE.json configs[1] workload -- synthetic 256-residue + 64-atom-ligand complex (N = 320),
 single_dim 512, pair_dim 64, 4 folding blocks, T = 1000 -- on N GPUs of one node.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1: starts N ranks itself (see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  Samples of ``sample()`` never interact, so the path shards by sample index
-with no collective in the data path (weak scaling: every rank runs ``--samples-per-gpu`` complexes);
-RCCL is used only for the barrier and the max-over-ranks of the elapsed time.  A "step" is one
-reverse-diffusion step of every complex on the rank, replayed from one captured hipGraph with all
-inputs (weights, static embeddings, noise table) resident in HBM.  Prints ONE JSON line on rank 0.
+One process per GPU over RCCL (backend "nccl").  Samples of ``sample()`` never interact, so the path shards by
+global sample index with no collective inside the loop (weak scaling: every rank runs ``--samples-per-gpu``
+complexes); the ONE collective of the sampling job -- the all_gather that returns every rank's samples
+(distributed.sample_sharded, ~2 MB for 64 samples) -- runs once at the end of the timed region.  A "step" is one
+reverse-diffusion step of every complex on the rank, replayed from one captured hipGraph with all inputs
+(weights, static embeddings, noise table) resident in HBM.  Rank 0 prints ONE JSON line.
+
+``--gpus N`` without a launcher (no WORLD_SIZE in the environment): this process starts
+``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a CHILD and exits with its code.  That happens
+before anything here touches the GPU (a process that has initialised HIP must never re-exec, and does not).
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 at the fp32 vector rate
 HBM_PEAK_GBS = 8000.0
+S, P, NB, T = 512, 64, 4, 1000
 
 
 def step_flops(N, S, P, H=4, c=16, nb=4):
@@ -44,46 +53,194 @@ def tri_attn_core_flops(b, N, P, H=4, c=16):
     return b * (8 * N * N * P * H * c + 4 * H * c * N ** 3)
 
 
-def main():
+def tri_attn_core_bytes(b, N, P):
+    """Algorithmic bytes of one launch: the pair tensor read once, the gated per-head output written once (2 U)."""
+    return b * (N * N * P * 4 + N * N * 64 * 4)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--samples-per-gpu", type=int, default=1)
     ap.add_argument("--residues", type=int, default=256)
     ap.add_argument("--atoms", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--no-traffic", action="store_true", help="skip the child rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-shard-check", action="store_true", help="N > 1: skip the sample_sharded == single-rank check")
+    ap.add_argument("--kernel-only", action="store_true", help="(internal) run only the dominant kernel, for the PMC passes")
+    return ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
 
-    from protein_redesign_amd import ops
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a):
+    """--gpus N without a launcher: run N ranks as a child torchrun.  Nothing in this process has touched the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if os.environ.get("PRD_BENCH_DRY_LAUNCH"):                  # tests: show the launch instead of performing it
+        print(json.dumps({"launch": cmd}))
+        return 0
+    return subprocess.run(cmd, env=env).returncode
+
+
+def build_model(dev, graph=True):
     from protein_redesign_amd.constants import make_args
-    from protein_redesign_amd.diffusion_model import ProteinReDiffModel, ReverseDiffusion
-    from protein_redesign_amd.synthetic import NoiseSource, batch_to, deterministic_state_dict, synthetic_batch
+    from protein_redesign_amd.diffusion_model import ProteinReDiffModel
+    from protein_redesign_amd.synthetic import deterministic_state_dict
     from protein_redesign_amd.weights import spec_tensors
-
-    S, P, NB, T = 512, 64, 4, 1000
     margs = make_args(single_dim=S, pair_dim=P, num_blocks=NB, num_steps=T, mask_prob=0.3)
     params = deterministic_state_dict(spec_tensors(margs), seed=1)
     model = ProteinReDiffModel(margs)
     model.load_state_dict(params)
     model = model.to(dev).eval()
-    model.use_hip_graph = not a.no_graph
+    model.use_hip_graph = graph
+    return model, margs, params
+
+
+def dominant_kernel(model, mask, bpg, N, dev, reps):
+    """tri_attn_core alone, starting / ending modes alternating as inside a step; returns its average launch time (us) measured
+    with HIP events on the stream the kernel is launched on (torch's current stream)."""
+    import torch
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(0)
+    pair = torch.randn(bpg, N, N, P, generator=g).to(dev)
+    ta = model.Denoiser.folding_blocks[0].pair_attn_starting.attn
+    wts = ta.weights()[:5]
+    og = torch.empty(bpg, N, N, 64, device=dev)
+    for i in range(4):
+        ops.tri_attn_core(pair, mask, wts, 4, 16, ending=bool(i & 1), og=og)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        ops.tri_attn_core(pair, mask, wts, 4, 16, ending=bool(i & 1), og=og)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def measure_traffic(a):
+    """HBM-side bytes per launch of the dominant kernel, measured NOW: two child ``rocprofv3 --kernel-trace --pmc`` passes
+    (FETCH_SIZE and WRITE_SIZE need separate passes: 3 + 2 of the 4 TCC slots) of ``python3 bench.py --kernel-only``.
+    Units / corrections per MI355X_MICROARCH.md §HBM: both counters are KiB; on gfx950 FETCH_SIZE reports half the bytes
+    of wide (16 B / lane) coalesced reads -> x2; WRITE_SIZE matched the byte count of this kernel's output exactly
+    (profiles/README.md) and is used as is.  Returns (bytes or None, note)."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="prd_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "t", "--",
+                   "python3", os.path.abspath(__file__), "--kernel-only", "--residues", str(a.residues), "--atoms", str(a.atoms),
+                   "--samples-per-gpu", str(a.samples_per_gpu)]
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            env.pop("WORLD_SIZE", None)
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return None, f"{counter} pass failed (exit {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
+            db = sqlite3.connect(dbs[0])
+            rows = list(db.execute("select dispatch_id, sum(value) from counters_collection where counter_name = ? "
+                                   "and kernel_name like '%tri_attn_core_kernel%' group by dispatch_id", (counter,)))
+            if not rows:
+                return None, f"{counter}: no tri_attn_core_kernel dispatch in the counter database"
+            vals[counter] = sum(v for _, v in rows) / len(rows)
+    except Exception as e:      # profiling is evidence, never a reason to lose the bench line
+        return None, f"PMC pass error: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = int(2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
+    return traffic, (f"measured in this run: child rocprofv3 --pmc passes, FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB x2 (gfx950 wide-read "
+                     f"correction) + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB per launch")
+
+
+def cpu_baseline(a, N, margs, params):
+    """The oracle (a port of the reference algorithm, oracle/prd_oracle.py) on this box's host cores: one network step of the
+    same complex per measurement.  Thread counts {8, 16, 32, 64, physical cores} are swept (one step each after a warm-up),
+    then the best one is re-run: min of 5 steps.  Reported baseline, not the target."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import prd_oracle as O
+    from protein_redesign_amd.synthetic import NoiseSource, synthetic_batch
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    logical = os.cpu_count()
+    pb = O.prepare_batch(synthetic_batch([(a.atoms, a.residues)], seed=0), 0.3, [NoiseSource(0, 0).randperm(a.residues)])
+    g = torch.Generator().manual_seed(0)
+    z, seq_t, t = torch.randn(1, N, 3, generator=g), torch.randn(1, N, 21, generator=g), torch.tensor([T // 2])
+
+    def one_step():
+        c0 = time.perf_counter()
+        with torch.inference_mode():
+            O.network_step(params, margs, pb, z, seq_t, pb["residue_and_atom_mask"], t)
+        return time.perf_counter() - c0
+
+    default_threads = torch.get_num_threads()
+    one_step()                                                   # warm-up (allocator, oneDNN primitives)
+    sweep = {}
+    for n in sorted({n for n in (8, 16, 32, 64, phys) if n <= logical}):
+        torch.set_num_threads(n)
+        sweep[n] = one_step()
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]] + [one_step() for _ in range(4)]
+    torch.set_num_threads(default_threads)
+    return {"value": round(1.0 / min(times), 4), "unit": "denoising-steps/s", "cores": best, "kind": "port",
+            "physical_cores": phys, "logical_cpus": logical,
+            "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": f"oracle/prd_oracle.py network_step on the same N={N} complex (reverse update negligible): 1 warm-up, one step "
+                      f"per thread count, then min of 5 steps at the best count ({best} threads)"}
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.kernel_only:
+        sys.exit(self_launch(a))                                 # before any GPU call in this process
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); n_gpus reports the RCCL world size",
+              file=sys.stderr, flush=True)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)           # "nccl" is RCCL on ROCm
+        world = dist.get_world_size()
+
+    from protein_redesign_amd import _lib
+    from protein_redesign_amd.diffusion_model import ReverseDiffusion
+    from protein_redesign_amd.distributed import gather_samples, sample_sharded
+    from protein_redesign_amd.synthetic import NoiseSource, batch_to, synthetic_batch
+
+    model, margs, params = build_model(dev, graph=not a.no_graph)
     bpg = a.samples_per_gpu
     N = a.atoms + a.residues
     batch = synthetic_batch([(a.atoms, a.residues)] * bpg, seed=0)
     sources = [NoiseSource(0, rank * bpg + k) for k in range(bpg)]      # keyed by GLOBAL sample index
     loop = ReverseDiffusion(model, batch_to(batch, dev), sources)
+
+    if a.kernel_only:                                            # child of measure_traffic(): only the dominant kernel
+        dominant_kernel(model, loop.mask, bpg, N, dev, reps=6)
+        return
 
     def advance(n):
         for _ in range(n):
@@ -93,12 +250,14 @@ def main():
 
     advance(2)                         # eager step + graph capture (setup, not warm-up)
     advance(a.warmup)
+    gather_samples(*loop.result(), world * bpg)                  # warm the collective (communicator setup is not a step)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     advance(a.steps)
+    pos_all, logits_all = gather_samples(*loop.result(), world * bpg)   # the sampling job's one collective (RCCL all_gather)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -108,62 +267,51 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    pos, logits = loop.result()
-    finite = bool(torch.isfinite(pos).all() and torch.isfinite(logits).all())
+    finite = bool(torch.isfinite(pos_all).all() and torch.isfinite(logits_all).all())
+
+    # ---- N > 1: the product's sharded sampler end to end, against single-rank runs (bit-identical by construction) ----
+    shard_check = None
+    if world > 1 and not a.no_shard_check:
+        model.num_steps, model.setup_schedule = 24, False        # a short loop: this is a correctness check, not the timed region
+        one = batch_to(synthetic_batch([(a.atoms, a.residues)], seed=0), dev)
+        c0 = time.perf_counter()
+        pos_s, log_s = sample_sharded(lambda bt, src: model.sample(bt, sources=src), one, world * bpg, seed=0, batch_size=bpg)
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - c0
+        k = ((rank + 1) % world) * bpg                           # a sample ANOTHER rank drew, recomputed here alone
+        pos_1, log_1 = model.sample({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in one.items()}, sources=[NoiseSource(0, k)])
+        same = torch.tensor([int(torch.equal(pos_s[k], pos_1[0]) and torch.equal(log_s[k], log_1[0]))], device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        shard_check = {"num_samples": world * bpg, "num_steps": 24, "identical_to_single_rank": bool(same.item()),
+                       "seconds": round(secs, 3)}
+        if not same.item():
+            raise SystemExit("bench.py: sample_sharded over RCCL differs from the single-rank samples")
+        model.num_steps, model.setup_schedule = T, False
 
     # ---- dominant kernel, measured live with HIP events on the launch stream (rank 0) ----
     roofline = None
     if rank == 0:
-        g = torch.Generator().manual_seed(0)
-        pair = torch.randn(bpg, N, N, P, generator=g).to(dev)
-        ta = model.Denoiser.folding_blocks[0].pair_attn_starting.attn
-        wts = ta.weights()[:5]
-        og = torch.empty(bpg, N, N, 64, device=dev)
-        for i in range(4):
-            ops.tri_attn_core(pair, loop.mask, wts, 4, 16, ending=bool(i & 1), og=og)
-        reps = 20
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(reps):                      # starting / ending modes alternate, as inside a step
-            ops.tri_attn_core(pair, loop.mask, wts, 4, 16, ending=bool(i & 1), og=og)
-        e1.record()
-        torch.cuda.synchronize()
-        kus = e0.elapsed_time(e1) * 1e3 / reps
+        kus = dominant_kernel(model, loop.mask, bpg, N, dev, reps=20)
         kfl = tri_attn_core_flops(bpg, N, P)
         ach = kfl / (kus * 1e-6) / 1e12
-        traffic = None          # HBM-side bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and bpg == 1 and N == 320:
-            traffic = json.load(open(tpath))["tri_attn_core_kernel"]["traffic_bytes_per_launch"]
+        traffic, note = (None, "not measured (--no-traffic or N > 1)")
+        if world == 1 and not a.no_traffic:
+            traffic, note = measure_traffic(a)
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
+                    "algorithmic_bytes_per_launch": tri_attn_core_bytes(bpg, N, P),
                     "kernel": "tri_attn_core_kernel", "launches_per_step": 2 * NB,
                     "flops_per_launch": kfl, "avg_launch_us": round(kus, 2)}
 
-    # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores, bounded sample ----
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import prd_oracle as O
-        pb = O.prepare_batch(synthetic_batch([(a.atoms, a.residues)], seed=0), 0.3, [NoiseSource(0, 0).randperm(a.residues)])
-        g = torch.Generator().manual_seed(0)
-        z, seq_t, t = torch.randn(1, N, 3, generator=g), torch.randn(1, N, 21, generator=g), torch.tensor([T // 2])
-        times = []
-        with torch.inference_mode():
-            for i in range(3):
-                c0 = time.perf_counter()
-                eps, lg = O.network_step(params, margs, pb, z, seq_t, pb["residue_and_atom_mask"], t)
-                z = (z - 0.01 * eps)                       # reverse update is negligible next to the network
-                seq_t = torch.softmax(lg, -1) * 2 - 1
-                times.append(time.perf_counter() - c0)
-        best = min(times[1:])
-        cpu = {"value": round(1.0 / best, 4), "unit": "denoising-steps/s", "cores": torch.get_num_threads(),
-               "kind": "port", "sample": f"oracle/prd_oracle.py network_step, same N={N} complex, 1 warm-up + min of 2 steps"}
+        cpu = cpu_baseline(a, N, margs, params)
 
     if rank == 0:
         total_steps = world * bpg * a.steps
         value = total_steps / dt
         flops = step_flops(N, S, P, nb=NB)
+        b3 = _lib.lib().prd_get_gemm_mode() == 1
         out = {
             "metric": "denoising-steps/sec (fwd+rev) per complex, N=256 res", "value": round(value, 3),
             "unit": "denoising-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -171,11 +319,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic {a.residues}-residue + {a.atoms}-atom ligand (N={N}), "
                                    f"single_dim={S} pair_dim={P} num_blocks={NB} num_steps={T}, "
-                                   f"{bpg} complex/GPU, sharded by sample index (no data-path collective)",
+                                   f"{bpg} complex/GPU, sharded by sample index (no data-path collective; one all_gather "
+                                   f"of the samples at the end of the timed region)",
                        "samples_per_gpu": bpg, "hip_graph": not a.no_graph, "outputs_finite": finite,
-                       # default: fp32 MFMA everywhere.  PRD_BF16X3=1 opts in to the experimental split-bf16 row GEMMs
-                       # (fp32-accurate); such a run says so here and is not the headline number
-                       "row_gemm": "bf16x3-split (opt-in, experimental)" if os.environ.get("PRD_BF16X3") else "fp32-mfma"},
+                       "row_gemm": _lib.row_gemm_description(b3),
+                       "backend": "nccl (RCCL)" if world > 1 else "single process", "sharded_sample_check": shard_check},
             "step_gflop": round(flops / 1e9, 1),
             "step_tflops": round(flops * bpg / (dt / a.steps) / 1e12, 2),
             "roofline": roofline, "cpu_baseline": cpu,

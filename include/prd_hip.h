@@ -3,14 +3,16 @@
  * The reference (HySonLab/Protein_Redesign) is pure eager PyTorch: it has no FFI of its own.  The
  * entry points below are therefore the operator boundary a maintainer would bind from Python
  * (ctypes): one function per nn.Module.forward on the hot path,
- * plus the building blocks they are composed of and a whole-step driver.  Each comment cites the
- * reference code the function replaces (paths relative to the reference repository).
+ * plus the building blocks they are composed of.  Each comment cites the reference code the
+ * function replaces (paths relative to the reference repository).
  *
  * Rules of the boundary
  *   - extern "C", plain pointers / ints / floats only.  All pointers are DEVICE pointers to
  *     contiguous fp32 (or int64 where stated) buffers owned by the caller (PyTorch's allocator).
- *   - The library never allocates or frees device memory and keeps no global state; scratch is
- *     passed in as `ws` with its size in bytes (query with prd_workspace_bytes).
+ *   - The library never allocates or frees device memory; scratch is passed in as `ws` with its
+ *     size in bytes (query with prd_workspace_bytes).  Its ONLY process-wide state is the row-GEMM
+ *     arithmetic mode below (one relaxed atomic int, read once per call) -- everything else is
+ *     re-entrant across threads and streams because outputs and workspace are caller-provided.
  *   - Every call only enqueues kernels on `stream` (the caller's current HIP stream), never
  *     synchronises, and is therefore capturable into a hipGraph.
  *   - Return value: 0 on success, a positive hipError_t from the launch, or a negative PRD_ERR_*.
@@ -40,12 +42,16 @@ typedef struct ihipStream_t* hipStream_t;
 
 int prd_version(void);
 
-/* Arithmetic of the row GEMMs inside the pair-track operators (process-wide, set before launching):
- *   0 (default)  fp32 MFMA (v_mfma_f32_32x32x2_f32) -- what every reported number and parity claim uses;
- *   1 (opt-in, experimental)  both operands split exactly into three bf16 parts, six products on the bf16 matrix pipe with
- *     fp32 accumulation: fp32-accurate (~1e-7 relative, tools/ubench/bf16x3_bench.hip), 2.1-2.4x the rate.  Round 1:
- *     implemented in prd_tri_mul's projection kernel only. */
+/* Arithmetic of the row GEMMs inside the pair-track operators.  PROCESS-WIDE (the single piece of global state of the
+ * library): set it before launching, not concurrently with launches whose arithmetic matters; calls read it once.
+ *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32): plain fp32 FMA chains;
+ *   1  both operands split exactly into three bf16 parts (truncation: 3 x 8 = 24 mantissa bits), six products on the bf16
+ *      matrix pipe with fp32 accumulation: fp32-accurate (~1e-7 relative, tools/ubench/bf16x3_bench.hip), 2.1-2.4x the rate.
+ *      Applied to: tri_mul projection / output kernels and the q|k|v|g projections of the short-row triangle attention core;
+ *      kernels without a split form run fp32 MFMA in either mode.
+ * Both modes meet every parity tolerance of tests/ (the GPU suite runs its step / trajectory tests in both). */
 int prd_set_gemm_mode(int mode);
+int prd_get_gemm_mode(void);
 
 /* ---- generic batched GEMM:  C[g] = epilogue(A[g] * B[g]^T)  (b_kn = 1: A[g] * B[g]) -------------
  * Replaces aten::linear / bmm / matmul on the single track (modules.py:185-225, 306-311;
@@ -137,6 +143,9 @@ int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w
 int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
                  const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
                  int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, hipStream_t stream);
+/* which core kernel prd_tri_attn uses for rows of N positions under the current gemm mode: 0 = short rows (K, V, Q and gate
+ * of a row resident in LDS), 1 = long rows (Q / gate re-projected per query block), PRD_ERR_UNSUPPORTED = N too large. */
+int prd_tri_attn_variant(int N, int P);
 /* the two launches of prd_tri_attn, exposed separately (og = gated per-head output [b,N,N,64]) */
 int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                       const float* wv, const float* wg, const float* bg, int ending,

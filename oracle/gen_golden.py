@@ -45,6 +45,15 @@ CASES = {
         args=dict(single_dim=256, pair_dim=32, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
                   num_steps=10, mask_prob=0.3),
         sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110)),
+    # the same complex through LONG reverse-diffusion loops (trajectory only): T = 200 and the T = 1000 of BASELINE configs[1]
+    "cfg1_t200": dict(
+        args=dict(single_dim=256, pair_dim=32, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
+                  num_steps=200, mask_prob=0.3),
+        sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110), traj_only=True),
+    "cfg1_t1000": dict(
+        args=dict(single_dim=256, pair_dim=32, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
+                  num_steps=1000, mask_prob=0.3),
+        sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110), traj_only=True),
 }
 
 NOISE_SEED = 7
@@ -90,6 +99,12 @@ def run_case(name, case, ref_model):
     out = {"case": np.array(json.dumps(dict(case, name=name)))}
     out["state_dict_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in model.state_dict().items()}))
     esm_dim = args["esm_dim"]
+    if case.get("traj_only"):
+        one = synthetic_batch([case["traj_sample"]], esm_dim=esm_dim, seed=case["batch_seed"] + 500)
+        with _Injected([NoiseSource(NOISE_SEED, 0)]):
+            pos, logits = model.sample(clone_batch(one))
+        out.update(traj_pos=pos.numpy(), traj_logits=logits.numpy())
+        return out
     batch = synthetic_batch(case["sizes"], esm_dim=esm_dim, seed=case["batch_seed"], n_total=case["n_total"])
     b, N = batch["atom_mask"].shape
     S, P = args["single_dim"], args["pair_dim"]

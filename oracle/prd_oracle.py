@@ -26,6 +26,7 @@ import torch
 import torch.nn.functional as F
 
 Params = Mapping[str, torch.Tensor]
+ROW_CHUNK_ELEMS = 1 << 28      # triangle attention: at most this many logits (1 GiB of fp32) are materialised at a time
 
 
 # ---------------------------------------------------------------------------
@@ -110,7 +111,13 @@ def triangle_attention(p: Params, prefix: str, pair: torch.Tensor, mask2d: torch
     if ending:
         pair = pair.transpose(-2, -3)
         mask2d = mask2d.transpose(-1, -2)
-    out = gated_attention(p, prefix + ".attn", pair, mask2d, heads, head_dim)
+    n = pair.shape[-2]
+    rows = max(1, ROW_CHUNK_ELEMS // (heads * n * n))
+    if rows >= pair.shape[-3]:
+        out = gated_attention(p, prefix + ".attn", pair, mask2d, heads, head_dim)
+    else:       # same arithmetic, row blocks at a time: the [b,N,H,N,N] logits of N = 769 would need 7.3 GB (x3 temporaries)
+        out = torch.cat([gated_attention(p, prefix + ".attn", pair[..., r:r + rows, :, :], mask2d[..., r:r + rows, :],
+                                         heads, head_dim) for r in range(0, pair.shape[-3], rows)], dim=-3)
     if ending:
         out = out.transpose(-2, -3)
     return out

@@ -36,6 +36,8 @@ class PrdGemm(C.Structure):
 SIGNATURES = {
     "prd_version": [],
     "prd_set_gemm_mode": [ci],
+    "prd_get_gemm_mode": [],
+    "prd_tri_attn_variant": [ci, ci],
     "prd_gemm": [C.POINTER(PrdGemm), vp],
     "prd_ln_rows": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "prd_softmax_rows": [vp, ci, ci, ci, vp],
@@ -60,6 +62,9 @@ SIGNATURES = {
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
 }
 
+GEMM_MODES = {"fp32": 0, "bf16x3": 1}
+DEFAULT_GEMM_MODE = "fp32"          # arithmetic the library is switched to when it is loaded (env PRD_GEMM_MODE overrides)
+
 _lib = None
 
 
@@ -76,9 +81,21 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes
             fn.restype = cz if name == "prd_workspace_bytes" else ci
-        if os.environ.get("PRD_BF16X3"):         # opt-in experimental row-GEMM arithmetic (prd_hip.h: prd_set_gemm_mode)
-            _lib.prd_set_gemm_mode(1)
+        mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)      # prd_hip.h: prd_set_gemm_mode
+        if os.environ.get("PRD_BF16X3"):                               # older spelling of PRD_GEMM_MODE=bf16x3
+            mode = "bf16x3"
+        if mode not in GEMM_MODES:
+            raise RuntimeError(f"PRD_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got {mode!r}")
+        _lib.prd_set_gemm_mode(GEMM_MODES[mode])
     return _lib
+
+
+def row_gemm_description(b3: bool) -> str:
+    """What the row GEMMs of the pair kernels compute in, for bench.py's JSON line (stated truthfully, not as a precision claim)."""
+    if b3:
+        return ("bf16x3-split: both operands split exactly into 3 bf16 parts, 6 products on the bf16 MFMA pipe, fp32 accumulate "
+                "(fp32-accurate ~1e-7; kernels without a split form run fp32 MFMA)")
+    return "fp32-mfma"
 
 
 def check(code: int, what: str):

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprd_hip.so")
-SOURCES = ["prd_gemm.hip", "prd_pair.hip", "prd_tri.hip", "prd_step.hip"]
+SOURCES = ["prd_gemm.hip", "prd_pair.hip", "prd_tri.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,7 +24,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
         if not os.path.exists(spath):
-            continue
+            raise FileNotFoundError(f"HIP source listed in build.py is missing: {spath}")
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(obj, [spath] + headers):
             cmd = [hipcc] + FLAGS + ["-c", spath, "-o", obj]

@@ -5,6 +5,7 @@
 // registers and every pair row is read and written exactly once per operator.
 #include "prd_common.h"
 #include "../../include/prd_hip.h"
+#include <mutex>
 
 namespace {
 
@@ -796,15 +797,17 @@ int grid_for(long tasks, int per_wg, int cap) {
 
 }  // namespace
 
-// raise the dynamic-LDS limit of a kernel once per process (idempotent; not a stream operation)
+// raise the dynamic-LDS limit of a kernel to the hardware maximum, once per process and kernel (thread-safe: std::call_once;
+// not a stream operation, so it is legal during hipGraph capture)
 #define PRD_SET_LDS(kernel, bytes)                                                                              \
     do {                                                                                                        \
-        static size_t prd_lds_set = 0;                                                                          \
-        if ((size_t)(bytes) > prd_lds_set) {                                                                    \
-            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-            prd_lds_set = (size_t)(bytes);                                                                      \
-        }                                                                                                       \
+        static std::once_flag prd_lds_once;                                                                     \
+        std::call_once(prd_lds_once, [] {                                                                       \
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        });                                                                                                     \
+        (void)(bytes);                                                                                          \
     } while (0)
+
 #define PRD_CHECK_P(P) if ((P) != 32 && (P) != 64) return PRD_ERR_UNSUPPORTED
 
 extern "C" int prd_version(void) { return PRD_VERSION; }

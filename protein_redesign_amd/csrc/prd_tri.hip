@@ -1,21 +1,27 @@
 // Pair-track kernels, part 2: triangle multiplication and triangle attention.
 //
 // Triangle multiplication (reference modules.py:262-274) = three launches:
-//   tri_mul_proj : p = LN(pair); ab = m2 * sigmoid(Wg p + bg) * (Wp p + bp), stored CHANNEL-MAJOR
-//                  AB[b][2P][N][ldn] (ldn = round_up(N,32), zero padded) so that the contraction is
-//                  2P... P independent, K-contiguous N x N x N GEMMs.  "incoming" writes the
-//                  transposed operand (a[k,i] -> A[i][k]) so both modes share one contraction.
-//   prd_gemm     : O[b][d][i][j] = sum_k A[d][i][k] B[d][j][k]      (batched, MFMA)
-//   tri_mul_out  : pair += sigmoid(Wog LN(pair) + bog) * (Wo LN_d(O) + bo)
+//   tri_mul_proj     : p = LN(pair); ab = m2 * sigmoid(Wg p + bg) * (Wp p + bp), stored CHANNEL-MAJOR AB[b][2P][N][ldn]
+//                      (ldn = round_up(N,32), zero padded) so that the contraction is P independent, K-contiguous N x N x N
+//                      GEMMs.  "incoming" writes the transposed operand (a[k,i] -> A[i][k]): both modes share one contraction.
+//                      Tasks are (32-row block, 32-output block) pairs, rows prefetched one task ahead.
+//   tri_mul_contract : O[b][d][i][j] = sum_k A[d][i][k] B[d][j][k]; persistent 64x64 tiles, double-buffered LDS, buffer loads,
+//                      the tiles of one channel on one XCD.
+//   tri_mul_out      : pair += sigmoid(Wog LN(pair) + bog) * (Wo LN_d(O) + bo); persistent waves, leftover tasks computed
+//                      cooperatively by the four SIMDs of a workgroup.
 // Triangle attention (modules.py:236-243 -> 185-225) = two launches:
-//   tri_attn_core: one workgroup per (b, row, head): K_h / V_h of the whole row live in LDS, the
-//                  N x N logits never exist in memory (flash-style online softmax in registers,
-//                  16x16x4 f32 MFMA for QK^T and PV in the "swapped" form so that every softmax
-//                  quantity of a query is lane-local); writes the gated per-head output
-//                  og[b,N,N,H*c].
-//   tri_attn_out : pair += Wo og + bo.
+//   tri_attn_core    : one PERSISTENT workgroup per CU serves one head for a strided set of pair rows.  Phase 1 projects
+//                      k | v | q | gate of the LayerNorm-ed row into LDS; phase 2 streams the keys in blocks of 64 on the
+//                      16x16x4 fp32 MFMA in the swapped form (S^T = K Q^T, O^T = V^T P^T: every softmax quantity of a query is
+//                      lane-local), softmax in the exp2 domain with a frozen reference maximum after the first block.  The
+//                      N x N logits never exist in memory.  Rows too long for Q / gate tiles in LDS use
+//                      tri_attn_core_long (queries re-projected per 32-query block, operands moved by wave shuffles).
+//   tri_attn_out     : pair += Wo og + bo (starting mode; the ending mode's projection is fused into block_tail, prd_pair.hip).
+// single_attn_core (single-track attention with pair bias, heads of width 16) lives here too: it shares the key-loop scheme.
 #include "prd_common.h"
 #include "../../include/prd_hip.h"
+#include <atomic>
+#include <mutex>
 
 #ifdef PRD_TIMING     // diagnostic builds only (tools/ta_timing.py, tools/phase_timing.py): in-kernel cycle stamps
 __device__ unsigned long long prd_dbg[256 * 16 * 8 * 4];
@@ -1068,7 +1074,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float
     }
 }
 
-int g_gemm_mode = 0;            // 0: fp32 MFMA (default, what every reported number uses); 1: bf16 x 3 split (experimental)
+// The ONE piece of process-wide state of the library (documented in prd_hip.h): relaxed atomic, read once per call.
+std::atomic<int> g_gemm_mode{0};
 
 int grid_for(long tasks, int per_wg, int cap) {
     long g = (tasks + per_wg - 1) / per_wg;
@@ -1079,19 +1086,44 @@ int grid_for(long tasks, int per_wg, int cap) {
 
 }  // namespace
 
+// raise the dynamic-LDS limit of a kernel to the hardware maximum, once per process and kernel (thread-safe: std::call_once;
+// not a stream operation, so it is legal during hipGraph capture)
 #define PRD_SET_LDS(kernel, bytes)                                                                              \
     do {                                                                                                        \
-        static size_t prd_lds_set = 0;                                                                          \
-        if ((size_t)(bytes) > prd_lds_set) {                                                                    \
-            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-            prd_lds_set = (size_t)(bytes);                                                                      \
-        }                                                                                                       \
+        static std::once_flag prd_lds_once;                                                                     \
+        std::call_once(prd_lds_once, [] {                                                                       \
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        });                                                                                                     \
+        (void)(bytes);                                                                                          \
     } while (0)
 
 extern "C" int prd_set_gemm_mode(int mode) {
     if (mode != 0 && mode != 1) return PRD_ERR_ARG;
-    g_gemm_mode = mode;
+    g_gemm_mode.store(mode, std::memory_order_relaxed);
     return 0;
+}
+
+extern "C" int prd_get_gemm_mode(void) { return g_gemm_mode.load(std::memory_order_relaxed); }
+
+namespace {
+// LDS bytes of the triangle-attention core for rows of N positions; long_row: the re-projecting variant is needed
+size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
+    const int npad = prd_round_up(N, 64);
+    const size_t wsz = b3 ? (size_t)3 * 64 * (2 * (P / 16) + 1) * 4 : (size_t)64 * (P + 4);
+    size_t lds = (wsz + (size_t)3 * npad * KP + 16 * (npad + 4) + npad + 32) * sizeof(float);
+    *long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
+    if (*long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    return lds;
+}
+}  // namespace
+
+extern "C" int prd_tri_attn_variant(int N, int P) {
+    if (N <= 0) return PRD_ERR_ARG;
+    if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
+    bool long_row;
+    const size_t lds = tri_attn_lds(N, P, g_gemm_mode.load(std::memory_order_relaxed) == 1, &long_row);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    return long_row ? 1 : 0;
 }
 
 extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P) {
@@ -1116,7 +1148,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
     {
         constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
-        const bool b3 = g_gemm_mode == 1;            // opt-in bf16 x 3 row GEMM (prd_set_gemm_mode)
+        const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;   // bf16 x 3 row GEMM (prd_set_gemm_mode)
         const size_t wsz = b3 ? (size_t)3 * 2 * P * (2 * (P / 16) + 1) * 4 : (size_t)2 * P * (P + 4);
         const size_t lds = (2 * wsz + 4 * P) * sizeof(float);
         const long ntask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);     // (row block, output block) tasks
@@ -1143,13 +1175,14 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     }
     {
         constexpr int NWO = 8;
+        const bool b3o = g_gemm_mode.load(std::memory_order_relaxed) == 1;
         const long ntask = (long)b * N * prd_ceil_div(N, 32);
         const int grid = grid_for(ntask, 4, 256);
 #define PRD_OUT_LAUNCH(PP, BB)                                                                                         \
         hipLaunchKernelGGL((tri_mul_out_kernel<PP, NWO, BB>), dim3(grid), dim3(NWO * 64), 0, stream, queue, out, pair, O, w_out, \
                            b_out, w_ogate, b_ogate, b, N, ldn, residual)
-        if (P == 64) { if (g_gemm_mode == 1) PRD_OUT_LAUNCH(64, true); else PRD_OUT_LAUNCH(64, false); }
-        else { if (g_gemm_mode == 1) PRD_OUT_LAUNCH(32, true); else PRD_OUT_LAUNCH(32, false); }
+        if (P == 64) { if (b3o) PRD_OUT_LAUNCH(64, true); else PRD_OUT_LAUNCH(64, false); }
+        else { if (b3o) PRD_OUT_LAUNCH(32, true); else PRD_OUT_LAUNCH(32, false); }
 #undef PRD_OUT_LAUNCH
     }
     return (int)hipGetLastError();
@@ -1162,11 +1195,9 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
-    const bool b3 = g_gemm_mode == 1;                    // opt-in bf16 x 3 projections (short-row kernel only)
-    const size_t wsz = b3 ? (size_t)3 * 64 * (2 * (P / 16) + 1) * 4 : (size_t)64 * (P + 4);
-    size_t lds = (wsz + (size_t)3 * npad * KP + 16 * (npad + 4) + npad + 32) * sizeof(float);
-    const bool long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
-    if (long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;   // bf16 x 3 projections (short-row kernel only)
+    bool long_row;
+    const size_t lds = tri_attn_lds(N, P, b3, &long_row);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     const int nw = 8;                                   // 2 waves / SIMD: room for the next-row prefetch registers
     // persistent workgroups (weights staged once per workgroup), one per CU: per head the SMALLEST workgroup

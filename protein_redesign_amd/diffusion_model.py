@@ -106,25 +106,50 @@ class SinusoidalProjection(nn.Module):
 
 
 class _Ema:
-    """Shadow-parameter EMA with torch-ema's call surface (model.py:124,194-201,217,238,250)."""
+    """Shadow-parameter EMA with torch-ema 0.3's call surface and checkpoint format (model.py:124,194-201,217,238,250;
+    environment.yml pins torch_ema==0.3): ``state_dict()`` carries decay / num_updates / shadow_params / collected_params,
+    ``update()`` uses the warm-up decay min(decay, (1 + n) / (10 + n)).  The shadow list covers EVERY parameter in
+    registration order (242 tensors for the reference configuration, as torch-ema 0.3 keeps them); checkpoints whose list
+    only holds the 240 trainable tensors (the 0.2 behaviour) load as well."""
 
-    def __init__(self, params, decay: float):
+    def __init__(self, params, decay: float, use_num_updates: bool = True):
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError("Decay must be between 0 and 1")
         self.decay = decay
-        self.shadow = [p.detach().clone() for p in params if p.requires_grad]
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow = [p.detach().clone() for p in params]
+        self.collected = None
         self.active = False          # becomes True once updated or loaded: until then shadow == init copy
 
     def to(self, device=None, dtype=None):
         self.shadow = [s.to(device=device) if device is not None else s for s in self.shadow]
         return self
 
+    def _match(self, params):
+        """Pairs (parameter, shadow) for a shadow list holding all parameters or only the trainable ones."""
+        params = list(params)
+        if len(self.shadow) == len(params):
+            return list(zip(params, self.shadow))
+        train = [p for p in params if p.requires_grad]
+        if len(self.shadow) != len(train):
+            raise ValueError(f"EMA holds {len(self.shadow)} shadow tensors, the model has {len(params)} parameters "
+                             f"({len(train)} trainable)")
+        return list(zip(train, self.shadow))
+
     def update(self, params):
         self.active = True
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
         with torch.no_grad():
-            for s, p in zip(self.shadow, [q for q in params if q.requires_grad]):
-                s.mul_(self.decay).add_(p.detach().to(s.device), alpha=1.0 - self.decay)
+            for p, s in self._match(params):
+                if p.requires_grad:
+                    s.sub_((s - p.detach().to(s.device)) * (1.0 - decay))
 
     def state_dict(self):
-        return {"decay": self.decay, "shadow_params": self.shadow}
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow,
+                "collected_params": self.collected}
 
     def load_state_dict(self, sd):
         shadow = sd.get("shadow_params")
@@ -132,26 +157,24 @@ class _Ema:
             self.shadow = [s.detach().clone() for s in shadow]
             self.active = True
         self.decay = sd.get("decay", self.decay)
+        self.num_updates = sd.get("num_updates", self.num_updates)
+        self.collected = sd.get("collected_params")
 
     @contextlib.contextmanager
     def average_parameters(self, params=None):
         if not self.active or params is None:
             yield
             return
-        params = list(params)
-        train = [p for p in params if p.requires_grad]
-        shadow = self.shadow
-        if len(shadow) == len(params):      # torch-ema kept every parameter (SURVEY.md §5 checkpoint row)
-            train = params
-        saved = [p.detach().clone() for p in train]
+        pairs = self._match(params)
+        saved = [p.detach().clone() for p, _ in pairs]
         with torch.no_grad():
-            for p, s in zip(train, shadow):
+            for p, s in pairs:
                 p.copy_(s.to(p.device))
         try:
             yield
         finally:
             with torch.no_grad():
-                for p, s in zip(train, saved):
+                for (p, _), s in zip(pairs, saved):
                     p.copy_(s)
 
 
@@ -169,7 +192,10 @@ class ProteinReDiffModel(_Base):
         self.diffusion_schedule = args.diffusion_schedule
         self.learning_rate, self.warmup_steps, self.ema_decay = args.learning_rate, args.warmup_steps, args.ema_decay
         self.n_recycles, self.training_mode = args.n_recycles, args.training_mode
-        self.sample_seed = 0                    # key of the injected randomness (see module docstring)
+        # key of the injected randomness (see module docstring).  None = taken from torch's seeded global RNG
+        # (torch.initial_seed(), i.e. what pl.seed_everything(args.seed) / generate.py --seed set) when a sample is drawn,
+        # so different seeds give different samples like in the reference; set an int to pin it regardless of the global seed.
+        self.sample_seed = None
         self.use_hip_graph = True               # replay one captured step graph inside sample()
         self._sample_counter = 0
 
@@ -298,13 +324,24 @@ class ProteinReDiffModel(_Base):
 
     def predict_step(self, batch, batch_idx):
         with self.ema.average_parameters(self.parameters()):
-            return self.sample(batch)
+            return self.sample(batch, batch_idx=batch_idx)
 
     # ------------------------------------------------------------------ batch preparation (model.py:424-468)
-    def _sources(self, b: int) -> List[NoiseSource]:
-        src = [NoiseSource(self.sample_seed, self._sample_counter + k) for k in range(b)]
-        self._sample_counter += b
-        return src
+    def _sources(self, b: int, batch_idx: Optional[int] = None) -> List[NoiseSource]:
+        """Default noise sources of a batch of b samples: keyed (seed, global sample index).  The seed follows the seeded
+        global RNG unless ``sample_seed`` pins it; the index interleaves the ranks of an initialised process group
+        (dataloader batch ``batch_idx`` of rank r holds samples (batch_idx * world + r) * b ...), so that ranks of a
+        multi-GPU ``Trainer.predict`` never draw the same sample twice (the reference's identically seeded ranks do)."""
+        seed = self.sample_seed if self.sample_seed is not None else (torch.initial_seed() & 0x7FFFFFFF)
+        world, rank = 1, 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        if batch_idx is None:           # direct sample() calls: running count of the samples this object has drawn
+            first = self._sample_counter * world + rank * b
+            self._sample_counter += b
+        else:
+            first = (int(batch_idx) * world + rank) * b
+        return [NoiseSource(seed, first + k) for k in range(b)]
 
     def prepare_batch(self, batch, id=None, sources: Optional[Sequence] = None):
         """Eval branch (:459-468).  The training-mode branches need ``residue_esm_tokens`` that no
@@ -384,7 +421,9 @@ class ProteinReDiffModel(_Base):
 
     # ------------------------------------------------------------------ reverse diffusion (model.py:377-422)
     @torch.inference_mode()
-    def sample(self, batch, sources: Optional[Sequence] = None):
+    def sample(self, batch, sources: Optional[Sequence] = None, batch_idx: Optional[int] = None):
+        if sources is None:
+            sources = self._sources(batch["atom_mask"].shape[0], batch_idx)
         loop = ReverseDiffusion(self, batch, sources)
         loop.run()
         return loop.result()

@@ -32,6 +32,29 @@ def repeat_batch(batch: Dict[str, torch.Tensor], n: int) -> Dict[str, torch.Tens
     return out
 
 
+def gather_samples(pos: torch.Tensor, logits: torch.Tensor, num_samples: int,
+                   group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The one collective of the sampling job: every rank contributes the samples of its shard (``pos [n_r,N,3]``,
+    ``logits [n_r,N,21]``, n_r = len(shard_range(num_samples, world, rank))) and receives all ``num_samples`` in global
+    index order.  RCCL all_gather when the backend is "nccl"; shards are padded to the largest one.  World size 1 (or no
+    process group): returns the inputs."""
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    mine = len(shard_range(num_samples, world, rank))
+    if pos.shape[0] != mine:
+        raise ValueError(f"rank {rank} holds {pos.shape[0]} samples, its shard of {num_samples} over {world} ranks is {mine}")
+    if world == 1:
+        return pos.contiguous(), logits.contiguous()
+    cap = len(shard_range(num_samples, world, 0))              # largest shard
+    packed = torch.zeros(cap, pos.shape[1], 3 + logits.shape[-1], device=pos.device, dtype=torch.float32)
+    packed[:mine] = torch.cat([pos, logits], dim=-1)
+    gathered = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(gathered, packed, group=group)
+    allr = torch.cat([gathered[r][:len(shard_range(num_samples, world, r))] for r in range(world)])
+    return allr[..., :3].contiguous(), allr[..., 3:].contiguous()
+
+
 def sample_sharded(sampler: Callable[[Dict[str, torch.Tensor], Sequence[NoiseSource]], Tuple[torch.Tensor, torch.Tensor]],
                    complex_batch: Dict[str, torch.Tensor], num_samples: int, seed: int = 0, batch_size: int = 1,
                    group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -53,17 +76,7 @@ def sample_sharded(sampler: Callable[[Dict[str, torch.Tensor], Sequence[NoiseSou
         pos_l.append(pos)
         log_l.append(logits)
     N = complex_batch["atom_mask"].shape[1]
-    ref = pos_l[0] if pos_l else None
-    device = ref.device if ref is not None else complex_batch["atom_mask"].device
-    cap = len(shard_range(num_samples, world, 0))              # largest shard
-    packed = torch.zeros(cap, N, 3 + 21, device=device, dtype=torch.float32)
-    if pos_l:
-        packed[:len(mine)] = torch.cat([torch.cat(pos_l), torch.cat(log_l)], dim=-1)
-    if world == 1:
-        gathered = [packed]
-    else:
-        gathered = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(gathered, packed, group=group)
-    rows = [gathered[r][:len(shard_range(num_samples, world, r))] for r in range(world)]
-    allr = torch.cat(rows)
-    return allr[..., :3].contiguous(), allr[..., 3:].contiguous()
+    device = pos_l[0].device if pos_l else complex_batch["atom_mask"].device
+    pos = torch.cat(pos_l) if pos_l else torch.zeros(0, N, 3, device=device)
+    logits = torch.cat(log_l) if log_l else torch.zeros(0, N, 21, device=device)
+    return gather_samples(pos, logits, num_samples, group=group)

@@ -207,6 +207,14 @@ def tri_mul(pair, mask, wts, *, incoming: bool, residual: bool, out=None, ws=Non
     return out
 
 
+def tri_attn_uses_long_rows(N: int, P: int) -> bool:
+    """True when rows of N positions take the re-projecting long-row core kernel (prd_hip.h: prd_tri_attn_variant)."""
+    v = lib().prd_tri_attn_variant(N, P)
+    if v < 0:
+        check(v, "prd_tri_attn_variant")
+    return v == 1
+
+
 def tri_attn(pair, mask, wts, H: int, c: int, *, ending: bool, residual: bool, out=None, ws=None) -> torch.Tensor:
     """wts = (q.w, k.w, v.w, gate.w, gate.b, out.w, out.b)"""
     b, N, _, P = pair.shape

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from .constants import NUM_RESIDUE_ATOMS, RESIDUE_TYPES
 
+UNKNOWN_RESIDUE_NAME = "UNK"          # PDB name written for aatype -1 ('X': undetermined / undecoded residue)
 RESIDUE_NAMES = ["ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE",
                  "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL"]
 RESIDUE_ATOMS = ["N", "CA", "C", "CB", "O", "CG", "CG1", "CG2", "OG", "OG1", "SG", "CD", "CD1", "CD2", "ND1", "ND2",
@@ -77,6 +78,20 @@ class RepeatDataset(torch.utils.data.Dataset):
         return self.data
 
 
+class InferenceDataset(torch.utils.data.Dataset):
+    """data.py:157-168: a LIST of featurised complexes, one entry per index (the ``predict_batch_*`` scripts' dataset);
+    ``repeat`` is the length the caller declares, as in the reference."""
+
+    def __init__(self, data: Sequence[Mapping[str, Any]], repeat: int):
+        self.data, self.repeat = data, repeat
+
+    def __len__(self):
+        return self.repeat
+
+    def __getitem__(self, index: int):
+        return self.data[index]
+
+
 class PDBDataset(torch.utils.data.Dataset):
     """data.py:170-185: ``root/<pdb_id>/{ligand,protein}_data.pt`` as written by preprocess_pdbbind.py:79-83."""
 
@@ -130,7 +145,9 @@ def protein_to_pdb_string(prot: Protein) -> str:
     """Fixed-column ATOM records, one per present atom (protein.py:124-156)."""
     lines, serial = [], 1
     for i in range(prot.chain_index.shape[0]):
-        chain, resi, resn = PDB_CHAIN_IDS[prot.chain_index[i]], prot.residue_index[i], RESIDUE_NAMES[prot.aatype[i]]
+        aa = int(prot.aatype[i])
+        chain, resi = PDB_CHAIN_IDS[prot.chain_index[i]], prot.residue_index[i]
+        resn = RESIDUE_NAMES[aa] if aa >= 0 else UNKNOWN_RESIDUE_NAME       # -1 must not wrap around to VAL
         for xyz, present, name in zip(prot.atom_pos[i], prot.atom_mask[i], RESIDUE_ATOMS):
             if present < 0.5:
                 continue
@@ -182,7 +199,14 @@ def generate_samples(model, data: Mapping[str, Any], num_samples: int, batch_siz
 
     Returns (positions [S,N,3] in Angstrom, logits [S,N,21], proteins, ligand_positions).  With ``output_dir`` the CA
     models go to ``sample_protein.pdb`` and the ligand coordinates to ``sample_ligand_pos.npy`` (the reference writes an
-    SDF through rdkit and aligns every sample with TM-align first -- both out of scope here)."""
+    SDF through rdkit and aligns every sample with TM-align first -- both out of scope here).
+
+    Every sample carries its DECODED sequence (generate.py:83-91 decodes every sample): residues decoded as 'X' become
+    aatype -1 and are written as UNK; the input sequence is never silently kept.  The reference strips leading / trailing X
+    and raises on an inner one (``RESIDUE_TYPES.index("X")``); keeping the length and marking the residue instead keeps the
+    CA trace and the sequence aligned.  A ``UserWarning`` names the samples that contain undetermined residues."""
+    import warnings
+
     from .synthetic import NoiseSource, batch_to
     device = model.device
     positions, logits = [], []
@@ -201,11 +225,13 @@ def generate_samples(model, data: Mapping[str, Any], num_samples: int, batch_siz
     proteins, ligands = [], []
     for pos, lg in zip(positions, logits):
         prot, lig = update_pos(template, na, pos)
-        seq = "".join(predict_seq(lg[na: na + nr]))
-        if "X" not in seq:                      # a fully decoded design replaces the residue types
-            prot = dataclasses.replace(prot, aatype=np.array([RESIDUE_TYPES.index(s) for s in seq], dtype=np.int64))
+        seq = predict_seq(lg[na: na + nr])
+        prot = dataclasses.replace(prot, aatype=np.array([RESIDUE_TYPES.index(s) if s != "X" else -1 for s in seq], dtype=np.int64))
         proteins.append(prot)
         ligands.append(lig)
+    undetermined = [k for k, p in enumerate(proteins) if (p.aatype < 0).any()]
+    if undetermined:
+        warnings.warn(f"samples {undetermined} decode to 'X' at some residues; those are written as UNK", UserWarning)
     if output_dir is not None:
         out = Path(output_dir)
         out.mkdir(parents=True, exist_ok=True)

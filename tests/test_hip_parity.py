@@ -397,6 +397,17 @@ def test_input_embedding_and_heads(setup):
 # whole step and trajectory vs the golden vectors of the imported reference
 # ---------------------------------------------------------------------------------------------------
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def gemm_mode(request):
+    """Row-GEMM arithmetic of the pair kernels (prd_hip.h: prd_set_gemm_mode): fp32 MFMA, or the exact three-way bf16 split on
+    the bf16 matrix pipe.  Both must meet every tolerance; the mode is restored afterwards."""
+    from protein_redesign_amd import _lib
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(1 if request.param == "bf16x3" else 0) == 0
+    yield request.param
+    assert _lib.lib().prd_set_gemm_mode(prev) == 0
+
+
 def golden_case(golden, name):
     case, z = golden(name)
     args = make_args(**case["args"])
@@ -405,7 +416,7 @@ def golden_case(golden, name):
 
 
 @pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
-def test_network_step_vs_reference_golden(golden, name):
+def test_network_step_vs_reference_golden(golden, name, gemm_mode):
     case, z, args, model, params = golden_case(golden, name)
     sizes = [tuple(s) for s in case["sizes"]]
     batch = synthetic_batch(sizes, esm_dim=args["esm_dim"], seed=case["batch_seed"], n_total=case["n_total"])
@@ -418,8 +429,8 @@ def test_network_step_vs_reference_golden(golden, name):
     assert rel_l2(logits.cpu(), z["step_seq_pred"]) < BLOCK_TOL * 2
 
 
-@pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
-def test_trajectory_vs_reference_golden(golden, name):
+@pytest.mark.parametrize("name", ["small32", "small64", "cfg1", "cfg1_t200", "cfg1_t1000"])
+def test_trajectory_vs_reference_golden(golden, name, gemm_mode):
     case, z, args, model, params = golden_case(golden, name)
     one = batch_to(synthetic_batch([tuple(case["traj_sample"])], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500), DEV)
     pos, logits = model.sample(one, sources=[NoiseSource(NOISE_SEED, 0)])
@@ -455,20 +466,101 @@ def test_batched_sampling_equals_single_samples(golden):
     assert not torch.allclose(both[0][0], both[0][1])
 
 
-def test_full_size_step_vs_oracle():
-    """BASELINE config 2 shape (N=320, S=512, P=64) with 1 block so the CPU oracle finishes in seconds."""
-    args = make_args(single_dim=512, pair_dim=64, num_blocks=1, num_steps=1000, mask_prob=0.3)
-    model, params = build(args, seed=4)
-    batch = synthetic_batch([(64, 256)], seed=0)
-    pb = O.prepare_batch(batch, 0.3, [NoiseSource(NOISE_SEED, 0).randperm(256)])
+def _full_size_case(na, nr, num_blocks, seed):
+    args = make_args(single_dim=512, pair_dim=64, num_blocks=num_blocks, num_steps=1000, mask_prob=0.3)
+    model, params = build(args, seed=seed)
+    N = na + nr
+    batch = synthetic_batch([(na, nr)], seed=0)
+    pb = O.prepare_batch(batch, 0.3, [NoiseSource(NOISE_SEED, 0).randperm(nr)])
     g = torch.Generator().manual_seed(8)
-    z, seq_t, t = torch.randn(1, 320, 3, generator=g), torch.randn(1, 320, 21, generator=g), torch.tensor([500])
+    z, seq_t, t = torch.randn(1, N, 3, generator=g), torch.randn(1, N, 21, generator=g), torch.tensor([500])
+    return args, model, params, pb, z, seq_t, t
+
+
+@pytest.mark.parametrize("num_blocks", [1, 4])
+def test_full_size_step_vs_oracle(num_blocks, gemm_mode):
+    """BASELINE configs[1] shape (N=320, S=512, P=64).  num_blocks = 4 is exactly the network the bench replays."""
+    args, model, params, pb, z, seq_t, t = _full_size_case(64, 256, num_blocks, seed=4)
     with torch.inference_mode():
         want = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
         dpb = batch_to(pb, DEV)
         got = model.sample_step(dpb, cu(z), cu(seq_t), dpb["residue_and_atom_mask"], cu(t))
     assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2
     assert rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
+
+
+def test_long_sequence_step_vs_oracle(gemm_mode):
+    """BASELINE configs[4]: 768 residues + 1 dummy atom (N = 769), one block: the whole step (long-row triangle attention
+    included) against the oracle, which evaluates triangle attention in row blocks (same arithmetic, bounded memory)."""
+    args, model, params, pb, z, seq_t, t = _full_size_case(1, 768, 1, seed=7)
+    with torch.inference_mode():
+        want = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
+        dpb = batch_to(pb, DEV)
+        got = model.sample_step(dpb, cu(z), cu(seq_t), dpb["residue_and_atom_mask"], cu(t))
+    assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2
+    assert rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
+
+
+@pytest.mark.parametrize("mode", ["starting", "ending"])
+@pytest.mark.parametrize("N,valid", [(449, 449), (640, 611), (769, 750)])
+def test_triangle_attention_long_rows(setup, mode, N, valid, gemm_mode):
+    """tri_attn_core_long_kernel (rows whose K / V leave no LDS for the Q / gate tiles, N > ~440) against the oracle, for
+    P in {32, 64}, both modes, with a masked tail.  The oracle is evaluated on a subset of rows (first, last valid, masked and
+    scattered ones) so that it costs seconds: row i of the update only depends on row i of the (transposed) pair."""
+    s = setup
+    P = s["P"]
+    H, c = s["args"]["num_heads"], s["args"]["head_dim"]
+    assert ops.tri_attn_uses_long_rows(N, P)
+    g = torch.Generator().manual_seed(N + (mode == "ending"))
+    pair = torch.randn(1, N, N, P, generator=g)
+    mask = torch.ones(1, N)
+    mask[0, valid:] = 0
+    rows = sorted({0, 1, 31, 32, 63, 64, N // 2, valid - 1, min(valid, N - 1), N - 1} | set(torch.randint(0, N, (6,), generator=g).tolist()))
+    pfx = f"Denoiser.folding_blocks.0.pair_attn_{mode}"
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    with torch.inference_mode():
+        if mode == "starting":
+            sub, msub = pair[:, rows], m2[:, rows]
+        else:
+            sub, msub = pair[:, :, rows].transpose(1, 2), m2[:, :, rows].transpose(1, 2)
+        want = O.gated_attention(s["params"], pfx + ".attn", sub, msub, H, c)          # [1, rows, N, P]
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
+    got = mod.run(cu(pair), cu(mask), residual=False).cpu()
+    got = got[:, rows] if mode == "starting" else got[:, :, rows].transpose(1, 2)
+    assert rel_l2(got, want) < OP_TOL
+    for k in range(len(rows)):                       # no single row may hide behind the aggregate
+        assert rel_l2(got[:, k], want[:, k]) < 2 * OP_TOL, rows[k]
+
+
+def test_eight_complexes_per_gpu_equal_single_runs(gemm_mode):
+    """BASELINE configs[2] per-GPU share: b = 8 complexes of the N = 320 shape (4 blocks) through the first three steps of the
+    reverse loop (eager step, graph capture, replay) == each sample run alone; and sample 0 against the oracle's first step."""
+    from protein_redesign_amd.diffusion_model import ReverseDiffusion
+    from protein_redesign_amd.distributed import repeat_batch
+    args = make_args(single_dim=512, pair_dim=64, num_blocks=4, num_steps=1000, mask_prob=0.3)
+    model, params = build(args, seed=5)
+    one = synthetic_batch([(64, 256)], seed=3)
+
+    def run(idx):
+        loop = ReverseDiffusion(model, batch_to(repeat_batch(clone_batch(one), len(idx)), DEV), [NoiseSource(11, k) for k in idx])
+        z0, s0 = loop.z.clone(), loop.seq_t.clone()
+        for _ in range(3):
+            loop.step()
+        torch.cuda.synchronize()
+        return loop.z.clone(), loop.seq_pred.clone(), z0, s0, loop
+
+    z8, l8, z0, s0, loop = run(list(range(8)))
+    for k in (0, 3, 7):
+        z1, l1, *_ = run([k])
+        assert rel_l2(z8[k].cpu(), z1[0].cpu()) < 1e-6 and rel_l2(l8[k].cpu(), l1[0].cpu()) < 1e-6
+    assert not torch.allclose(z8[0], z8[1])
+    with torch.inference_mode():                      # first network step of sample 5 vs the oracle (on this sample's own mask)
+        pb = {k: (v[5:6].cpu() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 8 else v) for k, v in loop.batch.items()}
+        t = torch.tensor([999])
+        want = O.network_step(params, args, pb, z0[5:6].cpu(), s0[5:6].cpu(), pb["residue_and_atom_mask"], t)
+        d = batch_to(pb, DEV)
+        got = model.sample_step(d, z0[5:6].contiguous(), s0[5:6].contiguous(), d["residue_and_atom_mask"], cu(t))
+    assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2 and rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -493,33 +585,46 @@ def test_se3_equivariance_full_size():
     assert float((mask.unsqueeze(-1) * e1).sum(1).abs().max()) < 1e-3   # masked mean removed
 
 
-def test_long_sequence_stress_runs():
-    """BASELINE config 5: 768 residues + 1 dummy atom (N = 769): finite outputs, zero masked mean."""
-    args = make_args(single_dim=512, pair_dim=64, num_blocks=1, num_steps=1000, mask_prob=0.3)
-    model, _ = build(args, seed=7)
-    batch = synthetic_batch([(1, 768)], seed=2)
-    pb = batch_to(O.prepare_batch(batch, 0.3, [NoiseSource(NOISE_SEED, 2).randperm(768)]), DEV)
-    g = torch.Generator().manual_seed(10)
-    z, seq_t, t = torch.randn(1, 769, 3, generator=g), torch.randn(1, 769, 21, generator=g), torch.tensor([10])
-    with torch.inference_mode():
-        eps, logits = model.sample_step(pb, cu(z), cu(seq_t), pb["residue_and_atom_mask"], cu(t))
-    assert torch.isfinite(eps).all() and torch.isfinite(logits).all()
-    assert float(eps.sum(1).abs().max()) < 1e-2
-
-
 def test_generate_samples_end_to_end(tmp_path):
-    """collate -> HIP sampling -> decoded sequence / CA trace -> multi-model PDB (generate.py flow, §8f next #2)."""
+    """collate -> HIP sampling -> decoded sequence / CA trace -> multi-model PDB (generate.py flow, §8f next #2): positions and
+    logits of every sample against the oracle's ``sample`` driven by the same keyed noise sources."""
     from protein_redesign_amd import pipeline as PL
     from protein_redesign_amd.synthetic import synthetic_sample
     args = make_args(single_dim=64, pair_dim=32, num_blocks=1, esm_dim=16, num_steps=4, mask_prob=0.5)
-    model, _ = build(args, seed=21)
+    model, params = build(args, seed=21)
     data = synthetic_sample(5, 19, esm_dim=16, seed=8)
-    pos, logits, proteins, ligands = PL.generate_samples(model, data, num_samples=3, batch_size=2, seed=4, output_dir=tmp_path)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)            # random weights decode some residues as 'X' (written as UNK)
+        pos, logits, proteins, ligands = PL.generate_samples(model, data, num_samples=3, batch_size=2, seed=4, output_dir=tmp_path)
     assert pos.shape == (3, 24, 3) and logits.shape == (3, 24, 21) and np.isfinite(pos).all()
+    for k in range(3):
+        one = PL.collate_fn([data])
+        want_pos, want_logits = O.sample(params, args, {kk: v for kk, v in one.items() if torch.is_tensor(v)}, [NoiseSource(4, k)])
+        assert rel_l2(pos[k], want_pos[0]) < TRAJ_TOL and rel_l2(logits[k], want_logits[0]) < TRAJ_TOL
+        seq = PL.predict_seq(want_logits[0, 5:24])
+        assert [int(a) for a in proteins[k].aatype] == [PL.RESIDUE_TYPES.index(c) if c != "X" else -1 for c in seq]
     assert len(proteins) == 3 and ligands[0].shape == (5, 3)
     assert np.allclose(proteins[1].atom_pos[:, 1], pos[1, 5:24])
     text = (tmp_path / "sample_protein.pdb").read_text()
     assert text.count("MODEL") == 3 and text.count(" CA ") == 3 * 19
     # same samples whatever the batch size (keyed noise)
-    pos1, *_ = PL.generate_samples(model, data, num_samples=3, batch_size=1, seed=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        pos1, *_ = PL.generate_samples(model, data, num_samples=3, batch_size=1, seed=4)
     assert np.array_equal(pos, pos1)
+
+
+def test_predict_step_follows_the_global_seed():
+    """INTEGRATION.md drop-in path: Trainer.predict -> predict_step(batch, batch_idx).  The samples follow
+    pl.seed_everything / torch.manual_seed like the reference's, instead of a hard-coded key."""
+    args = make_args(single_dim=64, pair_dim=32, num_blocks=1, esm_dim=16, num_steps=3, mask_prob=0.5)
+    model, _ = build(args, seed=22)
+    one = synthetic_batch([(4, 12)], esm_dim=16, seed=9)
+
+    def run(seed, idx):
+        torch.manual_seed(seed)
+        return model.predict_step(batch_to(clone_batch(one), DEV), idx)[0].cpu()
+
+    a, b, c, d = run(1, 0), run(2, 0), run(1, 0), run(1, 1)
+    assert torch.equal(a, c) and not torch.allclose(a, b) and not torch.allclose(a, d)

@@ -95,3 +95,93 @@ def test_argparse_surface():
     ns = p.parse_args(["--num_blocks", "4", "--num_steps", "1000"])
     assert ns.single_dim == 512 and ns.pair_dim == 64 and ns.num_blocks == 4 and ns.n_recycles == 4
     ProteinReDiffModel(ns)
+
+
+# ---------------------------------------------------------------------------------------------------
+# checkpoint / EMA surface (generate.py:103-105, model.py:124,197-201,215-217; torch_ema==0.3 key set)
+# ---------------------------------------------------------------------------------------------------
+
+def _pl17_checkpoint(model, shadow, nested: bool, as_namespace: bool):
+    """A checkpoint with the key set PyTorch-Lightning 1.7 writes for ``save_hyperparameters(args)``: state_dict +
+    hyper_parameters (either the flat argument dict or nested under the constructor's parameter name ``args``) + the
+    ``ema_state_dict`` the reference's on_save_checkpoint adds (torch-ema 0.3 keys)."""
+    from argparse import Namespace
+    hp = dict(make_args(**TINY))
+    hp = Namespace(**hp) if as_namespace else hp
+    return {
+        "epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.7.7",
+        "state_dict": {k: v.clone() for k, v in model.state_dict().items()},
+        "hyper_parameters": {"args": hp} if nested else hp,
+        "ema_state_dict": {"decay": 0.999, "num_updates": 1234, "shadow_params": shadow, "collected_params": None},
+        "optimizer_states": [], "lr_schedulers": [], "loops": {}, "callbacks": {},
+    }
+
+
+@pytest.mark.parametrize("nested,as_namespace,only_trainable", [(False, False, False), (True, True, False), (True, False, True)])
+def test_load_from_lightning_style_checkpoint(tmp_path, nested, as_namespace, only_trainable):
+    torch.manual_seed(0)
+    src = ProteinReDiffModel(make_args(**TINY))
+    params = list(src.parameters())
+    assert len(params) - len([p for p in params if p.requires_grad]) == 2       # the two frozen projection tables
+    g = torch.Generator().manual_seed(1)
+    kept = [p for p in params if p.requires_grad or not only_trainable]          # 242-style (all) or 240-style (trainable) list
+    shadow = [p.detach() + 0.25 * torch.randn(p.shape, generator=g) for p in kept]
+    path = tmp_path / "last.ckpt"
+    torch.save(_pl17_checkpoint(src, shadow, nested, as_namespace), path)
+    m = ProteinReDiffModel.load_from_checkpoint(str(path), num_steps=17)         # generate.py:103-105 overrides num_steps
+    assert m.num_steps == 17 and m.single_dim == TINY["single_dim"]
+    for (k, a), b in zip(m.state_dict().items(), src.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert m.ema.num_updates == 1234 and len(m.ema.shadow) == len(kept)
+    mine = list(m.parameters())
+    before = [p.detach().clone() for p in mine]
+    with m.ema.average_parameters(m.parameters()):                               # predict_step / validation_step context
+        tgt = [p for p in mine if p.requires_grad or not only_trainable]
+        assert all(torch.equal(p, s) for p, s in zip(tgt, shadow))
+    assert all(torch.equal(p, q) for p, q in zip(mine, before))                  # restored afterwards
+
+
+def test_ema_state_round_trip_and_warmup():
+    """on_save_checkpoint -> on_load_checkpoint round trip with torch-ema 0.3's key set, and its warm-up decay."""
+    torch.manual_seed(0)
+    m = ProteinReDiffModel(make_args(**TINY))
+    ck = {}
+    m.on_save_checkpoint(ck)
+    assert set(ck["ema_state_dict"]) == {"decay", "num_updates", "shadow_params", "collected_params"}
+    assert len(ck["ema_state_dict"]["shadow_params"]) == len(list(m.parameters()))
+    p0 = next(p for p in m.parameters() if p.requires_grad)
+    s0 = m.ema.shadow[0].clone()
+    with torch.no_grad():
+        p0.add_(1.0)
+    m.optimizer_step()                                   # model.py:215-217: EMA update after the optimizer step
+    d = min(0.999, 2.0 / 11.0)                           # first update: min(decay, (1 + 1) / (10 + 1))
+    assert torch.allclose(m.ema.shadow[0], s0 - (1 - d) * (s0 - p0.detach()), atol=1e-6)
+    assert m.ema.num_updates == 1
+    ck = {}
+    m.on_save_checkpoint(ck)
+    m2 = ProteinReDiffModel(make_args(**TINY))
+    m2.on_load_checkpoint(ck)
+    assert m2.ema.num_updates == 1 and all(torch.equal(a, b) for a, b in zip(m2.ema.shadow, m.ema.shadow))
+
+
+def test_default_noise_follows_the_global_seed():
+    """Without explicit sources the noise key comes from torch's seeded global RNG (pl.seed_everything / generate.py --seed):
+    different seeds -> different samples, same seed -> same samples; successive batches never repeat an index."""
+    m = ProteinReDiffModel(make_args(**TINY))
+
+    def draw(seed, batch_idx=None):
+        torch.manual_seed(seed)
+        return [s.randn(4) for s in m._sources(2, batch_idx)]
+
+    a, b, c = draw(11, 0), draw(12, 0), draw(11, 0)
+    assert all(torch.equal(x, y) for x, y in zip(a, c))
+    assert not any(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[0], a[1]) and not torch.equal(draw(11, 1)[0], a[0])
+    torch.manual_seed(5)
+    first, second = m._sources(2), m._sources(2)         # direct sample() calls: running sample counter
+    assert not torch.equal(first[0].randn(3), second[0].randn(3))
+    m.sample_seed = 3                                    # pinned: independent of the global seed
+    torch.manual_seed(1)
+    x = m._sources(1, 0)[0].randn(3)
+    torch.manual_seed(2)
+    assert torch.equal(x, m._sources(1, 0)[0].randn(3))

@@ -86,3 +86,17 @@ def test_checkpoint_roundtrip_with_ema_and_num_steps_override(tmp_path):
     with m2.ema.average_parameters(m2.parameters()):   # predict_step swaps the EMA weights in (model.py:249-252)
         assert not torch.equal(p0.detach(), before)
     assert torch.equal(p0.detach(), before)
+
+
+def test_inference_dataset_and_unknown_residues():
+    """data.py:157-168 (one featurised complex per index) and the PDB name of an undetermined residue."""
+    from protein_redesign_amd import pipeline as PL
+    from protein_redesign_amd.synthetic import synthetic_sample
+    items = [synthetic_sample(2, 4, esm_dim=8, seed=1), synthetic_sample(3, 5, esm_dim=8, seed=2)]
+    ds = PL.InferenceDataset(items, repeat=2)
+    assert len(ds) == 2 and ds[1] is items[1]
+    batch = PL.collate_fn([ds[0], ds[1]])
+    assert batch["atom_mask"].shape == (2, 8)
+    prot = PL.protein_from_sequence("AXW")
+    text = PL.protein_to_pdb_string(prot)
+    assert [ln[17:20] for ln in text.splitlines()] == ["ALA", "UNK", "TRP"]
