@@ -45,15 +45,26 @@ CASES = {
         args=dict(single_dim=256, pair_dim=32, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
                   num_steps=10, mask_prob=0.3),
         sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110)),
-    # the same complex through LONG reverse-diffusion loops (trajectory only): T = 200 and the T = 1000 of BASELINE configs[1]
+    # the same complex through LONG reverse-diffusion loops (trajectory only): T = 200 and the T = 1000 of BASELINE configs[1], with
+    # weights an N(0, 0.02^2) perturbation away from the reference's zero / gating initialisation (a network early in training:
+    # synthetic.deterministic_state_dict(style="near_init")) so that the loop is well conditioned
     "cfg1_t200": dict(
         args=dict(single_dim=256, pair_dim=32, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
                   num_steps=200, mask_prob=0.3),
-        sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110), traj_only=True),
+        sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110), traj_only=True,
+        weight_style="near_init", traj_every=10),
     "cfg1_t1000": dict(
         args=dict(single_dim=256, pair_dim=32, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
                   num_steps=1000, mask_prob=0.3),
-        sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110), traj_only=True),
+        sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110), traj_only=True,
+        weight_style="near_init", traj_every=25),
+    # ... and with full-strength random weights, where the loop amplifies round-off chaotically: the fixture holds the state every
+    # 10 steps so that implementations can be compared SEGMENT by segment, each restarted from the reference's own state
+    "cfg1_t200_random": dict(
+        args=dict(single_dim=256, pair_dim=32, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
+                  num_steps=200, mask_prob=0.3),
+        sizes=[(30, 110)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(30, 110), traj_only=True,
+        weight_style="random", traj_every=10),
 }
 
 NOISE_SEED = 7
@@ -86,7 +97,7 @@ class _Injected:
 def build_reference(ref_model, case):
     args = make_args(**case["args"])
     model = ref_model.ProteinReDiffModel(args).eval()
-    sd = deterministic_state_dict(model.state_dict(), seed=case["weight_seed"])
+    sd = deterministic_state_dict(model.state_dict(), seed=case["weight_seed"], style=case.get("weight_style", "random"))
     model.load_state_dict(sd)
     model.run_setup_schedule()
     model.setup_schedule = True
@@ -101,9 +112,24 @@ def run_case(name, case, ref_model):
     esm_dim = args["esm_dim"]
     if case.get("traj_only"):
         one = synthetic_batch([case["traj_sample"]], esm_dim=esm_dim, seed=case["batch_seed"] + 500)
+        states = []                      # (z, seq_t) entering every traj_every-th step, captured at the sample_step call
+        every = case.get("traj_every", 0)
+        inner = model.sample_step
+
+        def spy(batch, z, seq_t, mask, t):
+            step = args["num_steps"] - 1 - int(t[0])
+            if every and step % every == 0:
+                states.append((step, z.clone(), seq_t.clone()))
+            return inner(batch, z, seq_t, mask, t)
+
+        model.sample_step = spy
         with _Injected([NoiseSource(NOISE_SEED, 0)]):
             pos, logits = model.sample(clone_batch(one))
+        model.sample_step = inner
         out.update(traj_pos=pos.numpy(), traj_logits=logits.numpy())
+        if states:
+            out.update(seg_step=np.array([s_[0] for s_ in states]), seg_z=torch.cat([s_[1] for s_ in states]).numpy(),
+                       seg_seq_t=torch.cat([s_[2] for s_ in states]).numpy())
         return out
     batch = synthetic_batch(case["sizes"], esm_dim=esm_dim, seed=case["batch_seed"], n_total=case["n_total"])
     b, N = batch["atom_mask"].shape
@@ -178,6 +204,58 @@ def run_case(name, case, ref_model):
         pos, logits = model.sample(clone_batch(one))
     out.update(traj_pos=pos.numpy(), traj_logits=logits.numpy())
     return out
+
+
+GRAD_PROJECTIONS = 4
+
+
+def grad_fingerprint(named_grads):
+    """Per trainable tensor: L2 norm of the gradient and its projections on GRAD_PROJECTIONS seeded Gaussian directions
+    (direction k of tensor i: generator seed 4242 + 16 i + k, drawn in float64) -- 5 numbers pin a gradient without storing it."""
+    norms, projs = [], []
+    for i, (name, g) in enumerate(named_grads):
+        g = g.detach().double().reshape(-1)
+        norms.append(float(g.norm()))
+        row = []
+        for k in range(GRAD_PROJECTIONS):
+            gen = torch.Generator().manual_seed(4242 + 16 * i + k)
+            row.append(float(torch.dot(g, torch.randn(g.numel(), generator=gen, dtype=torch.float64))))
+        projs.append(row)
+    return np.array(norms), np.array(projs)
+
+
+def run_grad_case(name, case, ref_model):
+    """training_step of the imported reference (model.py:528-549) with injected t / noise: loss and gradient fingerprints of
+    all trainable tensors.  Runs with autograd enabled (not under inference_mode), per-block checkpointing included."""
+    model, args = build_reference(ref_model, case)
+    model.train()
+    esm_dim = args["esm_dim"]
+    batch = synthetic_batch(case["sizes"], esm_dim=esm_dim, seed=case["batch_seed"], n_total=case["n_total"])
+    b, N = batch["atom_mask"].shape
+    n_res = batch["residue_mask"].sum(-1).long().tolist()
+    perms = [NoiseSource(NOISE_SEED, 100 + k).randperm(n_res[k]) for k in range(b)]
+    prepared = []
+    for k in range(b):
+        one = {kk: (vv[k:k + 1].clone() if torch.is_tensor(vv) else vv) for kk, vv in batch.items()}
+        model.mask_prob = args["mask_prob"]
+        with _Injected([_FixedPerm(perms[k])]):
+            prepared.append(model.prepare_batch(one))
+    pb = {kk: torch.cat([p_[kk] for p_ in prepared]) for kk in prepared[0] if torch.is_tensor(prepared[0][kk])}
+    mask = pb["residue_and_atom_mask"]
+    g = torch.Generator().manual_seed(2000 + case["batch_seed"])
+    t = torch.tensor([(3 + 2 * k) % args["num_steps"] for k in range(b)], dtype=torch.long)
+    nz = O_remove_mean(torch.randn(b, N, 3, generator=g), mask)
+    ns = O_remove_mean(torch.randn(b, N, 21, generator=g), pb["residue_mask"])
+    with _Sequence([nz, ns]):
+        diff = model.diffusion_loss(pb, pb["x"], mask, t)
+    loss = torch.mean(diff / (mask > 0.5).sum(-1))                 # model.py:538-540
+    loss.backward()
+    named = [(n_, p_.grad) for n_, p_ in model.named_parameters() if p_.requires_grad]
+    assert all(g_ is not None for _, g_ in named)
+    norms, projs = grad_fingerprint(named)
+    return {"train_t": t.numpy(), "train_noise_z": nz.numpy(), "train_noise_seq": ns.numpy(),
+            "train_loss": np.array(float(loss)), "train_grad_names": np.array(json.dumps([n_ for n_, _ in named])),
+            "train_grad_norm": norms, "train_grad_proj": projs}
 
 
 def O_remove_mean(x, mask):
@@ -263,6 +341,9 @@ def main():
     for name in names:
         torch.manual_seed(0)
         res = run_case(name, CASES[name], ref_model)
+        if not CASES[name].get("traj_only"):
+            torch.manual_seed(0)
+            res.update(run_grad_case(name, CASES[name], ref_model))
         path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
         np.savez_compressed(path, **res)
         print(name, "->", path, f"{os.path.getsize(path) / 1024:.1f} KiB")

@@ -242,6 +242,7 @@ PRD_DEV void bias_acc(f32x16 (&acc)[NB], const float* vl) {
 // One MFMA consumes 16 channels: lane (r, hi) supplies its CLL elements 8*step .. 8*step+7 (two 16-byte groups of the row).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 PRD_DEV unsigned pack_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
 PRD_DEV void split3(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
@@ -329,6 +330,28 @@ PRD_DEV void rowgemm_b3(const u32x4* Wb, int nout, int row0, const u32x4 (&p)[3]
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[wp[t]]), __builtin_bit_cast(bf16x8, p[xp[t]][s]),
                                                                    acc[nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);          // keeps hipcc from hoisting every LDS read of the unrolled loops (spills)
+        }
+}
+
+// Same products with the operands SWAPPED: D = X * W^T, i.e. lane (r, hi) register q holds output channel row0 + 32 nb + r of
+// pair row drow32(q, hi) -- four CONSECUTIVE rows per register quad, which is what a channel-major store wants
+// (tri_mul_proj's bf16 x 3 operand planes: 8-byte stores of 4 bf16 instead of 2-byte scatters).
+template <int K, int NB>
+PRD_DEV void rowgemm_b3_t(const u32x4* Wb, int nout, int row0, const u32x4 (&p)[3][K / 16], f32x16 (&acc)[NB], int r, int hi) {
+    constexpr int S = K / 16, PITCH = 2 * S + 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            u32x4 w[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[pl] = Wb[((size_t)pl * nout + row0 + nb * 32 + r) * PITCH + 2 * s + hi];
+            const int wp[6] = {0, 0, 1, 0, 2, 1}, xp[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, p[xp[t]][s]), __builtin_bit_cast(bf16x8, w[wp[t]]),
+                                                                   acc[nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 }
 

@@ -93,11 +93,69 @@ PRD_DEV void proj_fetch(const ProjTask& t, const float* __restrict__ pair, const
     load_row_cll_buf<P>(rs, valid ? (rowi * P + 4 * hi) * 4u : BUF_OOB, x);
 }
 
+// bf16 x 3 operand planes of the contraction (gemm mode 1): AB3[b][2P channels][N rows u][3 planes][ldn] bf16, zero padded to
+// ldn like the fp32 form.  Written by tri_mul_proj (each value split ONCE, here), read by tri_mul_contract_b3.
+template <int P>
+PRD_DEV void proj_compute_b3(const ProjTask& t, float (&x)[P / 2], float mu, float mv, unsigned short* __restrict__ AB3,
+                             const float* Wpl, const float* Wgl, const float* bpl, const float* bgl,
+                             int N, int ldn, int r, int hi, PhaseTimer& pt) {
+    constexpr int KH = P / 2, OUT = 2 * P;
+    const bool valid = t.vb * 32 + r < N;
+    pt.mark(0);
+    const float m2 = valid ? mu * mv : 0.f;
+    const bool plain = __all(m2 == 1.0f);           // every row of the block valid and unmasked (the common case)
+    pt.mark(1);
+    ln_cll<KH>(x);
+    pt.mark(2);
+    // flipped orientation (rowgemm_b3_t): every register of lane (r, hi) belongs to output channel 32 ob + r; its bias sits at
+    // the CLL position of that channel in the staged vectors
+    const int c = 32 * t.ob + r, f = c >> 2;
+    const int bidx = (f & 1) * P + (f >> 1) * 4 + (c & 3);
+    const float bpv = bpl[bidx], bgv = bgl[bidx];
+    f32x16 ap[1], ag[1];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { ap[0][q] = bpv; ag[0][q] = bgv; }
+    u32x4 xs[3][P / 16];
+    split3_cll<P>(x, xs);
+    rowgemm_b3_t<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, t.ob * 32, xs, ap, r, hi);
+    rowgemm_b3_t<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, t.ob * 32, xs, ag, r, hi);
+    pt.mark(3);
+    // register quad g = rows 8 g + 4 hi + (0..3) of the block = four consecutive contraction indices of channel 32 ob + r
+    const long plane_bytes = (long)ldn * 2;
+    const long chan_bytes = (long)N * 3 * plane_bytes;
+    const prd_rsrc cb = make_rsrc(reinterpret_cast<const char*>(AB3) + (((long)t.bb * OUT + 32 * t.ob) * N + t.u) * 3 * plane_bytes
+                                  + (long)t.vb * 64);
+    const unsigned lane_off = (unsigned)(r * chan_bytes) + hi * 8u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = 4 * g + e;
+            float val = gate_from_scaled(ag[0][q]) * ap[0][q];
+            if (!plain) val *= __shfl(m2, 8 * g + 4 * hi + e);       // mask of THAT row (slow path: masked / edge blocks only)
+            v[e] = val;
+        }
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(v[0], v[1], h0, m0, l0);
+        split3(v[2], v[3], h1, m1, l1);
+        const unsigned uoff = g * 16u;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, cb, lane_off, uoff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, cb, lane_off, uoff + (unsigned)plane_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, cb, lane_off, uoff + 2u * (unsigned)plane_bytes, 0);
+    }
+    pt.mark(4);
+}
+
 template <int P, bool B3>
 PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float mv, float* __restrict__ AB,
                           const float* Wpl, const float* Wgl, const float* bpl, const float* bgl,
                           int N, int ldn, long cstride, unsigned lane_off, int r, int hi, PhaseTimer& pt) {
-    constexpr int KH = P / 2, OUT = 2 * P;
+    if (B3) {
+        proj_compute_b3<P>(t, x, mu, mv, reinterpret_cast<unsigned short*>(AB), Wpl, Wgl, bpl, bgl, N, ldn, r, hi, pt);
+        return;
+    }
+    constexpr int KH = P / 2;
     const bool valid = t.vb * 32 + r < N;
     pt.mark(0);                                     // 0: task fetch / decode, prefetch issue
     const float m2 = valid ? mu * mv : 0.f;
@@ -108,18 +166,11 @@ PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float 
     f32x16 ap[1], ag[1];
     bias_acc(ap, bpl + hi * P + 16 * t.ob);         // biases ride in the accumulators
     bias_acc(ag, bgl + hi * P + 16 * t.ob);
-    if (B3) {                                       // opt-in bf16 x 3 form (prd_common.h): same results to ~1e-7
-        u32x4 xs[3][P / 16];
-        split3_cll<P>(x, xs);
-        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, t.ob * 32, xs, ap, r, hi);
-        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, t.ob * 32, xs, ag, r, hi);
-    } else {
-        rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
-        rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
-    }
+    rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
+    rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
     pt.mark(3);                                     // 3: MFMAs
     // output channel of register q: 32*ob + (q&3) + 8*(q>>2) + 4*hi; the hi part sits in lane_off
-    const prd_rsrc cb = make_rsrc(AB + ((((long)t.bb * OUT) + 32 * t.ob) * N + t.u) * ldn + t.vb * 32);
+    const prd_rsrc cb = make_rsrc(AB + ((((long)t.bb * 2 * P) + 32 * t.ob) * N + t.u) * ldn + t.vb * 32);
     const unsigned cbytes = (unsigned)cstride * 4u;
     if (plain) {
 #pragma unroll
@@ -302,6 +353,118 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
             if (m < N) Oc[(size_t)m * ldn + n] = acc[q];
         }
     }
+    }   // virtual blocks
+}
+
+// The same contraction on the bf16 matrix pipe (gemm mode 1): operands are the exact three-way bf16 split written by
+// tri_mul_proj (AB3[b][2P][N][3 planes][ldn]); the six products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation reproduce the fp32 contraction to ~1e-7 at 16/6 of its matrix rate.
+// 64x64 tile per workgroup, 2x2 waves of 32x32, K in chunks of 32 (two MFMA K steps) through double-buffered LDS.
+// LDS rows are 64 B (32 bf16) without padding; the 16-byte slot j of row r is stored at j ^ ((r >> 2) & 3): the sixteen lanes
+// of a ds_read_b128 group (rows distinct mod 16, same logical slot) then hit sixteen different 4-bank groups.
+__global__ __launch_bounds__(256) void tri_mul_contract_b3_kernel(float* __restrict__ O, const unsigned short* __restrict__ AB3,
+                                                                  int N, int ldn, int P, int nbatch, int tiles) {
+    constexpr int KCH = 32;
+    constexpr int PLANE = 64 * 64;                        // bytes of one operand plane of a 64-row tile chunk
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][3 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int nch = nbatch * P;
+    const int t2 = tiles * tiles;
+    const unsigned plane_bytes = (unsigned)ldn * 2u, row_bytes = 3u * plane_bytes;
+    // staging: 768 16-byte pieces per operand and chunk (64 rows x 3 planes x 4 slots), 3 per thread
+    unsigned srow[3], sdst[3], ssrc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / 12, rem = idx - row * 12, pl = rem >> 2, slot = rem & 3;
+        srow[i] = row;
+        sdst[i] = pl * PLANE + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+        ssrc[i] = row * row_bytes + pl * plane_bytes + slot * 16;
+    }
+    for (int vblk = blockIdx.x; vblk < nch * t2; vblk += gridDim.x) {
+        int ch, tile;
+        if ((nch & 7) == 0 && (gridDim.x & 7) == 0) {     // the tiles of one channel stay on one XCD (they share A / B in L2)
+            const int xcd = vblk & 7, k = vblk >> 3;
+            ch = xcd + 8 * (k / t2);
+            tile = k % t2;
+        } else {
+            ch = vblk / t2;
+            tile = vblk % t2;
+        }
+        const int bb = ch / P, d = ch - bb * P;
+        const int m0 = (tile / tiles) * 64, n0 = (tile % tiles) * 64;
+        const unsigned char* A = reinterpret_cast<const unsigned char*>(AB3) + ((size_t)bb * 2 * P + d) * N * row_bytes;
+        const unsigned char* B = reinterpret_cast<const unsigned char*>(AB3) + ((size_t)bb * 2 * P + P + d) * N * row_bytes;
+        const prd_rsrc ra = make_rsrc(A + (size_t)m0 * row_bytes), rb = make_rsrc(B + (size_t)n0 * row_bytes);
+        unsigned oa[3], ob[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            oa[i] = (m0 + (int)srow[i] < N) ? ssrc[i] : BUF_OOB;     // rows past the edge load zeros
+            ob[i] = (n0 + (int)srow[i] < N) ? ssrc[i] : BUF_OOB;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        const int nchunk = ldn / KCH;
+        u32x4 ua[3], ub[3], va[3], vb[3];
+#define PRD_C3_LOAD(R, C)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                         \
+        R##a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, oa[i], (C) * 64, 0)); \
+        R##b[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ob[i], (C) * 64, 0)); \
+    }
+#define PRD_C3_STAGE(R, BUF)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                         \
+        *reinterpret_cast<u32x4*>(&As[BUF][sdst[i]]) = R##a[i];                                             \
+        *reinterpret_cast<u32x4*>(&Bs[BUF][sdst[i]]) = R##b[i];                                             \
+    }
+        // one chunk: loads of chunk c+2 are issued, chunk c is multiplied out of buffer CUR, register set R (chunk c+1) goes to
+        // the other buffer (the scheme of the fp32 kernel above)
+#define PRD_C3_CHUNK(C, CUR, R, NX)                                                                         \
+    {                                                                                                       \
+        const int c2 = (C) + 2 < nchunk ? (C) + 2 : nchunk - 1;                                             \
+        PRD_C3_LOAD(NX, c2)                                                                                 \
+        const int ar = wm0 + r, br = wn0 + r;                                                               \
+        _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                  \
+            const int j = 2 * st + hi;                                                                      \
+            u32x4 a[3], bq[3];                                                                              \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                              \
+                a[pl] = *reinterpret_cast<const u32x4*>(&As[CUR][pl * PLANE + ar * 64 + ((j ^ ((ar >> 2) & 3)) << 4)]); \
+                bq[pl] = *reinterpret_cast<const u32x4*>(&Bs[CUR][pl * PLANE + br * 64 + ((j ^ ((br >> 2) & 3)) << 4)]); \
+            }                                                                                               \
+            const int pa[6] = {0, 0, 1, 0, 2, 1}, pb[6] = {0, 1, 0, 2, 0, 1};                               \
+            _Pragma("unroll") for (int t = 0; t < 6; ++t)                                                   \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[pa[t]]),          \
+                                                              __builtin_bit_cast(bf16x8, bq[pb[t]]), acc, 0, 0, 0); \
+        }                                                                                                   \
+        if ((C) + 1 < nchunk) { PRD_C3_STAGE(R, (CUR) ^ 1) }                                                \
+        __syncthreads();                                                                                    \
+    }
+        PRD_C3_LOAD(u, 0)
+        PRD_C3_STAGE(u, 0)
+        {
+            const int c1 = 1 < nchunk ? 1 : 0;
+            PRD_C3_LOAD(u, c1)
+        }
+        __syncthreads();
+        for (int c = 0; c < nchunk; c += 2) {
+            PRD_C3_CHUNK(c, 0, u, v)
+            if (c + 1 < nchunk) PRD_C3_CHUNK(c + 1, 1, v, u)
+        }
+#undef PRD_C3_LOAD
+#undef PRD_C3_STAGE
+#undef PRD_C3_CHUNK
+        float* __restrict__ Oc = O + (size_t)ch * N * ldn;
+        const int n = n0 + wn0 + r;
+        if (n < N) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm0 + drow32(q, hi);
+                if (m < N) Oc[(size_t)m * ldn + n] = acc[q];
+            }
+        }
     }   // virtual blocks
 }
 
@@ -933,6 +1096,393 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Triangle attention core on the 16-bit matrix pipes (gemm mode 1), fp32-accurate by operand splitting:
+//   * projections: bf16 x 3 row GEMM (rowgemm_b3), as in the kernel above;
+//   * S^T = K Q^T: K and Q are split exactly into three bf16 parts ONCE per row in phase 1 (the key loop pays nothing for it).
+//     The head width is 16 but v_mfma_f32_16x16x32_bf16 contracts 32: two 16-wide products ride in one instruction,
+//       [kh | kh] x [qh | qm],  [km | kl] x [qh | qh],  [km | kh] x [qm | ql]
+//     = all six products of the three-way split in 3 MFMAs of ~17 cycles instead of 4 fp32 MFMAs of 32 cycles;
+//   * O^T = V^T P^T: V (x 16, a power of two) and the probabilities are split into fp16 hi + lo (RTZ hi, so hi + lo carries
+//     22 bits; |p| <= 1 after the first block, |16 v| is far inside the fp16 range); hi*hi + hi*lo + lo*hi on
+//     v_mfma_f32_16x16x32_f16: 6 MFMAs per 64 keys instead of 16 fp32 ones.  Splitting p costs VALU per logit
+//     (cvt_pkrtz, cvt, sub, cvt_pkrtz), which is why the probabilities use the 2-part fp16 form and not the 3-part bf16 one.
+//     A probability that would leave the fp16 range (only possible in the frozen-maximum blocks) sends the wave to the
+//     online pass, where p <= 1.
+// LDS per position: K / Q planes 3 x 32 B each (row pitch 32 B: the b128 operand reads of a 16-lane group are conflict free),
+// V hi / lo transposed [16][npad + 8] fp16, gate fp32.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));      // what __builtin_amdgcn_cvt_pkrtz returns
+
+PRD_DEV unsigned pk_f16_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+// fp16 hi / lo words of the pair (a, b): hi = RTZ(x), lo = RTZ(x - hi) (the subtraction is exact)
+PRD_DEV void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
+    const f16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = pk_f16_rtz(a - (float)h[0], b - (float)h[1]);
+}
+
+struct SplitLds {               // byte offsets from the dynamic LDS base
+    unsigned kp[3], qp[3], vh, vl, gl, kadd, bqg;
+    unsigned vpitch;            // halfs per V^T row
+};
+
+template <int NTQ, bool MASKED, bool ONLINE>
+PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[3],
+                            const u32x4 (&qb)[NTQ][3], int npad, int key0, int ql, int g4,
+                            float (&m_run)[NTQ], float (&l_run)[NTQ], f32x4 (&o)[NTQ], bool& big) {
+    constexpr int JT = 4;
+    ta_prio(npad - key0, npad);
+    const float* kadd = reinterpret_cast<const float*>(lds + L.kadd);
+    float4 ma[JT];
+    f32x4 s[NTQ][JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const unsigned krow = (unsigned)(key0 + 16 * j + ql) * 32u + (unsigned)(g4 & 1) * 16u;
+        const u32x4 ka0 = *reinterpret_cast<const u32x4*>(lds + kbase[0] + krow);
+        const u32x4 ka1 = *reinterpret_cast<const u32x4*>(lds + kbase[1] + krow);
+        const u32x4 ka2 = *reinterpret_cast<const u32x4*>(lds + kbase[2] + krow);
+        if (MASKED) ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            const float c0 = ONLINE ? 0.f : -m_run[t];
+            f32x4 z4 = {c0, c0, c0, c0};
+            z4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka0), __builtin_bit_cast(bf16x8, qb[t][0]), z4, 0, 0, 0);
+            z4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka1), __builtin_bit_cast(bf16x8, qb[t][1]), z4, 0, 0, 0);
+            z4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka2), __builtin_bit_cast(bf16x8, qb[t][2]), z4, 0, 0, 0);
+            s[t][j] = z4;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                  // V^T is fetched behind the QK^T MFMAs, not before them
+    // A operands of P V: lane (c = ql, g4) holds V^T[c][keys 16 j0 + 4 g4 .. +3 | 16 (j0 + 1) + 4 g4 .. +3] for j0 = 0, 2
+    u32x4 vh[2], vl[2];
+    {
+        const unsigned vrow = ((unsigned)ql * L.vpitch + (unsigned)key0 + 4u * g4) * 2u;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const u32x2 a = *reinterpret_cast<const u32x2*>(lds + L.vh + vrow + 64 * gi);
+            const u32x2 b = *reinterpret_cast<const u32x2*>(lds + L.vh + vrow + 64 * gi + 32);
+            const u32x2 c = *reinterpret_cast<const u32x2*>(lds + L.vl + vrow + 64 * gi);
+            const u32x2 d = *reinterpret_cast<const u32x2*>(lds + L.vl + vrow + 64 * gi + 32);
+            vh[gi] = u32x4{a[0], a[1], b[0], b[1]};
+            vl[gi] = u32x4{c[0], c[1], d[0], d[1]};
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        if (MASKED) {
+            const float mr = ONLINE ? 0.f : m_run[t];   // override values are absolute logits
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                s[t][j][0] = (ma[j].x == 0.f) ? s[t][j][0] : ma[j].x - mr;
+                s[t][j][1] = (ma[j].y == 0.f) ? s[t][j][1] : ma[j].y - mr;
+                s[t][j][2] = (ma[j].z == 0.f) ? s[t][j][2] : ma[j].z - mr;
+                s[t][j][3] = (ma[j].w == 0.f) ? s[t][j][3] : ma[j].w - mr;
+            }
+        }
+        f32x2 ps = {0.f, 0.f};
+        if (ONLINE) {
+            float tmax = max3f(s[t][0][0], s[t][0][1], s[t][0][2]);
+            tmax = max3f(tmax, s[t][0][3], s[t][1][0]);
+#pragma unroll
+            for (int j = 1; j < JT; ++j) {
+                tmax = max3f(tmax, s[t][j][1], s[t][j][2]);
+                if (j + 1 < JT) tmax = max3f(tmax, s[t][j][3], s[t][j + 1][0]);
+                else tmax = max2f(tmax, s[t][j][3]);
+            }
+            tmax = rows4_max(tmax);
+            const float m_new = max2f(m_run[t], tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+            m_run[t] = m_new;
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[t][j][e] = __builtin_amdgcn_exp2f(s[t][j][e] - m_new);
+                    ps[e & 1] += s[t][j][e];
+                }
+            l_run[t] = l_run[t] * alpha + (ps.x + ps.y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
+        } else {
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[t][j][e] = __builtin_amdgcn_exp2f(s[t][j][e]);
+                    ps[e & 1] += s[t][j][e];
+                }
+            const float bsum = ps.x + ps.y;
+            big |= !(bsum < 30000.0f);                  // a probability near the fp16 range (or inf / NaN): redo online
+            l_run[t] += bsum;
+        }
+        // probabilities -> fp16 hi / lo B operands of the two 32-key groups
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            u32x4 ph, pl;
+#pragma unroll
+            for (int hj = 0; hj < 2; ++hj) {
+                unsigned h0, l0, h1, l1;
+                split2_f16(s[t][2 * gi + hj][0], s[t][2 * gi + hj][1], h0, l0);
+                split2_f16(s[t][2 * gi + hj][2], s[t][2 * gi + hj][3], h1, l1);
+                ph[2 * hj] = h0; ph[2 * hj + 1] = h1;
+                pl[2 * hj] = l0; pl[2 * hj + 1] = l1;
+            }
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, ph), o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, pl), o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl[gi]), __builtin_bit_cast(f16x8, ph), o[t], 0, 0, 0);
+        }
+    }
+}
+
+template <int NTQ, bool MASKED>
+PRD_DEV void ta_keyloop_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[3],
+                              const u32x4 (&qb)[NTQ][3], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
+    float m_run[NTQ], l_run[NTQ];
+    bool online_all = false;
+    while (true) {
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            m_run[t] = -1e30f;
+            l_run[t] = 0.f;
+            o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        bool big = false;
+#pragma unroll 1
+        for (int key0 = 0; key0 < npad; key0 += 64) {
+            if (key0 == 0 || online_all) ta_block_split<NTQ, MASKED, true>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o, big);
+            else ta_block_split<NTQ, MASKED, false>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o, big);
+        }
+        bool bad = big;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            l_tot[t] = rows4_sum(l_run[t]);
+            bad |= !(l_tot[t] < 3.0e38f);
+        }
+        if (online_all || !__any(bad)) break;
+        online_all = true;
+    }
+}
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
+    float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    constexpr float VSCALE = 16.0f;             // V is staged x 16 (exact) so that small components keep a normal fp16 lo part
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr unsigned WBYTES = 3u * 64 * (2 * (P / 16) + 1) * 16;
+    SplitLds L;
+    {
+        unsigned off = WBYTES;
+        for (int pl = 0; pl < 3; ++pl) { L.kp[pl] = off; off += (unsigned)npad * 32u; }
+        for (int pl = 0; pl < 3; ++pl) { L.qp[pl] = off; off += (unsigned)npad * 32u; }
+        L.vpitch = (unsigned)npad + 8u;
+        L.vh = off; off += 16u * L.vpitch * 2u;
+        L.vl = off; off += 16u * L.vpitch * 2u;
+        L.gl = off; off += (unsigned)npad * KP * 4u;
+        L.kadd = off; off += (unsigned)npad * 4u;
+        L.bqg = off;
+    }
+    u32x4* Wb = reinterpret_cast<u32x4*>(lds);
+    float* Gl = reinterpret_cast<float*>(lds + L.gl);
+    float* kadd = reinterpret_cast<float*>(lds + L.kadd);
+    float* bqg = reinterpret_cast<float*>(lds + L.bqg);
+    _Float16* Vh = reinterpret_cast<_Float16*>(lds + L.vh);
+    _Float16* Vl = reinterpret_cast<_Float16*>(lds + L.vl);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int ql = lane & 15, g4 = lane >> 4;
+    const int nqb = (N + 31) / 32;
+    const int ntile = (N + 15) / 16;
+    const int rstride = gridDim.x / H;
+    int h, slot;
+    if ((rstride & 7) == 0) {                   // the H heads of one row on one XCD (see tri_attn_core_kernel)
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        h = idx % H;
+        slot = (idx / H) * 8 + xcd;
+    } else {
+        h = blockIdx.x % H;
+        slot = blockIdx.x / H;
+    }
+    const float sc = 0.25f * LOG2E;
+    stage_weight_b3_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, 1.0f);
+    stage_weight_b3_rows<P>(Wb, 64, C, wv + (long)h * C * P, C, P, tid, NT, VSCALE);
+    stage_weight_b3_rows<P>(Wb, 64, 2 * C, wq + (long)h * C * P, C, P, tid, NT, sc);
+    stage_weight_b3_rows<P>(Wb, 64, 3 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E);
+    if (tid < 32) {
+        const int hh = tid >> 4, e = tid & 15;
+        bqg[tid] = e < 8 ? 0.f : NEG_LOG2E * bg[h * C + (e < 12 ? 4 * hh + (e - 8) : 8 + 4 * hh + (e - 12))];
+    }
+    const long nrows = (long)b * N;
+    auto row_pos = [&](long bu, int v) -> long {
+        const long bb = bu / N;
+        const long u = bu - bb * N;
+        return ending ? ((bb * N + v) * N + u) : (bu * N + v);
+    };
+    const int full_rounds = nqb / NW, R = nqb - full_rounds * NW;
+    const int S = 2 * R <= NW ? R : NW - R;
+    const int F = R - S;
+    int last_blk = -1, last_halves = 0;
+    if (wave < F) { last_blk = full_rounds * NW + wave; last_halves = 3; }
+    else if (wave - F < 2 * S) { last_blk = full_rounds * NW + F + (wave - F) % S; last_halves = 1 << ((wave - F) / S); }
+    const int nunits = full_rounds + (last_blk >= 0 ? 1 : 0);
+    const int first_blk = full_rounds > 0 ? wave : last_blk;
+    // positions past the last real block never change: K = V = Q = 0, logit override -inf
+    for (int v = nqb * 32 + tid; v < npad; v += NT) {
+        for (int pl = 0; pl < 3; ++pl) {
+            *reinterpret_cast<u32x4*>(lds + L.kp[pl] + v * 32) = u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(lds + L.kp[pl] + v * 32 + 16) = u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(lds + L.qp[pl] + v * 32) = u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(lds + L.qp[pl] + v * 32 + 16) = u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int e = 0; e < C; ++e) { Gl[v * KP + e] = 0.f; Vh[e * L.vpitch + v] = (_Float16)0.f; Vl[e * L.vpitch + v] = (_Float16)0.f; }
+        kadd[v] = -INFINITY;
+    }
+    float xnext[KH];
+    {
+        const long bu0 = slot;
+        const int v = first_blk * 32 + r;
+        const bool ok = bu0 < nrows && first_blk >= 0 && v < N;
+        load_row_cll<P>(pair + row_pos(ok ? bu0 : 0, ok ? v : 0) * P, hi, ok, xnext);
+    }
+    // per-lane operand bases of the three QK^T MFMAs (see the header comment): A = K planes, B = Q planes
+    const unsigned kbase[3] = {L.kp[0], g4 < 2 ? L.kp[1] : L.kp[2], g4 < 2 ? L.kp[1] : L.kp[0]};
+    const unsigned qbase[3] = {g4 < 2 ? L.qp[0] : L.qp[1], L.qp[0], g4 < 2 ? L.qp[1] : L.qp[2]};
+    for (long bu = slot; bu < nrows; bu += rstride) {
+        const int bb = (int)(bu / N);
+        __syncthreads();                        // previous row's LDS fully consumed (and weights staged)
+        const float mu = mask[bu];
+        // ---- phase 1: project, split, store ----
+        for (int un = 0; un < nunits; ++un) {
+            const int vb = un < full_rounds ? un * NW + wave : last_blk;
+            const int halves = un < full_rounds ? 3 : last_halves;
+            const int v = vb * 32 + r;
+            const bool valid = v < N;
+            float x[KH];
+            if (un == 0) {
+#pragma unroll
+                for (int s_ = 0; s_ < KH; ++s_) x[s_] = xnext[s_];
+            } else {
+                load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
+            }
+            ln_cll<KH>(x);
+            u32x4 xs[3][P / 16];
+            split3_cll<P>(x, xs);
+            if (halves & 1) {
+                if (hi == 0) {
+                    const bool keep = valid && (mu * mask[(long)bb * N + (valid ? v : 0)] >= 0.5f);
+                    kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E : -INFINITY);
+                }
+                f32x16 acc[1];
+                zero_acc(acc);
+                rowgemm_b3<P, 1>(Wb, 64, 0, xs, acc, r, hi);
+                // k channels {4hi+e} in registers 0-3 and {8+4hi+e} in 4-7: three bf16 planes, 8 bytes each
+                unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                split3(acc[0][0], acc[0][1], h0, m0, l0);
+                split3(acc[0][2], acc[0][3], h1, m1, l1);
+                split3(acc[0][4], acc[0][5], h2, m2, l2);
+                split3(acc[0][6], acc[0][7], h3, m3, l3);
+                const unsigned ko = (unsigned)v * 32u + 8u * hi;
+                *reinterpret_cast<u32x2*>(lds + L.kp[0] + ko) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(lds + L.kp[0] + ko + 16) = u32x2{h2, h3};
+                *reinterpret_cast<u32x2*>(lds + L.kp[1] + ko) = u32x2{m0, m1};
+                *reinterpret_cast<u32x2*>(lds + L.kp[1] + ko + 16) = u32x2{m2, m3};
+                *reinterpret_cast<u32x2*>(lds + L.kp[2] + ko) = u32x2{l0, l1};
+                *reinterpret_cast<u32x2*>(lds + L.kp[2] + ko + 16) = u32x2{l2, l3};
+                // v channels likewise in registers 8-15 (already x 16): fp16 hi / lo, transposed
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const int c0 = (e < 4 ? 4 * hi : 8 + 4 * hi) + (e & 3);
+                    const f16x2 hh2 = __builtin_amdgcn_cvt_pkrtz(acc[0][8 + e], acc[0][9 + e]);
+                    const f16x2 ll2 = __builtin_amdgcn_cvt_pkrtz(acc[0][8 + e] - (float)hh2[0], acc[0][9 + e] - (float)hh2[1]);
+                    Vh[c0 * L.vpitch + v] = (_Float16)hh2[0];
+                    Vh[(c0 + 1) * L.vpitch + v] = (_Float16)hh2[1];
+                    Vl[c0 * L.vpitch + v] = (_Float16)ll2[0];
+                    Vl[(c0 + 1) * L.vpitch + v] = (_Float16)ll2[1];
+                }
+            }
+            if (halves & 2) {
+                f32x16 acc[1];
+                bias_acc(acc, bqg + 16 * hi);
+                rowgemm_b3<P, 1>(Wb, 64, 32, xs, acc, r, hi);
+                unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                split3(acc[0][0], acc[0][1], h0, m0, l0);
+                split3(acc[0][2], acc[0][3], h1, m1, l1);
+                split3(acc[0][4], acc[0][5], h2, m2, l2);
+                split3(acc[0][6], acc[0][7], h3, m3, l3);
+                const unsigned qo = (unsigned)v * 32u + 8u * hi;
+                *reinterpret_cast<u32x2*>(lds + L.qp[0] + qo) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(lds + L.qp[0] + qo + 16) = u32x2{h2, h3};
+                *reinterpret_cast<u32x2*>(lds + L.qp[1] + qo) = u32x2{m0, m1};
+                *reinterpret_cast<u32x2*>(lds + L.qp[1] + qo + 16) = u32x2{m2, m3};
+                *reinterpret_cast<u32x2*>(lds + L.qp[2] + qo) = u32x2{l0, l1};
+                *reinterpret_cast<u32x2*>(lds + L.qp[2] + qo + 16) = u32x2{l2, l3};
+                *reinterpret_cast<float4*>(Gl + v * KP + 4 * hi) = make_float4(gate_from_scaled(acc[0][8]), gate_from_scaled(acc[0][9]),
+                                                                                gate_from_scaled(acc[0][10]), gate_from_scaled(acc[0][11]));
+                *reinterpret_cast<float4*>(Gl + v * KP + 8 + 4 * hi) = make_float4(gate_from_scaled(acc[0][12]), gate_from_scaled(acc[0][13]),
+                                                                                    gate_from_scaled(acc[0][14]), gate_from_scaled(acc[0][15]));
+            }
+        }
+        __syncthreads();
+        {   // next row's first block: in flight during the whole key loop
+            const long bun = bu + rstride;
+            const int v = first_blk * 32 + r;
+            const bool ok = bun < nrows && first_blk >= 0 && v < N;
+            load_row_cll<P>(pair + row_pos(ok ? bun : 0, ok ? v : 0) * P, hi, ok, xnext);
+        }
+        // ---- phase 2 ----
+        bool row_masked = false;
+        for (int k = lane; k < npad; k += 64) row_masked |= (kadd[k] != 0.f);
+        row_masked = __any(row_masked);
+        const float inv_vs = 1.0f / VSCALE;
+        for (int t0 = wave; t0 < ntile; t0 += 2 * NW) {
+            const int t1 = t0 + NW;
+            const unsigned half16 = (unsigned)(g4 & 1) * 16u;
+            if (t1 < ntile) {
+                u32x4 qb[2][3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    qb[0][m] = *reinterpret_cast<const u32x4*>(lds + qbase[m] + (unsigned)(16 * t0 + ql) * 32u + half16);
+                    qb[1][m] = *reinterpret_cast<const u32x4*>(lds + qbase[m] + (unsigned)(16 * t1 + ql) * 32u + half16);
+                }
+                f32x4 o[2];
+                float l_tot[2];
+                if (row_masked) ta_keyloop_split<2, true>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+                else ta_keyloop_split<2, false>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int v = 16 * (t == 0 ? t0 : t1) + ql;
+                    if (v < N) {
+                        const float4 gf = *reinterpret_cast<const float4*>(Gl + v * KP + 4 * g4);
+                        const float il = inv_vs / l_tot[t];
+                        *reinterpret_cast<float4*>(og + row_pos(bu, v) * HC + h * C + 4 * g4) =
+                            make_float4(gf.x * (o[t][0] * il), gf.y * (o[t][1] * il), gf.z * (o[t][2] * il), gf.w * (o[t][3] * il));
+                    }
+                }
+            } else {
+                u32x4 qb[1][3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                    qb[0][m] = *reinterpret_cast<const u32x4*>(lds + qbase[m] + (unsigned)(16 * t0 + ql) * 32u + half16);
+                f32x4 o[1];
+                float l_tot[1];
+                if (row_masked) ta_keyloop_split<1, true>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+                else ta_keyloop_split<1, false>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+                const int v = 16 * t0 + ql;
+                if (v < N) {
+                    const float4 gf = *reinterpret_cast<const float4*>(Gl + v * KP + 4 * g4);
+                    const float il = inv_vs / l_tot[0];
+                    *reinterpret_cast<float4*>(og + row_pos(bu, v) * HC + h * C + 4 * g4) =
+                        make_float4(gf.x * (o[0][0] * il), gf.y * (o[0][1] * il), gf.z * (o[0][2] * il), gf.w * (o[0][3] * il));
+                }
+            }
+        }
+    }
+}
+
 // Long-row variant (K/V of the row fill the LDS, no room for Q / gate tiles): queries are re-projected per
 // 32-query block in phase 2 and reach the MFMA operand layout through wave shuffles instead of LDS.
 template <int P, int NW>
@@ -1111,6 +1661,8 @@ size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
     const int npad = prd_round_up(N, 64);
     const size_t wsz = b3 ? (size_t)3 * 64 * (2 * (P / 16) + 1) * 4 : (size_t)64 * (P + 4);
     size_t lds = (wsz + (size_t)3 * npad * KP + 16 * (npad + 4) + npad + 32) * sizeof(float);
+    // split-operand kernel (gemm mode 1): K / Q planes 6 x 32 B, V hi / lo 2 x 16 x (npad + 8) fp16, gate, override, bias
+    if (b3) lds = wsz * sizeof(float) + (size_t)npad * (192 + KP * 4 + 4) + (size_t)64 * (npad + 8) + 128;
     *long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
     if (*long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
     return lds;
@@ -1130,7 +1682,8 @@ extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P
     (void)S;
     if (!op || b <= 0 || N <= 0) return 0;
     const size_t ldn = (size_t)prd_round_up(N, 32);
-    if (op[0] == 't' && op[4] == 'm') return (size_t)3 * b * P * N * ldn * sizeof(float);   // "tri_mul"
+    // "tri_mul": operands (2 units fp32, or 3 units as bf16 x 3 planes in gemm mode 1) + contraction output (1 unit)
+    if (op[0] == 't' && op[4] == 'm') return (size_t)4 * b * P * N * ldn * sizeof(float);
     if (op[0] == 't' && op[4] == 'a') return (size_t)b * N * N * 64 * sizeof(float);        // "tri_attn"
     return 0;
 }
@@ -1144,11 +1697,12 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     if (ws_bytes < prd_workspace_bytes("tri_mul", b, N, 0, P)) return PRD_ERR_WORKSPACE;
     const int ldn = prd_round_up(N, 32);
-    float* AB = ws;                                   // [b][2P][N][ldn]
-    float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
+    float* AB = ws;                                   // fp32: [b][2P][N][ldn];  bf16 x 3: [b][2P][N][3][ldn] bf16 (3 units)
+    float* O = ws + (size_t)3 * b * P * N * ldn;      // [b][P][N][ldn]
+    const bool b3m = g_gemm_mode.load(std::memory_order_relaxed) == 1;
     {
         constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
-        const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;   // bf16 x 3 row GEMM (prd_set_gemm_mode)
+        const bool b3 = b3m;                        // bf16 x 3 row GEMM (prd_set_gemm_mode)
         const size_t wsz = b3 ? (size_t)3 * 2 * P * (2 * (P / 16) + 1) * 4 : (size_t)2 * P * (P + 4);
         const size_t lds = (2 * wsz + 4 * P) * sizeof(float);
         const long ntask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);     // (row block, output block) tasks
@@ -1169,13 +1723,17 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     {
         const int tiles = prd_ceil_div(N, 64);
         const int vblocks = b * P * tiles * tiles;
-        hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
+        if (b3m)
+            hipLaunchKernelGGL(tri_mul_contract_b3_kernel, dim3(vblocks < 768 ? vblocks : 768), dim3(256), 0, stream, O,
+                               reinterpret_cast<const unsigned short*>(AB), N, ldn, P, b, tiles);
+        else
+            hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
         int e = (int)hipGetLastError();
         if (e) return e;
     }
     {
         constexpr int NWO = 8;
-        const bool b3o = g_gemm_mode.load(std::memory_order_relaxed) == 1;
+        const bool b3o = b3m;
         const long ntask = (long)b * N * prd_ceil_div(N, 32);
         const int grid = grid_for(ntask, 4, 256);
 #define PRD_OUT_LAUNCH(PP, BB)                                                                                         \
@@ -1218,7 +1776,7 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     // 12 waves (3 per SIMD) + next-row prefetch: the ceil(N/16) query tiles dealt in pairs land 5 per SIMD at N = 320
     // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
     if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
-    else if (b3) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true, true); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true, true); }
+    else if (b3) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 32, 8); }
     else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true, false); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true, false); }
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();

@@ -318,9 +318,22 @@ class ProteinReDiffModel(_Base):
         self.log("val_loss", loss, on_epoch=True, sync_dist=True, batch_size=x.size(0))
         return loss
 
-    def training_step(self, batch, batch_idx):
-        raise NotImplementedError("the optimisation step needs the backward of the HIP kernels (SURVEY.md §8f 'next #1'); "
-                                  "forward / loss evaluation is available through validation_step / diffusion_loss")
+    def training_step(self, batch, batch_idx, t=None, noise_z=None, noise_seq=None, sources=None):
+        """model.py:528-549: mean over the batch of diffusion_loss / node count, differentiable with respect to every trainable
+        parameter (training.network: HIP forward, per-operator backward, per-block recompute).  ``t`` / the noises / the mask
+        sources may be injected (parity tests); otherwise they are drawn like the reference draws them."""
+        if not self.setup_schedule:
+            self.run_setup_schedule()
+            self.setup_schedule = True
+        batch = self.prepare_batch(batch, batch_idx, sources=sources)
+        x, mask = batch["x"], batch["residue_and_atom_mask"]
+        num_nodes = (mask > 0.5).sum(-1)
+        if t is None:
+            t = torch.randint(0, self.num_steps, size=(x.size(0),)).to(x.device)
+        diff_loss = self.diffusion_loss(batch, x, mask, t, noise_z, noise_seq)
+        loss = torch.mean(diff_loss / num_nodes)
+        self.log("train_loss", loss, on_step=True, on_epoch=True, sync_dist=True, batch_size=x.size(0))
+        return loss
 
     def predict_step(self, batch, batch_idx):
         with self.ema.average_parameters(self.parameters()):
@@ -344,15 +357,18 @@ class ProteinReDiffModel(_Base):
         return [NoiseSource(seed, first + k) for k in range(b)]
 
     def prepare_batch(self, batch, id=None, sources: Optional[Sequence] = None):
-        """Eval branch (:459-468).  The training-mode branches need ``residue_esm_tokens`` that no
-        published code produces and are out of scope."""
+        """Eval branch (:459-468): ``int(n_res * mask_prob)`` residues per sample leave the known set.  The training-mode
+        branches (:441-458) need ``residue_esm_tokens`` that no published code produces and are out of scope:
+        ``training_step`` therefore runs with ``training_mode=False`` masking, which is also what the reference does when it is
+        trained with its default flags (``--training_mode`` is a store_true option, model.py:133)."""
         if self.training_mode:
-            raise NotImplementedError("training-mode masking is out of scope (SURVEY.md §2)")
+            raise NotImplementedError("training-mode masking needs residue_esm_tokens, which no published code produces "
+                                      "(SURVEY.md §2/§5); run with training_mode=False")
         am, rm = batch["atom_mask"], batch["residue_mask"]
         dev = am.device
         b = am.shape[0]
         if sources is None:
-            sources = self._sources(b)
+            sources = self._sources(b, id if isinstance(id, int) else None)
         one_hot = F.one_hot(batch["residue_type"], num_classes=NUM_RESIDUE_CLASSES) * 2.0 - 1.0
         pos = am.unsqueeze(-1) * batch["atom_pos"] + rm.unsqueeze(-1) * batch["residue_atom_pos"][:, :, 1]
         rm_cpu = rm.detach().cpu()
@@ -414,6 +430,11 @@ class ProteinReDiffModel(_Base):
         return noise_pred, seq_pred
 
     def forward(self, batch, z, seq_t, mask, t):
+        """Inference (no_grad / inference_mode): the fused HIP path.  With autograd enabled: the same HIP operators, one
+        autograd node each (training.py), so that ``diffusion_loss(...).backward()`` reaches every parameter."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from . import training
+            return training.network(self, batch, z, seq_t, mask, t)
         return self._network(batch, z, seq_t, mask, t)
 
     def sample_step(self, batch, z, seq_t, mask, t):
@@ -477,6 +498,17 @@ class ReverseDiffusion:
         self.seq_t.copy_(self._init[1])
         self.t.fill_(self.T - 1)
         self.steps_done = 0
+
+    def restart(self, step: int, z: torch.Tensor, seq_t: torch.Tensor):
+        """Continue from a given state: ``z`` / ``seq_t`` are the tensors ENTERING denoising step number ``step`` (0 = the
+        first, t = T-1).  The pre-drawn noise table is indexed by the step counter, so the continuation consumes exactly the
+        noise the uninterrupted loop would (checkpointed sampling; segment-wise parity tests)."""
+        if not 0 <= step < self.T:
+            raise ValueError(f"step must be in [0, {self.T}), got {step}")
+        self.z.copy_(z.to(self.z.device))
+        self.seq_t.copy_(seq_t.to(self.seq_t.device))
+        self.t.fill_(self.T - 1 - step)
+        self.steps_done = step
 
     def _enqueue_step(self):
         m = self.model

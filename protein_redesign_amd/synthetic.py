@@ -113,15 +113,29 @@ def batch_to(batch: Mapping[str, torch.Tensor], device) -> Dict[str, torch.Tenso
 _FROZEN = ("embed_beta.0.weight", "embed_dist.0.center")
 
 
-def deterministic_state_dict(spec: Mapping[str, torch.Tensor], seed: int = 1) -> Dict[str, torch.Tensor]:
+# layers the reference initialises to ZERO ("final": modules.py:160-163, AF2_modules.py:151-153) or as pass-through gates
+# ("gating": weight 0, bias 1): every residual update starts as the identity and the heads start at zero
+_FINAL_INIT = ("out_proj.weight", "out_proj.bias", "single_fc.3.", "pair_fc.3.", "outer_linear.linear.", "linear_o.", "linear_out.",
+               "weight_radial.3.", "seq_mlp.3.")
+_GATING_INIT = ("gate_proj.", "ab_gate.", "out_gate.", "linear_g.")
+
+
+def deterministic_state_dict(spec: Mapping[str, torch.Tensor], seed: int = 1, style: str = "random") -> Dict[str, torch.Tensor]:
     """Seeded weights for every key of ``spec`` (a state_dict used for names/shapes).
 
-    Matrices ~ N(0, 1/fan_in), biases ~ N(0, 0.1^2), LayerNorm scales
-    1 + N(0, 0.1^2), embedding tables ~ N(0, 1).  The two frozen
-    buffers-as-parameters keep the values the reference constructs
-    (modules.py:77-79, 91-93).  Nothing is left at the reference's zero
-    ("final") initialisation, so every branch of the network is live.
-    """
+    ``style="random"``: matrices ~ N(0, 1/fan_in), biases ~ N(0, 0.1^2), LayerNorm scales 1 + N(0, 0.1^2), embedding
+    tables ~ N(0, 1).  Nothing is left at the reference's zero ("final") initialisation, so every branch of the network is
+    live at full strength -- the most demanding inputs for operator / step parity.  As a DENOISER such a network is a random
+    map: iterated over hundreds of reverse-diffusion steps it amplifies round-off chaotically.
+
+    ``style="near_init"``: the same, except that the layers the reference initialises to zero ("final") or to pass-through
+    gates ("gating") sit an N(0, 0.02^2) perturbation away from that initialisation -- a network early in training, the
+    recipe of SURVEY.md §8d.  Every branch is still live, residual updates are small, and the reverse-diffusion loop is
+    well conditioned: this is the style of the long-trajectory fixtures.
+
+    The two frozen buffers-as-parameters keep the values the reference constructs (modules.py:77-79, 91-93)."""
+    if style not in ("random", "near_init"):
+        raise ValueError(f"unknown weight style: {style}")
     g = torch.Generator().manual_seed(seed)
     out: Dict[str, torch.Tensor] = {}
     for name in sorted(spec):              # sorted: independent of module registration order
@@ -139,6 +153,11 @@ def deterministic_state_dict(spec: Mapping[str, torch.Tensor], seed: int = 1) ->
         else:
             fan_in = shape[-1]
             w = torch.randn(shape, generator=g) / (fan_in ** 0.5)
+        if style == "near_init":
+            if any(t in name for t in _FINAL_INIT):
+                w = 0.02 * torch.randn(shape, generator=g)
+            elif any(t in name for t in _GATING_INIT):
+                w = 0.02 * torch.randn(shape, generator=g) + (1.0 if name.endswith("bias") else 0.0)
         out[name] = w.float()
     return out
 

@@ -1,0 +1,155 @@
+"""Differentiable torch-op restatement of the hot-path operators, used ONLY inside backward passes.
+
+The forward of every operator is a HIP kernel (ops.py).  For the first cut of the training step (SURVEY.md §8f "next" #1:
+"HIP forward + PyTorch autograd over the restatement for backward, then hand-written backward kernels") the BACKWARD of an
+operator recomputes it here with torch ops on the GPU under ``torch.enable_grad()`` and lets autograd produce the gradients;
+operators with hand-written backward kernels (training.py lists them) do not come here at all.  Nothing in this file is ever used
+to produce a forward value of the product path, and none of it runs on the CPU.
+
+Every function takes explicit weight tensors (nn.Linear layout) and follows the reference lines it cites; shapes are
+single [b,N,S], pair [b,N,N,P], mask [b,N].
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+
+def ln(x, w=None, b=None):
+    return F.layer_norm(x, x.shape[-1:], w, b, 1e-5)
+
+
+def gated_attention(x, mask, wq, wk, wv, wg, bg, wo, bo, heads: int, head_dim: int, bias: Optional[torch.Tensor] = None):
+    """modules.py:185-225: LN, q/k/v (no bias), sigmoid gate, q pre-scaled by 1/sqrt(c), additive bias, key mask filled with
+    -2**15, softmax, gate, output projection.  ``x`` [..., n, E], ``mask`` [..., n] (keys)."""
+    x = ln(x)
+    lead, n = x.shape[:-2], x.shape[-2]
+
+    def split(t):
+        return t.reshape(*lead, n, heads, head_dim).transpose(-2, -3)
+
+    q, k, v = split(F.linear(x, wq)), split(F.linear(x, wk)), split(F.linear(x, wv))
+    g = split(torch.sigmoid(F.linear(x, wg, bg)))
+    logits = torch.matmul((1.0 / math.sqrt(head_dim)) * q, k.transpose(-1, -2))
+    if bias is not None:
+        logits = logits + bias
+    logits = logits.masked_fill(mask.unsqueeze(-2).unsqueeze(-2) < 0.5, -(2.0 ** 15))
+    out = g * torch.matmul(torch.softmax(logits, dim=-1), v)
+    out = out.transpose(-2, -3).reshape(*lead, n, heads * head_dim)
+    return F.linear(out, wo, bo)
+
+
+def pair_bias(pair, w, b=None, gamma=None, beta=None):
+    """modules.py:300-304 (no LN affine, bias) / AF2_modules.py:454-459 (LN affine, no bias) -> [b,H,N,N]."""
+    return F.linear(ln(pair, gamma, beta), w, b).permute(0, 3, 1, 2)
+
+
+def triangle_attention(pair, mask, wq, wk, wv, wg, bg, wo, bo, heads: int, head_dim: int, ending: bool, row_chunk: int = 64):
+    """modules.py:236-243; rows are processed ``row_chunk`` at a time so that the [rows,H,N,N] logits stay bounded."""
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    if ending:
+        pair, m2 = pair.transpose(1, 2), m2.transpose(1, 2)
+    outs = [gated_attention(pair[:, r:r + row_chunk], m2[:, r:r + row_chunk], wq, wk, wv, wg, bg, wo, bo, heads, head_dim)
+            for r in range(0, pair.shape[1], row_chunk)]
+    out = torch.cat(outs, dim=1)
+    return out.transpose(1, 2) if ending else out
+
+
+def triangle_multiplication(pair, mask, wp, bp, wg, bg, wo, bo, wog, bog, incoming: bool):
+    """modules.py:262-274."""
+    x = ln(pair)
+    m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
+    ab = m2 * torch.sigmoid(F.linear(x, wg, bg)) * F.linear(x, wp, bp)
+    a, b = torch.chunk(ab, 2, dim=-1)
+    o = torch.einsum("bkid,bkjd->bijd" if incoming else "bikd,bjkd->bijd", a, b)
+    return torch.sigmoid(F.linear(x, wog, bog)) * F.linear(ln(o), wo, bo)
+
+
+def outer_linear(single, w, b):
+    """modules.py:283-287 in the split form W1 (x_i * x_j) + W2 x_i - W2 x_j + b (no [N,N,2S] concat)."""
+    x = ln(single)
+    S = x.shape[-1]
+    w1, w2 = w[:, :S], w[:, S:]
+    u = F.linear(x, w2)
+    prod = torch.einsum("bis,bjs,ps->bijp", x, x, w1)
+    return prod + u.unsqueeze(2) - u.unsqueeze(1) + b
+
+
+def transition(x, w1, b1, w2, b2):
+    """single_fc / pair_fc: LN -> Linear -> ReLU -> Linear (modules.py:306-311, 321-326)."""
+    return F.linear(torch.relu(F.linear(ln(x), w1, b1)), w2, b2)
+
+
+def outer_product_update(single, mask, g, bta, w1, b1, w2, b2, wo, bo):
+    """AF2_modules.py:503-545 followed by the caller's mask (modules.py:395-397): m2 * upd."""
+    x = ln(single, g, bta)
+    m = mask.unsqueeze(-1)
+    a, b = F.linear(x, w1, b1) * m, F.linear(x, w2, b2) * m
+    outer = F.linear(a.unsqueeze(2) * b.unsqueeze(1), wo, bo)
+    m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
+    return m2 * (outer / (m2 + 1e-3))
+
+
+def single_pair_attention(single, pair, gm, bm, gz, bz, wz, wq, wk, wv, wg, bg, wo, bo, heads: int):
+    """AF2_modules.py:421-473: unmasked, residual on the LayerNorm-ed input, head width = single_dim."""
+    bias = pair_bias(pair, wz, None, gz, bz)
+    m = ln(single, gm, bm)
+    b_, n, _ = m.shape
+
+    def heads_of(t):
+        return t.view(b_, n, heads, -1).transpose(-2, -3)
+
+    q, k, v = heads_of(F.linear(m, wq)), heads_of(F.linear(m, wk)), heads_of(F.linear(m, wv))
+    a = torch.softmax(torch.matmul(q / math.sqrt(q.shape[-1]), k.transpose(-1, -2)) + bias, dim=-1)
+    o = torch.matmul(a, v).transpose(-2, -3)
+    gate = torch.sigmoid(F.linear(m, wg, bg)).view(b_, n, heads, -1)
+    return m + F.linear((o * gate).reshape(b_, n, -1), wo, bo)
+
+
+def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int, max_relpos: int,
+                atom_tabs: Sequence[torch.Tensor], bond_tabs: Sequence[torch.Tensor], bd_tab, rp_tab, w_rt, w_esm,
+                centers, w_dist, freqs, w_beta):
+    """model.py:332-361: single and pair inputs of the trunk."""
+    am, rm = batch["atom_mask"], batch["residue_mask"]
+    sa = 1.0 / math.sqrt(len(atom_tabs))
+    acc = 0.0
+    for f, tab in enumerate(atom_tabs):
+        acc = acc + sa * F.embedding(batch["atom_feats"][..., f], tab)
+    single = am.unsqueeze(-1) * acc + rm.unsqueeze(-1) * (
+        torch.relu(F.linear(ln(seq_t), w_rt)) + F.linear(ln(batch["residue_esm"]), w_esm))
+    sb = 1.0 / math.sqrt(len(bond_tabs))
+    bacc = 0.0
+    for f, tab in enumerate(bond_tabs):
+        bacc = bacc + sb * F.embedding(batch["bond_feats"][..., f], tab)
+    am2 = (am.unsqueeze(-1) * am.unsqueeze(-2)).unsqueeze(-1)
+    rm2 = (rm.unsqueeze(-1) * rm.unsqueeze(-2)).unsqueeze(-1)
+    m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
+    ri, ci = batch["residue_index"], batch["residue_chain_index"]
+    rel = (ri.unsqueeze(-1) - ri.unsqueeze(-2)).clamp(min=-max_relpos, max=max_relpos) + max_relpos
+    chain = (ci.unsqueeze(-1) == ci.unsqueeze(-2)).float().unsqueeze(-1)
+    pair = am2 * (batch["bond_mask"].unsqueeze(-1) * bacc + F.embedding(batch["bond_distance"].clamp(max=max_bond_distance), bd_tab))
+    pair = pair + rm2 * (chain * F.embedding(rel, rp_tab))
+    dist = torch.linalg.norm(z.unsqueeze(-2) - z.unsqueeze(-3), dim=-1)
+    scale = (centers.numel() - 1) / 2.0
+    rbf = torch.exp(-scale * torch.square(dist.unsqueeze(-1) - centers))
+    wx = freqs * (t / num_steps)[:, None, None].unsqueeze(-1)
+    sinus = torch.cat([torch.sin(wx), torch.cos(wx)], dim=-1)
+    pair = pair + m2 * (F.linear(rbf, w_dist) + F.linear(sinus, w_beta))
+    return single, pair
+
+
+def heads(single, pair, z, mask, wr1, br1, wr2, ws1, bs1, ws2):
+    """modules.py:403 (pair symmetrisation) + model.py:364-374: coordinate update and sequence logits."""
+    pair = 0.5 * (pair + pair.transpose(1, 2))
+    w = F.linear(torch.relu(F.linear(ln(pair), wr1, br1)), wr2)
+    zij = z.unsqueeze(-2) - z.unsqueeze(-3)
+    r = zij * torch.rsqrt(torch.sum(torch.square(zij), -1, keepdim=True) + 1e-4)
+    m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
+    eps = (m2 * w * r).sum(dim=2)
+    m = mask.unsqueeze(-1)
+    eps = eps - m * (m * eps).sum(dim=1, keepdim=True) / m.sum(dim=1, keepdim=True)
+    logits = F.linear(torch.relu(F.linear(ln(single), ws1, bs1)), ws2)
+    return eps, logits

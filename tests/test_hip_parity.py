@@ -30,8 +30,8 @@ CFG = {
 }
 
 
-def build(args, seed):
-    params = deterministic_state_dict(spec_tensors(args), seed=seed)
+def build(args, seed, style="random"):
+    params = deterministic_state_dict(spec_tensors(args), seed=seed, style=style)
     model = ProteinReDiffModel(args)
     model.load_state_dict(params)
     return model.to(DEV).eval(), params
@@ -39,6 +39,17 @@ def build(args, seed):
 
 def cu(x):
     return x.to(DEV).contiguous()
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def gemm_mode(request):
+    """Row-GEMM arithmetic of the pair kernels (prd_hip.h: prd_set_gemm_mode): fp32 MFMA, or the exact three-way bf16 split on
+    the bf16 matrix pipe.  Both must meet every tolerance; the mode is restored afterwards."""
+    from protein_redesign_amd import _lib
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(1 if request.param == "bf16x3" else 0) == 0
+    yield request.param
+    assert _lib.lib().prd_set_gemm_mode(prev) == 0
 
 
 @pytest.fixture(scope="module", params=[32, 64])
@@ -159,7 +170,7 @@ def test_outer_linear(setup):
 
 
 @pytest.mark.parametrize("mode", ["outgoing", "incoming"])
-def test_triangle_multiplication(setup, mode):
+def test_triangle_multiplication(setup, mode, gemm_mode):
     s = setup
     mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_mul_{mode}")
     m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
@@ -169,7 +180,7 @@ def test_triangle_multiplication(setup, mode):
 
 
 @pytest.mark.parametrize("mode", ["starting", "ending"])
-def test_triangle_attention(setup, mode):
+def test_triangle_attention(setup, mode, gemm_mode):
     s = setup
     mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
     m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
@@ -187,7 +198,7 @@ def test_pair_transition(setup):
 
 
 @pytest.mark.parametrize("scale", [30.0, 400.0])
-def test_triangle_attention_large_logit_spread(setup, scale):
+def test_triangle_attention_large_logit_spread(setup, scale, gemm_mode):
     """Key loop with a frozen reference maximum: logits that rise far above those of the first 64-key block.  scale = 30:
     p > 1 inside the fast path; scale = 400: the spread passes the fp32 exponent range, the sum overflows and the wave
     must redo its tiles with the online update (the oracle's softmax is stable either way)."""
@@ -206,7 +217,7 @@ def test_triangle_attention_large_logit_spread(setup, scale):
     assert rel_l2(got.cpu(), want) < 5 * OP_TOL
 
 
-def test_triangle_attention_row_longer_than_one_round(setup):
+def test_triangle_attention_row_longer_than_one_round(setup, gemm_mode):
     """N = 400: 13 key blocks on a 12-wave workgroup = one whole round of projection blocks + one block split in halves over
     two waves; 25 query tiles dealt two per wave; still the short-row kernel (K / V / Q / gate of a row fit the LDS)."""
     s = setup
@@ -345,7 +356,7 @@ def test_single_pair_attention(setup):
     assert rel_l2(got.cpu(), want) < OP_TOL
 
 
-def test_folding_block(setup):
+def test_folding_block(setup, gemm_mode):
     s = setup
     with torch.inference_mode():
         ws, wp = O.folding_block(s["params"], "Denoiser.folding_blocks.0", s["single"], s["pair"], s["mask"],
@@ -355,7 +366,7 @@ def test_folding_block(setup):
     assert rel_l2(gp.cpu(), wp) < BLOCK_TOL
 
 
-def test_denoiser(setup):
+def test_denoiser(setup, gemm_mode):
     s = setup
     with torch.inference_mode():
         ws, wp = O.denoiser(s["params"], s["args"], s["single"], s["pair"], s["mask"])
@@ -397,21 +408,10 @@ def test_input_embedding_and_heads(setup):
 # whole step and trajectory vs the golden vectors of the imported reference
 # ---------------------------------------------------------------------------------------------------
 
-@pytest.fixture(params=["fp32", "bf16x3"])
-def gemm_mode(request):
-    """Row-GEMM arithmetic of the pair kernels (prd_hip.h: prd_set_gemm_mode): fp32 MFMA, or the exact three-way bf16 split on
-    the bf16 matrix pipe.  Both must meet every tolerance; the mode is restored afterwards."""
-    from protein_redesign_amd import _lib
-    prev = _lib.lib().prd_get_gemm_mode()
-    assert _lib.lib().prd_set_gemm_mode(1 if request.param == "bf16x3" else 0) == 0
-    yield request.param
-    assert _lib.lib().prd_set_gemm_mode(prev) == 0
-
-
 def golden_case(golden, name):
     case, z = golden(name)
     args = make_args(**case["args"])
-    model, params = build(args, case["weight_seed"])
+    model, params = build(args, case["weight_seed"], case.get("weight_style", "random"))
     return case, z, args, model, params
 
 
@@ -429,13 +429,50 @@ def test_network_step_vs_reference_golden(golden, name, gemm_mode):
     assert rel_l2(logits.cpu(), z["step_seq_pred"]) < BLOCK_TOL * 2
 
 
-@pytest.mark.parametrize("name", ["small32", "small64", "cfg1", "cfg1_t200", "cfg1_t1000"])
+@pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
 def test_trajectory_vs_reference_golden(golden, name, gemm_mode):
+    """Free-running ``sample()`` against the reference's, T = 8-10.  (Longer loops: the segment test below.)"""
     case, z, args, model, params = golden_case(golden, name)
     one = batch_to(synthetic_batch([tuple(case["traj_sample"])], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500), DEV)
     pos, logits = model.sample(one, sources=[NoiseSource(NOISE_SEED, 0)])
     assert rel_l2(pos.cpu(), z["traj_pos"]) < TRAJ_TOL
     assert rel_l2(logits.cpu(), z["traj_logits"]) < TRAJ_TOL
+
+
+@pytest.mark.parametrize("name", ["cfg1_t200", "cfg1_t1000", "cfg1_t200_random"])
+def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
+    """T = 200 and T = 1000 (BASELINE configs[1]'s num_steps): every stretch of the loop, each restarted from the REFERENCE's own
+    state (stored every 10 / 25 steps); the state the HIP path reaches at the next stored step must agree to 1e-4.  With
+    UNTRAINED weights (no checkpoint is obtainable) the free-running loop is ill-conditioned whatever the implementation: the
+    imported reference itself, restarted from a z_T perturbed by 1e-6, ends 3e-3 (random weights) / 1.4e-2 (near-initialisation
+    weights: the point cloud collapses and the unit directions z_ij / |z_ij| of the coordinate head lose their meaning) away
+    from its own unperturbed run after 200 steps (DESIGN.md §2).  Segment-wise agreement is the statement that survives;
+    the free-running deviation is printed for the record."""
+    from protein_redesign_amd.diffusion_model import ReverseDiffusion
+    case, z, args, model, params = golden_case(golden, name)
+    one = batch_to(synthetic_batch([tuple(case["traj_sample"])], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500), DEV)
+    loop = ReverseDiffusion(model, one, [NoiseSource(NOISE_SEED, 0)])
+    steps = [int(v) for v in z["seg_step"]]
+    seg_z, seg_s = torch.from_numpy(z["seg_z"]), torch.from_numpy(z["seg_seq_t"])
+    assert steps[0] == 0 and rel_l2(loop.z.cpu(), seg_z[0:1]) < 1e-6 and rel_l2(loop.seq_t.cpu(), seg_s[0:1]) < 1e-6
+    worst = 0.0
+    with torch.inference_mode():
+        for k, start in enumerate(steps):
+            end = steps[k + 1] if k + 1 < len(steps) else args["num_steps"]
+            loop.restart(start, seg_z[k:k + 1], seg_s[k:k + 1])
+            while loop.steps_done < end:
+                loop.step()
+            if k + 1 < len(steps):
+                ez, es = rel_l2(loop.z.cpu(), seg_z[k + 1:k + 2]), rel_l2(loop.seq_t.cpu(), seg_s[k + 1:k + 2])
+            else:
+                pos, logits = loop.result()
+                ez, es = rel_l2(pos.cpu(), z["traj_pos"]), rel_l2(logits.cpu(), z["traj_logits"])
+            worst = max(worst, ez, es)
+            assert ez < TRAJ_TOL and es < TRAJ_TOL, (start, end, ez, es)
+        loop.restart(0, seg_z[0:1], seg_s[0:1])
+        loop.run()
+        pos, _ = loop.result()
+    print(f"\n{name} [{gemm_mode}]: worst segment rel-L2 {worst:.2e}; free-running final positions vs reference {rel_l2(pos.cpu(), z['traj_pos']):.2e}")
 
 
 @pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])

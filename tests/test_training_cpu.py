@@ -1,0 +1,142 @@
+"""CPU checks of the training step's backward machinery (SURVEY.md §8f "next" #1), without a GPU:
+
+* torch_ref.py (the differentiable restatement a HIP operator's backward recomputes) + the HipOp / per-block checkpoint wiring
+  of training.py against the ORACLE's autograd: loss value and the gradient of every trainable tensor.  The HIP forwards
+  cannot run here, so the test swaps ``training.HipOp`` for a double that evaluates the restatement in ``forward`` as well --
+  the product code itself has no such switch;
+* the oracle's loss + gradients against the fingerprints captured from the imported reference (tests/golden/*.npz);
+* the data-parallel gradient average over a world-size-2 gloo group.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import prd_oracle as O
+from conftest import rel_l2
+from protein_redesign_amd import training
+from protein_redesign_amd.constants import make_args
+from protein_redesign_amd.diffusion_model import ProteinReDiffModel
+from protein_redesign_amd.synthetic import NoiseSource, deterministic_state_dict, synthetic_batch
+from protein_redesign_amd.weights import spec_tensors
+
+NOISE_SEED = 7
+GRAD_PROJECTIONS = 4
+
+
+class _RefOp(torch.autograd.Function):
+    """Test double of training.HipOp: same contract, but ``forward`` evaluates the torch restatement (no GPU here)."""
+
+    @staticmethod
+    def forward(ctx, fwd, ref, *tensors):
+        ctx.ref = ref
+        ctx.save_for_backward(*tensors)
+        with torch.no_grad():
+            return ref(*[t.detach() for t in tensors])
+
+    backward = training.HipOp.backward
+
+
+def oracle_training_loss(params, args, pb, t, nz, ns):
+    """model.py:528-549 on the oracle: mean over the batch of diffusion_loss / node count."""
+    diff = O.diffusion_loss(params, args, pb, t, nz, ns)
+    return torch.mean(diff / (pb["residue_and_atom_mask"] > 0.5).sum(-1))
+
+
+def case_inputs(golden, name):
+    case, z = golden(name)
+    args = make_args(**case["args"])
+    params = deterministic_state_dict(spec_tensors(args), seed=case["weight_seed"], style=case.get("weight_style", "random"))
+    sizes = [tuple(s) for s in case["sizes"]]
+    batch = synthetic_batch(sizes, esm_dim=args["esm_dim"], seed=case["batch_seed"], n_total=case["n_total"])
+    perms = [NoiseSource(NOISE_SEED, 100 + k).randperm(n) for k, (_, n) in enumerate(sizes)]
+    pb = O.prepare_batch(batch, args["mask_prob"], perms)
+    return case, z, args, params, pb
+
+
+def oracle_grads(args, params, pb, t, nz, ns):
+    leaf = {k: v.clone().requires_grad_(k not in ("embed_beta.0.weight", "embed_dist.0.center")) for k, v in params.items()}
+    loss = oracle_training_loss(leaf, args, pb, t, nz, ns)
+    loss.backward()
+    return float(loss), {k: v.grad for k, v in leaf.items() if v.requires_grad}
+
+
+@pytest.mark.parametrize("name", ["tiny", "small32"])
+def test_backward_wiring_matches_oracle_autograd(golden, name, monkeypatch):
+    case, z, args, params, pb = case_inputs(golden, name)
+    t = torch.from_numpy(z["train_t"])
+    nz, ns = torch.from_numpy(z["train_noise_z"]), torch.from_numpy(z["train_noise_seq"])
+    want_loss, want = oracle_grads(args, params, pb, t, nz, ns)
+    monkeypatch.setattr(training, "HipOp", _RefOp)
+    model = ProteinReDiffModel(args)
+    model.load_state_dict(params)
+    model.run_setup_schedule()
+    model.setup_schedule = True
+    diff = model.diffusion_loss(dict(pb), pb["x"], pb["residue_and_atom_mask"], t, nz, ns)
+    loss = torch.mean(diff / (pb["residue_and_atom_mask"] > 0.5).sum(-1))
+    loss.backward()
+    assert abs(float(loss) - want_loss) < 1e-5 * abs(want_loss)
+    got = {k: p.grad for k, p in model.named_parameters() if p.requires_grad}
+    assert sorted(got) == sorted(want) and len(got) == len(list(model.parameters())) - 2
+    scale = float(torch.cat([g.reshape(-1) for g in want.values()]).double().norm())
+    for k in want:
+        assert got[k] is not None, k
+        # fp32 autograd of two op orders; tensors whose exact gradient is zero (e.g. a bias in front of a LayerNorm) hold round-off only
+        err = float((got[k].double() - want[k].double()).norm())
+        assert err < 2e-4 * float(want[k].double().norm()) + 1e-7 * scale, (k, err, float(want[k].norm()))
+
+
+@pytest.mark.parametrize("name", ["tiny", "small32", "small64", "cfg1"])
+def test_oracle_gradients_match_reference_fingerprints(golden, name):
+    """The oracle's autograd against the imported reference's training_step: loss and, for each of the trainable tensors, the
+    gradient norm and four seeded random projections (oracle/gen_golden.py: grad_fingerprint)."""
+    case, z, args, params, pb = case_inputs(golden, name)
+    t = torch.from_numpy(z["train_t"])
+    loss, grads = oracle_grads(args, params, pb, t, torch.from_numpy(z["train_noise_z"]), torch.from_numpy(z["train_noise_seq"]))
+    assert abs(loss - float(z["train_loss"])) < 1e-5 * abs(float(z["train_loss"]))
+    names = json.loads(str(z["train_grad_names"]))
+    assert sorted(names) == sorted(grads)
+    scale = float(np.linalg.norm(z["train_grad_norm"]))
+    for i, k in enumerate(names):
+        g = grads[k].double().reshape(-1)
+        n_ref = float(z["train_grad_norm"][i])
+        assert abs(float(g.norm()) - n_ref) < 2e-4 * n_ref + 1e-7 * scale, (k, float(g.norm()), n_ref)
+        for j in range(GRAD_PROJECTIONS):
+            gen = torch.Generator().manual_seed(4242 + 16 * i + j)
+            proj = float(torch.dot(g, torch.randn(g.numel(), generator=gen, dtype=torch.float64)))
+            assert abs(proj - float(z["train_grad_proj"][i, j])) < 2e-4 * n_ref + 1e-7 * scale, (k, j)
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+    unused = torch.nn.Parameter(torch.zeros(4))                  # never touched on rank 1: still part of the reduced layout
+    x = torch.arange(10.0).view(2, 5) + rank
+    loss = lin(x).square().sum() + (unused.sum() if rank == 0 else 0.0)
+    loss.backward()
+    training.all_reduce_gradients([lin.weight, lin.bias, frozen, unused])
+    torch.save({"w": lin.weight.grad, "b": lin.bias.grad, "u": unused.grad}, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_average_over_two_ranks(tmp_path):
+    port = 29700 + (os.getpid() % 500)
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = (torch.load(os.path.join(str(tmp_path), f"g{r}.pt")) for r in range(2))
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    want_w = torch.zeros_like(lin.weight)
+    for rank in range(2):
+        lin.zero_grad()
+        lin((torch.arange(10.0).view(2, 5) + rank)).square().sum().backward()
+        want_w += lin.weight.grad / 2
+    assert torch.allclose(g0["w"], want_w, rtol=1e-6) and torch.equal(g0["w"], g1["w"]) and torch.equal(g0["b"], g1["b"])
+    assert torch.allclose(g0["u"], torch.full((4,), 0.5)) and torch.equal(g0["u"], g1["u"])

@@ -1,0 +1,103 @@
+"""GPU: the optimisation step (SURVEY.md §8f "next" #1, BASELINE configs[3]).  ``training_step`` runs the HIP forward with one
+autograd node per operator and per-block recompute (training.py); its loss and the gradient of EVERY trainable tensor are held
+against (a) the fingerprints captured from the imported reference's ``training_step`` (tests/golden, oracle/gen_golden.py) and
+(b) the oracle's autograd, tensor by tensor."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import prd_oracle as O
+from conftest import rel_l2
+from protein_redesign_amd import training
+from protein_redesign_amd.constants import make_args
+from protein_redesign_amd.diffusion_model import ProteinReDiffModel
+from protein_redesign_amd.synthetic import NoiseSource, batch_to, deterministic_state_dict, synthetic_batch
+from protein_redesign_amd.weights import spec_tensors
+from test_training_cpu import GRAD_PROJECTIONS, NOISE_SEED, case_inputs, oracle_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GRAD_TOL = 1e-4
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def gemm_mode(request):
+    from protein_redesign_amd import _lib
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES[request.param]) == 0
+    yield request.param
+    assert _lib.lib().prd_set_gemm_mode(prev) == 0
+
+
+def hip_model(args, params):
+    model = ProteinReDiffModel(args)
+    model.load_state_dict(params)
+    model = model.to(DEV).train()
+    model.run_setup_schedule()
+    model.setup_schedule = True
+    return model
+
+
+@pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
+def test_training_step_gradients_vs_reference_and_oracle(golden, name, gemm_mode):
+    case, z, args, params, pb = case_inputs(golden, name)
+    t = torch.from_numpy(z["train_t"])
+    nz, ns = torch.from_numpy(z["train_noise_z"]), torch.from_numpy(z["train_noise_seq"])
+    want_loss, want = oracle_grads(args, params, pb, t, nz, ns)
+    model = hip_model(args, params)
+    dpb = batch_to(pb, DEV)
+    mask = dpb["residue_and_atom_mask"]
+    diff = model.diffusion_loss(dpb, dpb["x"], mask, t.to(DEV), nz.to(DEV), ns.to(DEV))
+    loss = torch.mean(diff / (mask > 0.5).sum(-1))
+    loss.backward()
+    assert abs(float(loss) - float(z["train_loss"])) < GRAD_TOL * abs(float(z["train_loss"]))
+    got = {k: p.grad for k, p in model.named_parameters() if p.requires_grad}
+    names = json.loads(str(z["train_grad_names"]))
+    assert sorted(got) == sorted(names) and all(g is not None for g in got.values())
+    scale = float(np.linalg.norm(z["train_grad_norm"]))
+    worst = 0.0
+    for i, k in enumerate(names):
+        g = got[k].detach().cpu().double().reshape(-1)
+        # (b) the whole tensor against the oracle's autograd; exactly-zero gradients hold round-off only
+        err = float((g - want[k].double().reshape(-1)).norm())
+        ref = float(want[k].double().norm())
+        assert err < GRAD_TOL * ref + 1e-6 * scale, (k, err, ref)
+        worst = max(worst, err / max(ref, 1e-3 * scale))
+        # (a) norm and seeded projections against the imported reference's training_step
+        n_ref = float(z["train_grad_norm"][i])
+        assert abs(float(g.norm()) - n_ref) < 2 * GRAD_TOL * n_ref + 1e-6 * scale, (k, float(g.norm()), n_ref)
+        for j in range(GRAD_PROJECTIONS):
+            gen = torch.Generator().manual_seed(4242 + 16 * i + j)
+            proj = float(torch.dot(g, torch.randn(g.numel(), generator=gen, dtype=torch.float64)))
+            assert abs(proj - float(z["train_grad_proj"][i, j])) < 2 * GRAD_TOL * n_ref + 1e-6 * scale, (k, j)
+    print(f"\n{name} [{gemm_mode}]: {len(names)} gradients, worst rel-L2 vs oracle autograd {worst:.2e}")
+
+
+def test_training_step_api_and_optimizer_step():
+    """training_step(batch, batch_idx) -> scalar loss (model.py:528-549), Adam + LinearLR + EMA as configure_optimizers /
+    optimizer_step wire them (model.py:203-217): a few steps on one synthetic batch lower the loss and move the EMA."""
+    args = make_args(single_dim=64, pair_dim=32, num_blocks=2, esm_dim=16, num_steps=50, mask_prob=0.3, learning_rate=1e-3,
+                     warmup_steps=2)
+    params = deterministic_state_dict(spec_tensors(args), seed=5, style="near_init")
+    model = hip_model(args, params)
+    cfg = model.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    batch = batch_to(synthetic_batch([(4, 18), (3, 14)], esm_dim=16, seed=6, n_total=24), DEV)
+    g = torch.Generator().manual_seed(3)
+    t = torch.tensor([11, 30], device=DEV)
+    nz = O.remove_mean(torch.randn(2, 24, 3, generator=g), (batch["atom_mask"] + batch["residue_mask"]).cpu()).to(DEV)
+    ns = O.remove_mean(torch.randn(2, 24, 21, generator=g), batch["residue_mask"].cpu()).to(DEV)
+    shadow0 = [s.clone() for s in model.ema.shadow]
+    losses = []
+    for step in range(4):
+        src = [NoiseSource(1, k) for k in range(2)]
+        losses.append(float(training.fit_step(model, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, step,
+                                              opt, sched, t=t, noise_z=nz, noise_seq=ns, sources=src)))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert model.ema.num_updates == 4
+    assert any(not torch.equal(a, b) for a, b in zip(shadow0, model.ema.shadow))
+    # free-running call (noise, t and mask drawn internally) returns a scalar with a graph
+    loss = model.training_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0)
+    assert loss.dim() == 0 and loss.requires_grad

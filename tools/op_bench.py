@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Time single operators of the hot path at the bench shape with HIP events (optionally with an experiment build:
-PRD_LIB=/path/to/lib.so).  usage: op_bench.py [N]"""
+"""Time single operators / kernels of the hot path at the bench shape with HIP events, in both row-GEMM modes (optionally with an
+experiment build: PRD_LIB=/path/to/lib.so).  usage: op_bench.py [N]"""
 import os
 import sys
 
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from protein_redesign_amd import ops  # noqa: E402
+from protein_redesign_amd import _lib, ops  # noqa: E402
 from protein_redesign_amd.constants import make_args  # noqa: E402
 from protein_redesign_amd.diffusion_model import ProteinReDiffModel  # noqa: E402
 from protein_redesign_amd.synthetic import deterministic_state_dict  # noqa: E402
@@ -42,18 +42,29 @@ def main():
     og = torch.empty(1, N, N, 64, device="cuda")
     ta = blk.pair_attn_ending.attn
     pf = blk.pair_fc
-    with torch.inference_mode():
-        res = {
-            "tri_mul(out: proj+contract+out)": timeit(lambda: blk.pair_mul_outgoing.run(pair, mask, residual=True, out=pair, ws=ws)),
-            "tri_attn_core": timeit(lambda: ops.tri_attn_core(pair, mask, ta.weights()[:5], 4, 16, ending=False, og=og)),
-            "outer_linear(+ln+u)": timeit(lambda: blk.outer_linear.run(single, pair, residual=True, out=pair)),
-            "block_tail": timeit(lambda: ops.block_tail_(pair, og, ta.out_proj.weight, ta.out_proj.bias, pf[1].weight, pf[1].bias,
-                                                         pf[3].weight, pf[3].bias, nxt.attn_bias[1].weight, nxt.attn_bias[1].bias)),
-            "tri_attn_out": timeit(lambda: blk.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)),
-            "pair_transition": timeit(lambda: ops.pair_transition(pair, pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias, residual=True, out=pair)),
-        }
-    for k, v in res.items():
-        print(f"{k:36s} {v:9.1f} us")
+    rows = {}
+    for mode in ("fp32", "bf16x3"):
+        _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES[mode])
+        with torch.inference_mode():
+            res = {
+                "tri_mul(out: proj+contract+out)": timeit(lambda: blk.pair_mul_outgoing.run(pair, mask, residual=True, out=pair, ws=ws)),
+                "tri_mul(in)": timeit(lambda: blk.pair_mul_incoming.run(pair, mask, residual=True, out=pair, ws=ws)),
+                "tri_attn_core(start)": timeit(lambda: ops.tri_attn_core(pair, mask, ta.weights()[:5], 4, 16, ending=False, og=og)),
+                "tri_attn_core(end)": timeit(lambda: ops.tri_attn_core(pair, mask, ta.weights()[:5], 4, 16, ending=True, og=og)),
+                "outer_linear(+ln+u)": timeit(lambda: blk.outer_linear.run(single, pair, residual=True, out=pair)),
+                "block_tail": timeit(lambda: ops.block_tail_(pair, og, ta.out_proj.weight, ta.out_proj.bias, pf[1].weight, pf[1].bias,
+                                                             pf[3].weight, pf[3].bias, nxt.attn_bias[1].weight, nxt.attn_bias[1].bias)),
+                "tri_attn(start: core+out)": timeit(lambda: blk.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)),
+                "pair_transition": timeit(lambda: ops.pair_transition(pair, pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias, residual=True, out=pair)),
+            }
+        for k, v in res.items():
+            rows.setdefault(k, {})[mode] = v
+        pair.copy_(torch.randn(1, N, N, 64, generator=g))       # in-place residual updates drift: fresh values per mode
+    print(f"# N = {N}, us per call (HIP events, back to back)")
+    print(f"{'operator':36s} {'fp32':>9s} {'bf16x3':>9s}")
+    for k, v in rows.items():
+        print(f"{k:36s} {v['fp32']:9.1f} {v['bf16x3']:9.1f}")
+    _lib.lib().prd_set_gemm_mode(0)
 
 
 if __name__ == "__main__":
