@@ -133,7 +133,7 @@ int prd_opm_pair(float* out, const float* pair, const float* ab, const float* ma
 int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
                      const float* bias, int residual, int b, int N, int P, int S, int* queue, hipStream_t stream);
 /* TriangleMultiplication (modules.py:262-274): out = (residual ? pair : 0) + update(pair).
- * ws: 4 * b * P * N * round_up(N,32) floats (query prd_workspace_bytes). */
+ * ws: 3 * b * P * N * round_up(N,32) floats (query prd_workspace_bytes). */
 int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w_proj, const float* b_proj,
                 const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
                 const float* w_ogate, const float* b_ogate, int incoming, int residual,

@@ -21,6 +21,7 @@
 #include "prd_common.h"
 #include "../../include/prd_hip.h"
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 #ifdef PRD_TIMING     // diagnostic builds only (tools/ta_timing.py, tools/phase_timing.py): in-kernel cycle stamps
@@ -93,69 +94,11 @@ PRD_DEV void proj_fetch(const ProjTask& t, const float* __restrict__ pair, const
     load_row_cll_buf<P>(rs, valid ? (rowi * P + 4 * hi) * 4u : BUF_OOB, x);
 }
 
-// bf16 x 3 operand planes of the contraction (gemm mode 1): AB3[b][2P channels][N rows u][3 planes][ldn] bf16, zero padded to
-// ldn like the fp32 form.  Written by tri_mul_proj (each value split ONCE, here), read by tri_mul_contract_b3.
-template <int P>
-PRD_DEV void proj_compute_b3(const ProjTask& t, float (&x)[P / 2], float mu, float mv, unsigned short* __restrict__ AB3,
-                             const float* Wpl, const float* Wgl, const float* bpl, const float* bgl,
-                             int N, int ldn, int r, int hi, PhaseTimer& pt) {
-    constexpr int KH = P / 2, OUT = 2 * P;
-    const bool valid = t.vb * 32 + r < N;
-    pt.mark(0);
-    const float m2 = valid ? mu * mv : 0.f;
-    const bool plain = __all(m2 == 1.0f);           // every row of the block valid and unmasked (the common case)
-    pt.mark(1);
-    ln_cll<KH>(x);
-    pt.mark(2);
-    // flipped orientation (rowgemm_b3_t): every register of lane (r, hi) belongs to output channel 32 ob + r; its bias sits at
-    // the CLL position of that channel in the staged vectors
-    const int c = 32 * t.ob + r, f = c >> 2;
-    const int bidx = (f & 1) * P + (f >> 1) * 4 + (c & 3);
-    const float bpv = bpl[bidx], bgv = bgl[bidx];
-    f32x16 ap[1], ag[1];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { ap[0][q] = bpv; ag[0][q] = bgv; }
-    u32x4 xs[3][P / 16];
-    split3_cll<P>(x, xs);
-    rowgemm_b3_t<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, t.ob * 32, xs, ap, r, hi);
-    rowgemm_b3_t<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, t.ob * 32, xs, ag, r, hi);
-    pt.mark(3);
-    // register quad g = rows 8 g + 4 hi + (0..3) of the block = four consecutive contraction indices of channel 32 ob + r
-    const long plane_bytes = (long)ldn * 2;
-    const long chan_bytes = (long)N * 3 * plane_bytes;
-    const prd_rsrc cb = make_rsrc(reinterpret_cast<const char*>(AB3) + (((long)t.bb * OUT + 32 * t.ob) * N + t.u) * 3 * plane_bytes
-                                  + (long)t.vb * 64);
-    const unsigned lane_off = (unsigned)(r * chan_bytes) + hi * 8u;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int q = 4 * g + e;
-            float val = gate_from_scaled(ag[0][q]) * ap[0][q];
-            if (!plain) val *= __shfl(m2, 8 * g + 4 * hi + e);       // mask of THAT row (slow path: masked / edge blocks only)
-            v[e] = val;
-        }
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3(v[0], v[1], h0, m0, l0);
-        split3(v[2], v[3], h1, m1, l1);
-        const unsigned uoff = g * 16u;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, cb, lane_off, uoff, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, cb, lane_off, uoff + (unsigned)plane_bytes, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, cb, lane_off, uoff + 2u * (unsigned)plane_bytes, 0);
-    }
-    pt.mark(4);
-}
-
 template <int P, bool B3>
 PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float mv, float* __restrict__ AB,
                           const float* Wpl, const float* Wgl, const float* bpl, const float* bgl,
                           int N, int ldn, long cstride, unsigned lane_off, int r, int hi, PhaseTimer& pt) {
-    if (B3) {
-        proj_compute_b3<P>(t, x, mu, mv, reinterpret_cast<unsigned short*>(AB), Wpl, Wgl, bpl, bgl, N, ldn, r, hi, pt);
-        return;
-    }
-    constexpr int KH = P / 2;
+    constexpr int KH = P / 2, OUT = 2 * P;
     const bool valid = t.vb * 32 + r < N;
     pt.mark(0);                                     // 0: task fetch / decode, prefetch issue
     const float m2 = valid ? mu * mv : 0.f;
@@ -166,8 +109,15 @@ PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float 
     f32x16 ap[1], ag[1];
     bias_acc(ap, bpl + hi * P + 16 * t.ob);         // biases ride in the accumulators
     bias_acc(ag, bgl + hi * P + 16 * t.ob);
-    rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
-    rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
+    if (B3) {                                       // bf16 x 3 form (prd_common.h): same results to ~1e-7
+        u32x4 xs[3][P / 16];
+        split3_cll<P>(x, xs);
+        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, t.ob * 32, xs, ap, r, hi);
+        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, t.ob * 32, xs, ag, r, hi);
+    } else {
+        rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
+        rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
+    }
     pt.mark(3);                                     // 3: MFMAs
     // output channel of register q: 32*ob + (q&3) + 8*(q>>2) + 4*hi; the hi part sits in lane_off
     const prd_rsrc cb = make_rsrc(AB + ((((long)t.bb * 2 * P) + 32 * t.ob) * N + t.u) * ldn + t.vb * 32);
@@ -356,34 +306,36 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
     }   // virtual blocks
 }
 
-// The same contraction on the bf16 matrix pipe (gemm mode 1): operands are the exact three-way bf16 split written by
-// tri_mul_proj (AB3[b][2P][N][3 planes][ldn]); the six products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulation reproduce the fp32 contraction to ~1e-7 at 16/6 of its matrix rate.
-// 64x64 tile per workgroup, 2x2 waves of 32x32, K in chunks of 32 (two MFMA K steps) through double-buffered LDS.
-// LDS rows are 64 B (32 bf16) without padding; the 16-byte slot j of row r is stored at j ^ ((r >> 2) & 3): the sixteen lanes
-// of a ds_read_b128 group (rows distinct mod 16, same logical slot) then hit sixteen different 4-bank groups.
-__global__ __launch_bounds__(256) void tri_mul_contract_b3_kernel(float* __restrict__ O, const unsigned short* __restrict__ AB3,
-                                                                  int N, int ldn, int P, int nbatch, int tiles) {
-    constexpr int KCH = 32;
-    constexpr int PLANE = 64 * 64;                        // bytes of one operand plane of a 64-row tile chunk
-    __shared__ __attribute__((aligned(16))) unsigned char As[2][3 * PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3 * PLANE];
+// The same contraction on the bf16 matrix pipe (gemm mode 1).  The fp32 operands are split exactly into three bf16 parts while
+// they are staged into LDS (each element is split N / 160 times in total); the six products hi*hi, hi*mid, mid*hi, hi*lo,
+// lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 with fp32 accumulation reproduce the fp32 contraction to ~1e-7 at 16/6 of its
+// matrix rate.  At that rate a 64x64 tile is bound by the CU's 64 B/clk memory path (6 T cycles of loads against
+// 96 (T/32)^2 cycles of MFMAs per 32-wide K chunk), so the tile is 160 x 160: 5 x 5 sub-tiles of 32 x 32 dealt to 8 waves
+// (N = 320: exactly 2 x 2 tiles per channel, one tile per CU), K in chunks of 32 through double-buffered LDS.
+// LDS rows are 64 B (32 bf16) per plane without padding; the 16-byte slot j of row r sits at j ^ ((r >> 2) & 3), so the
+// sixteen lanes of a ds_read_b128 group (rows distinct mod 16, same logical slot) hit sixteen different 4-bank groups.
+constexpr int TMS_T = 160, TMS_PLANE = TMS_T * 64, TMS_OPER = 3 * TMS_PLANE;       // bytes
+__global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __restrict__ O, const float* __restrict__ AB,
+                                                                     int N, int ldn, int P, int nbatch, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tms[];          // [2 buffers][A | B][3 planes][160 rows][64 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int nch = nbatch * P;
     const int t2 = tiles * tiles;
-    const unsigned plane_bytes = (unsigned)ldn * 2u, row_bytes = 3u * plane_bytes;
-    // staging: 768 16-byte pieces per operand and chunk (64 rows x 3 planes x 4 slots), 3 per thread
-    unsigned srow[3], sdst[3], ssrc[3];
+    // staging: 2 x 160 rows x 8 pieces of 4 floats per chunk = 2560 pieces, 5 per thread.  Piece p = tid + 512 i:
+    // i = 0, 1 -> A rows, i = 2 -> A (waves 0-3) or B (waves 4-7), i = 3, 4 -> B rows: the operand is wave-uniform.
+    unsigned srow[5], sdst[5], ssrc[5];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx / 12, rem = idx - row * 12, pl = rem >> 2, slot = rem & 3;
+    for (int i = 0; i < 5; ++i) {
+        const int p = tid + 512 * i;
+        const int oper = p >= 1280 ? 1 : 0, q = p - 1280 * oper;
+        const int row = q >> 3, f = q & 7;
         srow[i] = row;
-        sdst[i] = pl * PLANE + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-        ssrc[i] = row * row_bytes + pl * plane_bytes + slot * 16;
+        sdst[i] = oper * TMS_OPER + row * 64 + (((f >> 1) ^ ((row >> 2) & 3)) << 4) + (f & 1) * 8;
+        ssrc[i] = ((unsigned)row * ldn + 4 * f) * 4u;
     }
+    const bool mid_is_b = wave >= 4;
+    const unsigned swz = (unsigned)((r >> 2) & 3);
     for (int vblk = blockIdx.x; vblk < nch * t2; vblk += gridDim.x) {
         int ch, tile;
         if ((nch & 7) == 0 && (gridDim.x & 7) == 0) {     // the tiles of one channel stay on one XCD (they share A / B in L2)
@@ -395,74 +347,99 @@ __global__ __launch_bounds__(256) void tri_mul_contract_b3_kernel(float* __restr
             tile = vblk % t2;
         }
         const int bb = ch / P, d = ch - bb * P;
-        const int m0 = (tile / tiles) * 64, n0 = (tile % tiles) * 64;
-        const unsigned char* A = reinterpret_cast<const unsigned char*>(AB3) + ((size_t)bb * 2 * P + d) * N * row_bytes;
-        const unsigned char* B = reinterpret_cast<const unsigned char*>(AB3) + ((size_t)bb * 2 * P + P + d) * N * row_bytes;
-        const prd_rsrc ra = make_rsrc(A + (size_t)m0 * row_bytes), rb = make_rsrc(B + (size_t)n0 * row_bytes);
-        unsigned oa[3], ob[3];
+        const int m0 = (tile / tiles) * TMS_T, n0 = (tile % tiles) * TMS_T;
+        const float* __restrict__ A = AB + ((size_t)bb * 2 * P + d) * N * ldn;
+        const float* __restrict__ B = AB + ((size_t)bb * 2 * P + P + d) * N * ldn;
+        const prd_rsrc ra = make_rsrc(A + (size_t)m0 * ldn), rb = make_rsrc(B + (size_t)n0 * ldn);
+        const prd_rsrc rmid = mid_is_b ? rb : ra;
+        unsigned off[5];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            oa[i] = (m0 + (int)srow[i] < N) ? ssrc[i] : BUF_OOB;     // rows past the edge load zeros
-            ob[i] = (n0 + (int)srow[i] < N) ? ssrc[i] : BUF_OOB;
+        for (int i = 0; i < 5; ++i) {
+            const bool isb = i > 2 || (i == 2 && mid_is_b);
+            off[i] = ((isb ? n0 : m0) + (int)srow[i] < N) ? ssrc[i] : BUF_OOB;        // rows past the edge load zeros
         }
-        f32x16 acc;
+        // sub-tiles of this wave: s = wave + 8 k (k < 4) of the 5 x 5 grid, skipped when outside the matrix
+        int si[4], sj[4];
+        bool sv[4];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-        const int nchunk = ldn / KCH;
-        u32x4 ua[3], ub[3], va[3], vb[3];
-#define PRD_C3_LOAD(R, C)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                         \
-        R##a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, oa[i], (C) * 64, 0)); \
-        R##b[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ob[i], (C) * 64, 0)); \
+        for (int k = 0; k < 4; ++k) {
+            const int s_ = wave + 8 * k;
+            si[k] = s_ / 5;
+            sj[k] = s_ - 5 * si[k];
+            sv[k] = s_ < 25 && m0 + 32 * si[k] < N && n0 + 32 * sj[k] < N;
+        }
+        f32x16 acc[4];
+        zero_acc(acc);
+        const int nchunk = ldn / 32;
+        u32x4 u[5], v[5];
+#define PRD_TMS_LOAD(R, C)                                                                                          \
+    R[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[0], (C) * 128, 0));              \
+    R[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[1], (C) * 128, 0));              \
+    R[2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rmid, off[2], (C) * 128, 0));            \
+    R[3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[3], (C) * 128, 0));              \
+    R[4] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[4], (C) * 128, 0));
+        // four fp32 values -> three planes of four bf16 (8 bytes each)
+#define PRD_TMS_STAGE(R, BUF)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                                 \
+        unsigned h0, m0_, l0, h1, m1_, l1;                                                                          \
+        split3(__uint_as_float(R[i][0]), __uint_as_float(R[i][1]), h0, m0_, l0);                                    \
+        split3(__uint_as_float(R[i][2]), __uint_as_float(R[i][3]), h1, m1_, l1);                                    \
+        unsigned char* dst = tms + (BUF) * 2 * TMS_OPER + sdst[i];                                                  \
+        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};                                                             \
+        *reinterpret_cast<u32x2*>(dst + TMS_PLANE) = u32x2{m0_, m1_};                                               \
+        *reinterpret_cast<u32x2*>(dst + 2 * TMS_PLANE) = u32x2{l0, l1};                                             \
     }
-#define PRD_C3_STAGE(R, BUF)                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                         \
-        *reinterpret_cast<u32x4*>(&As[BUF][sdst[i]]) = R##a[i];                                             \
-        *reinterpret_cast<u32x4*>(&Bs[BUF][sdst[i]]) = R##b[i];                                             \
+#define PRD_TMS_CHUNK(C, CUR, R, NX)                                                                                \
+    {                                                                                                               \
+        const int c2 = (C) + 2 < nchunk ? (C) + 2 : nchunk - 1;                                                     \
+        PRD_TMS_LOAD(NX, c2)                                                                                        \
+        const unsigned char* base = tms + (CUR) * 2 * TMS_OPER;                                                     \
+        _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                          \
+            const unsigned col = (((unsigned)(2 * st + hi)) ^ swz) << 4;                                            \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                         \
+                if (sv[k]) {                                                                                        \
+                    const unsigned char* ap = base + (32 * si[k] + r) * 64 + col;                                   \
+                    const unsigned char* bp = base + TMS_OPER + (32 * sj[k] + r) * 64 + col;                        \
+                    u32x4 a[3], bq[3];                                                                              \
+                    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                              \
+                        a[pl] = *reinterpret_cast<const u32x4*>(ap + pl * TMS_PLANE);                               \
+                        bq[pl] = *reinterpret_cast<const u32x4*>(bp + pl * TMS_PLANE);                              \
+                    }                                                                                               \
+                    const int pa[6] = {0, 0, 1, 0, 2, 1}, pb[6] = {0, 1, 0, 2, 0, 1};                               \
+                    _Pragma("unroll") for (int t = 0; t < 6; ++t)                                                   \
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[pa[t]]),      \
+                                                                         __builtin_bit_cast(bf16x8, bq[pb[t]]), acc[k], 0, 0, 0); \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        if ((C) + 1 < nchunk) { PRD_TMS_STAGE(R, (CUR) ^ 1) }                                                       \
+        __syncthreads();                                                                                            \
     }
-        // one chunk: loads of chunk c+2 are issued, chunk c is multiplied out of buffer CUR, register set R (chunk c+1) goes to
-        // the other buffer (the scheme of the fp32 kernel above)
-#define PRD_C3_CHUNK(C, CUR, R, NX)                                                                         \
-    {                                                                                                       \
-        const int c2 = (C) + 2 < nchunk ? (C) + 2 : nchunk - 1;                                             \
-        PRD_C3_LOAD(NX, c2)                                                                                 \
-        const int ar = wm0 + r, br = wn0 + r;                                                               \
-        _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                  \
-            const int j = 2 * st + hi;                                                                      \
-            u32x4 a[3], bq[3];                                                                              \
-            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                              \
-                a[pl] = *reinterpret_cast<const u32x4*>(&As[CUR][pl * PLANE + ar * 64 + ((j ^ ((ar >> 2) & 3)) << 4)]); \
-                bq[pl] = *reinterpret_cast<const u32x4*>(&Bs[CUR][pl * PLANE + br * 64 + ((j ^ ((br >> 2) & 3)) << 4)]); \
-            }                                                                                               \
-            const int pa[6] = {0, 0, 1, 0, 2, 1}, pb[6] = {0, 1, 0, 2, 0, 1};                               \
-            _Pragma("unroll") for (int t = 0; t < 6; ++t)                                                   \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[pa[t]]),          \
-                                                              __builtin_bit_cast(bf16x8, bq[pb[t]]), acc, 0, 0, 0); \
-        }                                                                                                   \
-        if ((C) + 1 < nchunk) { PRD_C3_STAGE(R, (CUR) ^ 1) }                                                \
-        __syncthreads();                                                                                    \
-    }
-        PRD_C3_LOAD(u, 0)
-        PRD_C3_STAGE(u, 0)
+        PRD_TMS_LOAD(u, 0)
+        PRD_TMS_STAGE(u, 0)
         {
             const int c1 = 1 < nchunk ? 1 : 0;
-            PRD_C3_LOAD(u, c1)
+            PRD_TMS_LOAD(u, c1)
         }
         __syncthreads();
         for (int c = 0; c < nchunk; c += 2) {
-            PRD_C3_CHUNK(c, 0, u, v)
-            if (c + 1 < nchunk) PRD_C3_CHUNK(c + 1, 1, v, u)
+            PRD_TMS_CHUNK(c, 0, u, v)
+            if (c + 1 < nchunk) PRD_TMS_CHUNK(c + 1, 1, v, u)
         }
-#undef PRD_C3_LOAD
-#undef PRD_C3_STAGE
-#undef PRD_C3_CHUNK
+#undef PRD_TMS_LOAD
+#undef PRD_TMS_STAGE
+#undef PRD_TMS_CHUNK
         float* __restrict__ Oc = O + (size_t)ch * N * ldn;
-        const int n = n0 + wn0 + r;
-        if (n < N) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int m = m0 + wm0 + drow32(q, hi);
-                if (m < N) Oc[(size_t)m * ldn + n] = acc[q];
+        for (int k = 0; k < 4; ++k) {
+            if (!sv[k]) continue;
+            const int n = n0 + 32 * sj[k] + r;
+            if (n < N) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + 32 * si[k] + drow32(q, hi);
+                    if (m < N) Oc[(size_t)m * ldn + n] = acc[k][q];
+                }
             }
         }
     }   // virtual blocks
@@ -1130,29 +1107,34 @@ struct SplitLds {               // byte offsets from the dynamic LDS base
 template <int NTQ, bool MASKED, bool ONLINE>
 PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[3],
                             const u32x4 (&qb)[NTQ][3], int npad, int key0, int ql, int g4,
-                            float (&m_run)[NTQ], float (&l_run)[NTQ], f32x4 (&o)[NTQ], bool& big) {
+                            float (&m_run)[NTQ], float (&l_run)[NTQ], f32x4 (&o)[NTQ][2], bool& big) {
     constexpr int JT = 4;
     ta_prio(npad - key0, npad);
     const float* kadd = reinterpret_cast<const float*>(lds + L.kadd);
     float4 ma[JT];
     f32x4 s[NTQ][JT];
+    u32x4 ka[JT][3];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const unsigned krow = (unsigned)(key0 + 16 * j + ql) * 32u + (unsigned)(g4 & 1) * 16u;
-        const u32x4 ka0 = *reinterpret_cast<const u32x4*>(lds + kbase[0] + krow);
-        const u32x4 ka1 = *reinterpret_cast<const u32x4*>(lds + kbase[1] + krow);
-        const u32x4 ka2 = *reinterpret_cast<const u32x4*>(lds + kbase[2] + krow);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) ka[j][m] = *reinterpret_cast<const u32x4*>(lds + kbase[m] + krow);
         if (MASKED) ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
             const float c0 = ONLINE ? 0.f : -m_run[t];
-            f32x4 z4 = {c0, c0, c0, c0};
-            z4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka0), __builtin_bit_cast(bf16x8, qb[t][0]), z4, 0, 0, 0);
-            z4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka1), __builtin_bit_cast(bf16x8, qb[t][1]), z4, 0, 0, 0);
-            z4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka2), __builtin_bit_cast(bf16x8, qb[t][2]), z4, 0, 0, 0);
-            s[t][j] = z4;
+            s[t][j] = f32x4{c0, c0, c0, c0};
         }
     }
+    // the three MFMAs of a logit tile are issued NTQ * JT independent accumulators apart (no back-to-back dependent pair)
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t)
+                s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j][m]), __builtin_bit_cast(bf16x8, qb[t][m]),
+                                                                  s[t][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);                  // V^T is fetched behind the QK^T MFMAs, not before them
     // A operands of P V: lane (c = ql, g4) holds V^T[c][keys 16 j0 + 4 g4 .. +3 | 16 (j0 + 1) + 4 g4 .. +3] for j0 = 0, 2
     u32x4 vh[2], vl[2];
@@ -1203,7 +1185,7 @@ PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLd
                 }
             l_run[t] = l_run[t] * alpha + (ps.x + ps.y);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[t][e] *= alpha;
+            for (int e = 0; e < 4; ++e) { o[t][0][e] *= alpha; o[t][1][e] *= alpha; }
         } else {
 #pragma unroll
             for (int j = 0; j < JT; ++j)
@@ -1228,9 +1210,9 @@ PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLd
                 ph[2 * hj] = h0; ph[2 * hj + 1] = h1;
                 pl[2 * hj] = l0; pl[2 * hj + 1] = l1;
             }
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, ph), o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, pl), o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl[gi]), __builtin_bit_cast(f16x8, ph), o[t], 0, 0, 0);
+            o[t][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, ph), o[t][gi], 0, 0, 0);
+            o[t][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, pl), o[t][gi], 0, 0, 0);
+            o[t][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl[gi]), __builtin_bit_cast(f16x8, ph), o[t][gi], 0, 0, 0);
         }
     }
 }
@@ -1239,23 +1221,26 @@ template <int NTQ, bool MASKED>
 PRD_DEV void ta_keyloop_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[3],
                               const u32x4 (&qb)[NTQ][3], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
     float m_run[NTQ], l_run[NTQ];
+    f32x4 o2[NTQ][2];                            // one accumulator per 32-key group: two independent MFMA chains per tile
     bool online_all = false;
     while (true) {
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
             m_run[t] = -1e30f;
             l_run[t] = 0.f;
-            o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o2[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         bool big = false;
 #pragma unroll 1
         for (int key0 = 0; key0 < npad; key0 += 64) {
-            if (key0 == 0 || online_all) ta_block_split<NTQ, MASKED, true>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o, big);
-            else ta_block_split<NTQ, MASKED, false>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o, big);
+            if (key0 == 0 || online_all) ta_block_split<NTQ, MASKED, true>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o2, big);
+            else ta_block_split<NTQ, MASKED, false>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o2, big);
         }
         bool bad = big;
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
+            o[t] = o2[t][0] + o2[t][1];
             l_tot[t] = rows4_sum(l_run[t]);
             bad |= !(l_tot[t] < 3.0e38f);
         }
@@ -1264,7 +1249,7 @@ PRD_DEV void ta_keyloop_split(const unsigned char* __restrict__ lds, const Split
     }
 }
 
-template <int P, int NW>
+template <int P, int NW, int NTQ, bool PREFETCH>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -1341,19 +1326,21 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
         for (int e = 0; e < C; ++e) { Gl[v * KP + e] = 0.f; Vh[e * L.vpitch + v] = (_Float16)0.f; Vl[e * L.vpitch + v] = (_Float16)0.f; }
         kadd[v] = -INFINITY;
     }
-    float xnext[KH];
-    {
+    float xnext[PREFETCH ? KH : 1];
+    if (PREFETCH) {
         const long bu0 = slot;
         const int v = first_blk * 32 + r;
         const bool ok = bu0 < nrows && first_blk >= 0 && v < N;
-        load_row_cll<P>(pair + row_pos(ok ? bu0 : 0, ok ? v : 0) * P, hi, ok, xnext);
+        load_row_cll<P>(pair + row_pos(ok ? bu0 : 0, ok ? v : 0) * P, hi, ok, reinterpret_cast<float (&)[KH]>(xnext));
     }
     // per-lane operand bases of the three QK^T MFMAs (see the header comment): A = K planes, B = Q planes
     const unsigned kbase[3] = {L.kp[0], g4 < 2 ? L.kp[1] : L.kp[2], g4 < 2 ? L.kp[1] : L.kp[0]};
     const unsigned qbase[3] = {g4 < 2 ? L.qp[0] : L.qp[1], L.qp[0], g4 < 2 ? L.qp[1] : L.qp[2]};
-    for (long bu = slot; bu < nrows; bu += rstride) {
+    int it = 0;
+    for (long bu = slot; bu < nrows; bu += rstride, ++it) {
         const int bb = (int)(bu / N);
         __syncthreads();                        // previous row's LDS fully consumed (and weights staged)
+        PRD_STAMP(0);
         const float mu = mask[bu];
         // ---- phase 1: project, split, store ----
         for (int un = 0; un < nunits; ++un) {
@@ -1362,9 +1349,9 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
             const int v = vb * 32 + r;
             const bool valid = v < N;
             float x[KH];
-            if (un == 0) {
+            if (PREFETCH && un == 0) {
 #pragma unroll
-                for (int s_ = 0; s_ < KH; ++s_) x[s_] = xnext[s_];
+                for (int s_ = 0; s_ < KH; ++s_) x[s_] = xnext[PREFETCH ? s_ : 0];
             } else {
                 load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
             }
@@ -1426,22 +1413,24 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
                                                                                     gate_from_scaled(acc[0][14]), gate_from_scaled(acc[0][15]));
             }
         }
+        PRD_STAMP(1);
         __syncthreads();
-        {   // next row's first block: in flight during the whole key loop
+        PRD_STAMP(2);
+        if (PREFETCH) {   // next row's first block: in flight during the whole key loop
             const long bun = bu + rstride;
             const int v = first_blk * 32 + r;
             const bool ok = bun < nrows && first_blk >= 0 && v < N;
-            load_row_cll<P>(pair + row_pos(ok ? bun : 0, ok ? v : 0) * P, hi, ok, xnext);
+            load_row_cll<P>(pair + row_pos(ok ? bun : 0, ok ? v : 0) * P, hi, ok, reinterpret_cast<float (&)[KH]>(xnext));
         }
         // ---- phase 2 ----
         bool row_masked = false;
         for (int k = lane; k < npad; k += 64) row_masked |= (kadd[k] != 0.f);
         row_masked = __any(row_masked);
         const float inv_vs = 1.0f / VSCALE;
-        for (int t0 = wave; t0 < ntile; t0 += 2 * NW) {
+        for (int t0 = wave; t0 < ntile; t0 += NTQ * NW) {
             const int t1 = t0 + NW;
             const unsigned half16 = (unsigned)(g4 & 1) * 16u;
-            if (t1 < ntile) {
+            if (NTQ == 2 && t1 < ntile) {
                 u32x4 qb[2][3];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
@@ -1480,6 +1469,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
                 }
             }
         }
+        PRD_STAMP(3);
     }
 }
 
@@ -1682,8 +1672,7 @@ extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P
     (void)S;
     if (!op || b <= 0 || N <= 0) return 0;
     const size_t ldn = (size_t)prd_round_up(N, 32);
-    // "tri_mul": operands (2 units fp32, or 3 units as bf16 x 3 planes in gemm mode 1) + contraction output (1 unit)
-    if (op[0] == 't' && op[4] == 'm') return (size_t)4 * b * P * N * ldn * sizeof(float);
+    if (op[0] == 't' && op[4] == 'm') return (size_t)3 * b * P * N * ldn * sizeof(float);   // "tri_mul": operands a | b + output
     if (op[0] == 't' && op[4] == 'a') return (size_t)b * N * N * 64 * sizeof(float);        // "tri_attn"
     return 0;
 }
@@ -1697,8 +1686,8 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     if (ws_bytes < prd_workspace_bytes("tri_mul", b, N, 0, P)) return PRD_ERR_WORKSPACE;
     const int ldn = prd_round_up(N, 32);
-    float* AB = ws;                                   // fp32: [b][2P][N][ldn];  bf16 x 3: [b][2P][N][3][ldn] bf16 (3 units)
-    float* O = ws + (size_t)3 * b * P * N * ldn;      // [b][P][N][ldn]
+    float* AB = ws;                                   // [b][2P][N][ldn]
+    float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
     const bool b3m = g_gemm_mode.load(std::memory_order_relaxed) == 1;
     {
         constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
@@ -1723,9 +1712,13 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     {
         const int tiles = prd_ceil_div(N, 64);
         const int vblocks = b * P * tiles * tiles;
-        if (b3m)
-            hipLaunchKernelGGL(tri_mul_contract_b3_kernel, dim3(vblocks < 768 ? vblocks : 768), dim3(256), 0, stream, O,
-                               reinterpret_cast<const unsigned short*>(AB), N, ldn, P, b, tiles);
+        if (b3m) {
+            const int tl = prd_ceil_div(N, TMS_T);
+            const int vb3 = b * P * tl * tl;
+            const size_t lds3 = (size_t)4 * TMS_OPER;
+            PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
+            hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl);
+        }
         else
             hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
         int e = (int)hipGetLastError();
@@ -1776,7 +1769,17 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     // 12 waves (3 per SIMD) + next-row prefetch: the ceil(N/16) query tiles dealt in pairs land 5 per SIMD at N = 320
     // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
     if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
-    else if (b3) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 32, 8); }
+    else if (b3) {
+        static const int variant = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;     // tuning only
+        if (P == 64) {
+            if (variant == 1) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 16, 64, 16, 1, false);
+            else if (variant == 2) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 12, 64, 12, 1, false);
+            else if (variant == 3) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 64, 8, 1, true);
+            else PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 64, 8, 2, true);
+        } else {
+            PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 32, 8, 2, true);
+        }
+    }
     else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true, false); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true, false); }
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();

@@ -589,7 +589,8 @@ def test_eight_complexes_per_gpu_equal_single_runs(gemm_mode):
     z8, l8, z0, s0, loop = run(list(range(8)))
     for k in (0, 3, 7):
         z1, l1, *_ = run([k])
-        assert rel_l2(z8[k].cpu(), z1[0].cpu()) < 1e-6 and rel_l2(l8[k].cpu(), l1[0].cpu()) < 1e-6
+        # not bit-identical: the task -> wave assignment (and with it the cooperative leftover path) depends on the batch size
+        assert rel_l2(z8[k].cpu(), z1[0].cpu()) < BLOCK_TOL and rel_l2(l8[k].cpu(), l1[0].cpu()) < BLOCK_TOL
     assert not torch.allclose(z8[0], z8[1])
     with torch.inference_mode():                      # first network step of sample 5 vs the oracle (on this sample's own mask)
         pb = {k: (v[5:6].cpu() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 8 else v) for k, v in loop.batch.items()}

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_workspace_query_is_host_only():
-    assert ops.workspace_bytes("tri_mul", 1, 320, 512, 64) == 4 * 64 * 320 * 320 * 4
+    assert ops.workspace_bytes("tri_mul", 1, 320, 512, 64) == 3 * 64 * 320 * 320 * 4
     assert ops.workspace_bytes("tri_attn", 2, 100, 512, 32) == 2 * 100 * 100 * 64 * 4
 
 

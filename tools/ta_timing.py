@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from protein_redesign_amd import _lib, ops  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 320
+if len(sys.argv) > 2:
+    _lib.lib().prd_set_gemm_mode(int(sys.argv[2]))       # 1: the split-operand kernel
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(0)
 pair = torch.randn(1, N, N, 64, generator=g).to(dev)
