@@ -355,6 +355,87 @@ PRD_DEV void rowgemm_b3_t(const u32x4* Wb, int nout, int row0, const u32x4 (&p)[
         }
 }
 
+// ---- the row GEMM on the fp16 matrix pipe, operands split in two ---------------------------------------------------------
+// x = hi + lo with hi = RTZ_fp16(x) and lo = RTZ_fp16(x - hi) (the subtraction is exact): hi + lo carries 22 bits.  The three
+// products hi*hi, hi*lo, lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation give a row GEMM whose error (2^-22 per
+// operand) is of the size of the fp32 MFMA's own accumulation error, at 16/3 of its rate, and -- unlike the bf16 x 3 form --
+// a weight image of the SAME size as fp32 (2 x 2 bytes), so the kernels whose fp32 weights fill the LDS can use it.
+// Range: fp16 saturates at 65504 (RTZ never produces inf); LayerNorm-ed rows, gated attention outputs, ReLU hidden units and
+// weights are far inside it.  Weights are staged x 16 (exact) so that their small components keep a normal lo part; the
+// factor is taken back out in the epilogue (H2_WSCALE / H2_INV_WSCALE).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr float H2_WSCALE = 16.0f, H2_INV_WSCALE = 1.0f / 16.0f;
+
+PRD_DEV void split2h(float a, float b, unsigned& hi, unsigned& lo) {
+    const f16x2_t h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+}
+// NE CLL elements x[0 .. NE) (NE a multiple of 8) -> 2 planes x NE/8 operand registers of 8 fp16
+template <int NE>
+PRD_DEV void split2h_cll(const float (&x)[NE], u32x4 (&p)[2][NE / 8]) {
+#pragma unroll
+    for (int s = 0; s < NE / 8; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h, l;
+            split2h(x[8 * s + 2 * q], x[8 * s + 2 * q + 1], h, l);
+            p[0][s][q] = h;
+            p[1][s][q] = l;
+        }
+}
+// LDS image of W [nout][K] fp32: plane pl (hi / lo) at Wh + pl * nout * (K/8) (in 16-byte units), row o = K/8 slots of 8 fp16
+// without padding; slot j of row o is stored at j ^ (o & SWZ) with SWZ = min(K/8, 16) - 1... see h2_slot: the sixteen lanes of a
+// ds_read_b128 group read one logical slot of sixteen rows that are distinct mod 16 -> sixteen different 16-byte bank groups.
+template <int K>
+PRD_DEV int h2_slot(int row, int j) {
+    constexpr int SL = K / 8;                     // slots per row (8: K = 64, 32: K = 256)
+    if (SL >= 16) return j ^ (row & 15);
+    return j ^ ((row >> 1) & (SL - 1));           // SL = 8: rows 2a, 2a+1 differ in bit 3 of the bank-group index already
+}
+template <int K>
+PRD_DEV void stage_weight_h2(u32x4* Wh, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads, float scale) {
+    constexpr int S = K / 16;
+    for (int idx = tid; idx < nout * S * 2; idx += nthreads) {
+        const int o = idx / (2 * S), rem = idx - o * (2 * S), st = rem >> 1, h = rem & 1;
+        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 4 * h);        // CLL elements 8st .. 8st+3
+        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 8 + 4 * h);    // 8st+4 .. 8st+7
+        const float v[8] = {scale * g0.x, scale * g0.y, scale * g0.z, scale * g0.w, scale * g1.x, scale * g1.y, scale * g1.z, scale * g1.w};
+        u32x4 ph, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b;
+            split2h(v[2 * q], v[2 * q + 1], a, b);
+            ph[q] = a;
+            pl[q] = b;
+        }
+        const int slot = h2_slot<K>(o, 2 * st + h);
+        Wh[(size_t)o * (K / 8) + slot] = ph;
+        Wh[(size_t)(nout + o) * (K / 8) + slot] = pl;
+    }
+}
+// acc[nb] += W[row0 + 32 nb .. +31][16 S0 .. 16 S1) * x for the split row p (K-steps S0 .. S1 of the image's K)
+template <int K, int NB, int S0, int S1>
+PRD_DEV void rowgemm_h2_part(const u32x4* Wh, int nout, int row0, const u32x4 (&p)[2][S1 - S0], f32x16 (&acc)[NB], int r, int hi) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = S0; s < S1; ++s) {
+            const int o = row0 + nb * 32 + r;
+            const int slot = h2_slot<K>(o, 2 * s + hi);
+            const u32x4 wh = Wh[(size_t)o * (K / 8) + slot], wl = Wh[(size_t)(nout + o) * (K / 8) + slot];
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, p[0][s - S0]), acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, p[1][s - S0]), acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wl), __builtin_bit_cast(f16x8_t, p[0][s - S0]), acc[nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // keeps hipcc from hoisting every LDS read of the unrolled loops (spills)
+        }
+}
+template <int K, int NB>
+PRD_DEV void rowgemm_h2(const u32x4* Wh, int nout, int row0, const u32x4 (&p)[2][K / 16], f32x16 (&acc)[NB], int r, int hi) {
+    rowgemm_h2_part<K, NB, 0, K / 16>(Wh, nout, row0, p, acc, r, hi);
+}
+
 template <int NB>
 PRD_DEV void zero_acc(f32x16 (&acc)[NB]) {
 #pragma unroll

@@ -650,6 +650,101 @@ __global__ __launch_bounds__(NW * 64) void block_tail_kernel(int* queue, float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same row pass on the fp16 matrix pipe (gemm mode 1): every operand split into fp16 hi + lo, three products per GEMM
+// (rowgemm_h2, prd_common.h).  The weight images have the size of the fp32 ones, so W1, W2 and W_o stay resident together
+// (the bf16 x 3 image, 1.5x larger, would not fit the 160 KB of a CU).  Serves prd_block_tail (og given) and
+// prd_pair_transition (og == nullptr: no attention projection, optional residual, out may differ from pair).
+//   raw = pair (+ W_o og + b_o);  out = (residual ? raw : 0) + W_2 relu(W_1 LN(raw) + b_1) + b_2;  bias_out = Linear_h(LN(out))
+// ------------------------------------------------------------------------------------------------
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const float* pair, const float* __restrict__ og,
+                                                               const float* __restrict__ wo, const float* __restrict__ bo,
+                                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               const float* __restrict__ w2, const float* __restrict__ b2,
+                                                               const float* __restrict__ wb, const float* __restrict__ bb_,
+                                                               float* __restrict__ bias_out, int H, long rows, long nn, int residual) {
+    constexpr int KH = P / 2, HID = 4 * P, HH = HID / 2, NB = P / 32, HC = 64;
+    constexpr int PASSES = 4, HBP = HID / 32 / PASSES, HHP = HH / PASSES;     // hidden units per pass: 32 HBP, per lane HHP
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+    u32x4* W1h = reinterpret_cast<u32x4*>(smem_h2);                 // [2][HID][P/8]
+    u32x4* W2h = W1h + 2 * HID * (P / 8);                           // [2][P][HID/8]
+    u32x4* Woh = W2h + 2 * P * (HID / 8);                           // [2][P][HC/8]
+    float* b1l = reinterpret_cast<float*>(Woh + 2 * P * (HC / 8));  // [HID] CLL
+    float* b2l = b1l + HID;                                         // [P] CLL
+    float* bol = b2l + P;                                           // [P] CLL
+    float* wbl = bol + P;                                           // [8][P] CLL (bias head)
+    const int NT = NW * 64;
+    stage_weight_h2<P>(W1h, w1, HID, P, threadIdx.x, NT, H2_WSCALE);
+    stage_weight_h2<HID>(W2h, w2, P, HID, threadIdx.x, NT, H2_WSCALE);
+    if (og) stage_weight_h2<HC>(Woh, wo, P, HC, threadIdx.x, NT, H2_WSCALE);
+    stage_vec_cll(b1l, b1, HID, threadIdx.x, NT);
+    stage_vec_cll(b2l, b2, P, threadIdx.x, NT);
+    stage_vec_cll(bol, og ? bo : nullptr, P, threadIdx.x, NT);
+    if (bias_out)
+        for (int h = 0; h < H; ++h) stage_vec_cll(wbl + h * P, wb + h * P, P, threadIdx.x, NT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long ntask = (rows + 31) / 32;
+    WaveTasks tasks(nullptr, ntask, NW);
+    // the first task's rows are in flight while the weights are staged; afterwards the loads of task i+1 are issued before
+    // task i is computed (vmcnt retires in order: a load issued after a task's stores would wait for all of them)
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        const long pos = task * 32 + r;
+        const bool valid = pos < rows;
+        float raw[KH];
+        load_row_cll<P>(pair + pos * P, hi, valid, raw);
+        if (og) {
+            float xo[HC / 2];
+            load_row_cll<HC>(og + pos * HC, hi, valid, xo);
+            u32x4 os[2][HC / 16];
+            split2h_cll<HC / 2>(xo, os);
+            f32x16 acc[NB];
+            zero_acc(acc);
+            rowgemm_h2<HC, NB>(Woh, P, 0, os, acc, r, hi);
+#pragma unroll
+            for (int s_ = 0; s_ < KH; ++s_) raw[s_] = raw[s_] + (acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bol[hi * KH + s_]);
+        }
+        float x[KH];
+#pragma unroll
+        for (int s_ = 0; s_ < KH; ++s_) x[s_] = raw[s_];
+        ln_cll<KH>(x);
+        u32x4 xs[2][P / 16];
+        split2h_cll<KH>(x, xs);
+        f32x16 acc2[NB];
+        zero_acc(acc2);
+#define PRD_H2_PASS(Q)                                                                                              \
+        {                                                                                                           \
+            float h[HHP];                                                                                           \
+            f32x16 acc[HBP];                                                                                        \
+            zero_acc(acc);                                                                                          \
+            rowgemm_h2<P, HBP>(W1h, HID, (Q) * HBP * 32, xs, acc, r, hi);                                           \
+            _Pragma("unroll") for (int s_ = 0; s_ < HHP; ++s_)                                                      \
+                h[s_] = fmaxf(acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + b1l[hi * HH + (Q) * HHP + s_], 0.f);          \
+            u32x4 hs[2][HHP / 8];                                                                                   \
+            split2h_cll<HHP>(h, hs);                                                                                \
+            rowgemm_h2_part<HID, NB, (Q) * HHP / 8, ((Q) + 1) * HHP / 8>(W2h, P, 0, hs, acc2, r, hi);               \
+        }
+        PRD_H2_PASS(0) PRD_H2_PASS(1) PRD_H2_PASS(2) PRD_H2_PASS(3)
+#undef PRD_H2_PASS
+#pragma unroll
+        for (int s_ = 0; s_ < KH; ++s_) raw[s_] = (residual ? raw[s_] : 0.f) + (acc2[s_ >> 4][s_ & 15] * H2_INV_WSCALE + b2l[hi * KH + s_]);
+        store_row_cll<P>(out + pos * P, hi, valid, raw);
+        if (bias_out) {
+            ln_cll<KH>(raw);
+            const long bb = pos / nn, rem = pos - bb * nn;
+            for (int h = 0; h < H; ++h) {
+                float a = 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < KH; ++s_) a += raw[s_] * wbl[h * P + hi * KH + s_];
+                a = xhalf_sum(a);
+                if (bb_) a += bb_[h];
+                if (valid && hi == 0) bias_out[(bb * H + h) * nn + rem] = a;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // coordinate head: one workgroup per (b,i); 4 waves split the j blocks; fixed-order reduction
 // ------------------------------------------------------------------------------------------------
 template <int P>
@@ -929,10 +1024,31 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
     return (int)hipGetLastError();
 }
 
+namespace {
+template <int P>
+int launch_pair_tail_h2(float* out, const float* pair, const float* og, const float* wo, const float* bo, const float* w1,
+                        const float* b1, const float* w2, const float* b2, const float* bias_w, const float* bias_b,
+                        float* bias_out, int H, long rows, long nn, int residual, hipStream_t stream) {
+    constexpr int NWH = 8;
+    const size_t lds = ((size_t)2 * 4 * P * (P / 8) + (size_t)2 * P * (4 * P / 8) + (size_t)2 * P * 8) * 16 + (size_t)(4 * P + 2 * P + 8 * P) * 4;
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    const int grid = grid_for((rows + 31) / 32, 4, 256);
+    PRD_SET_LDS((pair_tail_h2_kernel<P, NWH>), lds);
+    hipLaunchKernelGGL((pair_tail_h2_kernel<P, NWH>), dim3(grid), dim3(NWH * 64), lds, stream, out, pair, og, wo, bo, w1, b1, w2, b2,
+                       bias_w, bias_b, bias_out, H, rows, nn, residual);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
 extern "C" int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
                                    const float* b2, int residual, int b, int N, int P, int* queue, hipStream_t stream) {
     if (!out || !pair || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
+    if (prd_get_gemm_mode() == 1) {             // split 16-bit operands (fp16 x 2), see pair_tail_h2_kernel
+        const long rows_ = (long)b * N * N;
+        return P == 64 ? launch_pair_tail_h2<64>(out, pair, nullptr, nullptr, nullptr, w1, b1, w2, b2, nullptr, nullptr, nullptr, 0, rows_, (long)N * N, residual, stream)
+                       : launch_pair_tail_h2<32>(out, pair, nullptr, nullptr, nullptr, w1, b1, w2, b2, nullptr, nullptr, nullptr, 0, rows_, (long)N * N, residual, stream);
+    }
     constexpr int NWT = 12;                    // one persistent 12-wave workgroup per CU (weights: 137 KB of LDS at P=64)
     const long rows = (long)b * N * N;
     const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + 5 * P) * sizeof(float);
@@ -953,6 +1069,11 @@ extern "C" int prd_block_tail(float* pair, const float* og, const float* wo, con
     if (!pair || !og || !wo || !bo || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (bias_out && (!bias_w || H <= 0 || H > 8)) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
+    if (prd_get_gemm_mode() == 1) {             // split 16-bit operands (fp16 x 2), see pair_tail_h2_kernel
+        const long rows_ = (long)b * N * N;
+        return P == 64 ? launch_pair_tail_h2<64>(pair, pair, og, wo, bo, w1, b1, w2, b2, bias_w, bias_b, bias_out, H, rows_, (long)N * N, 1, stream)
+                       : launch_pair_tail_h2<32>(pair, pair, og, wo, bo, w1, b1, w2, b2, bias_w, bias_b, bias_out, H, rows_, (long)N * N, 1, stream);
+    }
     constexpr int NWT = 8;
     const long rows = (long)b * N * N;
     const size_t lds = ((size_t)4 * P * (P + 4) + (size_t)P * (4 * P + 4) + (size_t)P * 68 + 6 * P + 8 * P) * sizeof(float);

@@ -163,7 +163,7 @@ def test_single_transition(setup):
     assert rel_l2(got.cpu(), O.transition(s["params"], "Denoiser.folding_blocks.0.single_fc", s["single"])) < OP_TOL
 
 
-def test_outer_linear(setup):
+def test_outer_linear(setup, gemm_mode):
     s = setup
     got = s["model"].Denoiser.folding_blocks[0].outer_linear(cu(s["single"]))
     assert rel_l2(got.cpu(), O.outer_linear(s["params"], "Denoiser.folding_blocks.0.outer_linear", s["single"])) < OP_TOL
@@ -190,7 +190,7 @@ def test_triangle_attention(setup, mode, gemm_mode):
     assert rel_l2(got.cpu(), want) < OP_TOL
 
 
-def test_pair_transition(setup):
+def test_pair_transition(setup, gemm_mode):
     s = setup
     pf = s["model"].Denoiser.folding_blocks[0].pair_fc
     got = ops.pair_transition(cu(s["pair"]), pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias, residual=False)
@@ -236,7 +236,7 @@ def test_triangle_attention_row_longer_than_one_round(setup, gemm_mode):
 
 
 @pytest.mark.parametrize("use_queue", [False, True])
-def test_block_tail_fusion_and_queue_reset(setup, monkeypatch, use_queue):
+def test_block_tail_fusion_and_queue_reset(setup, monkeypatch, use_queue, gemm_mode):
     """Fused tail (ending tri-attn output projection + pair transition + next block's bias) == the three separate
     oracle ops, with the static task order and with the opt-in device task queue; every queue counter is back at
     zero afterwards."""
@@ -343,7 +343,7 @@ def test_bf16x3_gemm_mode_is_fp32_accurate(setup):
     assert _lib.lib().prd_set_gemm_mode(7) != 0
 
 
-def test_outer_product_update(setup):
+def test_outer_product_update(setup, gemm_mode):
     s = setup
     got = s["model"].Denoiser.opm(cu(s["single"]), cu(s["mask"]))
     assert rel_l2(got.cpu(), O.outer_product_update(s["params"], "Denoiser.opm", s["single"], s["mask"])) < OP_TOL
@@ -375,7 +375,7 @@ def test_denoiser(setup, gemm_mode):
     assert rel_l2(gp.cpu(), wp) < BLOCK_TOL
 
 
-def test_input_embedding_and_heads(setup):
+def test_input_embedding_and_heads(setup, gemm_mode):
     s = setup
     m, p, args, pb = s["model"], s["params"], s["args"], s["batch"]
     g = torch.Generator().manual_seed(3)
