@@ -415,6 +415,29 @@ PRD_DEV void stage_weight_h2(u32x4* Wh, const float* __restrict__ W, int nout, i
         Wh[(size_t)(nout + o) * (K / 8) + slot] = pl;
     }
 }
+// same, for `nrows` rows of W placed at rows row0.. of an image of `nout` rows
+template <int K>
+PRD_DEV void stage_weight_h2_rows(u32x4* Wh, int nout, int row0, const float* __restrict__ W, int nrows, int ldw, int tid, int nthreads,
+                                  float scale) {
+    constexpr int S = K / 16;
+    for (int idx = tid; idx < nrows * S * 2; idx += nthreads) {
+        const int o = idx / (2 * S), rem = idx - o * (2 * S), st = rem >> 1, h = rem & 1;
+        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 4 * h);
+        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 8 + 4 * h);
+        const float v[8] = {scale * g0.x, scale * g0.y, scale * g0.z, scale * g0.w, scale * g1.x, scale * g1.y, scale * g1.z, scale * g1.w};
+        u32x4 ph, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b;
+            split2h(v[2 * q], v[2 * q + 1], a, b);
+            ph[q] = a;
+            pl[q] = b;
+        }
+        const int slot = h2_slot<K>(row0 + o, 2 * st + h);
+        Wh[(size_t)(row0 + o) * (K / 8) + slot] = ph;
+        Wh[(size_t)(nout + row0 + o) * (K / 8) + slot] = pl;
+    }
+}
 // acc[nb] += W[row0 + 32 nb .. +31][16 S0 .. 16 S1) * x for the split row p (K-steps S0 .. S1 of the image's K)
 template <int K, int NB, int S0, int S1>
 PRD_DEV void rowgemm_h2_part(const u32x4* Wh, int nout, int row0, const u32x4 (&p)[2][S1 - S0], f32x16 (&acc)[NB], int r, int hi) {

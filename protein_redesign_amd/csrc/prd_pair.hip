@@ -442,6 +442,107 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, f
     }
 }
 
+// The same on the fp16 matrix pipe (gemm mode 1): W1 as fp16 hi | lo planes (the size of the fp32 image, so it stays resident),
+// the generated operand x_i * x_j split per K step, three products per step (prd_common.h: rowgemm_h2 scheme).  K runs in
+// natural order: K step s of lane (r, hi) covers k = 16 s + 8 hi .. + 7.  S must be a multiple of 128.
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out, const float* pair,
+                                                                      const float* __restrict__ x, const float* __restrict__ u,
+                                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                                      int b, int N, int S, int residual) {
+    constexpr int NB = P / 32, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ol[];
+    u32x4* Wh = reinterpret_cast<u32x4*>(smem_ol);          // [2 planes][P rows][S/8 slots]
+    const int SL = S / 8;
+    float* bl = reinterpret_cast<float*>(Wh + 2 * P * SL);  // [P] CLL
+    for (int idx = threadIdx.x; idx < P * SL; idx += NW * 64) {
+        const int o = idx / SL, j = idx - o * SL;
+        const float4 g0 = *reinterpret_cast<const float4*>(w + (size_t)o * 2 * S + 8 * j);
+        const float4 g1 = *reinterpret_cast<const float4*>(w + (size_t)o * 2 * S + 8 * j + 4);
+        const float v[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        u32x4 ph, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a_, b_;
+            split2h(H2_WSCALE * v[2 * q], H2_WSCALE * v[2 * q + 1], a_, b_);
+            ph[q] = a_;
+            pl[q] = b_;
+        }
+        const int slot = j ^ (o & 15);                      // SL is a multiple of 16: conflict-free b128 operand reads
+        Wh[(size_t)o * SL + slot] = ph;
+        Wh[(size_t)(P + o) * SL + slot] = pl;
+    }
+    stage_vec_cll(bl, bias, P, threadIdx.x, NW * 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int nvb = (N + 31) / 32;
+    const int npairs = nvb * (nvb + 1) / 2;                // block pairs (ib <= jb)
+    const long ntask = (long)b * npairs * 32;              // 32 rows i per block pair
+    WaveTasks tasks(nullptr, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        const int ii = (int)(task & 31);
+        const long t2 = task >> 5;
+        const int bb = (int)(t2 / npairs);
+        int pidx = (int)(t2 - (long)bb * npairs);
+        int ib = 0;
+        while (pidx >= nvb - ib) { pidx -= nvb - ib; ++ib; }
+        const int jb = ib + pidx;
+        const int i = ib * 32 + ii;
+        if (i >= N) continue;                              // wave-uniform
+        const long bi = (long)bb * N + i;
+        const int j = jb * 32 + r;
+        const bool valid = j < N;
+        const int jj = valid ? j : 0;
+        const float* xi = x + bi * S + 8 * hi;
+        const float* xj = x + ((long)bb * N + jj) * S + 8 * hi;
+        f32x16 acc[NB];
+        zero_acc(acc);
+        // software pipeline: the operands of K step s+1 are in flight while step s is split and multiplied
+        float4 ca0 = *reinterpret_cast<const float4*>(xi), ca1 = *reinterpret_cast<const float4*>(xi + 4);
+        float4 cb0 = *reinterpret_cast<const float4*>(xj), cb1 = *reinterpret_cast<const float4*>(xj + 4);
+        const int nsteps = S / 16;
+        for (int st = 0; st < nsteps; ++st) {
+            const int sn = (st + 1 < nsteps) ? st + 1 : st;             // unconditional prefetch (clamped)
+            const float4 na0 = *reinterpret_cast<const float4*>(xi + 16 * sn), na1 = *reinterpret_cast<const float4*>(xi + 16 * sn + 4);
+            const float4 nb0 = *reinterpret_cast<const float4*>(xj + 16 * sn), nb1 = *reinterpret_cast<const float4*>(xj + 16 * sn + 4);
+            u32x4 ph, pl;
+            {
+                unsigned a_, b_;
+                split2h(ca0.x * cb0.x, ca0.y * cb0.y, a_, b_); ph[0] = a_; pl[0] = b_;
+                split2h(ca0.z * cb0.z, ca0.w * cb0.w, a_, b_); ph[1] = a_; pl[1] = b_;
+                split2h(ca1.x * cb1.x, ca1.y * cb1.y, a_, b_); ph[2] = a_; pl[2] = b_;
+                split2h(ca1.z * cb1.z, ca1.w * cb1.w, a_, b_); ph[3] = a_; pl[3] = b_;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int o = nb * 32 + r;
+                const int slot = (2 * st + hi) ^ (o & 15);
+                const u32x4 wh = Wh[(size_t)o * SL + slot], wl = Wh[(size_t)(P + o) * SL + slot];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, pl), acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wl), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
+        }
+        // epilogue: (i,j) for j >= i and the mirrored (j,i) for j > i (see outer_linear_res_kernel)
+        float ui[KH], uj[KH], pr[KH];
+        load_row_cll<P>(u + bi * P, hi, true, ui);
+        load_row_cll<P>(u + ((long)bb * N + jj) * P, hi, true, uj);
+        const bool upper = valid && j >= i, mirror = valid && j > i;
+        const long off = (bi * N + jj) * P;
+        load_row_cll<P>(pair + off, hi, upper && residual, pr);
+#pragma unroll
+        for (int s_ = 0; s_ < KH; ++s_) pr[s_] = pr[s_] + (((acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + ui[s_]) - uj[s_]) + bl[hi * KH + s_]);
+        store_row_cll<P>(out + off, hi, upper, pr);
+        const long offm = (((long)bb * N + jj) * N + i) * P;
+        load_row_cll<P>(pair + offm, hi, mirror && residual, pr);
+#pragma unroll
+        for (int s_ = 0; s_ < KH; ++s_) pr[s_] = pr[s_] + (((acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + uj[s_]) - ui[s_]) + bl[hi * KH + s_]);
+        store_row_cll<P>(out + offm, hi, mirror, pr);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pair transition: pair += W2 relu(W1 LN(pair) + b1) + b2  (hidden 4P kept in registers)
 // ------------------------------------------------------------------------------------------------
@@ -1002,6 +1103,21 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
     if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const size_t lds = ((size_t)P * (S + 4) + P) * sizeof(float);
+    if (prd_get_gemm_mode() == 1 && (S % 128) == 0 && (size_t)4 * P * S + 4 * P <= 160 * 1024) {   // fp16 x 2 split operands
+        constexpr int NWL = 8;
+        const int nvb = prd_ceil_div(N, 32);
+        const long nsym = (long)b * (nvb * (nvb + 1) / 2) * 32;
+        const int grid = grid_for(nsym, 4, 256);
+        const size_t lds2 = (size_t)4 * P * S + 4 * P;
+        if (P == 64) {
+            PRD_SET_LDS((outer_linear_res_h2_kernel<64, NWL>), lds2);
+            hipLaunchKernelGGL((outer_linear_res_h2_kernel<64, NWL>), dim3(grid), dim3(NWL * 64), lds2, stream, out, pair, x, u, w, bias, b, N, S, residual);
+        } else {
+            PRD_SET_LDS((outer_linear_res_h2_kernel<32, NWL>), lds2);
+            hipLaunchKernelGGL((outer_linear_res_h2_kernel<32, NWL>), dim3(grid), dim3(NWL * 64), lds2, stream, out, pair, x, u, w, bias, b, N, S, residual);
+        }
+        return (int)hipGetLastError();
+    }
     if (lds <= 150 * 1024 && (S % 64) == 0) {   // W1 resident in LDS: persistent 8-wave workgroups, queue-fed
         constexpr int NWL = 8;
         const int nvb = prd_ceil_div(N, 32);

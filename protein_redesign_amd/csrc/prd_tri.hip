@@ -109,11 +109,13 @@ PRD_DEV void proj_compute(const ProjTask& t, float (&x)[P / 2], float mu, float 
     f32x16 ap[1], ag[1];
     bias_acc(ap, bpl + hi * P + 16 * t.ob);         // biases ride in the accumulators
     bias_acc(ag, bgl + hi * P + 16 * t.ob);
-    if (B3) {                                       // bf16 x 3 form (prd_common.h): same results to ~1e-7
-        u32x4 xs[3][P / 16];
-        split3_cll<P>(x, xs);
-        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, t.ob * 32, xs, ap, r, hi);
-        rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, t.ob * 32, xs, ag, r, hi);
+    if (B3) {                                       // fp16 x 2 form (prd_common.h: rowgemm_h2); weights and biases staged x 16
+        u32x4 xs[2][P / 16];
+        split2h_cll<KH>(x, xs);
+        rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, t.ob * 32, xs, ap, r, hi);
+        rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, t.ob * 32, xs, ag, r, hi);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ap[0][q] *= H2_INV_WSCALE; ag[0][q] *= H2_INV_WSCALE; }
     } else {
         rowgemm<P, 1>(Wpl + t.ob * 32 * (P + 4), x, ap, r, hi);
         rowgemm<P, 1>(Wgl + t.ob * 32 * (P + 4), x, ag, r, hi);
@@ -147,20 +149,20 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
     constexpr int KH = P / 2, OUT = 2 * P, OB = OUT / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     PhaseTimer pt;
-    constexpr int WSZ = B3 ? 3 * OUT * (2 * (P / 16) + 1) * 4 : OUT * (P + 4);    // floats per staged weight matrix
+    constexpr int WSZ = B3 ? OUT * P : OUT * (P + 4);    // floats per staged weight matrix (fp16 hi | lo planes, or fp32 rows)
     float* Wpl = smem;                       // fp32: [2P][P+4]; bf16 x 3: 3 planes of [2P] rows (prd_common.h)
     float* Wgl = Wpl + WSZ;
     float* bpl = Wgl + WSZ;                  // [2P] CLL
     float* bgl = bpl + OUT;
     if (B3) {
-        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wpl), wp, OUT, P, threadIdx.x, NW * 64);
-        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wgl), wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E);
+        stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wpl), wp, OUT, P, threadIdx.x, NW * 64, H2_WSCALE);
+        stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wgl), wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E * H2_WSCALE);
     } else {
         stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NW * 64);
         stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E);
     }
-    stage_vec_cll(bpl, bp, OUT, threadIdx.x, NW * 64);
-    stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64, NEG_LOG2E);
+    stage_vec_cll(bpl, bp, OUT, threadIdx.x, NW * 64, B3 ? H2_WSCALE : 1.0f);                 // biases ride in the accumulators
+    stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64, NEG_LOG2E * (B3 ? H2_WSCALE : 1.0f));
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const int nvb = ldn / 32;
     const int nrb = b * N * nvb;                        // 32-row blocks
@@ -451,14 +453,15 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
                                                               const float* __restrict__ wog, const float* __restrict__ bog,
                                                               int b, int N, int ldn, int residual) {
     constexpr int KH = P / 2, NB = P / 32;
-    constexpr int WSZ = B3 ? 3 * P * (2 * (P / 16) + 1) * 4 : P * (P + 4);        // B3: opt-in bf16 x 3 row GEMMs (prd_common.h)
+    constexpr int WSZ = B3 ? P * P : P * (P + 4);        // B3: fp16 x 2 row GEMMs (prd_common.h: rowgemm_h2), weights x 16
     __shared__ __attribute__((aligned(16))) float Wol[WSZ];
     __shared__ __attribute__((aligned(16))) float Wgl[WSZ];
     __shared__ __attribute__((aligned(16))) float bol[P];
     __shared__ __attribute__((aligned(16))) float bgl[P];
+    constexpr float ASC = B3 ? H2_INV_WSCALE : 1.0f;     // accumulator scale of the split form
     if (B3) {
-        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wol), wo, P, P, threadIdx.x, NW * 64);
-        stage_weight_b3<P>(reinterpret_cast<u32x4*>(Wgl), wog, P, P, threadIdx.x, NW * 64);
+        stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wol), wo, P, P, threadIdx.x, NW * 64, H2_WSCALE);
+        stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wgl), wog, P, P, threadIdx.x, NW * 64, H2_WSCALE);
     } else {
         stage_weight_cll<P>(Wol, wo, P, P, threadIdx.x, NW * 64);
         stage_weight_cll<P>(Wgl, wog, P, P, threadIdx.x, NW * 64);
@@ -493,14 +496,14 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
             f32x16 ag[NB];
             zero_acc(ag);
             if (B3) {
-                u32x4 xs[3][P / 16];
-                split3_cll<P>(x, xs);
-                rowgemm_b3<P, NB>(reinterpret_cast<const u32x4*>(Wgl), P, 0, xs, ag, r, hi);
+                u32x4 xs[2][P / 16];
+                split2h_cll<KH>(x, xs);
+                rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wgl), P, 0, xs, ag, r, hi);
             } else {
                 rowgemm<P, NB>(Wgl, x, ag, r, hi);
             }
 #pragma unroll
-            for (int s = 0; s < KH; ++s) gate[s] = sigmoid_fast(ag[s >> 4][s & 15] + bgl[hi * KH + s]);
+            for (int s = 0; s < KH; ++s) gate[s] = sigmoid_fast(ag[s >> 4][s & 15] * ASC + bgl[hi * KH + s]);
         }
         float x[KH];
         // contraction output of this (i,j) for the lane's channels (coalesced over j per channel)
@@ -511,15 +514,15 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
         f32x16 ao[NB];
         zero_acc(ao);
         if (B3) {
-            u32x4 xs[3][P / 16];
-            split3_cll<P>(x, xs);
-            rowgemm_b3<P, NB>(reinterpret_cast<const u32x4*>(Wol), P, 0, xs, ao, r, hi);
+            u32x4 xs[2][P / 16];
+            split2h_cll<KH>(x, xs);
+            rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wol), P, 0, xs, ao, r, hi);
         } else {
             rowgemm<P, NB>(Wol, x, ao, r, hi);
         }
         load_row_cll<P>(pair + off, hi, valid && residual, x);       // raw row again (cache hit) for the residual
 #pragma unroll
-        for (int s = 0; s < KH; ++s) x[s] = x[s] + gate[s] * (ao[s >> 4][s & 15] + bol[hi * KH + s]);
+        for (int s = 0; s < KH; ++s) x[s] = x[s] + gate[s] * (ao[s >> 4][s & 15] * ASC + bol[hi * KH + s]);
         store_row_cll<P>(out + off, hi, valid, x);
     }
     if (coop) {
@@ -540,9 +543,9 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
                 load_row_cll<P>(pair + off, hi, valid, x);
                 ln_cll<KH>(x);
                 if (B3) {
-                    u32x4 xs[3][P / 16];
-                    split3_cll<P>(x, xs);
-                    rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wgl), P, nb * 32, xs, acc, r, hi);
+                    u32x4 xs[2][P / 16];
+                    split2h_cll<KH>(x, xs);
+                    rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wgl), P, nb * 32, xs, acc, r, hi);
                 } else {
                     rowgemm<P, 1>(Wgl + nb * 32 * (P + 4), x, acc, r, hi);
                 }
@@ -552,14 +555,14 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
                     x[s] = valid ? O[(((long)bb * P + cll_ch(s, hi)) * N + i) * ldn + jj] : 0.f;
                 ln_cll<KH>(x);
                 if (B3) {
-                    u32x4 xs[3][P / 16];
-                    split3_cll<P>(x, xs);
-                    rowgemm_b3<P, 1>(reinterpret_cast<const u32x4*>(Wol), P, nb * 32, xs, acc, r, hi);
+                    u32x4 xs[2][P / 16];
+                    split2h_cll<KH>(x, xs);
+                    rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wol), P, nb * 32, xs, acc, r, hi);
                 } else {
                     rowgemm<P, 1>(Wol + nb * 32 * (P + 4), x, acc, r, hi);
                 }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) part[nb][lane][q] = acc[0][q];
+                for (int q = 0; q < 16; ++q) part[nb][lane][q] = acc[0][q] * ASC;
             }
             __syncthreads();
             if (wave < 2) {
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int q = 4 * gq + e, sidx = 16 * nb + q;
-                        const float gt = sigmoid_fast(acc[0][q] + bgl[hi * KH + sidx]);
+                        const float gt = sigmoid_fast(acc[0][q] * ASC + bgl[hi * KH + sidx]);
                         o4[e] = o4[e] + gt * (part[nb][lane][q] + bol[hi * KH + sidx]);
                     }
                     if (valid) *reinterpret_cast<float4*>(orow + 8 * gq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
@@ -1255,9 +1258,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
-    constexpr float VSCALE = 16.0f;             // V is staged x 16 (exact) so that small components keep a normal fp16 lo part
+    constexpr float VSCALE = H2_WSCALE;         // the projection weights are staged x 16 (rowgemm_h2): V stays x 16 (exact), so
+                                                // that its small components keep a normal fp16 lo part; k, q, gate are scaled back
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr unsigned WBYTES = 3u * 64 * (2 * (P / 16) + 1) * 16;
+    constexpr unsigned WBYTES = 2u * 64 * (P / 8) * 16;      // fp16 hi | lo planes of the 64 projection rows
     SplitLds L;
     {
         unsigned off = WBYTES;
@@ -1292,13 +1296,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
         slot = blockIdx.x / H;
     }
     const float sc = 0.25f * LOG2E;
-    stage_weight_b3_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, 1.0f);
-    stage_weight_b3_rows<P>(Wb, 64, C, wv + (long)h * C * P, C, P, tid, NT, VSCALE);
-    stage_weight_b3_rows<P>(Wb, 64, 2 * C, wq + (long)h * C * P, C, P, tid, NT, sc);
-    stage_weight_b3_rows<P>(Wb, 64, 3 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E);
+    stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
     if (tid < 32) {
         const int hh = tid >> 4, e = tid & 15;
-        bqg[tid] = e < 8 ? 0.f : NEG_LOG2E * bg[h * C + (e < 12 ? 4 * hh + (e - 8) : 8 + 4 * hh + (e - 12))];
+        bqg[tid] = e < 8 ? 0.f : H2_WSCALE * NEG_LOG2E * bg[h * C + (e < 12 ? 4 * hh + (e - 8) : 8 + 4 * hh + (e - 12))];
     }
     const long nrows = (long)b * N;
     auto row_pos = [&](long bu, int v) -> long {
@@ -1356,8 +1360,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
                 load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
             }
             ln_cll<KH>(x);
-            u32x4 xs[3][P / 16];
-            split3_cll<P>(x, xs);
+            u32x4 xs[2][P / 16];
+            split2h_cll<KH>(x, xs);
             if (halves & 1) {
                 if (hi == 0) {
                     const bool keep = valid && (mu * mask[(long)bb * N + (valid ? v : 0)] >= 0.5f);
@@ -1365,7 +1369,9 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
                 }
                 f32x16 acc[1];
                 zero_acc(acc);
-                rowgemm_b3<P, 1>(Wb, 64, 0, xs, acc, r, hi);
+                rowgemm_h2<P, 1>(Wb, 64, 0, xs, acc, r, hi);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[0][e] *= H2_INV_WSCALE;
                 // k channels {4hi+e} in registers 0-3 and {8+4hi+e} in 4-7: three bf16 planes, 8 bytes each
                 unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
                 split3(acc[0][0], acc[0][1], h0, m0, l0);
@@ -1394,7 +1400,9 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
             if (halves & 2) {
                 f32x16 acc[1];
                 bias_acc(acc, bqg + 16 * hi);
-                rowgemm_b3<P, 1>(Wb, 64, 32, xs, acc, r, hi);
+                rowgemm_h2<P, 1>(Wb, 64, 32, xs, acc, r, hi);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[0][e] *= H2_INV_WSCALE;
                 unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
                 split3(acc[0][0], acc[0][1], h0, m0, l0);
                 split3(acc[0][2], acc[0][3], h1, m1, l1);
@@ -1586,13 +1594,14 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_long_kernel(
     }
 }
 
-template <int P, int NW>
+template <int P, int NW, bool B3>
 __global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float* out, const float* pair, const float* __restrict__ og,
                                                                const float* __restrict__ wo, const float* __restrict__ bo, long rows, int residual) {
     constexpr int KH = P / 2, NB = P / 32, HC = 64;
-    __shared__ __attribute__((aligned(16))) float Wl[P * (HC + 4)];
+    __shared__ __attribute__((aligned(16))) float Wl[B3 ? P * HC : P * (HC + 4)];      // B3: fp16 hi | lo planes (rowgemm_h2)
     __shared__ __attribute__((aligned(16))) float bl[P];
-    stage_weight_cll<HC>(Wl, wo, P, HC, threadIdx.x, NW * 64);
+    if (B3) stage_weight_h2<HC>(reinterpret_cast<u32x4*>(Wl), wo, P, HC, threadIdx.x, NW * 64, H2_WSCALE);
+    else stage_weight_cll<HC>(Wl, wo, P, HC, threadIdx.x, NW * 64);
     stage_vec_cll(bl, bo, P, threadIdx.x, NW * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
@@ -1605,11 +1614,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float
         load_row_cll<HC>(og + pos * HC, hi, valid, x);
         f32x16 acc[NB];
         zero_acc(acc);
-        rowgemm<HC, NB>(Wl, x, acc, r, hi);
+        if (B3) {
+            u32x4 xs[2][HC / 16];
+            split2h_cll<HC / 2>(x, xs);
+            rowgemm_h2<HC, NB>(reinterpret_cast<const u32x4*>(Wl), P, 0, xs, acc, r, hi);
+        } else {
+            rowgemm<HC, NB>(Wl, x, acc, r, hi);
+        }
         float pr[KH];
         load_row_cll<P>(pair + pos * P, hi, valid && residual, pr);
 #pragma unroll
-        for (int s = 0; s < KH; ++s) pr[s] = pr[s] + (acc[s >> 4][s & 15] + bl[hi * KH + s]);
+        for (int s = 0; s < KH; ++s) pr[s] = pr[s] + (acc[s >> 4][s & 15] * (B3 ? H2_INV_WSCALE : 1.0f) + bl[hi * KH + s]);
         store_row_cll<P>(out + pos * P, hi, valid, pr);
     }
 }
@@ -1652,7 +1667,7 @@ size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
     const size_t wsz = b3 ? (size_t)3 * 64 * (2 * (P / 16) + 1) * 4 : (size_t)64 * (P + 4);
     size_t lds = (wsz + (size_t)3 * npad * KP + 16 * (npad + 4) + npad + 32) * sizeof(float);
     // split-operand kernel (gemm mode 1): K / Q planes 6 x 32 B, V hi / lo 2 x 16 x (npad + 8) fp16, gate, override, bias
-    if (b3) lds = wsz * sizeof(float) + (size_t)npad * (192 + KP * 4 + 4) + (size_t)64 * (npad + 8) + 128;
+    if (b3) lds = (size_t)64 * P * 4 + (size_t)npad * (192 + KP * 4 + 4) + (size_t)64 * (npad + 8) + 128;
     *long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
     if (*long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
     return lds;
@@ -1692,7 +1707,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     {
         constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
         const bool b3 = b3m;                        // bf16 x 3 row GEMM (prd_set_gemm_mode)
-        const size_t wsz = b3 ? (size_t)3 * 2 * P * (2 * (P / 16) + 1) * 4 : (size_t)2 * P * (P + 4);
+        const size_t wsz = b3 ? (size_t)2 * P * P : (size_t)2 * P * (P + 4);
         const size_t lds = (2 * wsz + 4 * P) * sizeof(float);
         const long ntask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);     // (row block, output block) tasks
         const int grid = grid_for(ntask, 4, 256);
@@ -1804,8 +1819,11 @@ extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, 
     constexpr int NWA = 12;
     const long rows = (long)b * N * N;
     const int grid2 = grid_for((rows + 31) / 32, 4, 256);
-    if (P == 64) hipLaunchKernelGGL((tri_attn_out_kernel<64, NWA>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual);
-    else hipLaunchKernelGGL((tri_attn_out_kernel<32, NWA>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual);
+    const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;
+#define PRD_TAO(PP, BB) hipLaunchKernelGGL((tri_attn_out_kernel<PP, NWA, BB>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual)
+    if (P == 64) { if (b3) PRD_TAO(64, true); else PRD_TAO(64, false); }
+    else { if (b3) PRD_TAO(32, true); else PRD_TAO(32, false); }
+#undef PRD_TAO
     return (int)hipGetLastError();
 }
 

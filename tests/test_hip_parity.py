@@ -169,6 +169,23 @@ def test_outer_linear(setup, gemm_mode):
     assert rel_l2(got.cpu(), O.outer_linear(s["params"], "Denoiser.folding_blocks.0.outer_linear", s["single"])) < OP_TOL
 
 
+@pytest.mark.parametrize("P", [32, 64])
+def test_outer_linear_full_width(P, gemm_mode):
+    """OuterLinear at the reference's single_dim = 512 (W1 resident in LDS; in gemm mode 1 the fp16 x 2 split kernel), ragged
+    N = 70: (i, j) / (j, i) symmetric-half tasks with a partial last 32-block."""
+    from protein_redesign_amd.trunk import OuterLinear
+    g = torch.Generator().manual_seed(40 + P)
+    S, N = 512, 70
+    mod = OuterLinear(S, P)
+    w, b = torch.randn(P, 2 * S, generator=g) / math.sqrt(2 * S), 0.1 * torch.randn(P, generator=g)
+    mod.load_state_dict({"linear.weight": w, "linear.bias": b})
+    mod = mod.to(DEV)
+    single = torch.randn(2, N, S, generator=g) * 1.5 + 0.3
+    want = O.outer_linear({"ol.linear.weight": w, "ol.linear.bias": b}, "ol", single)
+    got = mod(cu(single))
+    assert rel_l2(got.cpu(), want) < OP_TOL
+
+
 @pytest.mark.parametrize("mode", ["outgoing", "incoming"])
 def test_triangle_multiplication(setup, mode, gemm_mode):
     s = setup
