@@ -42,14 +42,19 @@ typedef struct ihipStream_t* hipStream_t;
 
 int prd_version(void);
 
-/* Arithmetic of the row GEMMs inside the pair-track operators.  PROCESS-WIDE (the single piece of global state of the
- * library): set it before launching, not concurrently with launches whose arithmetic matters; calls read it once.
- *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32): plain fp32 FMA chains;
- *   1  both operands split exactly into three bf16 parts (truncation: 3 x 8 = 24 mantissa bits), six products on the bf16
- *      matrix pipe with fp32 accumulation: fp32-accurate (~1e-7 relative, tools/ubench/bf16x3_bench.hip), 2.1-2.4x the rate.
- *      Applied to: tri_mul projection / output kernels and the q|k|v|g projections of the short-row triangle attention core;
- *      kernels without a split form run fp32 MFMA in either mode.
- * Both modes meet every parity tolerance of tests/ (the GPU suite runs its step / trajectory tests in both). */
+/* Arithmetic of the GEMMs inside the pair-track operators.  PROCESS-WIDE (the single piece of global state of the library):
+ * set it before launching, not concurrently with launches whose arithmetic matters; every call reads it once.
+ *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): plain fp32 FMA chains;
+ *   1  (default) "split16": fp32 operands are split into 16-bit parts and multiplied on the fp16 / bf16 matrix pipes with fp32
+ *      accumulation, every product whose weight exceeds 2^-22 included:
+ *        - row GEMMs (tri_mul projection / output, attention projections and output projection, pair transition / block tail,
+ *          outer-linear) and P*V of the triangle attention: fp16 hi + lo (RTZ, 22 bits), 3 products, 16/3 of the fp32 rate;
+ *          weight images stay the size of the fp32 ones.  fp16 saturates at 65504: LayerNorm-ed rows, gated attention outputs,
+ *          ReLU hidden units, probabilities and weights (staged x 16) are far inside that range;
+ *        - Q*K^T of the triangle attention and the triangle-multiplication contraction (operands of unbounded range): bf16 x 3
+ *          by truncation (exact, 24 bits), 6 products, 16/6 of the fp32 rate;
+ *      kernels without a split form (single track, input stage, heads) run fp32 MFMA in either mode.
+ * Both modes meet every parity tolerance of tests/ (the GPU suite runs its operator / step / trajectory / gradient tests in both). */
 int prd_set_gemm_mode(int mode);
 int prd_get_gemm_mode(void);
 

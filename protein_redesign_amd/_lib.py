@@ -62,8 +62,8 @@ SIGNATURES = {
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
 }
 
-GEMM_MODES = {"fp32": 0, "bf16x3": 1}
-DEFAULT_GEMM_MODE = "fp32"          # arithmetic the library is switched to when it is loaded (env PRD_GEMM_MODE overrides)
+GEMM_MODES = {"fp32": 0, "split16": 1, "bf16x3": 1}      # "bf16x3": earlier name of the split-operand mode
+DEFAULT_GEMM_MODE = "split16"       # arithmetic the library is switched to when it is loaded (env PRD_GEMM_MODE overrides)
 
 _lib = None
 
@@ -91,10 +91,12 @@ def lib():
 
 
 def row_gemm_description(b3: bool) -> str:
-    """What the row GEMMs of the pair kernels compute in, for bench.py's JSON line (stated truthfully, not as a precision claim)."""
+    """What the GEMMs of the pair kernels compute in, for bench.py's JSON line (stated truthfully, not as a precision claim)."""
     if b3:
-        return ("bf16x3-split: both operands split exactly into 3 bf16 parts, 6 products on the bf16 MFMA pipe, fp32 accumulate "
-                "(fp32-accurate ~1e-7; kernels without a split form run fp32 MFMA)")
+        return ("split16: fp32 operands split into 16-bit parts -- fp16 hi+lo (22 bits, 3 products) in the row GEMMs and P*V, "
+                "bf16 x3 (24 bits, 6 products) in Q*K^T and the triangle-multiplication contraction -- multiplied on the "
+                "fp16/bf16 MFMA pipes with fp32 accumulation; kernels without a split form (single track, input stage) run "
+                "fp32 MFMA.  Parity tolerances are the same as in fp32 mode (PRD_GEMM_MODE=fp32)")
     return "fp32-mfma"
 
 

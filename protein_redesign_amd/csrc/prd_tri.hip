@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float
 }
 
 // The ONE piece of process-wide state of the library (documented in prd_hip.h): relaxed atomic, read once per call.
-std::atomic<int> g_gemm_mode{0};
+std::atomic<int> g_gemm_mode{1};
 
 int grid_for(long tasks, int per_wg, int cap) {
     long g = (tasks + per_wg - 1) / per_wg;

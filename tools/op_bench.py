@@ -43,7 +43,7 @@ def main():
     ta = blk.pair_attn_ending.attn
     pf = blk.pair_fc
     rows = {}
-    for mode in ("fp32", "bf16x3"):
+    for mode in ("fp32", "split16"):
         _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES[mode])
         with torch.inference_mode():
             res = {
@@ -61,9 +61,9 @@ def main():
             rows.setdefault(k, {})[mode] = v
         pair.copy_(torch.randn(1, N, N, 64, generator=g))       # in-place residual updates drift: fresh values per mode
     print(f"# N = {N}, us per call (HIP events, back to back)")
-    print(f"{'operator':36s} {'fp32':>9s} {'bf16x3':>9s}")
+    print(f"{'operator':36s} {'fp32':>9s} {'split16':>9s}")
     for k, v in rows.items():
-        print(f"{k:36s} {v['fp32']:9.1f} {v['bf16x3']:9.1f}")
+        print(f"{k:36s} {v['fp32']:9.1f} {v['split16']:9.1f}")
     _lib.lib().prd_set_gemm_mode(0)
 
 
