@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 at the fp32 vector rate
+PEAK_16BIT_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 HBM_PEAK_GBS = 8000.0
 S, P, NB, T = 512, 64, 4, 1000
 
@@ -151,9 +152,9 @@ def measure_traffic(a):
                 return None, f"{counter} pass failed (exit {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
             db = sqlite3.connect(dbs[0])
             rows = list(db.execute("select dispatch_id, sum(value) from counters_collection where counter_name = ? "
-                                   "and kernel_name like '%tri_attn_core_kernel%' group by dispatch_id", (counter,)))
+                                   "and kernel_name like '%tri_attn_core%' group by dispatch_id", (counter,)))
             if not rows:
-                return None, f"{counter}: no tri_attn_core_kernel dispatch in the counter database"
+                return None, f"{counter}: no tri_attn_core dispatch in the counter database"
             vals[counter] = sum(v for _, v in rows) / len(rows)
     except Exception as e:      # profiling is evidence, never a reason to lose the bench line
         return None, f"PMC pass error: {e!r}"
@@ -226,7 +227,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)           # "nccl" is RCCL on ROCm
         world = dist.get_world_size()
 
-    from protein_redesign_amd import _lib
+    from protein_redesign_amd import _lib, ops
     from protein_redesign_amd.diffusion_model import ReverseDiffusion
     from protein_redesign_amd.distributed import gather_samples, sample_sharded
     from protein_redesign_amd.synthetic import NoiseSource, batch_to, synthetic_batch
@@ -297,11 +298,19 @@ def main():
         traffic, note = (None, "not measured (--no-traffic or N > 1)")
         if world == 1 and not a.no_traffic:
             traffic, note = measure_traffic(a)
+        split = _lib.lib().prd_get_gemm_mode() == 1 and not ops.tri_attn_uses_long_rows(N, P)
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
                     "algorithmic_bytes_per_launch": tri_attn_core_bytes(bpg, N, P),
-                    "kernel": "tri_attn_core_kernel", "launches_per_step": 2 * NB,
-                    "flops_per_launch": kfl, "avg_launch_us": round(kus, 2)}
+                    "kernel": "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel", "launches_per_step": 2 * NB,
+                    "flops_per_launch": kfl, "avg_launch_us": round(kus, 2),
+                    "peak_note": "achieved = ALGORITHMIC fp32 flops of the launch / its duration; peak = the dense fp32 MFMA rate the "
+                                 "reference arithmetic (fp32) is priced against"}
+        if split:      # what the split-operand kernel actually issues: 3 fp16 products per projection / P*V MAC, 6 bf16 products per Q*K^T MAC
+            ex = bpg * (3 * 8 * N * N * P * 64 + (6 + 3) * 2 * 64 * N ** 3)
+            roofline.update({"executed_16bit_mfma_flops_per_launch": ex,
+                             "executed_16bit_tflops": round(ex / (kus * 1e-6) / 1e12, 1), "peak_16bit_tflops": PEAK_16BIT_TFLOPS,
+                             "frac_of_16bit_peak": round(ex / (kus * 1e-6) / 1e12 / PEAK_16BIT_TFLOPS, 4)})
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -438,6 +438,49 @@ PRD_DEV void stage_weight_h2_rows(u32x4* Wh, int nout, int row0, const float* __
         Wh[(size_t)(nout + row0 + o) * (K / 8) + slot] = pl;
     }
 }
+// NATURAL K order (for operands generated per K step, not rows in CLL): slot j of row o holds W[o][k0 + 8 j .. + 7]; K must be a
+// multiple of 128 (16 | K/8), slot j is stored at j ^ (o & 15).  K step s of lane (r, hi) then covers k = 16 s + 8 hi .. + 7.
+PRD_DEV void stage_weight_h2_nat(u32x4* Wh, const float* __restrict__ W, int nout, int K, int ldw, int k0, int tid, int nthreads, float scale) {
+    const int SL = K / 8;
+    for (int idx = tid; idx < nout * SL; idx += nthreads) {
+        const int o = idx / SL, j = idx - o * SL;
+        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + k0 + 8 * j);
+        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + k0 + 8 * j + 4);
+        const float v[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        u32x4 ph, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b;
+            split2h(scale * v[2 * q], scale * v[2 * q + 1], a, b);
+            ph[q] = a;
+            pl[q] = b;
+        }
+        const int slot = j ^ (o & 15);
+        Wh[(size_t)o * SL + slot] = ph;
+        Wh[(size_t)(nout + o) * SL + slot] = pl;
+    }
+}
+// one K step of the natural-order form: acc[nb] += W[32 nb + r][16 st + 8 hi ..] * f (f = the lane's 8 generated operand values)
+template <int NB>
+PRD_DEV void h2_nat_step(const u32x4* Wh, int nout, int SL, int st, const float (&f)[8], f32x16 (&acc)[NB], int r, int hi) {
+    u32x4 ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned a, b;
+        split2h(f[2 * q], f[2 * q + 1], a, b);
+        ph[q] = a;
+        pl[q] = b;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int o = nb * 32 + r;
+        const int slot = (2 * st + hi) ^ (o & 15);
+        const u32x4 wh = Wh[(size_t)o * SL + slot], wl = Wh[(size_t)(nout + o) * SL + slot];
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, pl), acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wl), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
+    }
+}
 // acc[nb] += W[row0 + 32 nb .. +31][16 S0 .. 16 S1) * x for the split row p (K-steps S0 .. S1 of the image's K)
 template <int K, int NB, int S0, int S1>
 PRD_DEV void rowgemm_h2_part(const u32x4* Wh, int nout, int row0, const u32x4 (&p)[2][S1 - S0], f32x16 (&acc)[NB], int r, int hi) {

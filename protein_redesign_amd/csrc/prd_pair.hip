@@ -185,6 +185,110 @@ __global__ __launch_bounds__(WG) void pair_init_kernel(float* __restrict__ pair,
     }
 }
 
+// pair_init on the fp16 matrix pipe (gemm mode 1; dist_dim a multiple of 128): the radial-basis features are generated per K
+// step in natural order and split into fp16 hi + lo, W_d sits in LDS as hi | lo planes (prd_common.h: h2_nat_step).
+template <int P>
+__global__ __launch_bounds__(WG) void pair_init_h2_kernel(float* __restrict__ pair, const float* __restrict__ stat,
+                                                          const float* __restrict__ z, const float* __restrict__ mask,
+                                                          const float* __restrict__ centers, const float* __restrict__ wd,
+                                                          const float* __restrict__ ebeta, int b, int N, int DK) {
+    constexpr int NB = P / 32, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pi[];
+    u32x4* Wh = reinterpret_cast<u32x4*>(smem_pi);          // [2][P][DK/8]
+    const int SL = DK / 8;
+    float* cl = reinterpret_cast<float*>(Wh + 2 * P * SL);  // [DK]
+    stage_weight_h2_nat(Wh, wd, P, DK, DK, 0, threadIdx.x, WG, H2_WSCALE);
+    for (int k = threadIdx.x; k < DK; k += WG) cl[k] = centers[k];
+    __syncthreads();
+    const float scale = (float)((DK - 1) / 2.0);
+    const float c2 = -scale * 1.4426950408889634f;
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long rows = (long)b * N * N;
+    const long ntask = (rows + 31) / 32;
+    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+        const long pos = task * 32 + r;
+        const bool valid = pos < rows;
+        int bb = 0, i = 0, j = 0;
+        if (valid) decode_pos(pos, N, bb, i, j);
+        const float* zi = z + ((long)bb * N + i) * 3;
+        const float* zj = z + ((long)bb * N + j) * 3;
+        const float dx = zi[0] - zj[0], dy = zi[1] - zj[1], dz = zi[2] - zj[2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float m2 = mask[bb * N + i] * mask[bb * N + j];
+        f32x16 acc[NB];
+        zero_acc(acc);
+        for (int st = 0; st < DK / 16; ++st) {
+            const float4 c0 = *reinterpret_cast<const float4*>(cl + 16 * st + 8 * hi);
+            const float4 c1 = *reinterpret_cast<const float4*>(cl + 16 * st + 8 * hi + 4);
+            const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = d - cc[e];
+                f[e] = __builtin_amdgcn_exp2f(c2 * (t * t));       // exp(-scale t^2) on v_exp_f32
+            }
+            h2_nat_step<NB>(Wh, P, SL, st, f, acc, r, hi);
+        }
+        float st_[KH], eb[KH];
+        load_row_cll<P>(stat + pos * P, hi, valid, st_);
+        load_row_cll<P>(ebeta + bb * P, hi, true, eb);
+        float o[KH];
+#pragma unroll
+        for (int s_ = 0; s_ < KH; ++s_) o[s_] = st_[s_] + m2 * (acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + eb[s_]);
+        store_row_cll<P>(pair + pos * P, hi, valid, o);
+    }
+}
+
+// OPM tail on the fp16 matrix pipe (gemm mode 1; C a multiple of 128): the products a_i * b_j are generated per K step.
+template <int P>
+__global__ __launch_bounds__(WG) void opm_pair_h2_kernel(float* out, const float* pair, const float* __restrict__ ab,
+                                                         const float* __restrict__ mask, const float* __restrict__ wo,
+                                                         const float* __restrict__ bo, int b, int N, int C, int flags) {
+    constexpr int NB = P / 32, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_op[];
+    u32x4* Wh = reinterpret_cast<u32x4*>(smem_op);          // [2][P][C/8]
+    const int SL = C / 8;
+    float* bl = reinterpret_cast<float*>(Wh + 2 * P * SL);  // [P] CLL
+    stage_weight_h2_nat(Wh, wo, P, C, C, 0, threadIdx.x, WG, H2_WSCALE);
+    stage_vec_cll(bl, bo, P, threadIdx.x, WG);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int nvb = (N + 31) / 32;
+    const long ntask = (long)b * N * nvb;
+    for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
+        const int vb = (int)(task % nvb);
+        const long bi = task / nvb;            // bb*N + i
+        const int bb = (int)(bi / N);
+        const int j = vb * 32 + r;
+        const bool valid = j < N;
+        const int jj = valid ? j : 0;
+        const float* ai = ab + bi * 2 * C + 8 * hi;
+        const float* bj = ab + ((long)bb * N + jj) * 2 * C + C + 8 * hi;
+        f32x16 acc[NB];
+        zero_acc(acc);
+        float4 a0 = *reinterpret_cast<const float4*>(ai), a1 = *reinterpret_cast<const float4*>(ai + 4);
+        float4 b0 = *reinterpret_cast<const float4*>(bj), b1 = *reinterpret_cast<const float4*>(bj + 4);
+        const int nst = C / 16;
+        for (int st = 0; st < nst; ++st) {
+            const int sn = st + 1 < nst ? st + 1 : st;                   // unconditional prefetch (clamped)
+            const float4 na0 = *reinterpret_cast<const float4*>(ai + 16 * sn), na1 = *reinterpret_cast<const float4*>(ai + 16 * sn + 4);
+            const float4 nb0 = *reinterpret_cast<const float4*>(bj + 16 * sn), nb1 = *reinterpret_cast<const float4*>(bj + 16 * sn + 4);
+            const float f[8] = {a0.x * b0.x, a0.y * b0.y, a0.z * b0.z, a0.w * b0.w, a1.x * b1.x, a1.y * b1.y, a1.z * b1.z, a1.w * b1.w};
+            h2_nat_step<NB>(Wh, P, SL, st, f, acc, r, hi);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        const float m2 = mask[bi] * mask[(long)bb * N + jj];
+        const float norm = m2 + 1e-3f;
+        const long off = (bi * N + jj) * P;
+        float x[KH];
+        load_row_cll<P>(pair + off, hi, valid && (flags & 1), x);
+        const float mm = (flags & 2) ? m2 : 1.f;
+#pragma unroll
+        for (int s_ = 0; s_ < KH; ++s_) x[s_] = x[s_] + mm * ((acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bl[hi * KH + s_]) / norm);
+        store_row_cll<P>(out + off, hi, valid, x);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pair bias: [b,H,N,N] = Linear(LN(pair))  (HBM bound: one read of pair, H/P of it written)
 // ------------------------------------------------------------------------------------------------
@@ -455,23 +559,7 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out
     u32x4* Wh = reinterpret_cast<u32x4*>(smem_ol);          // [2 planes][P rows][S/8 slots]
     const int SL = S / 8;
     float* bl = reinterpret_cast<float*>(Wh + 2 * P * SL);  // [P] CLL
-    for (int idx = threadIdx.x; idx < P * SL; idx += NW * 64) {
-        const int o = idx / SL, j = idx - o * SL;
-        const float4 g0 = *reinterpret_cast<const float4*>(w + (size_t)o * 2 * S + 8 * j);
-        const float4 g1 = *reinterpret_cast<const float4*>(w + (size_t)o * 2 * S + 8 * j + 4);
-        const float v[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        u32x4 ph, pl;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a_, b_;
-            split2h(H2_WSCALE * v[2 * q], H2_WSCALE * v[2 * q + 1], a_, b_);
-            ph[q] = a_;
-            pl[q] = b_;
-        }
-        const int slot = j ^ (o & 15);                      // SL is a multiple of 16: conflict-free b128 operand reads
-        Wh[(size_t)o * SL + slot] = ph;
-        Wh[(size_t)(P + o) * SL + slot] = pl;
-    }
+    stage_weight_h2_nat(Wh, w, P, S, 2 * S, 0, threadIdx.x, NW * 64, H2_WSCALE);
     stage_vec_cll(bl, bias, P, threadIdx.x, NW * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
@@ -505,23 +593,9 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out
             const int sn = (st + 1 < nsteps) ? st + 1 : st;             // unconditional prefetch (clamped)
             const float4 na0 = *reinterpret_cast<const float4*>(xi + 16 * sn), na1 = *reinterpret_cast<const float4*>(xi + 16 * sn + 4);
             const float4 nb0 = *reinterpret_cast<const float4*>(xj + 16 * sn), nb1 = *reinterpret_cast<const float4*>(xj + 16 * sn + 4);
-            u32x4 ph, pl;
-            {
-                unsigned a_, b_;
-                split2h(ca0.x * cb0.x, ca0.y * cb0.y, a_, b_); ph[0] = a_; pl[0] = b_;
-                split2h(ca0.z * cb0.z, ca0.w * cb0.w, a_, b_); ph[1] = a_; pl[1] = b_;
-                split2h(ca1.x * cb1.x, ca1.y * cb1.y, a_, b_); ph[2] = a_; pl[2] = b_;
-                split2h(ca1.z * cb1.z, ca1.w * cb1.w, a_, b_); ph[3] = a_; pl[3] = b_;
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int o = nb * 32 + r;
-                const int slot = (2 * st + hi) ^ (o & 15);
-                const u32x4 wh = Wh[(size_t)o * SL + slot], wl = Wh[(size_t)(P + o) * SL + slot];
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, pl), acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wl), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
-            }
+            const float f[8] = {ca0.x * cb0.x, ca0.y * cb0.y, ca0.z * cb0.z, ca0.w * cb0.w,
+                                ca1.x * cb1.x, ca1.y * cb1.y, ca1.z * cb1.z, ca1.w * cb1.w};
+            h2_nat_step<NB>(Wh, P, SL, st, f, acc, r, hi);
             __builtin_amdgcn_sched_barrier(0);
             ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
         }
@@ -1056,6 +1130,17 @@ extern "C" int prd_pair_init(float* pair, const float* static_pair, const float*
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     const long ntask = ((long)b * N * N + 31) / 32;
     const int grid = grid_for(ntask, 4, 512);
+    if (prd_get_gemm_mode() == 1 && (dist_dim % 128) == 0) {        // fp16 x 2 split operands
+        const size_t lds2 = (size_t)4 * P * dist_dim + (size_t)dist_dim * 4;
+        if (P == 64) {
+            PRD_SET_LDS(pair_init_h2_kernel<64>, lds2);
+            hipLaunchKernelGGL(pair_init_h2_kernel<64>, dim3(grid), dim3(WG), lds2, stream, pair, static_pair, z, mask, centers, w_dist, ebeta, b, N, dist_dim);
+        } else {
+            PRD_SET_LDS(pair_init_h2_kernel<32>, lds2);
+            hipLaunchKernelGGL(pair_init_h2_kernel<32>, dim3(grid), dim3(WG), lds2, stream, pair, static_pair, z, mask, centers, w_dist, ebeta, b, N, dist_dim);
+        }
+        return (int)hipGetLastError();
+    }
     if (P == 64) {
         PRD_SET_LDS(pair_init_kernel<64>, lds);
         hipLaunchKernelGGL(pair_init_kernel<64>, dim3(grid), dim3(WG), lds, stream, pair, static_pair, z, mask, centers, w_dist, ebeta, b, N, dist_dim);
@@ -1086,6 +1171,17 @@ extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, cons
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const int grid = grid_for(ntask, 4, 1024);
+    if (prd_get_gemm_mode() == 1 && (C % 128) == 0) {               // fp16 x 2 split operands
+        const size_t lds2 = (size_t)4 * P * C + (size_t)P * 4;
+        if (P == 64) {
+            PRD_SET_LDS(opm_pair_h2_kernel<64>, lds2);
+            hipLaunchKernelGGL(opm_pair_h2_kernel<64>, dim3(grid), dim3(WG), lds2, stream, out, pair, ab, mask, w_out, b_out, b, N, C, flags);
+        } else {
+            PRD_SET_LDS(opm_pair_h2_kernel<32>, lds2);
+            hipLaunchKernelGGL(opm_pair_h2_kernel<32>, dim3(grid), dim3(WG), lds2, stream, out, pair, ab, mask, w_out, b_out, b, N, C, flags);
+        }
+        return (int)hipGetLastError();
+    }
     if (P == 64) {
         PRD_SET_LDS(opm_pair_kernel<64>, lds);
         hipLaunchKernelGGL(opm_pair_kernel<64>, dim3(grid), dim3(WG), lds, stream, out, pair, ab, mask, w_out, b_out, b, N, C, flags);

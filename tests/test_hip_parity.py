@@ -186,6 +186,26 @@ def test_outer_linear_full_width(P, gemm_mode):
     assert rel_l2(got.cpu(), want) < OP_TOL
 
 
+@pytest.mark.parametrize("P", [32, 64])
+def test_outer_product_update_full_width(P, gemm_mode):
+    """OuterProductUpdate at the reference's single_dim = 512 (c_hidden = 128: the fp16 x 2 split kernel in gemm mode 1), ragged."""
+    from protein_redesign_amd.af2_blocks import OuterProductUpdate
+    g = torch.Generator().manual_seed(50 + P)
+    S, N = 512, 45
+    mod = OuterProductUpdate(c_m=S, c_z=P, c_hidden=S // 4)
+    sd = {k: (torch.randn(v.shape, generator=g) / math.sqrt(v.shape[-1]) if v.dim() == 2 else 0.1 * torch.randn(v.shape, generator=g))
+          for k, v in mod.state_dict().items()}
+    sd["layer_norm.weight"] = 1.0 + 0.1 * torch.randn(S, generator=g)
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV)
+    single = torch.randn(2, N, S, generator=g)
+    mask = torch.ones(2, N)
+    mask[1, 37:] = 0
+    want = O.outer_product_update({"opm." + k: v for k, v in sd.items()}, "opm", single, mask)
+    got = mod(cu(single), cu(mask))
+    assert rel_l2(got.cpu(), want) < OP_TOL
+
+
 @pytest.mark.parametrize("mode", ["outgoing", "incoming"])
 def test_triangle_multiplication(setup, mode, gemm_mode):
     s = setup
