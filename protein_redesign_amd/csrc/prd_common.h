@@ -367,10 +367,13 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef __fp16 f16x2_t __attribute__((ext_vector_type(2)));
 constexpr float H2_WSCALE = 16.0f, H2_INV_WSCALE = 1.0f / 16.0f;
 
+// hi = RTZ_fp16(x); lo = fp16(x - hi) in ONE mixed-precision FMA per element (v_fma_mixlo/hi_f16: fp16 source half * -1 + fp32
+// source, result rounded once to fp16 into the low / high half of the destination): 3 VALU instructions per PAIR of values
+// instead of 6 (cvt_pkrtz, 2 x cvt_f32_f16, 2 x sub, cvt_pkrtz) -- VALU issue time is what the split kernels are bound by.
 PRD_DEV void split2h(float a, float b, unsigned& hi, unsigned& lo) {
-    const f16x2_t h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
 }
 // NE CLL elements x[0 .. NE) (NE a multiple of 8) -> 2 planes x NE/8 operand registers of 8 fp16
 template <int NE>

@@ -1095,11 +1095,7 @@ typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));      // what __builtin
 
 PRD_DEV unsigned pk_f16_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 // fp16 hi / lo words of the pair (a, b): hi = RTZ(x), lo = RTZ(x - hi) (the subtraction is exact)
-PRD_DEV void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
-    const f16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = pk_f16_rtz(a - (float)h[0], b - (float)h[1]);
-}
+PRD_DEV void split2_f16(float a, float b, unsigned& hi, unsigned& lo) { split2h(a, b, hi, lo); }
 
 struct SplitLds {               // byte offsets from the dynamic LDS base
     unsigned kp[3], qp[3], vh, vl, gl, kadd, bqg;
@@ -1152,6 +1148,7 @@ PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLd
             vl[gi] = u32x4{c[0], c[1], d[0], d[1]};
         }
     }
+    u32x4 php[NTQ][2], plp[NTQ][2];
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) {
         if (MASKED) {
@@ -1203,20 +1200,25 @@ PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLd
         // probabilities -> fp16 hi / lo B operands of the two 32-key groups
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-            u32x4 ph, pl;
 #pragma unroll
             for (int hj = 0; hj < 2; ++hj) {
                 unsigned h0, l0, h1, l1;
                 split2_f16(s[t][2 * gi + hj][0], s[t][2 * gi + hj][1], h0, l0);
                 split2_f16(s[t][2 * gi + hj][2], s[t][2 * gi + hj][3], h1, l1);
-                ph[2 * hj] = h0; ph[2 * hj + 1] = h1;
-                pl[2 * hj] = l0; pl[2 * hj + 1] = l1;
+                php[t][gi][2 * hj] = h0; php[t][gi][2 * hj + 1] = h1;
+                plp[t][gi][2 * hj] = l0; plp[t][gi][2 * hj + 1] = l1;
             }
-            o[t][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, ph), o[t][gi], 0, 0, 0);
-            o[t][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh[gi]), __builtin_bit_cast(f16x8, pl), o[t][gi], 0, 0, 0);
-            o[t][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl[gi]), __builtin_bit_cast(f16x8, ph), o[t][gi], 0, 0, 0);
         }
     }
+    // O^T += V^T P^T: the three products of an accumulator are issued 2 NTQ independent accumulators apart
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+                o[t][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, pr == 2 ? vl[gi] : vh[gi]),
+                                                                  __builtin_bit_cast(f16x8, pr == 1 ? plp[t][gi] : php[t][gi]), o[t][gi], 0, 0, 0);
 }
 
 template <int NTQ, bool MASKED>
@@ -1388,8 +1390,9 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const int c0 = (e < 4 ? 4 * hi : 8 + 4 * hi) + (e & 3);
-                    const f16x2 hh2 = __builtin_amdgcn_cvt_pkrtz(acc[0][8 + e], acc[0][9 + e]);
-                    const f16x2 ll2 = __builtin_amdgcn_cvt_pkrtz(acc[0][8 + e] - (float)hh2[0], acc[0][9 + e] - (float)hh2[1]);
+                    unsigned hw, lw;
+                    split2h(acc[0][8 + e], acc[0][9 + e], hw, lw);
+                    const f16x2 hh2 = __builtin_bit_cast(f16x2, hw), ll2 = __builtin_bit_cast(f16x2, lw);
                     Vh[c0 * L.vpitch + v] = (_Float16)hh2[0];
                     Vh[(c0 + 1) * L.vpitch + v] = (_Float16)hh2[1];
                     Vl[c0 * L.vpitch + v] = (_Float16)ll2[0];
