@@ -40,5 +40,33 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_asan(verbose: bool = True) -> str:
+    """Host-side AddressSanitizer build: libprd_hip_asan.so with the HOST code of every source instrumented
+    (-fsanitize=address; device code is compiled as usual: -fno-gpu-sanitize, GPU ASan is not available on this pool) and the
+    argument-validation driver tests/native/host_abi_check.c linked against it.  Runs on a machine without a GPU: every call of
+    the driver is rejected by the argument checks before any HIP API is used.  Returns the path of the driver binary."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(HERE, "csrc", "asan")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(HERE, "libprd_hip_asan.so")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(out_dir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-g", "-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize", "-o", lib] + objs)
+    exe = os.path.join(out_dir, "host_abi_check")
+    driver = os.path.join(os.path.dirname(HERE), "tests", "native", "host_abi_check.c")
+    subprocess.check_call([hipcc, "-x", "c", driver, "-x", "none", "-g", "-fsanitize=address", "-fno-gpu-sanitize", "-o", exe, lib,
+                           "-Wl,-rpath," + HERE])
+    return exe
+
+
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        exe = build_asan()
+        sys.exit(subprocess.call([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")))
     build(force="--force" in sys.argv)

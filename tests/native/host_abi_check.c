@@ -1,0 +1,65 @@
+/* Host-side check of the C ABI's argument validation (include/prd_hip.h), meant to run under AddressSanitizer on a machine
+ * WITHOUT a GPU: every call below must be rejected by the argument checks (negative PRD_ERR_* code) before any HIP API is
+ * touched, with no out-of-bounds access, leak or use of uninitialised memory on the host side of libprd_hip.
+ * Build + run: python -m protein_redesign_amd.build --asan   (tests/test_host_cpu.py::test_c_abi_argument_checks_under_asan) */
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/prd_hip.h"
+
+static int failures = 0;
+#define EXPECT(call, code)                                                                 \
+    do {                                                                                   \
+        const int got_ = (call);                                                           \
+        if (got_ != (code)) { printf("FAIL %s -> %d (want %d)\n", #call, got_, (code)); ++failures; } \
+    } while (0)
+
+int main(void) {
+    float buf[16];                      /* host memory standing in for device pointers: never dereferenced by the checks */
+    int64_t ibuf[4];
+    float* p = buf;
+    hipStream_t s = 0;
+    EXPECT(prd_version(), PRD_VERSION);
+    EXPECT(prd_set_gemm_mode(7), PRD_ERR_ARG);
+    EXPECT(prd_set_gemm_mode(0), 0);
+    EXPECT(prd_get_gemm_mode(), 0);
+    EXPECT(prd_set_gemm_mode(1), 0);
+    PrdGemm g;
+    memset(&g, 0, sizeof g);
+    EXPECT(prd_gemm(&g, s), PRD_ERR_ARG);                              /* null operands */
+    g.A = g.B = p; g.C = p; g.M = g.N = g.K = 8; g.G1 = g.G2 = 1; g.lda = 6; g.ldb = 8; g.ldc = 8;
+    EXPECT(prd_gemm(&g, s), PRD_ERR_ALIGN);                            /* lda not a multiple of 4 */
+    g.lda = 8; g.a_ln = 1; g.K = 1024; g.lda = g.ldb = 1024;
+    EXPECT(prd_gemm(&g, s), PRD_ERR_UNSUPPORTED);                      /* fused LayerNorm beyond K = 512 */
+    EXPECT(prd_ln_rows(0, p, 0, 0, 4, 4, 4, 4, s), PRD_ERR_ARG);
+    EXPECT(prd_ln_rows(p, p, p, 0, 4, 4, 4, 4, s), PRD_ERR_ARG);       /* gamma without beta */
+    EXPECT(prd_softmax_rows(p, 4, 8, 4, s), PRD_ERR_ARG);             /* ld < n */
+    EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 48, 256, s), PRD_ERR_UNSUPPORTED);        /* pair_dim 48 */
+    EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 64, 100, s), PRD_ERR_UNSUPPORTED);       /* dist_dim % 8 */
+    EXPECT(prd_pair_bias(p, p, p, 0, p, p, 1, 8, 64, 4, s), PRD_ERR_ARG);                    /* gamma without beta */
+    EXPECT(prd_pair_bias(p, p, 0, 0, p, p, 1, 8, 64, 9, s), PRD_ERR_ARG);                    /* more than 8 heads */
+    EXPECT(prd_opm_pair(p, p, p, p, p, p, 3, 1, 8, 64, 12, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_outer_linear(p, p, p, p, p, p, 1, 1, 8, 64, 36, 0, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, p, 16, 0, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 40, p, 1 << 20, 0, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn(p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, 4, 16, 0, 0, 0, s), PRD_ERR_ARG);   /* no workspace */
+    EXPECT(prd_tri_attn(p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, 4, 16, p, 16, 0, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 8, 64, 2, 32, s), PRD_ERR_UNSUPPORTED);        /* head_dim 32 */
+    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row too long for LDS */
+    EXPECT(prd_tri_attn_variant(320, 64), 0);
+    EXPECT(prd_tri_attn_variant(769, 64), 1);
+    EXPECT(prd_tri_attn_variant(100000, 64), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn_variant(320, 48), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_single_attn_core(p, p, p, p, 1, 8, 2, 32, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_block_tail(p, p, p, p, p, p, p, p, 0, 0, p, 1, 8, 64, 4, 0, s), PRD_ERR_ARG);   /* bias_out without bias weights */
+    EXPECT(prd_coord_head(p, p, p, p, p, p, 0, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_remove_mean(p, p, p, 1, 8, 65, s), PRD_ERR_ARG);
+    EXPECT(prd_reverse_update(p, p, ibuf, p, p, p, p, 0, 1, 8, 21, 10, s), PRD_ERR_ARG);
+    EXPECT(prd_static_pair(p, p, p, p, ibuf, ibuf, ibuf, ibuf, p, p, p, p, p, 7, 32, 1, 8, 62, s), PRD_ERR_ALIGN);
+    EXPECT(prd_time_embed(p, ibuf, p, p, 10, 1, 64, 255, s), PRD_ERR_ARG);                    /* odd time_dim */
+    EXPECT((int)(prd_workspace_bytes("tri_mul", 1, 320, 512, 64) != (size_t)3 * 64 * 320 * 320 * 4), 0);
+    EXPECT((int)prd_workspace_bytes("nonsense", 1, 320, 512, 64), 0);
+    EXPECT((int)prd_workspace_bytes(0, 1, 320, 512, 64), 0);
+    printf(failures ? "host ABI check: %d failure(s)\n" : "host ABI check: OK\n", failures);
+    return failures ? 1 : 0;
+}

@@ -185,3 +185,19 @@ def test_default_noise_follows_the_global_seed():
     x = m._sources(1, 0)[0].randn(3)
     torch.manual_seed(2)
     assert torch.equal(x, m._sources(1, 0)[0].randn(3))
+
+
+def test_c_abi_argument_checks_under_asan():
+    """the host side of the C ABI under AddressSanitizer (python -m protein_redesign_amd.build --asan): every
+    entry point is called with an invalid argument set and must return its PRD_ERR_* code without touching the GPU, and ASan
+    must stay silent.  Needs hipcc only (no GPU)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    from protein_redesign_amd.build import build_asan
+    exe = build_asan(verbose=False)
+    out = subprocess.run([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode(errors="replace")
+    assert out.returncode == 0 and "host ABI check: OK" in text and "AddressSanitizer" not in text, text[-2000:]
