@@ -86,20 +86,33 @@ class SPAttention(nn.Module):
             self.linear_z = nn.Sequential(LayerNorm(c_z), Linear(c_z, no_heads, bias=False, init="normal"))
         self.mha = Attention(c_in, c_in, c_in, c_hidden, no_heads)
 
+    def _packed(self):
+        a = self.mha
+        ws = (a.linear_q.weight, a.linear_k.weight, a.linear_v.weight, a.linear_g.weight, a.linear_g.bias)
+        return ops.cached_pack(self, "qkvg", ws, lambda: ops.pack_attention(*ws, 1.0 / math.sqrt(self.c_hidden)))
+
+    def project(self, m: torch.Tensor):
+        """The part that only needs the single representation: LayerNorm + the packed q|k|v|gate projection."""
+        mn = ops.layer_norm(m.contiguous(), self.layer_norm_m.weight, self.layer_norm_m.bias)
+        return mn, ops.project_qkvg(mn, self._packed(), self.no_heads * self.c_hidden)
+
+    def bias_from_pair(self, z: torch.Tensor) -> torch.Tensor:
+        return ops.pair_bias(z.contiguous(), self.linear_z[1].weight, None, self.linear_z[0].weight, self.linear_z[0].bias)
+
+    def attend(self, mn: torch.Tensor, qkvg: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+        a = self.mha
+        # no mask: the reference builds a mask bias and drops it (AF2_modules.py:447 vs 461-463)
+        return ops.gated_attention_single(mn, mn, bias, self._packed(), a.linear_o.weight, a.linear_o.bias,
+                                          self.no_heads, self.c_hidden, key_mask=False, resid=mn, qkvg=qkvg)
+
     def forward(self, m: torch.Tensor, z: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, N, _ = m.shape
         if self.pair_bias and z is not None:
-            bias = ops.pair_bias(z.contiguous(), self.linear_z[1].weight, None,
-                                 self.linear_z[0].weight, self.linear_z[0].bias)
+            bias = self.bias_from_pair(z)
         else:
             bias = torch.zeros(b, self.no_heads, N, N, device=m.device, dtype=torch.float32)
-        mn = ops.layer_norm(m.contiguous(), self.layer_norm_m.weight, self.layer_norm_m.bias)
-        a = self.mha
-        ws = (a.linear_q.weight, a.linear_k.weight, a.linear_v.weight, a.linear_g.weight, a.linear_g.bias)
-        packed = ops.cached_pack(self, "qkvg", ws, lambda: ops.pack_attention(*ws, 1.0 / math.sqrt(self.c_hidden)))
-        # the mask argument is unused: the reference builds a mask bias and drops it (AF2_modules.py:447 vs 461-463)
-        return ops.gated_attention_single(mn, mn, bias, packed, a.linear_o.weight, a.linear_o.bias,
-                                          self.no_heads, self.c_hidden, key_mask=False, resid=mn)
+        mn, qkvg = self.project(m)
+        return self.attend(mn, qkvg, bias)
 
 
 class OuterProductUpdate(nn.Module):
@@ -113,7 +126,8 @@ class OuterProductUpdate(nn.Module):
         self.linear_2 = Linear(c_m, c_hidden)
         self.linear_out = Linear(c_hidden, c_z, init="final")
 
-    def run(self, m, pair, mask, *, residual: bool, apply_mask: bool, out=None):
+    def project(self, m, mask):
+        """The part that only needs the single representation: LayerNorm (affine) + the packed a | b projection, masked."""
         b, N, S = m.shape
         Ch = self.c_hidden
         x = ops.layer_norm(m, self.layer_norm.weight, self.layer_norm.bias)
@@ -121,6 +135,11 @@ class OuterProductUpdate(nn.Module):
         ws = (self.linear_1.weight, self.linear_2.weight, self.linear_1.bias, self.linear_2.bias)
         w12, b12 = ops.cached_pack(self, "ab", ws, lambda: (torch.cat(ws[:2]).contiguous(), torch.cat(ws[2:]).contiguous()))
         ops.gemm(x, w12, ab, b * N, 2 * Ch, S, S, S, 2 * Ch, bias=b12, rowmask=mask)
+        return ab
+
+    def run(self, m, pair, mask, *, residual: bool, apply_mask: bool, out=None, ab=None):
+        if ab is None:
+            ab = self.project(m, mask)
         return ops.opm_pair(pair, ab, mask, self.linear_out.weight, self.linear_out.bias,
                             residual=residual, apply_mask=apply_mask, out=out)
 

@@ -197,6 +197,7 @@ class ProteinReDiffModel(_Base):
         # so different seeds give different samples like in the reference; set an int to pin it regardless of the global seed.
         self.sample_seed = None
         self.use_hip_graph = True               # replay one captured step graph inside sample()
+        self._side = None                       # ops.SideStream of the device the model runs on (created on first use)
         self._sample_counter = 0
 
         self.Denoiser = Denoiser(args)
@@ -417,16 +418,26 @@ class ProteinReDiffModel(_Base):
         rm = batch["residue_mask"].contiguous()
         mask = mask.contiguous()
         z = z.contiguous()
-        single = ops.single_init(static["single"], seq_t.contiguous(), rm, self.embed_residue_type[1].weight)
+        side = self._side
+        if side is None or side.stream is not None and side.stream.device != z.device:
+            side = self._side = ops.SideStream(z.device)
+        # head of the step: the single-track chain (single input, OPM a|b projection, SPA LayerNorm + q|k|v|g projection) only
+        # needs seq_t; it runs beside the pair input stage (time embedding, radial basis -> pair) and is joined at the OPM
+        with side.fork():
+            single = ops.single_init(static["single"], seq_t.contiguous(), rm, self.embed_residue_type[1].weight)
+            pre = self.Denoiser.project_single(single, mask)
         eb = ops.time_embed(t.contiguous(), self.embed_beta[0].weight, self.embed_beta[1].weight, self.num_steps)
         pair = ops.pair_init(static["pair"], z, mask, self.embed_dist[0].center, self.embed_dist[1].weight, eb)
-        single, pair = self.Denoiser.run_(single, pair, mask)
+        single, pair = self.Denoiser.run_(single, pair, mask, pre=pre, join=side.join)
+        # tail: the sequence head (single only) beside the coordinate head (pair only)
+        sm = self.seq_mlp
+        with side.fork():
+            h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)    # LayerNorm (no affine) fused into the linear
+            seq_pred = ops.linear(h, sm[3].weight)
         wr = self.weight_radial
         eps_raw = ops.coord_head(pair, z, mask, wr[1].weight, wr[1].bias, wr[3].weight)
         noise_pred = ops.remove_mean(eps_raw, mask)
-        sm = self.seq_mlp
-        h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)        # LayerNorm (no affine) fused into the linear
-        seq_pred = ops.linear(h, sm[3].weight)
+        side.join()
         return noise_pred, seq_pred
 
     def forward(self, batch, z, seq_t, mask, t):

@@ -33,6 +33,32 @@ def task_queue(device) -> int:
     return q.data_ptr()
 
 
+class SideStream:
+    """Fork / join of a second HIP stream around kernels that do not depend on each other (works eagerly and inside
+    ``torch.cuda.graph`` capture, where the branches become parallel paths of the hipGraph): the single track's small kernels at
+    the head and tail of a step are independent of the pair-track kernels next to them.  MEASURED SLOWER on MI355X (2.388 vs
+    2.350 ms per step, two A/B pairs on one box: the cross-branch dependencies of the replayed graph cost more than the ~70 us
+    of small kernels they take off the critical path), so it is OFF unless ``PRD_SIDE_STREAM=1``."""
+
+    def __init__(self, device):
+        import os
+        self.enabled = os.environ.get("PRD_SIDE_STREAM", "0") == "1"
+        self.stream = torch.cuda.Stream(device=device) if self.enabled else None
+
+    def fork(self):
+        """Context manager: launches inside run on the side stream, ordered after everything enqueued so far on the current one."""
+        import contextlib
+        if not self.enabled:
+            return contextlib.nullcontext()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.stream)
+
+    def join(self):
+        """The current stream waits for everything enqueued on the side stream."""
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
 def _off(t: torch.Tensor, elem_offset: int = 0) -> int:
     return dptr(t) + 4 * elem_offset
 
@@ -310,22 +336,34 @@ def pack_attention(wq, wk, wv, wg, bg, q_scale: float):
     return w, bias, colscale
 
 
+def project_qkvg(x_normed, packed, HC: int, ln_a: bool = False) -> torch.Tensor:
+    """[q * scale | k | v | sigmoid(gate)] = one packed GEMM over the node rows (``packed`` from ``pack_attention``)."""
+    b, N, S = x_normed.shape
+    w, pbias, colscale = packed
+    L = 4 * HC
+    qkvg = torch.empty(b, N, L, device=x_normed.device, dtype=F32)
+    gemm(x_normed, w, qkvg, b * N, L, S, S, S, L, bias=pbias, colscale=colscale, act=2, act_from=3 * HC, a_ln=ln_a)
+    return qkvg
+
+
 def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int, *,
-                           key_mask: bool, resid: Optional[torch.Tensor], ln_a: bool = False) -> torch.Tensor:
+                           key_mask: bool, resid: Optional[torch.Tensor], ln_a: bool = False,
+                           qkvg: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Multi-head gated attention over the node axis with an additive [b,H,N,N] bias.
 
     Covers reference modules.py:185-225 (c = head_dim, key mask filled with -2**15, q pre-scaled by
     1/sqrt(c)) and models/AF2_modules.py:251-293,613-628 (c = single_dim, no mask).  ``packed`` comes
     from ``pack_attention``.  Returns ``resid + out_proj(...)`` (or the bare update when ``resid`` is None).
-    ``ln_a``: ``x_normed`` is the raw input and its (affine-free) LayerNorm is fused into the q|k|v|g projection."""
+    ``ln_a``: ``x_normed`` is the raw input and its (affine-free) LayerNorm is fused into the q|k|v|g projection.
+    ``qkvg``: the projection, if the caller already computed it (``project_qkvg``, e.g. on a side stream)."""
     b, N, S = x_normed.shape
     HC = H * c
     w, pbias, colscale = packed
     L = 4 * HC
-    if ln_a and not ln_fusable(S):
-        x_normed, ln_a = layer_norm(x_normed.contiguous()), False
-    qkvg = torch.empty(b, N, L, device=x_normed.device, dtype=F32)
-    gemm(x_normed, w, qkvg, b * N, L, S, S, S, L, bias=pbias, colscale=colscale, act=2, act_from=3 * HC, a_ln=ln_a)
+    if qkvg is None:
+        if ln_a and not ln_fusable(S):
+            x_normed, ln_a = layer_norm(x_normed.contiguous()), False
+        qkvg = project_qkvg(x_normed, packed, HC, ln_a)
     o = torch.empty(b, N, HC, device=x_normed.device, dtype=F32)
     if c == 16 and HC == 64:
         # heads of width 16 (FoldingBlock.single_attn): fused logits + bias + mask + softmax + PV + gate

@@ -269,14 +269,29 @@ class Denoiser(nn.Module):
         P = self.pair_dim
         return max(ops.workspace_bytes("tri_mul", b, N, 0, P), ops.workspace_bytes("tri_attn", b, N, 0, P)) // 4
 
-    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None):
+    def project_single(self, single: torch.Tensor, mask: torch.Tensor):
+        """Everything at the head of the trunk that depends on the single representation only (OPM's a | b projection, SPA's
+        LayerNorm + q|k|v|g projection): independent of the pair input stage, so the caller may run it on a side stream."""
+        ab = self.opm.project(single, mask)
+        mn, qkvg = self.SPAAttnBlock.project(single)
+        return ab, mn, qkvg
+
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, pre=None, join=None):
         """OPM, SPA and the folding blocks, in place on ``pair``, WITHOUT the final symmetrisation
-        (the fused coordinate head symmetrises on the fly, so the hot path never writes it back)."""
+        (the fused coordinate head symmetrises on the fly, so the hot path never writes it back).
+        ``pre`` = ``project_single(single, mask)`` if the caller already enqueued it; ``join()`` is then called before its
+        results are consumed."""
         b, N = mask.shape
         if ws is None:
             ws = torch.empty(self.ws_floats(b, N), device=pair.device, dtype=torch.float32)
-        self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair)
-        single = self.SPAAttnBlock(single, pair, mask)
+        if pre is None:
+            pre = self.project_single(single, mask)
+        ab, mn, qkvg = pre
+        if join is not None:
+            join()
+        self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair, ab=ab)
+        spa = self.SPAAttnBlock
+        single = spa.attend(mn, qkvg, spa.bias_from_pair(pair))
         bias = None
         blocks = list(self.folding_blocks)
         for i, block in enumerate(blocks):
