@@ -183,6 +183,17 @@ int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pr
                        const float* noise, const float* mask, const float* coef,
                        int b, int N, int n_cls, int num_steps, hipStream_t stream);
 
+/* The whole step boundary of the sampling loop in one launch (model.py:373, 405-420 and the next step's model.py:341-346):
+ * noise_pred = remove_mean(eps_raw); z, seq_t advanced as in prd_reverse_update; t <- t - 1; and the NEXT step's inputs
+ * ebeta_next[b,P] = time embedding of t - 1 (prd_time_embed) and single_next[b,N,S] = prd_single_init of the new seq_t.
+ * sync: one int32, zero before the first launch, owned by the caller and shared only by stream-ordered launches (the last
+ * workgroup to arrive advances t and resets it).  n_cls must be 21 (20 residue types + 'X'), time_dim <= 512 and even. */
+int prd_step_boundary(float* z, float* seq_t, int64_t* t, const float* eps_raw, const float* seq_pred,
+                      const float* noise, const float* mask, const float* coef,
+                      float* single_next, const float* static_single, const float* residue_mask, const float* w_rt,
+                      float* ebeta_next, const float* freqs, const float* w_beta, int* sync,
+                      int b, int N, int n_cls, int num_steps, int S, int P, int time_dim, hipStream_t stream);
+
 /* bytes of scratch an operator needs: op = "tri_mul" | "tri_attn" */
 size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P);
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
+    "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 6 + [vp],
     "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],

@@ -1058,6 +1058,158 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
     if (threadIdx.x == 0) t[bb] = tt - 1;
 }
 
+// Step boundary of the reverse-diffusion loop in ONE multi-workgroup launch (instead of remove_mean, reverse_update on a single
+// workgroup, and the next step's single_init and time_embed -- four dependent launches):
+//   noise_pred = remove_mean(eps_raw)                                   (utils.py:32-36; model.py:373)
+//   z <- (z - w_t noise_pred) / sqrt(alpha_t) [+ sqrt(beta_t) remove_mean(noise_t)],  seq_t <- 2 softmax(seq_pred) - 1   (model.py:405-420)
+//   t <- t - 1;   ebeta <- W_beta sinus(t / T);   single <- static + rm * relu(W_rt LN(seq_t))    (model.py:341-346, the NEXT step's inputs)
+// Workgroups [0, nblk) of a sample own 8 nodes each (a 32-node version ran 42 us: one long chain of dependent L2 round trips
+// per workgroup -- the work has to be wide, not deep); the masked means over all nodes are recomputed by every one of them
+// (N x 7 loads).  Workgroups [nblk, nblk + P/4) compute four time-embedding outputs each.  The step counter is advanced by the
+// LAST workgroup to arrive at `sync` (one int, zero before the first launch; every workgroup reads t before it arrives), which
+// also resets the counter for the next replay of the graph.
+constexpr int SB_NODES = 8;
+template <int NCLS>
+__global__ __launch_bounds__(256) void step_boundary_kernel(
+    float* __restrict__ z, float* __restrict__ seq_t, int64_t* __restrict__ t, const float* __restrict__ eps_raw,
+    const float* __restrict__ seq_pred, const float* __restrict__ noise, const float* __restrict__ mask, const float* __restrict__ coef,
+    float* __restrict__ single_next, const float* __restrict__ stat, const float* __restrict__ rm, const float* __restrict__ w_rt,
+    float* __restrict__ ebeta_next, const float* __restrict__ freqs, const float* __restrict__ w_beta, int* __restrict__ sync,
+    int b, int N, int num_steps, int S, int P, int TD, int nblk, int neb) {
+    constexpr int ncls = NCLS, CPL = (NCLS + 7) / 8;      // classes per lane in the 8-lanes-per-node softmax
+    __shared__ float red[4][8];
+    __shared__ float mean[8];
+    __shared__ float xs[SB_NODES][NCLS + 3];     // LayerNorm-ed new seq_t of the workgroup's nodes
+    __shared__ float feat[512];
+    __shared__ int last;
+    const int per = nblk + neb;
+    const int bb = blockIdx.x / per, blk = blockIdx.x - bb * per;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long tt = t[bb];
+    if (blk >= nblk) {                           // ---- time embedding of the NEXT step (t - 1; unused after the last step) ----
+        const float tau = (float)(tt - 1) / (float)num_steps;
+        const int half = TD / 2;
+        for (int k = tid; k < half; k += 256) {
+            const float wx = freqs[k] * tau;
+            feat[k] = sinf(wx);
+            feat[half + k] = cosf(wx);
+        }
+        __syncthreads();
+        const int p = (blk - nblk) * 4 + wave;   // one wave per output: coalesced reads of W_beta's row, shuffle reduction
+        if (p < P) {
+            float acc = 0.f;
+            for (int k = lane; k < TD; k += 64) acc += feat[k] * w_beta[p * TD + k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) ebeta_next[bb * P + p] = acc;
+        }
+    } else {                                     // ---- 8 nodes: z, seq_t, and the next step's single input ----
+        const int i0 = blk * SB_NODES;
+        const float wn = coef[tt * 4 + 0], isa = coef[tt * 4 + 1], sb = coef[tt * 4 + 2];
+        const float* nz = noise + ((long)(tt > 0 ? num_steps - 1 - tt : 0) * b + bb) * N * 3;
+        const float* ep = eps_raw + (long)bb * N * 3;
+        {   // masked sums over ALL nodes: predicted noise (3), drawn noise (3), node count
+            float s7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int i = tid; i < N; i += 256) {
+                const float m = mask[bb * N + i];
+                s7[0] += m * ep[i * 3]; s7[1] += m * ep[i * 3 + 1]; s7[2] += m * ep[i * 3 + 2];
+                s7[3] += m * nz[i * 3]; s7[4] += m * nz[i * 3 + 1]; s7[5] += m * nz[i * 3 + 2];
+                s7[6] += m;
+            }
+#pragma unroll
+            for (int d = 0; d < 7; ++d) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s7[d] += __shfl_xor(s7[d], o);
+                if (lane == 0) red[wave][d] = s7[d];
+            }
+        }
+        if (tid < 8 * SB_NODES) {   // seq_t: 2 softmax - 1 and its LayerNorm; 8 lanes per node, classes l, l+8, ...
+            const int n = tid >> 3, l = tid & 7, i = i0 + n;
+            const bool ok = i < N;
+            const float* lp = seq_pred + ((long)bb * N + (ok ? i : 0)) * ncls;
+            float v[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v[q] = (l + 8 * q < ncls) ? lp[l + 8 * q] : -INFINITY;
+            float mx = v[0];
+#pragma unroll
+            for (int q = 1; q < CPL; ++q) mx = fmaxf(mx, v[q]);
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { v[q] = (l + 8 * q < ncls) ? expf(v[q] - mx) : 0.f; sum += v[q]; }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+            float mu = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { v[q] = (l + 8 * q < ncls) ? v[q] / sum * 2.f - 1.f : 0.f; mu += v[q]; }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) mu += __shfl_xor(mu, o);
+            mu /= ncls;
+            float var = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { const float dlt = (l + 8 * q < ncls) ? v[q] - mu : 0.f; var += dlt * dlt; }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) var += __shfl_xor(var, o);
+            const float rstd = 1.0f / sqrtf(var / ncls + 1e-5f);
+            float* sp = seq_t + ((long)bb * N + (ok ? i : 0)) * ncls;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+                if (l + 8 * q < ncls) {
+                    if (ok) sp[l + 8 * q] = v[q];
+                    xs[n][l + 8 * q] = ok ? (v[q] - mu) * rstd : 0.f;
+                }
+        }
+        __syncthreads();
+        if (tid < 7) mean[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        __syncthreads();
+        if (tid >= 64 && tid < 64 + 3 * SB_NODES) {      // z of the workgroup's nodes
+            const int q = tid - 64, i = i0 + q / 3, d = q - (q / 3) * 3;
+            if (i < N) {
+                const long g = ((long)bb * N + i) * 3 + d;
+                const float m = mask[bb * N + i];
+                const float npred = eps_raw[g] - m * mean[d] / mean[6];
+                float out = isa * (z[g] - wn * npred);
+                if (tt > 0) out = out + sb * (nz[i * 3 + d] - m * mean[3 + d] / mean[6]);
+                z[g] = out;
+            }
+        }
+        // single input of the next step: thread -> channels c, c + 256, ...; W_rt row in registers; the static-single / mask loads
+        // of the 8 nodes are issued together
+        for (int c = tid; c < S; c += 256) {
+            float w[NCLS], st8[SB_NODES], rm8[SB_NODES];
+#pragma unroll
+            for (int u = 0; u < SB_NODES; ++u) {
+                const int i = i0 + u;
+                const long row = (long)bb * N + (i < N ? i : N - 1);
+                st8[u] = stat[row * S + c];
+                rm8[u] = rm[row];
+            }
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) w[k] = w_rt[c * NCLS + k];
+#pragma unroll
+            for (int u = 0; u < SB_NODES; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NCLS; ++k) acc += xs[u][k] * w[k];
+                if (i0 + u < N) single_next[((long)bb * N + i0 + u) * S + c] = st8[u] + rm8[u] * fmaxf(acc, 0.f);
+            }
+        }
+    }
+    // advance the step counters once every workgroup has read them
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const int arrived = atomicAdd(sync, 1);
+        last = (arrived == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last) {
+        for (int k = tid; k < b; k += 256) t[k] = t[k] - 1;
+        if (tid == 0) atomicExch(sync, 0);
+    }
+}
+
 int grid_for(long tasks, int per_wg, int cap) {
     long g = (tasks + per_wg - 1) / per_wg;
     if (g > cap) g = cap;
@@ -1324,5 +1476,20 @@ extern "C" int prd_reverse_update(float* z, float* seq_t, int64_t* t, const floa
                                   int b, int N, int n_cls, int num_steps, hipStream_t stream) {
     if (!z || !seq_t || !t || !noise_pred || !seq_pred || !noise || !mask || !coef || b <= 0 || N <= 0 || n_cls <= 0) return PRD_ERR_ARG;
     hipLaunchKernelGGL(reverse_update_kernel, dim3(b), dim3(256), 0, stream, z, seq_t, t, noise_pred, seq_pred, noise, mask, coef, N, n_cls, num_steps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_step_boundary(float* z, float* seq_t, int64_t* t, const float* eps_raw, const float* seq_pred,
+                                 const float* noise, const float* mask, const float* coef,
+                                 float* single_next, const float* static_single, const float* residue_mask, const float* w_rt,
+                                 float* ebeta_next, const float* freqs, const float* w_beta, int* sync,
+                                 int b, int N, int n_cls, int num_steps, int S, int P, int time_dim, hipStream_t stream) {
+    if (!z || !seq_t || !t || !eps_raw || !seq_pred || !noise || !mask || !coef || !single_next || !static_single || !residue_mask ||
+        !w_rt || !ebeta_next || !freqs || !w_beta || !sync || b <= 0 || N <= 0 || S <= 0 || P <= 0) return PRD_ERR_ARG;
+    if (n_cls != 21 || time_dim <= 0 || time_dim > 512 || (time_dim & 1)) return PRD_ERR_UNSUPPORTED;    // 20 residue types + 'X'
+    const int nblk = prd_ceil_div(N, SB_NODES), neb = prd_ceil_div(P, 4);
+    hipLaunchKernelGGL(step_boundary_kernel<21>, dim3(b * (nblk + neb)), dim3(256), 0, stream, z, seq_t, t, eps_raw, seq_pred, noise, mask, coef,
+                       single_next, static_single, residue_mask, w_rt, ebeta_next, freqs, w_beta, sync, b, N, num_steps, S, P,
+                       time_dim, nblk, neb);
     return (int)hipGetLastError();
 }

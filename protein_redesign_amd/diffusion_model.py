@@ -412,7 +412,16 @@ class ProteinReDiffModel(_Base):
         ss = ops.linear(esm, self.embed_residue_esm[1].weight, rowmask=rm, resid=ss)
         return {"pair": sp, "single": ss}
 
-    def _network(self, batch, z, seq_t, mask, t, static=None):
+    def _step_inputs(self, static, seq_t, rm, t):
+        """Per-step inputs of the network that do not depend on the coordinates: single (model.py:343-346) and the time
+        embedding (model.py:341, 360).  Inside ``sample()`` the fused step-boundary kernel produces them for the next step."""
+        single = ops.single_init(static["single"], seq_t.contiguous(), rm, self.embed_residue_type[1].weight)
+        eb = ops.time_embed(t.contiguous(), self.embed_beta[0].weight, self.embed_beta[1].weight, self.num_steps)
+        return single, eb
+
+    def _network(self, batch, z, seq_t, mask, t, static=None, step_inputs=None, raw_noise=False):
+        """``step_inputs`` = (single, ebeta) if already computed; ``raw_noise``: return the coordinate head's output before
+        remove_mean (the step-boundary kernel removes the mean itself)."""
         if static is None:
             static = self._static_inputs(batch)
         rm = batch["residue_mask"].contiguous()
@@ -421,22 +430,21 @@ class ProteinReDiffModel(_Base):
         side = self._side
         if side is None or side.stream is not None and side.stream.device != z.device:
             side = self._side = ops.SideStream(z.device)
-        # head of the step: the single-track chain (single input, OPM a|b projection, SPA LayerNorm + q|k|v|g projection) only
-        # needs seq_t; it runs beside the pair input stage (time embedding, radial basis -> pair) and is joined at the OPM
+        if step_inputs is None:
+            step_inputs = self._step_inputs(static, seq_t, rm, t)
+        single, eb = step_inputs
+        # (opt-in, measured slower: ops.SideStream) the single-only chain beside the pair input stage, joined at the OPM
         with side.fork():
-            single = ops.single_init(static["single"], seq_t.contiguous(), rm, self.embed_residue_type[1].weight)
             pre = self.Denoiser.project_single(single, mask)
-        eb = ops.time_embed(t.contiguous(), self.embed_beta[0].weight, self.embed_beta[1].weight, self.num_steps)
         pair = ops.pair_init(static["pair"], z, mask, self.embed_dist[0].center, self.embed_dist[1].weight, eb)
         single, pair = self.Denoiser.run_(single, pair, mask, pre=pre, join=side.join)
-        # tail: the sequence head (single only) beside the coordinate head (pair only)
         sm = self.seq_mlp
         with side.fork():
             h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)    # LayerNorm (no affine) fused into the linear
             seq_pred = ops.linear(h, sm[3].weight)
         wr = self.weight_radial
         eps_raw = ops.coord_head(pair, z, mask, wr[1].weight, wr[1].bias, wr[3].weight)
-        noise_pred = ops.remove_mean(eps_raw, mask)
+        noise_pred = eps_raw if raw_noise else ops.remove_mean(eps_raw, mask)
         side.join()
         return noise_pred, seq_pred
 
@@ -502,6 +510,16 @@ class ReverseDiffusion:
         self.steps_done = 0
         self.graph = None
         self.seq_pred = None
+        # inputs of the coming step that the previous step's boundary kernel prepares (single, time embedding)
+        import os
+        self.fused_boundary = os.environ.get("PRD_FUSED_BOUNDARY", "1") != "0"
+        self.sync = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.single_in, self.eb_in = m._step_inputs(self.static, self.seq_t, self.rm, self.t)
+
+    def _refresh_step_inputs(self):
+        single, eb = self.model._step_inputs(self.static, self.seq_t, self.rm, self.t)
+        self.single_in.copy_(single)
+        self.eb_in.copy_(eb)
 
     def reset(self):
         """Back to step T-1 with the same initial noise (bench / repeated runs)."""
@@ -509,6 +527,7 @@ class ReverseDiffusion:
         self.seq_t.copy_(self._init[1])
         self.t.fill_(self.T - 1)
         self.steps_done = 0
+        self._refresh_step_inputs()
 
     def restart(self, step: int, z: torch.Tensor, seq_t: torch.Tensor):
         """Continue from a given state: ``z`` / ``seq_t`` are the tensors ENTERING denoising step number ``step`` (0 = the
@@ -520,11 +539,21 @@ class ReverseDiffusion:
         self.seq_t.copy_(seq_t.to(self.seq_t.device))
         self.t.fill_(self.T - 1 - step)
         self.steps_done = step
+        self._refresh_step_inputs()
 
     def _enqueue_step(self):
+        """Network forward on the inputs the previous boundary prepared, then ONE step-boundary launch: remove_mean, reverse
+        update, t <- t - 1 and the next step's single / time-embedding inputs (ops.step_boundary_)."""
         m = self.model
-        noise_pred, seq_pred = m._network(self.batch, self.z, self.seq_t, self.mask, self.t, static=self.static)
-        ops.reverse_update_(self.z, self.seq_t, self.t, noise_pred, seq_pred, self.noise, self.mask, m._coef, self.T)
+        if not self.fused_boundary:             # the four separate launches (kept for A/B measurements: PRD_FUSED_BOUNDARY=0)
+            noise_pred, seq_pred = m._network(self.batch, self.z, self.seq_t, self.mask, self.t, static=self.static)
+            ops.reverse_update_(self.z, self.seq_t, self.t, noise_pred, seq_pred, self.noise, self.mask, m._coef, self.T)
+            return seq_pred
+        eps_raw, seq_pred = m._network(self.batch, self.z, self.seq_t, self.mask, self.t, static=self.static,
+                                       step_inputs=(self.single_in, self.eb_in), raw_noise=True)
+        ops.step_boundary_(self.z, self.seq_t, self.t, eps_raw, seq_pred, self.noise, self.mask, m._coef, self.T,
+                           self.single_in, self.static["single"], self.rm, m.embed_residue_type[1].weight,
+                           self.eb_in, m.embed_beta[0].weight, m.embed_beta[1].weight, self.sync)
         return seq_pred
 
     @torch.inference_mode()

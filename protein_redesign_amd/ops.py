@@ -301,6 +301,17 @@ def reverse_update_(z, seq_t, t, noise_pred, seq_pred, noise, mask, coef, num_st
           "prd_reverse_update")
 
 
+def step_boundary_(z, seq_t, t, eps_raw, seq_pred, noise, mask, coef, num_steps: int, single_next, static_single, residue_mask,
+                   w_rt, ebeta_next, freqs, w_beta, sync):
+    """Reverse update + the next step's single / time-embedding inputs in one launch (prd_hip.h: prd_step_boundary)."""
+    b, N, _ = z.shape
+    P, TD = w_beta.shape
+    check(lib().prd_step_boundary(dptr(z), dptr(seq_t), dptr(t, torch.int64), dptr(eps_raw), dptr(seq_pred), dptr(noise), dptr(mask),
+                                  dptr(coef), dptr(single_next), dptr(static_single), dptr(residue_mask), dptr(w_rt),
+                                  dptr(ebeta_next), dptr(freqs), dptr(w_beta), dptr(sync, torch.int32), b, N, seq_pred.shape[-1],
+                                  num_steps, static_single.shape[-1], P, TD, stream()), "prd_step_boundary")
+
+
 def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> torch.Tensor:
     """First launch of tri_attn alone (bench / profiling): og[b,N,N,64]; wts = (q.w, k.w, v.w, gate.w, gate.b)."""
     b, N, _, P = pair.shape

@@ -22,6 +22,14 @@ def ln(x, w=None, b=None):
     return F.layer_norm(x, x.shape[-1:], w, b, 1e-5)
 
 
+def small_table_lookup(idx, table):
+    """F.embedding for a table of a few rows over a huge index tensor, as one-hot @ table: the backward is then a dense
+    [rows x positions] GEMM instead of a scatter-add with millions of collisions per row (4 ms per table at N = 320)."""
+    if table.shape[0] > 128:
+        return F.embedding(idx, table)
+    return F.one_hot(idx, table.shape[0]).to(table.dtype) @ table
+
+
 def gated_attention(x, mask, wq, wk, wv, wg, bg, wo, bo, heads: int, head_dim: int, bias: Optional[torch.Tensor] = None):
     """modules.py:185-225: LN, q/k/v (no bias), sigmoid gate, q pre-scaled by 1/sqrt(c), additive bias, key mask filled with
     -2**15, softmax, gate, output projection.  ``x`` [..., n, E], ``mask`` [..., n] (keys)."""
@@ -123,15 +131,15 @@ def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int
     sb = 1.0 / math.sqrt(len(bond_tabs))
     bacc = 0.0
     for f, tab in enumerate(bond_tabs):
-        bacc = bacc + sb * F.embedding(batch["bond_feats"][..., f], tab)
+        bacc = bacc + sb * small_table_lookup(batch["bond_feats"][..., f], tab)
     am2 = (am.unsqueeze(-1) * am.unsqueeze(-2)).unsqueeze(-1)
     rm2 = (rm.unsqueeze(-1) * rm.unsqueeze(-2)).unsqueeze(-1)
     m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
     ri, ci = batch["residue_index"], batch["residue_chain_index"]
     rel = (ri.unsqueeze(-1) - ri.unsqueeze(-2)).clamp(min=-max_relpos, max=max_relpos) + max_relpos
     chain = (ci.unsqueeze(-1) == ci.unsqueeze(-2)).float().unsqueeze(-1)
-    pair = am2 * (batch["bond_mask"].unsqueeze(-1) * bacc + F.embedding(batch["bond_distance"].clamp(max=max_bond_distance), bd_tab))
-    pair = pair + rm2 * (chain * F.embedding(rel, rp_tab))
+    pair = am2 * (batch["bond_mask"].unsqueeze(-1) * bacc + small_table_lookup(batch["bond_distance"].clamp(max=max_bond_distance), bd_tab))
+    pair = pair + rm2 * (chain * small_table_lookup(rel, rp_tab))
     dist = torch.linalg.norm(z.unsqueeze(-2) - z.unsqueeze(-3), dim=-1)
     scale = (centers.numel() - 1) / 2.0
     rbf = torch.exp(-scale * torch.square(dist.unsqueeze(-1) - centers))

@@ -10,7 +10,7 @@ import sys
 def main():
     db = sqlite3.connect(sys.argv[1])
     rows = list(db.execute("select name, start, end, grid_x from kernels order by start"))
-    idx = [i for i, r in enumerate(rows) if "reverse_update" in r[0]]
+    idx = [i for i, r in enumerate(rows) if "reverse_update" in r[0] or "step_boundary" in r[0]]
     a, b = idx[-2], idx[-1]
     agg = collections.OrderedDict()
     for r in rows[a + 1: b + 1]:
