@@ -6,6 +6,7 @@
 // (ProteinReDiff/modules.py:185-225, 306-311; models/AF2_modules.py:251-293, 613-628).
 #include "prd_common.h"
 #include "../../include/prd_hip.h"
+#include <mutex>
 
 namespace {
 
@@ -332,6 +333,153 @@ __global__ __launch_bounds__(NWK * 64) void gemm_skinny_kernel(PrdGemm g) {   //
     }
 }
 
+// ---- single-track GEMM on the fp16 matrix pipe (gemm mode 1) ---------------------------------------------------------------
+// C = epilogue(A B^T) for the node-row linears (M = b N rows, a few hundred): both operands are split into fp16 hi + lo while
+// they are staged into LDS (prd_common.h: split2h; weights x 16), three products per K step on v_mfma_f32_32x32x16_f16.
+// What bounded the fp32 skinny kernel was not the MFMA but operand traffic and latency: 32x32 tiles re-load every A row N/32
+// times (82 MB of L2 reads for the 512 -> 2048 linear) through row-per-lane loads (64 cache lines per instruction).  Here a
+// workgroup owns a 64x64 tile (2x2 waves of 32x32), streams K in 32-wide chunks through double-buffered LDS with coalesced
+// 128-byte row segments, and -- for long K -- KG groups of four waves take every KG-th chunk (split-K inside the workgroup,
+// merged in LDS in a fixed order).  Optional fused LayerNorm of the A rows (statistics in a prologue pass).
+template <int KG>
+__global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
+    constexpr int PLANE = 64 * 64;                      // bytes of one operand plane of a 64-row, 32-wide chunk
+    constexpr int BUF = 4 * PLANE;                      // A hi | A lo | B hi | B lo
+    extern __shared__ __attribute__((aligned(16))) unsigned char gh[];      // [KG][2 buffers][BUF] + [64] mean + [64] rstd
+    float* mean_l = reinterpret_cast<float*>(gh + KG * 2 * BUF);
+    float* rstd_l = mean_l + 64;
+    const int tid = threadIdx.x, kg = tid >> 8, t8 = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int r = lane & 31, hi = lane >> 5;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int tiles_n = (g.N + 63) / 64;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 64, n0 = tile_n * 64;
+    const int gb = blockIdx.y, g1 = gb / g.G2, g2 = gb - g1 * g.G2;
+    const float* __restrict__ A = g.A + g1 * g.sa1 + g2 * g.sa2;
+    const float* __restrict__ B = g.B + g1 * g.sb1 + g2 * g.sb2;
+    if (g.a_ln) {                                       // per-row LayerNorm statistics of the 64 A rows (4 threads per row)
+        if (tid < 256) {
+            const int row = tid >> 2, part = tid & 3, m = m0 + row;
+            const float* ar = A + (size_t)(m < g.M ? m : 0) * g.lda;
+            float s1 = 0.f;
+            for (int k = 4 * part; k < g.K; k += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(ar + k);
+                s1 += (v.x + v.y) + (v.z + v.w);
+            }
+            s1 += __shfl_xor(s1, 1);
+            s1 += __shfl_xor(s1, 2);
+            const float mu = s1 / (float)g.K;
+            float s2 = 0.f;
+            for (int k = 4 * part; k < g.K; k += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(ar + k);
+                const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            s2 += __shfl_xor(s2, 1);
+            s2 += __shfl_xor(s2, 2);
+            if (part == 0) { mean_l[row] = mu; rstd_l[row] = 1.0f / sqrtf(s2 / (float)g.K + 1e-5f); }
+        }
+        __syncthreads();
+    }
+    // staging of a K-group: 64 A rows + 64 B rows x 8 pieces of 4 floats per chunk = 1024 pieces, 4 per thread (2 A, 2 B)
+    const prd_rsrc ra = make_rsrc(A + (size_t)m0 * g.lda), rb = make_rsrc(B + (size_t)n0 * g.ldb);
+    unsigned off[4], dst[4];
+    float amu[2], ars[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (t8 + 256 * i) & 511, row = p >> 3, f = p & 7;
+        const bool isb = i >= 2;
+        const bool ok = isb ? (n0 + row < g.N) : (m0 + row < g.M);
+        off[i] = ok ? ((unsigned)row * (isb ? g.ldb : g.lda) + 4 * f) * 4u : BUF_OOB;
+        dst[i] = (isb ? 2 * PLANE : 0) + row * 64 + (((f >> 1) ^ ((row >> 2) & 3)) << 4) + (f & 1) * 8;
+        if (!isb) { amu[i] = g.a_ln ? mean_l[row] : 0.f; ars[i] = g.a_ln ? (ok ? rstd_l[row] : 0.f) : 1.f; }
+    }
+    unsigned char* mybuf = gh + kg * 2 * BUF;
+    const unsigned swz = (unsigned)((r >> 2) & 3);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int nchunk = g.K / 32;                        // K is a multiple of 32 on this path
+    const int myn = (nchunk - kg + KG - 1) / KG;        // chunks kg, kg + KG, ... of this K-group
+    u32x4 u[4], v[4];
+#define PRD_GH_LOAD(R, CI)                                                                                          \
+    {                                                                                                               \
+        const int c_ = kg + KG * ((CI) < myn ? (CI) : (myn > 0 ? myn - 1 : 0));                                     \
+        R[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[0], c_ * 128, 0));           \
+        R[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[1], c_ * 128, 0));           \
+        R[2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[2], c_ * 128, 0));           \
+        R[3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[3], c_ * 128, 0));           \
+    }
+#define PRD_GH_STAGE(R, BUFI)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
+        float x0 = __uint_as_float(R[i][0]), x1 = __uint_as_float(R[i][1]), x2 = __uint_as_float(R[i][2]), x3 = __uint_as_float(R[i][3]); \
+        if (i < 2) { x0 = (x0 - amu[i]) * ars[i]; x1 = (x1 - amu[i]) * ars[i]; x2 = (x2 - amu[i]) * ars[i]; x3 = (x3 - amu[i]) * ars[i]; } \
+        else { x0 *= H2_WSCALE; x1 *= H2_WSCALE; x2 *= H2_WSCALE; x3 *= H2_WSCALE; }                                \
+        unsigned h0, l0, h1, l1;                                                                                    \
+        split2h(x0, x1, h0, l0);                                                                                    \
+        split2h(x2, x3, h1, l1);                                                                                    \
+        unsigned char* d_ = mybuf + (BUFI) * BUF + dst[i];                                                          \
+        *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};                                                              \
+        *reinterpret_cast<u32x2*>(d_ + PLANE) = u32x2{l0, l1};                                                      \
+    }
+#define PRD_GH_CHUNK(CI, CUR, R, NX)                                                                                \
+    {                                                                                                               \
+        PRD_GH_LOAD(NX, (CI) + 2)                                                                                   \
+        if ((CI) < myn) {                                                                                           \
+            const unsigned char* base = mybuf + (CUR) * BUF;                                                        \
+            _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                      \
+                const unsigned col = (((unsigned)(2 * st + hi)) ^ swz) << 4;                                        \
+                const unsigned char* ap = base + (wm0 + r) * 64 + col;                                              \
+                const unsigned char* bp = base + 2 * PLANE + (wn0 + r) * 64 + col;                                  \
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ap), al = *reinterpret_cast<const u32x4*>(ap + PLANE); \
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(bp), bl = *reinterpret_cast<const u32x4*>(bp + PLANE); \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0); \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bl), acc, 0, 0, 0); \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0); \
+            }                                                                                                       \
+        }                                                                                                           \
+        if ((CI) + 1 < myn) { PRD_GH_STAGE(R, (CUR) ^ 1) }                                                          \
+        __syncthreads();                                                                                            \
+    }
+    const int maxn = (nchunk + KG - 1) / KG;            // trip count of the longest K-group: barriers are workgroup-wide
+    PRD_GH_LOAD(u, 0)
+    if (myn > 0) { PRD_GH_STAGE(u, 0) }
+    PRD_GH_LOAD(u, 1)
+    __syncthreads();
+    for (int ci = 0; ci < maxn; ci += 2) {
+        PRD_GH_CHUNK(ci, 0, u, v)
+        if (ci + 1 < maxn) PRD_GH_CHUNK(ci + 1, 1, v, u)
+    }
+#undef PRD_GH_LOAD
+#undef PRD_GH_STAGE
+#undef PRD_GH_CHUNK
+    if (KG > 1) {                                       // merge the K-groups in LDS (over the staging buffers), fixed order
+        float* part = reinterpret_cast<float*>(gh);     // [KG - 1][256 threads][17]
+        if (kg > 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) part[((kg - 1) * 256 + t8) * 17 + q] = acc[q];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < KG - 1; ++k2)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] += part[(k2 * 256 + t8) * 17 + q];
+        }
+    }
+    if (kg == 0) {
+        float* __restrict__ C = g.C + g1 * g.sc1 + g2 * g.sc2;
+        const int n = n0 + wn0 + r;
+        if (n < g.N) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm0 + drow32(q, hi);
+                if (m < g.M) epilogue_store(g, g1, g2, m, n, acc[q] * H2_INV_WSCALE, C);
+            }
+        }
+    }
+}
+
 // ---- LayerNorm rows: one wave per row ------------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -379,6 +527,25 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     if ((g.lda & 3) || (g.ldb & 3)) return PRD_ERR_ALIGN;
     const int batches = g.G1 * g.G2;
     const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
+    // gemm mode 1: THROUGHPUT-bound linears (>= 512 tiles of 64x64: SPAttention's 512 -> 4 x 2048 projection) go to the fp16 x 2
+    // split kernel (41 -> 26 us).  The other single-track linears (20-160 tiles) are latency-bound: there the LDS-staged kernel
+    // measured SLOWER than the skinny fp32 kernel, which has all its operand loads in flight at once (512 -> 2048: 27 vs 20 us,
+    // 2048 -> 512: 31 vs 22, 512 -> 256: 27 vs 11; a two-chunk prefetch does not cover the ~2 us operand latency of a 0.25 us chunk).
+    if (prd_get_gemm_mode() == 1 && g.tile_hint == 0 && !g.b_kn && (g.K % 32) == 0 && tiles64 >= 512 && g.G1 * g.G2 == 1 &&
+        (!g.a_ln || (g.K % 16) == 0)) {
+        dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
+        static std::once_flag once1, once4;
+        if (g.K >= 1024) {
+            const size_t lds = (size_t)4 * 2 * 4 * 64 * 64 + 512;
+            std::call_once(once4, [] { (void)hipFuncSetAttribute((const void*)gemm_h2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+            hipLaunchKernelGGL((gemm_h2_kernel<4>), grid, dim3(1024), lds, stream, g);
+        } else {
+            const size_t lds = (size_t)2 * 4 * 64 * 64 + 512;
+            std::call_once(once1, [] { (void)hipFuncSetAttribute((const void*)gemm_h2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+            hipLaunchKernelGGL((gemm_h2_kernel<1>), grid, dim3(256), lds, stream, g);
+        }
+        return (int)hipGetLastError();
+    }
     int tile = g.tile_hint;
     if (g.a_ln) {                                   // fused LayerNorm lives in the K-split kernel only; the K slice of a lane
         // (K / splits / 2 values) has to fit its 16 register groups: K <= 512 with 4 splits
