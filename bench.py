@@ -298,16 +298,19 @@ def main():
         traffic, note = (None, "not measured (--no-traffic or N > 1)")
         if world == 1 and not a.no_traffic:
             traffic, note = measure_traffic(a)
-        split = _lib.lib().prd_get_gemm_mode() == 1 and not ops.tri_attn_uses_long_rows(N, P)
+        variant = ops.tri_attn_variant(N, P)
+        split = _lib.lib().prd_get_gemm_mode() == 1 and variant in (0, 2)
+        kname = {0: "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel", 1: "tri_attn_core_long_kernel",
+                 2: "tri_attn_core_split_long_kernel"}[variant]
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
                     "algorithmic_bytes_per_launch": tri_attn_core_bytes(bpg, N, P),
-                    "kernel": "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel", "launches_per_step": 2 * NB,
+                    "kernel": kname, "launches_per_step": 2 * NB,
                     "flops_per_launch": kfl, "avg_launch_us": round(kus, 2),
                     "peak_note": "achieved = ALGORITHMIC fp32 flops of the launch / its duration; peak = the dense fp32 MFMA rate the "
                                  "reference arithmetic (fp32) is priced against"}
         if split:      # what the split-operand kernel actually issues: 3 fp16 products per projection / P*V MAC, 6 bf16 products per Q*K^T MAC
-            ex = bpg * (3 * 8 * N * N * P * 64 + (6 + 3) * 2 * 64 * N ** 3)
+            ex = bpg * (3 * 8 * N * N * P * 64 + ((6 if variant == 0 else 4) + 3) * 2 * 64 * N ** 3)   # long rows: fp16 x 2 QK^T in 2 MFMAs
             roofline.update({"executed_16bit_mfma_flops_per_launch": ex,
                              "executed_16bit_tflops": round(ex / (kus * 1e-6) / 1e12, 1), "peak_16bit_tflops": PEAK_16BIT_TFLOPS,
                              "frac_of_16bit_peak": round(ex / (kus * 1e-6) / 1e12 / PEAK_16BIT_TFLOPS, 4)})

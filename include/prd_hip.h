@@ -149,7 +149,9 @@ int prd_tri_attn(float* out, const float* pair, const float* mask, const float* 
                  const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
                  int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, hipStream_t stream);
 /* which core kernel prd_tri_attn uses for rows of N positions under the current gemm mode: 0 = short rows (K, V, Q and gate
- * of a row resident in LDS), 1 = long rows (Q / gate re-projected per query block), PRD_ERR_UNSUPPORTED = N too large. */
+ * of a row resident in LDS: N <= 448 in fp32 mode, N <= 384 with split operands), 1 = long rows on the fp32 kernel (Q / gate
+ * re-projected per query block), 2 = long rows on the split-operand kernel (gemm mode 1, N <= 832),
+ * PRD_ERR_UNSUPPORTED = N too large (beyond ~1000). */
 int prd_tri_attn_variant(int N, int P);
 /* the two launches of prd_tri_attn, exposed separately (og = gated per-head output [b,N,N,64]) */
 int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,

@@ -1102,21 +1102,28 @@ struct SplitLds {               // byte offsets from the dynamic LDS base
     unsigned vpitch;            // halfs per V^T row
 };
 
-template <int NTQ, bool MASKED, bool ONLINE>
-PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[3],
-                            const u32x4 (&qb)[NTQ][3], int npad, int key0, int ql, int g4,
+// NM = QK^T MFMAs per 16-key tile: 3 = bf16 x 3 operands (short rows), 2 = fp16 x 2 operands (long rows, see the long kernel)
+template <int NM>
+PRD_DEV f32x4 qk_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    if (NM == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int NTQ, int NM, bool MASKED, bool ONLINE>
+PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[NM],
+                            const u32x4 (&qb)[NTQ][NM], int npad, int key0, int ql, int g4,
                             float (&m_run)[NTQ], float (&l_run)[NTQ], f32x4 (&o)[NTQ][2], bool& big) {
     constexpr int JT = 4;
     ta_prio(npad - key0, npad);
     const float* kadd = reinterpret_cast<const float*>(lds + L.kadd);
     float4 ma[JT];
     f32x4 s[NTQ][JT];
-    u32x4 ka[JT][3];
+    u32x4 ka[JT][NM];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const unsigned krow = (unsigned)(key0 + 16 * j + ql) * 32u + (unsigned)(g4 & 1) * 16u;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) ka[j][m] = *reinterpret_cast<const u32x4*>(lds + kbase[m] + krow);
+        for (int m = 0; m < NM; ++m) ka[j][m] = *reinterpret_cast<const u32x4*>(lds + kbase[m] + krow);
         if (MASKED) ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
@@ -1126,13 +1133,11 @@ PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLd
     }
     // the three MFMAs of a logit tile are issued NTQ * JT independent accumulators apart (no back-to-back dependent pair)
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int j = 0; j < JT; ++j)
 #pragma unroll
-            for (int t = 0; t < NTQ; ++t)
-                s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j][m]), __builtin_bit_cast(bf16x8, qb[t][m]),
-                                                                  s[t][j], 0, 0, 0);
+            for (int t = 0; t < NTQ; ++t) s[t][j] = qk_mfma<NM>(ka[j][m], qb[t][m], s[t][j]);
     __builtin_amdgcn_sched_barrier(0);                  // V^T is fetched behind the QK^T MFMAs, not before them
     // A operands of P V: lane (c = ql, g4) holds V^T[c][keys 16 j0 + 4 g4 .. +3 | 16 (j0 + 1) + 4 g4 .. +3] for j0 = 0, 2
     u32x4 vh[2], vl[2];
@@ -1221,9 +1226,9 @@ PRD_DEV void ta_block_split(const unsigned char* __restrict__ lds, const SplitLd
                                                                   __builtin_bit_cast(f16x8, pr == 1 ? plp[t][gi] : php[t][gi]), o[t][gi], 0, 0, 0);
 }
 
-template <int NTQ, bool MASKED>
-PRD_DEV void ta_keyloop_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[3],
-                              const u32x4 (&qb)[NTQ][3], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
+template <int NTQ, int NM, bool MASKED>
+PRD_DEV void ta_keyloop_split(const unsigned char* __restrict__ lds, const SplitLds& L, const unsigned (&kbase)[NM],
+                              const u32x4 (&qb)[NTQ][NM], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
     float m_run[NTQ], l_run[NTQ];
     f32x4 o2[NTQ][2];                            // one accumulator per 32-key group: two independent MFMA chains per tile
     bool online_all = false;
@@ -1238,8 +1243,8 @@ PRD_DEV void ta_keyloop_split(const unsigned char* __restrict__ lds, const Split
         bool big = false;
 #pragma unroll 1
         for (int key0 = 0; key0 < npad; key0 += 64) {
-            if (key0 == 0 || online_all) ta_block_split<NTQ, MASKED, true>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o2, big);
-            else ta_block_split<NTQ, MASKED, false>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o2, big);
+            if (key0 == 0 || online_all) ta_block_split<NTQ, NM, MASKED, true>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o2, big);
+            else ta_block_split<NTQ, NM, MASKED, false>(lds, L, kbase, qb, npad, key0, ql, g4, m_run, l_run, o2, big);
         }
         bool bad = big;
 #pragma unroll
@@ -1449,8 +1454,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
                 }
                 f32x4 o[2];
                 float l_tot[2];
-                if (row_masked) ta_keyloop_split<2, true>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
-                else ta_keyloop_split<2, false>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+                if (row_masked) ta_keyloop_split<2, 3, true>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+                else ta_keyloop_split<2, 3, false>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int v = 16 * (t == 0 ? t0 : t1) + ql;
@@ -1468,8 +1473,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
                     qb[0][m] = *reinterpret_cast<const u32x4*>(lds + qbase[m] + (unsigned)(16 * t0 + ql) * 32u + half16);
                 f32x4 o[1];
                 float l_tot[1];
-                if (row_masked) ta_keyloop_split<1, true>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
-                else ta_keyloop_split<1, false>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+                if (row_masked) ta_keyloop_split<1, 3, true>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+                else ta_keyloop_split<1, 3, false>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
                 const int v = 16 * t0 + ql;
                 if (v < N) {
                     const float4 gf = *reinterpret_cast<const float4*>(Gl + v * KP + 4 * g4);
@@ -1480,6 +1485,178 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
             }
         }
         PRD_STAMP(3);
+    }
+}
+
+// Long rows on the 16-bit pipes (gemm mode 1, 512 < N <= 832): K / V of the whole row as fp16 hi | lo planes (132 B per position)
+// fill the LDS, so the queries are re-projected per 32-query block in phase 2 into a small per-wave scratch (Q hi | lo planes and
+// the gate), which the key loop then reads exactly like the short-row kernel reads its row-wide Q planes.  Q K^T uses the
+// fp16 x 2 form here (2 MFMAs per 16-key tile: [kh|kh] x [qh|ql] and [kl|kl] x [qh|0]; 22-bit operands, |q|, |k| = O(1) projections
+// of LayerNorm-ed rows) because three bf16 planes of K do not fit; P V as in the short-row kernel.  The H heads of a row run on
+// one XCD (the fp32 long-row kernel fetched every row into four L2s: 1.19 GB of fabric reads per launch at N = 769).
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_core_split_long_kernel(
+    float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    constexpr float VSCALE = H2_WSCALE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr unsigned WBYTES = 2u * 64 * (P / 8) * 16;
+    SplitLds L;
+    unsigned scratch0;
+    {
+        unsigned off = WBYTES;
+        L.kp[0] = off; off += (unsigned)npad * 32u;         // K hi
+        L.kp[1] = off; off += (unsigned)npad * 32u;         // K lo
+        L.kp[2] = 0;
+        L.vpitch = (unsigned)npad + 8u;
+        L.vh = off; off += 16u * L.vpitch * 2u;
+        L.vl = off; off += 16u * L.vpitch * 2u;
+        L.kadd = off; off += (unsigned)npad * 4u;
+        L.bqg = off; off += 128u;
+        scratch0 = off;                                      // per wave: Q hi [32][16] fp16 | Q lo | gate [32][16] fp32 = 4 KB
+        L.qp[0] = L.qp[1] = L.qp[2] = L.gl = 0;
+    }
+    u32x4* Wb = reinterpret_cast<u32x4*>(lds);
+    float* kadd = reinterpret_cast<float*>(lds + L.kadd);
+    float* bqg = reinterpret_cast<float*>(lds + L.bqg);
+    _Float16* Vh = reinterpret_cast<_Float16*>(lds + L.vh);
+    _Float16* Vl = reinterpret_cast<_Float16*>(lds + L.vl);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int ql = lane & 15, g4 = lane >> 4;
+    const int nvb = npad / 32, nqb = (N + 31) / 32;
+    const int rstride = gridDim.x / H;
+    int h, slot;
+    if ((rstride & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        h = idx % H;
+        slot = (idx / H) * 8 + xcd;
+    } else {
+        h = blockIdx.x % H;
+        slot = blockIdx.x / H;
+    }
+    const float sc = 0.25f * LOG2E;
+    stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
+    if (tid < 32) {
+        const int hh = tid >> 4, e = tid & 15;
+        bqg[tid] = e < 8 ? 0.f : H2_WSCALE * NEG_LOG2E * bg[h * C + (e < 12 ? 4 * hh + (e - 8) : 8 + 4 * hh + (e - 12))];
+    }
+    const unsigned qsc = scratch0 + (unsigned)wave * 4096u;          // this wave's scratch: Q hi at +0, Q lo at +1024, gate at +2048
+    float* Gs = reinterpret_cast<float*>(lds + qsc + 2048);
+    // operand bases of the two QK^T MFMAs: A = [kh | kh], [kl | kl];  B = [qh | ql], [qh | 0]
+    const unsigned kbase[2] = {L.kp[0], L.kp[1]};
+    const long nrows = (long)b * N;
+    auto row_pos = [&](long bu, int v) -> long {
+        const long bb = bu / N;
+        const long u = bu - bb * N;
+        return ending ? ((bb * N + v) * N + u) : (bu * N + v);
+    };
+    for (long bu = slot; bu < nrows; bu += rstride) {
+        const int bb = (int)(bu / N);
+        __syncthreads();                        // previous row's K / V fully consumed (and weights staged)
+        const float mu = mask[bu];
+        // ---- phase 1: K, V of every position of the row ----
+        for (int vb = wave; vb < nvb; vb += NW) {
+            const int v = vb * 32 + r;
+            const bool valid = v < N;
+            f32x16 acc[1];
+            zero_acc(acc);
+            if (vb < nqb) {
+                float x[KH];
+                load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
+                ln_cll<KH>(x);
+                u32x4 xs[2][P / 16];
+                split2h_cll<KH>(x, xs);
+                rowgemm_h2<P, 1>(Wb, 64, 0, xs, acc, r, hi);
+            }
+            if (hi == 0) {
+                const bool keep = valid && (mu * mask[(long)bb * N + (valid ? v : 0)] >= 0.5f);
+                kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E : -INFINITY);
+            }
+            unsigned kh0, kl0, kh1, kl1, kh2, kl2, kh3, kl3;
+            split2h(acc[0][0] * H2_INV_WSCALE, acc[0][1] * H2_INV_WSCALE, kh0, kl0);
+            split2h(acc[0][2] * H2_INV_WSCALE, acc[0][3] * H2_INV_WSCALE, kh1, kl1);
+            split2h(acc[0][4] * H2_INV_WSCALE, acc[0][5] * H2_INV_WSCALE, kh2, kl2);
+            split2h(acc[0][6] * H2_INV_WSCALE, acc[0][7] * H2_INV_WSCALE, kh3, kl3);
+            const unsigned ko = (unsigned)v * 32u + 8u * hi;
+            *reinterpret_cast<u32x2*>(lds + L.kp[0] + ko) = u32x2{kh0, kh1};
+            *reinterpret_cast<u32x2*>(lds + L.kp[0] + ko + 16) = u32x2{kh2, kh3};
+            *reinterpret_cast<u32x2*>(lds + L.kp[1] + ko) = u32x2{kl0, kl1};
+            *reinterpret_cast<u32x2*>(lds + L.kp[1] + ko + 16) = u32x2{kl2, kl3};
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const int c0 = (e < 4 ? 4 * hi : 8 + 4 * hi) + (e & 3);
+                unsigned hw, lw;
+                split2h(acc[0][8 + e], acc[0][9 + e], hw, lw);
+                const f16x2 hh2 = __builtin_bit_cast(f16x2, hw), ll2 = __builtin_bit_cast(f16x2, lw);
+                Vh[c0 * L.vpitch + v] = (_Float16)hh2[0];
+                Vh[(c0 + 1) * L.vpitch + v] = (_Float16)hh2[1];
+                Vl[c0 * L.vpitch + v] = (_Float16)ll2[0];
+                Vl[(c0 + 1) * L.vpitch + v] = (_Float16)ll2[1];
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: per 32-query block: project q | gate into the wave's scratch, then the key loop for its two tiles ----
+        const float inv_vs = 1.0f / VSCALE;
+        for (int qb_ = wave; qb_ < nqb; qb_ += NW) {
+            {
+                const int v = qb_ * 32 + r;
+                const bool valid = v < N;
+                float x[KH];
+                load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
+                ln_cll<KH>(x);
+                u32x4 xs[2][P / 16];
+                split2h_cll<KH>(x, xs);
+                f32x16 acc[1];
+                bias_acc(acc, bqg + 16 * hi);
+                rowgemm_h2<P, 1>(Wb, 64, 32, xs, acc, r, hi);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[0][e] *= H2_INV_WSCALE;
+                unsigned qh0, ql0, qh1, ql1, qh2, ql2, qh3, ql3;
+                split2h(acc[0][0], acc[0][1], qh0, ql0);
+                split2h(acc[0][2], acc[0][3], qh1, ql1);
+                split2h(acc[0][4], acc[0][5], qh2, ql2);
+                split2h(acc[0][6], acc[0][7], qh3, ql3);
+                const unsigned qo = qsc + (unsigned)r * 32u + 8u * hi;
+                *reinterpret_cast<u32x2*>(lds + qo) = u32x2{qh0, qh1};
+                *reinterpret_cast<u32x2*>(lds + qo + 16) = u32x2{qh2, qh3};
+                *reinterpret_cast<u32x2*>(lds + qo + 1024) = u32x2{ql0, ql1};
+                *reinterpret_cast<u32x2*>(lds + qo + 1024 + 16) = u32x2{ql2, ql3};
+                *reinterpret_cast<float4*>(Gs + r * 16 + 4 * hi) = make_float4(gate_from_scaled(acc[0][8]), gate_from_scaled(acc[0][9]),
+                                                                                gate_from_scaled(acc[0][10]), gate_from_scaled(acc[0][11]));
+                *reinterpret_cast<float4*>(Gs + r * 16 + 8 + 4 * hi) = make_float4(gate_from_scaled(acc[0][12]), gate_from_scaled(acc[0][13]),
+                                                                                    gate_from_scaled(acc[0][14]), gate_from_scaled(acc[0][15]));
+            }
+            wave_lds_fence();
+            u32x4 qb[2][2];
+            const unsigned half16 = (unsigned)(g4 & 1) * 16u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned qrow = qsc + (unsigned)(16 * t + ql) * 32u + half16;
+                const u32x4 qh = *reinterpret_cast<const u32x4*>(lds + qrow), qlo = *reinterpret_cast<const u32x4*>(lds + qrow + 1024);
+                qb[t][0] = g4 < 2 ? qh : qlo;                            // [qh | ql]
+                qb[t][1] = g4 < 2 ? qh : u32x4{0, 0, 0, 0};              // [qh | 0]
+            }
+            f32x4 o[2];
+            float l_tot[2];
+            ta_keyloop_split<2, 2, true>(lds, L, kbase, qb, npad, ql, g4, o, l_tot);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int v = qb_ * 32 + 16 * t + ql;
+                if (v < N) {
+                    const float4 gf = *reinterpret_cast<const float4*>(Gs + (16 * t + ql) * 16 + 4 * g4);
+                    const float il = inv_vs / l_tot[t];
+                    *reinterpret_cast<float4*>(og + row_pos(bu, v) * HC + h * C + 4 * g4) =
+                        make_float4(gf.x * (o[t][0] * il), gf.y * (o[t][1] * il), gf.z * (o[t][2] * il), gf.w * (o[t][3] * il));
+                }
+            }
+            wave_lds_fence();                   // scratch consumed before the next query block overwrites it
+        }
     }
 }
 
@@ -1671,7 +1848,12 @@ size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
     // split-operand kernel (gemm mode 1): K / Q planes 6 x 32 B, V hi / lo 2 x 16 x (npad + 8) fp16, gate, override, bias
     if (b3) lds = (size_t)64 * P * 4 + (size_t)npad * (192 + KP * 4 + 4) + (size_t)64 * (npad + 8) + 128;
     *long_row = lds > 160 * 1024;              // Q / gate tiles do not fit next to the row's K / V
-    if (*long_row) lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    if (*long_row) {
+        // split-operand long rows: weights + K hi|lo (64 B) + V hi|lo + override per position + bias + 8 waves x 4 KB of scratch
+        const size_t lds_sl = (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096;
+        if (b3 && lds_sl <= 160 * 1024) return lds_sl;
+        lds = ((size_t)64 * (P + 4) + (size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
+    }
     return lds;
 }
 }  // namespace
@@ -1680,9 +1862,12 @@ extern "C" int prd_tri_attn_variant(int N, int P) {
     if (N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     bool long_row;
-    const size_t lds = tri_attn_lds(N, P, g_gemm_mode.load(std::memory_order_relaxed) == 1, &long_row);
+    const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;
+    const size_t lds = tri_attn_lds(N, P, b3, &long_row);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
-    return long_row ? 1 : 0;
+    if (!long_row) return 0;
+    const int npad = prd_round_up(N, 64);
+    return (b3 && lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096) ? 2 : 1;
 }
 
 extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P) {
@@ -1785,7 +1970,10 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     (void)nqb; (void)nw;
     // 12 waves (3 per SIMD) + next-row prefetch: the ceil(N/16) query tiles dealt in pairs land 5 per SIMD at N = 320
     // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
-    if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
+    const bool split_long = long_row && b3 &&
+        lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096;      // tri_attn_lds chose it
+    if (split_long) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 32, 8); }
+    else if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
     else if (b3) {
         static const int variant = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;     // tuning only
         if (P == 64) {

@@ -235,10 +235,15 @@ def tri_mul(pair, mask, wts, *, incoming: bool, residual: bool, out=None, ws=Non
 
 def tri_attn_uses_long_rows(N: int, P: int) -> bool:
     """True when rows of N positions take the re-projecting long-row core kernel (prd_hip.h: prd_tri_attn_variant)."""
+    return tri_attn_variant(N, P) >= 1
+
+
+def tri_attn_variant(N: int, P: int) -> int:
+    """0 short rows, 1 long rows (fp32 kernel), 2 long rows (split-operand kernel) -- prd_hip.h: prd_tri_attn_variant."""
     v = lib().prd_tri_attn_variant(N, P)
     if v < 0:
         check(v, "prd_tri_attn_variant")
-    return v == 1
+    return v
 
 
 def tri_attn(pair, mask, wts, H: int, c: int, *, ending: bool, residual: bool, out=None, ws=None) -> torch.Tensor:

@@ -47,7 +47,8 @@ int main(void) {
     EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 8, 64, 2, 32, s), PRD_ERR_UNSUPPORTED);        /* head_dim 32 */
     EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row too long for LDS */
     EXPECT(prd_tri_attn_variant(320, 64), 0);
-    EXPECT(prd_tri_attn_variant(769, 64), 1);
+    EXPECT(prd_tri_attn_variant(769, 64), 2);       /* gemm mode 1: the split-operand long-row kernel */
+    EXPECT(prd_tri_attn_variant(900, 64), 1);
     EXPECT(prd_tri_attn_variant(100000, 64), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_variant(320, 48), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_single_attn_core(p, p, p, p, 1, 8, 2, 32, s), PRD_ERR_UNSUPPORTED);
