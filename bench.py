@@ -221,7 +221,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run, also with one rank
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)           # "nccl" is RCCL on ROCm
@@ -253,18 +254,18 @@ def main():
     advance(a.warmup)
     gather_samples(*loop.result(), world * bpg)                  # warm the collective (communicator setup is not a step)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     advance(a.steps)
     pos_all, logits_all = gather_samples(*loop.result(), world * bpg)   # the sampling job's one collective (RCCL all_gather)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -272,7 +273,7 @@ def main():
 
     # ---- N > 1: the product's sharded sampler end to end, against single-rank runs (bit-identical by construction) ----
     shard_check = None
-    if world > 1 and not a.no_shard_check:
+    if dist is not None and not a.no_shard_check:
         model.num_steps, model.setup_schedule = 24, False        # a short loop: this is a correctness check, not the timed region
         one = batch_to(synthetic_batch([(a.atoms, a.residues)], seed=0), dev)
         c0 = time.perf_counter()
@@ -335,13 +336,13 @@ def main():
                                    f"of the samples at the end of the timed region)",
                        "samples_per_gpu": bpg, "hip_graph": not a.no_graph, "outputs_finite": finite,
                        "row_gemm": _lib.row_gemm_description(b3),
-                       "backend": "nccl (RCCL)" if world > 1 else "single process", "sharded_sample_check": shard_check},
+                       "backend": "nccl (RCCL)" if dist is not None else "single process", "sharded_sample_check": shard_check},
             "step_gflop": round(flops / 1e9, 1),
             "step_tflops": round(flops * bpg / (dt / a.steps) / 1e12, 2),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

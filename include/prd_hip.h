@@ -47,13 +47,13 @@ int prd_version(void);
  *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): plain fp32 FMA chains;
  *   1  (default) "split16": fp32 operands are split into 16-bit parts and multiplied on the fp16 / bf16 matrix pipes with fp32
  *      accumulation, every product whose weight exceeds 2^-22 included:
- *        - row GEMMs (tri_mul projection / output, attention projections and output projection, pair transition / block tail,
- *          outer-linear) and P*V of the triangle attention: fp16 hi + lo (RTZ, 22 bits), 3 products, 16/3 of the fp32 rate;
- *          weight images stay the size of the fp32 ones.  fp16 saturates at 65504: LayerNorm-ed rows, gated attention outputs,
- *          ReLU hidden units, probabilities and weights (staged x 16) are far inside that range;
- *        - Q*K^T of the triangle attention and the triangle-multiplication contraction (operands of unbounded range): bf16 x 3
- *          by truncation (exact, 24 bits), 6 products, 16/6 of the fp32 rate;
- *      kernels without a split form (single track, input stage, heads) run fp32 MFMA in either mode.
+ *        - fp16 hi + lo (RTZ + one mixed-precision FMA, 22 bits), 3 products, 16/3 of the fp32 rate: the row GEMMs (tri_mul
+ *          projection / output, attention projections and output projection, pair transition / block tail, outer-linear,
+ *          pair_init, OPM), the triangle-multiplication contraction, P*V of the triangle attention, Q*K^T of long rows
+ *          (N > 384) and SPAttention's large projection.  Weight images stay the size of the fp32 ones.  fp16 saturates at
+ *          65504: LayerNorm-ed rows, their gated / ReLU-ed projections, probabilities and weights (staged x 16) are far inside;
+ *        - bf16 x 3 by truncation (exact, 24 bits), 6 products, 16/6 of the fp32 rate: Q*K^T of short rows;
+ *      the latency-bound single-track kernels, pair_bias and the coordinate head run fp32 MFMA in either mode.
  * Both modes meet every parity tolerance of tests/ (the GPU suite runs its operator / step / trajectory / gradient tests in both). */
 int prd_set_gemm_mode(int mode);
 int prd_get_gemm_mode(void);

@@ -44,9 +44,9 @@ def gather_samples(pos: torch.Tensor, logits: torch.Tensor, num_samples: int,
     mine = len(shard_range(num_samples, world, rank))
     if pos.shape[0] != mine:
         raise ValueError(f"rank {rank} holds {pos.shape[0]} samples, its shard of {num_samples} over {world} ranks is {mine}")
-    if world == 1:
+    if not distributed:
         return pos.contiguous(), logits.contiguous()
-    cap = len(shard_range(num_samples, world, 0))              # largest shard
+    cap = len(shard_range(num_samples, world, 0))              # largest shard (a one-rank group still runs the collective)
     packed = torch.zeros(cap, pos.shape[1], 3 + logits.shape[-1], device=pos.device, dtype=torch.float32)
     packed[:mine] = torch.cat([pos, logits], dim=-1)
     gathered = [torch.empty_like(packed) for _ in range(world)]
