@@ -143,6 +143,25 @@ int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w
                 const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
                 const float* w_ogate, const float* b_ogate, int incoming, int residual,
                 int b, int N, int P, float* ws, size_t ws_bytes, int* queue, hipStream_t stream);
+/* ---- backward of TriangleMultiplication (autograd of modules.py:262-274; used by training.py) -------------------------------
+ * The contraction of prd_tri_mul alone: O[b][d][i][j] = sum_k A[b][d][i][k] B[b][d][j][k], operands channel-major
+ * AB[b][2P][N][ldn] (A = channels 0..P-1, B = channels P..2P-1, ldn = round_up(N,32), zero padded), O[b][P][N][ldn].
+ * The backward calls it on transposed operands for dA and dB. */
+int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, hipStream_t stream);
+/* Output stage backward.  dy = gradient of the update [b,N,N,P]; O = contraction output (channel-major, as left in prd_tri_mul's
+ * workspace); w_*_t = the transposed weights [in][out].  Writes dz = dy * gate and dgp = d(pre-activation of the output gate)
+ * (row layout [b,N,N,P]; dW_out = dz^T LN(O), dW_ogate = dgp^T LN(pair) are left to the caller's BLAS), dO (channel-major) and
+ * dx1 = W_ogate^T dgp (row layout), the output-gate path of the gradient of LN(pair). */
+int prd_tri_mul_out_bwd(float* dz, float* dgp, float* dO, float* dx1, const float* dy, const float* pair, const float* O,
+                        const float* w_out, const float* b_out, const float* w_ogate, const float* b_ogate,
+                        const float* w_out_t, const float* w_ogate_t, int b, int N, int P, hipStream_t stream);
+/* Projection stage backward.  dAB = gradient of the operands (channel-major [b][2P][N][ldn]); writes dpair [b,N,N,P] (gradient of
+ * the update with respect to its input pair tensor), and dpp / dpg = d(pre-activations of ab_proj / ab_gate) in row layout
+ * [b,N,N,2P] by pair position (dW_proj = dpp^T LN(pair), dW_gate = dpg^T LN(pair) are left to the caller's BLAS). */
+int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const float* dAB, const float* dx1, const float* pair,
+                         const float* mask, const float* w_proj, const float* b_proj, const float* w_gate, const float* b_gate,
+                         const float* w_proj_t, const float* w_gate_t, int incoming, int b, int N, int P, hipStream_t stream);
+
 /* TriangleAttention (modules.py:236-243 -> 185-225): out = (residual ? pair : 0) + update(pair).
  * ws: b * N * N * 64 floats. */
 int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,

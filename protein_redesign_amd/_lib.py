@@ -50,6 +50,9 @@ SIGNATURES = {
     "prd_opm_pair": [vp] * 6 + [ci] * 5 + [vp],
     "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp, vp],
     "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, vp],
+    "prd_tri_mul_contract": [vp, vp, ci, ci, ci, vp],
+    "prd_tri_mul_out_bwd": [vp] * 13 + [ci] * 3 + [vp],
+    "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 4 + [vp],
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, vp],

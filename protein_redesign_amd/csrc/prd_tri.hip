@@ -1941,6 +1941,24 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     return (int)hipGetLastError();
 }
 
+extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, hipStream_t stream) {
+    if (!O || !AB || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
+    const int ldn = prd_round_up(N, 32);
+    if (g_gemm_mode.load(std::memory_order_relaxed) == 1) {
+        const int tl = prd_ceil_div(N, TMS_T);
+        const int vb3 = b * P * tl * tl;
+        const size_t lds3 = (size_t)4 * TMS_OPER;
+        PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
+        hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl);
+    } else {
+        const int tiles = prd_ceil_div(N, 64);
+        const int vblocks = b * P * tiles * tiles;
+        hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
+    }
+    return (int)hipGetLastError();
+}
+
 extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                                  const float* wv, const float* wg, const float* bg, int ending,
                                  int b, int N, int P, int H, int c, hipStream_t stream) {

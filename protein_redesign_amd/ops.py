@@ -233,6 +233,58 @@ def tri_mul(pair, mask, wts, *, incoming: bool, residual: bool, out=None, ws=Non
     return out
 
 
+def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
+    """Gradients of the TriangleMultiplication update (ops.tri_mul with residual=False) with respect to ``pair`` and its eight
+    weight tensors, on the hand-written backward kernels (csrc/prd_bwd.hip): forward recompute (projection, contraction) ->
+    output-stage backward -> the two gradient contractions on the forward contraction kernel -> projection-stage backward.
+    The weight gradients are tall-skinny GEMMs over all N^2 rows and go through torch (rocBLAS)."""
+    wp, bp, wg, bg, wo, bo, wog, bog = wts
+    b, N, _, P = pair.shape
+    ldn = round_up(N, 32)
+    dev = pair.device
+    unit = b * P * N * ldn
+    ws = torch.empty(3 * unit, device=dev, dtype=F32)
+    scratch = torch.empty_like(pair)
+    check(lib().prd_tri_mul(dptr(scratch), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(incoming), 0, b, N, P,
+                            dptr(ws), ws.numel() * 4, 0, stream()), "prd_tri_mul (recompute)")
+    AB = ws[:2 * unit].view(b, 2 * P, N, ldn)
+    O = ws[2 * unit:].view(b, P, N, ldn)
+    dy = dy.contiguous()
+    dz, dgp, dx1 = torch.empty_like(pair), torch.empty_like(pair), torch.empty_like(pair)
+    dO = torch.zeros(b, P, N, ldn, device=dev, dtype=F32)
+    woT, wogT = wo.t().contiguous(), wog.t().contiguous()
+    check(lib().prd_tri_mul_out_bwd(dptr(dz), dptr(dgp), dptr(dO), dptr(dx1), dptr(dy), dptr(pair), dptr(O), dptr(wo), dptr(bo),
+                                    dptr(wog), dptr(bog), dptr(woT), dptr(wogT), b, N, P, stream()), "prd_tri_mul_out_bwd")
+
+    def transposed(t):                                   # [b, C, N, ldn] (valid [.., :N, :N]) -> [b, C, N, ldn] with the two node axes swapped
+        out = torch.zeros_like(t)
+        out[..., :N] = t[..., :N].transpose(-1, -2)
+        return out
+
+    A, B = AB[:, :P], AB[:, P:]
+    dAB = torch.empty(b, 2 * P, N, ldn, device=dev, dtype=F32)
+    # dA[i][k] = sum_j dO[i][j] B^T[k][j];  dB[j][k] = sum_i dO^T[j][i] A^T[k][i]
+    ops_a = torch.cat([dO, transposed(B)], dim=1).contiguous()
+    ops_b = torch.cat([transposed(dO), transposed(A)], dim=1).contiguous()
+    dA, dB = torch.empty(b, P, N, ldn, device=dev, dtype=F32), torch.empty(b, P, N, ldn, device=dev, dtype=F32)
+    check(lib().prd_tri_mul_contract(dptr(dA), dptr(ops_a), b, N, P, stream()), "prd_tri_mul_contract")
+    check(lib().prd_tri_mul_contract(dptr(dB), dptr(ops_b), b, N, P, stream()), "prd_tri_mul_contract")
+    dAB[:, :P], dAB[:, P:] = dA, dB
+    dpair = torch.empty_like(pair)
+    dpp = torch.empty(b, N, N, 2 * P, device=dev, dtype=F32)
+    dpg = torch.empty(b, N, N, 2 * P, device=dev, dtype=F32)
+    wpT, wgT = wp.t().contiguous(), wg.t().contiguous()
+    check(lib().prd_tri_mul_proj_bwd(dptr(dpair), dptr(dpp), dptr(dpg), dptr(dAB), dptr(dx1), dptr(pair), dptr(mask), dptr(wp),
+                                     dptr(bp), dptr(wg), dptr(bg), dptr(wpT), dptr(wgT), int(incoming), b, N, P, stream()),
+          "prd_tri_mul_proj_bwd")
+    # weight gradients: dW = dOut^T In over all rows (library GEMMs); LN(pair), LN(O) recomputed by the LayerNorm kernel
+    x = layer_norm(pair.contiguous()).view(-1, P)
+    lo = layer_norm(O[..., :N].permute(0, 2, 3, 1).contiguous()).view(-1, P)
+    dz2, dgp2, dpp2, dpg2 = dz.view(-1, P), dgp.view(-1, P), dpp.view(-1, 2 * P), dpg.view(-1, 2 * P)
+    grads = (dpp2.t() @ x, dpp2.sum(0), dpg2.t() @ x, dpg2.sum(0), dz2.t() @ lo, dz2.sum(0), dgp2.t() @ x, dgp2.sum(0))
+    return dpair, grads
+
+
 def tri_attn_uses_long_rows(N: int, P: int) -> bool:
     """True when rows of N positions take the re-projecting long-row core kernel (prd_hip.h: prd_tri_attn_variant)."""
     return tri_attn_variant(N, P) >= 1

@@ -48,6 +48,30 @@ class HipOp(torch.autograd.Function):
         return (None, None) + tuple(next(it) if i.requires_grad else None for i in ins)
 
 
+class TriMulFn(torch.autograd.Function):
+    """TriangleMultiplication update with a hand-written backward (csrc/prd_bwd.hip through ops.tri_mul_backward): output-stage and
+    projection-stage row kernels, the two gradient contractions on the forward contraction kernel; only the weight-gradient
+    reductions (tall-skinny GEMMs over all N^2 rows) go through the BLAS library.  Nothing is recomputed in torch ops."""
+
+    @staticmethod
+    def forward(ctx, pair, mask, incoming: bool, *wts):
+        ctx.incoming = incoming
+        ctx.save_for_backward(pair, mask, *wts)
+        with torch.no_grad():
+            return ops.tri_mul(pair.detach().contiguous(), mask, [w.detach() for w in wts], incoming=incoming, residual=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pair, mask, *wts = ctx.saved_tensors
+        with torch.no_grad():
+            dpair, grads = ops.tri_mul_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], incoming=ctx.incoming)
+        return (dpair, None, None, *grads)
+
+
+def tri_mul_update(tm, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    return TriMulFn.apply(pair, mask, tm.mode == "incoming", *tm.weights())
+
+
 def _lin(m) -> Tuple[torch.Tensor, ...]:
     return (m.weight, m.bias) if m.bias is not None else (m.weight,)
 
@@ -90,15 +114,7 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
     pair = pair + HipOp.apply(ol_hip, R.outer_linear, single, ol.linear.weight, ol.linear.bias)
 
     for tm in (blk.pair_mul_outgoing, blk.pair_mul_incoming):
-        inc = tm.mode == "incoming"
-
-        def tm_ref(p, *w, inc=inc):
-            return R.triangle_multiplication(p, mask, *w, incoming=inc)
-
-        def tm_hip(p, *w, inc=inc):
-            return ops.tri_mul(p.contiguous(), mask, w, incoming=inc, residual=False)
-
-        pair = pair + HipOp.apply(tm_hip, tm_ref, pair, *tm.weights())
+        pair = pair + tri_mul_update(tm, pair, mask)
 
     for ta in (blk.pair_attn_starting, blk.pair_attn_ending):
         end = ta.mode == "ending"

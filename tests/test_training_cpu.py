@@ -73,6 +73,10 @@ def test_backward_wiring_matches_oracle_autograd(golden, name, monkeypatch):
     nz, ns = torch.from_numpy(z["train_noise_z"]), torch.from_numpy(z["train_noise_seq"])
     want_loss, want = oracle_grads(args, params, pb, t, nz, ns)
     monkeypatch.setattr(training, "HipOp", _RefOp)
+    # TriangleMultiplication has a hand-written HIP backward (training.TriMulFn): on the CPU its restatement stands in
+    from protein_redesign_amd import torch_ref as R
+    monkeypatch.setattr(training, "tri_mul_update",
+                        lambda tm, pair, mask: R.triangle_multiplication(pair, mask, *tm.weights(), incoming=tm.mode == "incoming"))
     model = ProteinReDiffModel(args)
     model.load_state_dict(params)
     model.run_setup_schedule()

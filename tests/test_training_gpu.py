@@ -3,6 +3,7 @@ autograd node per operator and per-block recompute (training.py); its loss and t
 against (a) the fingerprints captured from the imported reference's ``training_step`` (tests/golden, oracle/gen_golden.py) and
 (b) the oracle's autograd, tensor by tensor."""
 import json
+import math
 
 import numpy as np
 import pytest
@@ -101,3 +102,29 @@ def test_training_step_api_and_optimizer_step():
     # free-running call (noise, t and mask drawn internally) returns a scalar with a graph
     loss = model.training_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0)
     assert loss.dim() == 0 and loss.requires_grad
+
+
+@pytest.mark.parametrize("mode", ["outgoing", "incoming"])
+@pytest.mark.parametrize("P", [32, 64])
+def test_triangle_multiplication_backward_kernels(mode, P, gemm_mode):
+    """The hand-written backward of TriangleMultiplication (prd_tri_mul_out_bwd / prd_tri_mul_contract / prd_tri_mul_proj_bwd)
+    against the oracle's autograd: gradient with respect to the pair input and all eight weight tensors, ragged masked batch."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(70 + P)
+    b, N = 2, 45
+    pair = torch.randn(b, N, N, P, generator=g)
+    mask = torch.ones(b, N)
+    mask[1, 38:] = 0
+    names = ["ab_proj.weight", "ab_proj.bias", "ab_gate.weight", "ab_gate.bias", "out_proj.weight", "out_proj.bias", "out_gate.weight", "out_gate.bias"]
+    shapes = [(2 * P, P), (2 * P,), (2 * P, P), (2 * P,), (P, P), (P,), (P, P), (P,)]
+    wts = [torch.randn(s, generator=g) / (math.sqrt(P) if len(s) == 2 else 4.0) for s in shapes]
+    dy = torch.randn(b, N, N, P, generator=g)
+    pl = pair.clone().requires_grad_(True)
+    leaf = {"tm." + n: w.clone().requires_grad_(True) for n, w in zip(names, wts)}
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    out = O.triangle_multiplication(leaf, "tm", pl, m2, mode == "incoming")
+    out.backward(dy)
+    dpair, grads = ops.tri_mul_backward(dy.to(DEV), pair.to(DEV), mask.to(DEV), [w.to(DEV) for w in wts], incoming=mode == "incoming")
+    assert rel_l2(dpair.cpu(), pl.grad) < 1e-5
+    for n, got in zip(names, grads):
+        assert rel_l2(got.cpu(), leaf["tm." + n].grad) < 1e-5, n
