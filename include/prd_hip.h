@@ -162,6 +162,15 @@ int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const float* dAB,
                          const float* mask, const float* w_proj, const float* b_proj, const float* w_gate, const float* b_gate,
                          const float* w_proj_t, const float* w_gate_t, int incoming, int b, int N, int P, hipStream_t stream);
 
+/* ---- backward of TriangleAttention (autograd of modules.py:236-243 -> 185-225; used by training.py) -------------------------
+ * Core: dog = W_out^T d(update) [b,N,N,64] (a row GEMM by the caller) -> dqkvg[b,N,N,4,64] by pair position =
+ * d(W_q x) | d(W_k x) | d(W_v x) | d(gate pre-activation), channels head-major (x = LN(pair row)).  Rows up to N ~ 400. */
+int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float* pair, const float* mask, const float* wq,
+                          const float* wk, const float* wv, const float* wg, const float* bg, int ending,
+                          int b, int N, int P, int H, int c, hipStream_t stream);
+/* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x). */
+int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream);
+
 /* TriangleAttention (modules.py:236-243 -> 185-225): out = (residual ? pair : 0) + update(pair).
  * ws: b * N * N * 64 floats. */
 int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,

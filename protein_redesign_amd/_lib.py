@@ -53,6 +53,8 @@ SIGNATURES = {
     "prd_tri_mul_contract": [vp, vp, ci, ci, ci, vp],
     "prd_tri_mul_out_bwd": [vp] * 13 + [ci] * 3 + [vp],
     "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 4 + [vp],
+    "prd_tri_attn_bwd_core": [vp] * 9 + [ci] * 6 + [vp],
+    "prd_ln_rows_bwd": [vp, vp, vp, cll, ci, vp],
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, vp],

@@ -220,6 +220,190 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Triangle attention backward, core (reference modules.py:236-243 -> 185-225 under autograd).  One workgroup per (pair row, head),
+// persistent.  Given dog = d(gated per-head output) [b,N,N,64] (= W_o^T d(update), a row GEMM done by the caller) it recomputes
+// q, k, v, gate of the row (fp32 MFMA row GEMMs into LDS), then
+//   pass A (thread = query):  sweep 1 over the keys: softmax statistics m, l and o = P v;  delta = do . o;  d(gate pre-activation);
+//                             sweep 2: p = exp(s - m) / l,  dS = p (do . v_j - delta),  dq += dS k_j
+//   pass B (thread = key):    sweep over the queries: p and dS again from the stored m, l, delta;  dk += dS q,  dv += p do
+// on the fp32 VALU (the logits are recomputed three times; 16-wide dot products in registers, the other operand broadcast from
+// LDS).  Masked keys (mask_2d < 0.5) have their logit REPLACED by -2^15 in the forward: no gradient flows into q, k through them,
+// while v still receives p * do.  Output: dqkvg[b,N,N,4,64] by pair position = d(W_q x) | d(W_k x) | d(W_v x) | d(gate pre-act.),
+// channels head-major; the projections' input gradient, the LayerNorm backward and the weight gradients are row GEMMs / BLAS
+// reductions on the caller's side.
+constexpr int TB_PITCH = 17;        // LDS pitch (floats) of the [N][16] arrays: conflict-free when thread = row
+template <int P>
+__global__ __launch_bounds__(256) void tri_attn_bwd_core_kernel(
+    float* __restrict__ dqkvg, const float* __restrict__ dog, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ wg,
+    const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
+    constexpr int C = 16, HC = 64, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem_tb[];
+    float* Wl = smem_tb;                         // [64][P+4]: rows 0-15 k_h, 16-31 v_h, 32-47 q_h, 48-63 g_h
+    float* Ql = Wl + 64 * (P + 4);               // [npad][17]   (scaled by 1/sqrt(c))
+    float* Kl = Ql + npad * TB_PITCH;
+    float* Vl = Kl + npad * TB_PITCH;
+    float* Gl = Vl + npad * TB_PITCH;            // sigmoid gate
+    float* Dl = Gl + npad * TB_PITCH;            // dog, then do = dog * gate
+    float* Ml = Dl + npad * TB_PITCH;            // [npad] running max
+    float* Ll = Ml + npad;                       // [npad] softmax denominator
+    float* El = Ll + npad;                       // [npad] delta = do . o
+    float* kml = El + npad;                      // [npad] key mask of this row (1 keep / 0 masked)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const float scale = 0.25f;                   // 1 / sqrt(head_dim)
+    const long nrows = (long)b * N;
+    const long nwork = nrows * H;
+    int h_staged = -1;
+    for (long w = blockIdx.x; w < nwork; w += gridDim.x) {
+        // consecutive workgroups take the H heads of one row (same XCD neighbourhood is not needed for correctness)
+        const int h = (int)(w % H);
+        const long bu = w / H;
+        const int bb = (int)(bu / N);
+        const long u = bu - (long)bb * N;
+        auto row_pos = [&](int v) -> long { return ending ? (((long)bb * N + v) * N + u) : (bu * N + v); };
+        __syncthreads();                         // previous work item fully done with the LDS
+        if (h != h_staged) {
+            stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, 256);
+            stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, 256);
+            stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, 256, scale);
+            stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, 256);
+            h_staged = h;
+            __syncthreads();
+        }
+        const float mu = mask[bu];
+        // ---- projections of the row: 4 waves x 32-position blocks ----
+        for (int vb = wave; vb * 32 < N; vb += 4) {
+            const int v = vb * 32 + r;
+            const bool valid = v < N;
+            float x[KH];
+            load_row_cll<P>(pair + row_pos(valid ? v : 0) * P, hi, valid, x);
+            ln_cll<KH>(x);
+            f32x16 a0[1], a1[1];
+            zero_acc(a0);
+            zero_acc(a1);
+            rowgemm<P, 1>(Wl, x, a0, r, hi);                         // [k; v]
+            rowgemm<P, 1>(Wl + 2 * C * (P + 4), x, a1, r, hi);       // [q; g]
+            if (valid) {
+                // D rows of a 32-output block: channels {4hi+e} in registers 0-3, {8+4hi+e} in 4-7; second 16 outputs in 8-15
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    Kl[v * TB_PITCH + 4 * hi + e] = a0[0][e];
+                    Kl[v * TB_PITCH + 8 + 4 * hi + e] = a0[0][4 + e];
+                    Vl[v * TB_PITCH + 4 * hi + e] = a0[0][8 + e];
+                    Vl[v * TB_PITCH + 8 + 4 * hi + e] = a0[0][12 + e];
+                    Ql[v * TB_PITCH + 4 * hi + e] = a1[0][e];
+                    Ql[v * TB_PITCH + 8 + 4 * hi + e] = a1[0][4 + e];
+                    Gl[v * TB_PITCH + 4 * hi + e] = sigmoidf_(a1[0][8 + e] + bg[h * C + 4 * hi + e]);
+                    Gl[v * TB_PITCH + 8 + 4 * hi + e] = sigmoidf_(a1[0][12 + e] + bg[h * C + 8 + 4 * hi + e]);
+                }
+                if (hi == 0) kml[v] = (mu * mask[(long)bb * N + v] >= 0.5f) ? 1.f : 0.f;
+            }
+        }
+        for (int idx = tid; idx < N * C; idx += 256) {               // dog of this head, row by row
+            const int v = idx >> 4, c = idx & 15;
+            Dl[v * TB_PITCH + c] = dog[row_pos(v) * HC + h * C + c];
+        }
+        __syncthreads();
+        // ---- pass A: one query per thread ----
+        for (int q = tid; q < N; q += 256) {
+            float qv[C], dov[C], gv[C], o[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { qv[c] = Ql[q * TB_PITCH + c]; gv[c] = Gl[q * TB_PITCH + c]; dov[c] = Dl[q * TB_PITCH + c]; o[c] = 0.f; }
+            float m = -INFINITY, l = 0.f;
+            for (int j = 0; j < N; ++j) {
+                float sdot = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) sdot += qv[c] * Kl[j * TB_PITCH + c];
+                if (kml[j] == 0.f) sdot = -32768.0f;
+                const float mn = fmaxf(m, sdot);
+                const float alpha = expf(m - mn), pj = expf(sdot - mn);
+                l = l * alpha + pj;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = o[c] * alpha + pj * Vl[j * TB_PITCH + c];
+                m = mn;
+            }
+            const float il = 1.0f / l;
+            float delta = 0.f;
+            float* outp = dqkvg + row_pos(q) * (4 * HC) + h * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                o[c] *= il;
+                const float dogc = dov[c];
+                outp[3 * HC + c] = dogc * o[c] * gv[c] * (1.0f - gv[c]);     // d(gate pre-activation)
+                dov[c] = dogc * gv[c];                                         // do
+                delta += dov[c] * o[c];
+            }
+            float dq[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) dq[c] = 0.f;
+            for (int j = 0; j < N; ++j) {
+                float sdot = 0.f, dp = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { sdot += qv[c] * Kl[j * TB_PITCH + c]; dp += dov[c] * Vl[j * TB_PITCH + c]; }
+                const bool keep = kml[j] != 0.f;
+                if (!keep) sdot = -32768.0f;
+                const float pj = expf(sdot - m) * il;
+                const float ds = keep ? pj * (dp - delta) : 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) dq[c] += ds * Kl[j * TB_PITCH + c];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) outp[c] = scale * dq[c];             // d(W_q x): q = scale * W_q x
+            Ml[q] = m;
+            Ll[q] = il;
+            El[q] = delta;
+#pragma unroll
+            for (int c = 0; c < C; ++c) Dl[q * TB_PITCH + c] = dov[c];         // pass B reads do
+        }
+        __syncthreads();
+        // ---- pass B: one key per thread ----
+        for (int j = tid; j < N; j += 256) {
+            float kv[C], vv[C], dk[C], dv[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { kv[c] = Kl[j * TB_PITCH + c]; vv[c] = Vl[j * TB_PITCH + c]; dk[c] = 0.f; dv[c] = 0.f; }
+            const bool keep = kml[j] != 0.f;
+            for (int q = 0; q < N; ++q) {
+                float sdot = 0.f, dp = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { sdot += Ql[q * TB_PITCH + c] * kv[c]; dp += Dl[q * TB_PITCH + c] * vv[c]; }
+                if (!keep) sdot = -32768.0f;
+                const float pj = expf(sdot - Ml[q]) * Ll[q];
+                const float ds = keep ? pj * (dp - El[q]) : 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { dk[c] += ds * Ql[q * TB_PITCH + c]; dv[c] += pj * Dl[q * TB_PITCH + c]; }
+            }
+            float* outp = dqkvg + row_pos(j) * (4 * HC) + h * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { outp[HC + c] = dk[c]; outp[2 * HC + c] = dv[c]; }
+        }
+    }
+}
+
+// d/dx of LayerNorm (no affine) over the last axis: one wave per row, C a multiple of 64
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy, const float* __restrict__ x,
+                                                          long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    const float* gr = dy + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / C + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { const float y = (xr[c] - mean) * rstd; s1 += gr[c]; s2 += gr[c] * y; }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    const float m1 = s1 / C, m2 = s2 / C;
+    for (int c = lane; c < C; c += 64) { const float y = (xr[c] - mean) * rstd; dx[row * C + c] = rstd * (gr[c] - m1 - y * m2); }
+}
+
 }  // namespace
 
 #define PRD_BWD_SET_LDS(kernel)                                                                                 \
@@ -272,5 +456,31 @@ extern "C" int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const 
         hipLaunchKernelGGL((tri_mul_proj_bwd_kernel<32, NWB>), dim3(grid), dim3(NWB * 64), lds, stream, dpair, dpp, dpg, dAB, dx1, pair, mask,
                            w_proj, b_proj, w_gate, b_gate, w_proj_t, w_gate_t, b, N, ldn, incoming);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float* pair, const float* mask, const float* wq,
+                                     const float* wk, const float* wv, const float* wg, const float* bg, int ending,
+                                     int b, int N, int P, int H, int c, hipStream_t stream) {
+    if (!dqkvg || !dog || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
+    const int npad = prd_round_up(N, 32);
+    const size_t lds = ((size_t)64 * (P + 4) + (size_t)5 * npad * TB_PITCH + 4 * (size_t)npad) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;          // rows beyond N ~ 400: not in this first cut
+    const long nwork = (long)b * N * H;
+    const int grid = (int)(nwork < 256 ? nwork : 256);
+    if (P == 64) {
+        PRD_BWD_SET_LDS(tri_attn_bwd_core_kernel<64>);
+        hipLaunchKernelGGL(tri_attn_bwd_core_kernel<64>, dim3(grid), dim3(256), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
+    } else {
+        PRD_BWD_SET_LDS(tri_attn_bwd_core_kernel<32>);
+        hipLaunchKernelGGL(tri_attn_bwd_core_kernel<32>, dim3(grid), dim3(256), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream) {
+    if (!dx || !dy || !x || rows <= 0 || C <= 0) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dx, dy, x, (long)rows, C);
     return (int)hipGetLastError();
 }

@@ -285,6 +285,31 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
     return dpair, grads
 
 
+def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool):
+    """Gradients of the TriangleAttention update (ops.tri_attn with residual=False) with respect to ``pair`` and its seven weight
+    tensors on the hand-written backward (csrc/prd_bwd.hip): out-projection backward (row GEMM) -> attention core backward per
+    (row, head) -> projections backward (row GEMM) -> LayerNorm backward.  Weight gradients: BLAS reductions over all N^2 rows."""
+    wq, wk, wv, wg, bg, wo, bo = wts
+    b, N, _, P = pair.shape
+    HC = H * c
+    dev = pair.device
+    dy = dy.contiguous()
+    og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending)                  # forward recompute: gated head outputs
+    dog = linear(dy, wo.t().contiguous())                                                         # d og = dy W_o
+    dqkvg = torch.empty(b, N, N, 4, HC, device=dev, dtype=F32)
+    check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
+                                      int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core")
+    wcat_t = torch.cat([wq, wk, wv, wg], dim=0).t().contiguous()                                  # [P, 4 HC]
+    dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat_t)                                             # gradient of LN(pair)
+    dpair = torch.empty_like(pair)
+    check(lib().prd_ln_rows_bwd(dptr(dpair), dptr(dxn), dptr(pair), b * N * N, P, stream()), "prd_ln_rows_bwd")
+    x = layer_norm(pair.contiguous()).view(-1, P)
+    d2 = dqkvg.view(-1, 4, HC)
+    dy2 = dy.view(-1, P)
+    grads = (d2[:, 0].t() @ x, d2[:, 1].t() @ x, d2[:, 2].t() @ x, d2[:, 3].t() @ x, d2[:, 3].sum(0), dy2.t() @ og.view(-1, HC), dy2.sum(0))
+    return dpair, grads
+
+
 def tri_attn_uses_long_rows(N: int, P: int) -> bool:
     """True when rows of N positions take the re-projecting long-row core kernel (prd_hip.h: prd_tri_attn_variant)."""
     return tri_attn_variant(N, P) >= 1

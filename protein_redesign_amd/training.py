@@ -68,6 +68,45 @@ class TriMulFn(torch.autograd.Function):
         return (dpair, None, None, *grads)
 
 
+class TriAttnFn(torch.autograd.Function):
+    """TriangleAttention update with a hand-written backward (ops.tri_attn_backward: out-projection backward, flash-style attention
+    core backward per (row, head), projection + LayerNorm backward on HIP kernels; weight-gradient reductions through BLAS).
+    Rows longer than the backward core's LDS layout (N > ~400) fall back to the recompute-in-torch node (HipOp)."""
+
+    @staticmethod
+    def forward(ctx, pair, mask, ending: bool, H: int, c: int, *wts):
+        ctx.cfg = (ending, H, c)
+        ctx.save_for_backward(pair, mask, *wts)
+        with torch.no_grad():
+            return ops.tri_attn(pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, residual=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pair, mask, *wts = ctx.saved_tensors
+        ending, H, c = ctx.cfg
+        with torch.no_grad():
+            dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending)
+        return (dpair, None, None, None, None, *grads)
+
+
+TRI_ATTN_BWD_MAX_N = 400        # prd_tri_attn_bwd_core keeps q, k, v, gate, do of a row in LDS
+
+
+def tri_attn_update(ta, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    a = ta.attn
+    H, c, end = a.num_heads, a.head_dim, ta.mode == "ending"
+    if pair.shape[1] <= TRI_ATTN_BWD_MAX_N:
+        return TriAttnFn.apply(pair, mask, end, H, c, *a.weights())
+
+    def ref(p, *w):
+        return R.triangle_attention(p, mask, *w, H, c, ending=end)
+
+    def hip(p, *w):
+        return ops.tri_attn(p.contiguous(), mask, w, H, c, ending=end, residual=False)
+
+    return HipOp.apply(hip, ref, pair, *a.weights())
+
+
 def tri_mul_update(tm, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return TriMulFn.apply(pair, mask, tm.mode == "incoming", *tm.weights())
 
@@ -117,15 +156,7 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
         pair = pair + tri_mul_update(tm, pair, mask)
 
     for ta in (blk.pair_attn_starting, blk.pair_attn_ending):
-        end = ta.mode == "ending"
-
-        def ta_ref(p, *w, end=end):
-            return R.triangle_attention(p, mask, *w, H, c, ending=end)
-
-        def ta_hip(p, *w, end=end):
-            return ops.tri_attn(p.contiguous(), mask, w, H, c, ending=end, residual=False)
-
-        pair = pair + HipOp.apply(ta_hip, ta_ref, pair, *ta.attn.weights())
+        pair = pair + tri_attn_update(ta, pair, mask)
 
     pf = blk.pair_fc
     pfw = (pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias)

@@ -128,3 +128,30 @@ def test_triangle_multiplication_backward_kernels(mode, P, gemm_mode):
     assert rel_l2(dpair.cpu(), pl.grad) < 1e-5
     for n, got in zip(names, grads):
         assert rel_l2(got.cpu(), leaf["tm." + n].grad) < 1e-5, n
+
+
+@pytest.mark.parametrize("mode", ["starting", "ending"])
+@pytest.mark.parametrize("P", [32, 64])
+def test_triangle_attention_backward_kernels(mode, P, gemm_mode):
+    """The hand-written backward of TriangleAttention (prd_tri_attn_bwd_core + row GEMMs + prd_ln_rows_bwd) against the oracle's
+    autograd: gradient with respect to the pair input and all seven weight tensors; ragged masked batch, one fully masked row."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(80 + P)
+    b, N, H, c = 2, 45, 4, 16
+    pair = torch.randn(b, N, N, P, generator=g)
+    mask = torch.ones(b, N)
+    mask[1, 38:] = 0
+    names = ["attn.q_proj.weight", "attn.k_proj.weight", "attn.v_proj.weight", "attn.gate_proj.weight", "attn.gate_proj.bias",
+             "attn.out_proj.weight", "attn.out_proj.bias"]
+    shapes = [(64, P), (64, P), (64, P), (64, P), (64,), (P, 64), (P,)]
+    wts = [torch.randn(s, generator=g) / (math.sqrt(s[-1]) if len(s) == 2 else 4.0) for s in shapes]
+    dy = torch.randn(b, N, N, P, generator=g)
+    pl = pair.clone().requires_grad_(True)
+    leaf = {"ta." + n: w.clone().requires_grad_(True) for n, w in zip(names, wts)}
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    out = O.triangle_attention(leaf, "ta", pl, m2, H, c, mode == "ending")
+    out.backward(dy)
+    dpair, grads = ops.tri_attn_backward(dy.to(DEV), pair.to(DEV), mask.to(DEV), [w.to(DEV) for w in wts], H, c, ending=mode == "ending")
+    assert rel_l2(dpair.cpu(), pl.grad) < 1e-5
+    for n, got in zip(names, grads):
+        assert rel_l2(got.cpu(), leaf["ta." + n].grad) < 1e-5, n
