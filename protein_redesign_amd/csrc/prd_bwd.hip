@@ -232,9 +232,23 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
 // while v still receives p * do.  Output: dqkvg[b,N,N,4,64] by pair position = d(W_q x) | d(W_k x) | d(W_v x) | d(gate pre-act.),
 // channels head-major; the projections' input gradient, the LayerNorm backward and the weight gradients are row GEMMs / BLAS
 // reductions on the caller's side.
-constexpr int TB_PITCH = 17;        // LDS pitch (floats) of the [N][16] arrays: conflict-free when thread = row
+constexpr int TB_PITCH = 20;        // LDS pitch (floats) of the [N][16] arrays: 16-byte aligned rows (float4 reads), conflict-free when thread = row
+PRD_DEV void tb_load16(const float* __restrict__ p, float (&v)[16]) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 4 * f);
+        v[4 * f] = t.x; v[4 * f + 1] = t.y; v[4 * f + 2] = t.z; v[4 * f + 3] = t.w;
+    }
+}
+PRD_DEV float tb_dot16(const float (&a)[16], const float (&b)[16]) {      // four independent chains
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) { s0 += a[c] * b[c]; s1 += a[c + 1] * b[c + 1]; s2 += a[c + 2] * b[c + 2]; s3 += a[c + 3] * b[c + 3]; }
+    return (s0 + s1) + (s2 + s3);
+}
+
 template <int P>
-__global__ __launch_bounds__(256) void tri_attn_bwd_core_kernel(
+__global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
     float* __restrict__ dqkvg, const float* __restrict__ dog, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ wg,
     const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(256) void tri_attn_bwd_core_kernel(
     float* Ll = Ml + npad;                       // [npad] softmax denominator
     float* El = Ll + npad;                       // [npad] delta = do . o
     float* kml = El + npad;                      // [npad] key mask of this row (1 keep / 0 masked)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x, NWV = NT >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const float scale = 0.25f;                   // 1 / sqrt(head_dim)
     const long nrows = (long)b * N;
@@ -265,16 +279,16 @@ __global__ __launch_bounds__(256) void tri_attn_bwd_core_kernel(
         auto row_pos = [&](int v) -> long { return ending ? (((long)bb * N + v) * N + u) : (bu * N + v); };
         __syncthreads();                         // previous work item fully done with the LDS
         if (h != h_staged) {
-            stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, 256);
-            stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, 256);
-            stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, 256, scale);
-            stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, 256);
+            stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
+            stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
+            stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT, scale);
+            stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
             h_staged = h;
             __syncthreads();
         }
         const float mu = mask[bu];
         // ---- projections of the row: 4 waves x 32-position blocks ----
-        for (int vb = wave; vb * 32 < N; vb += 4) {
+        for (int vb = wave; vb * 32 < N; vb += NWV) {
             const int v = vb * 32 + r;
             const bool valid = v < N;
             float x[KH];
@@ -301,27 +315,31 @@ __global__ __launch_bounds__(256) void tri_attn_bwd_core_kernel(
                 if (hi == 0) kml[v] = (mu * mask[(long)bb * N + v] >= 0.5f) ? 1.f : 0.f;
             }
         }
-        for (int idx = tid; idx < N * C; idx += 256) {               // dog of this head, row by row
+        for (int idx = tid; idx < N * C; idx += NT) {                // dog of this head, row by row
             const int v = idx >> 4, c = idx & 15;
             Dl[v * TB_PITCH + c] = dog[row_pos(v) * HC + h * C + c];
         }
         __syncthreads();
         // ---- pass A: one query per thread ----
-        for (int q = tid; q < N; q += 256) {
+        for (int q = tid; q < N; q += NT) {
             float qv[C], dov[C], gv[C], o[C];
+            tb_load16(Ql + q * TB_PITCH, qv);
+            tb_load16(Gl + q * TB_PITCH, gv);
+            tb_load16(Dl + q * TB_PITCH, dov);
 #pragma unroll
-            for (int c = 0; c < C; ++c) { qv[c] = Ql[q * TB_PITCH + c]; gv[c] = Gl[q * TB_PITCH + c]; dov[c] = Dl[q * TB_PITCH + c]; o[c] = 0.f; }
+            for (int c = 0; c < C; ++c) o[c] = 0.f;
             float m = -INFINITY, l = 0.f;
             for (int j = 0; j < N; ++j) {
-                float sdot = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) sdot += qv[c] * Kl[j * TB_PITCH + c];
+                float kj[C], vj[C];
+                tb_load16(Kl + j * TB_PITCH, kj);
+                tb_load16(Vl + j * TB_PITCH, vj);
+                float sdot = tb_dot16(qv, kj);
                 if (kml[j] == 0.f) sdot = -32768.0f;
                 const float mn = fmaxf(m, sdot);
                 const float alpha = expf(m - mn), pj = expf(sdot - mn);
                 l = l * alpha + pj;
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = o[c] * alpha + pj * Vl[j * TB_PITCH + c];
+                for (int c = 0; c < C; ++c) o[c] = o[c] * alpha + pj * vj[c];
                 m = mn;
             }
             const float il = 1.0f / l;
@@ -339,40 +357,49 @@ __global__ __launch_bounds__(256) void tri_attn_bwd_core_kernel(
 #pragma unroll
             for (int c = 0; c < C; ++c) dq[c] = 0.f;
             for (int j = 0; j < N; ++j) {
-                float sdot = 0.f, dp = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) { sdot += qv[c] * Kl[j * TB_PITCH + c]; dp += dov[c] * Vl[j * TB_PITCH + c]; }
+                float kj[C], vj[C];
+                tb_load16(Kl + j * TB_PITCH, kj);
+                tb_load16(Vl + j * TB_PITCH, vj);
+                float sdot = tb_dot16(qv, kj);
+                const float dp = tb_dot16(dov, vj);
                 const bool keep = kml[j] != 0.f;
                 if (!keep) sdot = -32768.0f;
                 const float pj = expf(sdot - m) * il;
                 const float ds = keep ? pj * (dp - delta) : 0.f;
 #pragma unroll
-                for (int c = 0; c < C; ++c) dq[c] += ds * Kl[j * TB_PITCH + c];
+                for (int c = 0; c < C; ++c) dq[c] += ds * kj[c];
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) outp[c] = scale * dq[c];             // d(W_q x): q = scale * W_q x
             Ml[q] = m;
             Ll[q] = il;
             El[q] = delta;
+        }
+        __syncthreads();                                                       // every thread is done reading dog before it becomes do
+        for (int q = tid; q < N; q += NT) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) Dl[q * TB_PITCH + c] = dov[c];         // pass B reads do
+            for (int c = 0; c < C; ++c) Dl[q * TB_PITCH + c] *= Gl[q * TB_PITCH + c];      // pass B reads do = dog * gate
         }
         __syncthreads();
         // ---- pass B: one key per thread ----
-        for (int j = tid; j < N; j += 256) {
+        for (int j = tid; j < N; j += NT) {
             float kv[C], vv[C], dk[C], dv[C];
+            tb_load16(Kl + j * TB_PITCH, kv);
+            tb_load16(Vl + j * TB_PITCH, vv);
 #pragma unroll
-            for (int c = 0; c < C; ++c) { kv[c] = Kl[j * TB_PITCH + c]; vv[c] = Vl[j * TB_PITCH + c]; dk[c] = 0.f; dv[c] = 0.f; }
+            for (int c = 0; c < C; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
             const bool keep = kml[j] != 0.f;
             for (int q = 0; q < N; ++q) {
-                float sdot = 0.f, dp = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) { sdot += Ql[q * TB_PITCH + c] * kv[c]; dp += Dl[q * TB_PITCH + c] * vv[c]; }
+                float qq[C], dd[C];
+                tb_load16(Ql + q * TB_PITCH, qq);
+                tb_load16(Dl + q * TB_PITCH, dd);
+                float sdot = tb_dot16(qq, kv);
+                const float dp = tb_dot16(dd, vv);
                 if (!keep) sdot = -32768.0f;
                 const float pj = expf(sdot - Ml[q]) * Ll[q];
                 const float ds = keep ? pj * (dp - El[q]) : 0.f;
 #pragma unroll
-                for (int c = 0; c < C; ++c) { dk[c] += ds * Ql[q * TB_PITCH + c]; dv[c] += pj * Dl[q * TB_PITCH + c]; }
+                for (int c = 0; c < C; ++c) { dk[c] += ds * qq[c]; dv[c] += pj * dd[c]; }
             }
             float* outp = dqkvg + row_pos(j) * (4 * HC) + h * C;
 #pragma unroll
@@ -469,12 +496,15 @@ extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;          // rows beyond N ~ 400: not in this first cut
     const long nwork = (long)b * N * H;
     const int grid = (int)(nwork < 256 ? nwork : 256);
+    int nthreads = prd_round_up(N, 64);                         // one query / key per thread in a single round where possible
+    if (nthreads > 512) nthreads = 512;
+    if (nthreads < 256) nthreads = 256;
     if (P == 64) {
         PRD_BWD_SET_LDS(tri_attn_bwd_core_kernel<64>);
-        hipLaunchKernelGGL(tri_attn_bwd_core_kernel<64>, dim3(grid), dim3(256), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
+        hipLaunchKernelGGL(tri_attn_bwd_core_kernel<64>, dim3(grid), dim3(nthreads), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
     } else {
         PRD_BWD_SET_LDS(tri_attn_bwd_core_kernel<32>);
-        hipLaunchKernelGGL(tri_attn_bwd_core_kernel<32>, dim3(grid), dim3(256), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
+        hipLaunchKernelGGL(tri_attn_bwd_core_kernel<32>, dim3(grid), dim3(nthreads), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
     }
     return (int)hipGetLastError();
 }
