@@ -480,6 +480,157 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
     }
 }
 
+// ---- node-row linears of the single track in gemm mode 1: 32x32 tiles, deep operand ring ---------------------------------
+// What bounds the M = b N (a few hundred) linears is neither the matrix pipe nor the launch (1.7 us between dependent
+// kernels in a graph), but operand delivery (tools/ubench/nodegemm_bench.hip, profiles/r02_nodegemm_ubench.txt):
+//   * a lane-per-row load touches 32 cache lines per instruction and the CU's L1 tag pipe saturates (TCP_TOTAL_CACHE_ACCESSES
+//     = one per cycle for the whole launch of gemm_skinny_kernel);
+//   * a CU streams operands at ~50 GB/s however many loads it has in flight, and a chunked loop with two chunks in flight pays
+//     the L2-miss latency once per chunk.
+// Here eight lanes read one 128-byte line of a row (4x fewer tag accesses), a group of four waves keeps D chunks of 64 k in
+// flight in registers (16 KB each), splits fp16 hi | lo while staging a chunk into LDS in the MFMA operand layout (16-byte
+// columns XOR-swizzled by row), and -- for long K -- KG groups take every KG-th chunk with their own LDS stages.  The four
+// waves of a group each take one 16-wide k-step of a chunk; partial tiles are merged in LDS in a fixed order.  LayerNorm
+// statistics come from the ring itself (the whole row is in flight: K <= 64 D KG), so the first load is the only exposed one.
+template <int D, int KG, bool LN>
+__global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
+    constexpr int KCH = 64, NJ = KCH / 32, PL = 32 * KCH * 2, STAGE = 4 * PL;      // plane = 32 rows x 64 fp16; A hi | A lo | B hi | B lo
+    extern __shared__ __attribute__((aligned(16))) unsigned char gr[];             // [KG][2][STAGE] (the partial tiles alias it) + LN sums
+    const int tid = threadIdx.x, kg = tid >> 8, t8 = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int r = lane & 31, hi = lane >> 5;
+    const int tiles_n = (g.N + 31) / 32;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int gb = blockIdx.y, g1 = gb / g.G2, g2 = gb - g1 * g.G2;
+    const int row = t8 >> 3, seg = t8 & 7;
+    // rows past the edge read row 0 (their outputs are never stored)
+    const float* ap = g.A + g1 * g.sa1 + g2 * g.sa2 + (size_t)(m0 + row < g.M ? m0 + row : 0) * g.lda + 4 * seg;
+    const float* bp = g.B + g1 * g.sb1 + g2 * g.sb2 + (size_t)(n0 + row < g.N ? n0 + row : 0) * g.ldb + 4 * seg;
+    const int nch = g.K / KCH;
+    const int myn = (nch - kg + KG - 1) / KG;           // chunks kg, kg + KG, ... of this group (>= 1: the host picks KG <= nch)
+    unsigned char* mysm = gr + kg * 2 * STAGE;
+    float4 ra[D][NJ], rb[D][NJ];
+#define PRD_GR_LOAD(SLOT, CI)                                                                            \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
+        const int c_ = kg + KG * ((CI) < myn ? (CI) : myn - 1);                                          \
+        ra[SLOT][j] = *reinterpret_cast<const float4*>(ap + c_ * KCH + 32 * j);                          \
+        rb[SLOT][j] = *reinterpret_cast<const float4*>(bp + c_ * KCH + 32 * j);                          \
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { PRD_GR_LOAD(d, d) }
+    float mean = 0.f, rz = 1.f;
+    if (LN) {                                           // two-pass statistics over the row values held in the ring (myn <= D)
+        float* st = reinterpret_cast<float*>(gr + KG * 2 * STAGE);      // [KG][32 rows][2]
+        float s1 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s1 += d < myn ? (ra[d][j].x + ra[d][j].y) + (ra[d][j].z + ra[d][j].w) : 0.f;
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+        if (KG > 1) {
+            if (seg == 0) st[(kg * 32 + row) * 2] = s1;
+            __syncthreads();
+            s1 = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < KG; ++k2) s1 += st[(k2 * 32 + row) * 2];
+        }
+        mean = s1 / (float)g.K;
+        float s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float d0 = ra[d][j].x - mean, d1 = ra[d][j].y - mean, d2 = ra[d][j].z - mean, d3 = ra[d][j].w - mean;
+                s2 += d < myn ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+            }
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+        if (KG > 1) {
+            if (seg == 0) st[(kg * 32 + row) * 2 + 1] = s2;
+            __syncthreads();
+            s2 = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < KG; ++k2) s2 += st[(k2 * 32 + row) * 2 + 1];
+        }
+        rz = 1.0f / sqrtf(s2 / (float)g.K + 1e-5f);
+    }
+#define PRD_GR_STAGE(SLOT, ST)                                                                           \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
+        float4 a = ra[SLOT][j];                                                                          \
+        const float4 b = rb[SLOT][j];                                                                    \
+        if (LN) { a.x = (a.x - mean) * rz; a.y = (a.y - mean) * rz; a.z = (a.z - mean) * rz; a.w = (a.w - mean) * rz; } \
+        unsigned h0, l0, h1, l1;                                                                         \
+        unsigned char* d_ = mysm + (ST) * STAGE + row * (KCH * 2) + (((4 * j + (seg >> 1)) ^ (row & 7)) << 4) + (seg & 1) * 8; \
+        split2h(a.x, a.y, h0, l0); split2h(a.z, a.w, h1, l1);                                            \
+        *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};                                                   \
+        *reinterpret_cast<u32x2*>(d_ + PL) = u32x2{l0, l1};                                              \
+        split2h(H2_WSCALE * b.x, H2_WSCALE * b.y, h0, l0); split2h(H2_WSCALE * b.z, H2_WSCALE * b.w, h1, l1); \
+        *reinterpret_cast<u32x2*>(d_ + 2 * PL) = u32x2{h0, h1};                                          \
+        *reinterpret_cast<u32x2*>(d_ + 3 * PL) = u32x2{l0, l1};                                          \
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#define PRD_GR_MFMA(ST)                                                                                  \
+    {                                                                                                    \
+        const int col = 2 * wave + hi;                   /* wave w takes k-step w of the chunk */        \
+        const unsigned char* a_ = mysm + (ST) * STAGE + r * (KCH * 2) + ((col ^ (r & 7)) << 4);         \
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(a_), al = *reinterpret_cast<const u32x4*>(a_ + PL); \
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(a_ + 2 * PL), bl = *reinterpret_cast<const u32x4*>(a_ + 3 * PL); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bl), acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0); \
+    }
+    // chunk c: stage it (LDS stage c & 1 was last read by MFMA(c - 2), which every wave finished before the barrier of
+    // chunk c - 1), refill its ring slot with chunk c + D, barrier, multiply.  One barrier per chunk.
+    const int maxn = (nch + KG - 1) / KG;               // trip count of the longest group: the barriers are workgroup-wide
+    for (int c0 = 0; c0 < maxn; c0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int c = c0 + d;
+            if (c < maxn) {
+                if (c < myn) { PRD_GR_STAGE(d, d & 1) }
+                PRD_GR_LOAD(d, c + D)
+                __syncthreads();
+                if (c < myn) PRD_GR_MFMA(d & 1)
+            }
+        }
+    }
+#undef PRD_GR_LOAD
+#undef PRD_GR_STAGE
+#undef PRD_GR_MFMA
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(gr);          // [KG * 4 waves][16][64]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[((kg * 4 + wave) * 16 + q) * 64 + lane] = acc[q];
+    __syncthreads();
+    if (kg == 0) {
+        float* __restrict__ C = g.C + g1 * g.sc1 + g2 * g.sc2;
+        const int n = n0 + r;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = 4 * wave + qq;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4 * KG; ++w) v += red[(w * 16 + q) * 64 + lane];
+            const int m = m0 + drow32(q, hi);
+            if (m < g.M && n < g.N) epilogue_store(g, g1, g2, m, n, v * H2_INV_WSCALE, C);
+        }
+    }
+}
+
+template <int D, int KG>
+static int launch_ring(const PrdGemm& g, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)KG * 2 * 4 * 32 * 64 * 2 + 1024;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<D, KG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<D, KG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (g.a_ln) hipLaunchKernelGGL((gemm_ring_kernel<D, KG, true>), grid, dim3(256 * KG), lds, stream, g);
+    else hipLaunchKernelGGL((gemm_ring_kernel<D, KG, false>), grid, dim3(256 * KG), lds, stream, g);
+    return (int)hipGetLastError();
+}
+
 // ---- LayerNorm rows: one wave per row ------------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -545,6 +696,22 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
             hipLaunchKernelGGL((gemm_h2_kernel<1>), grid, dim3(256), lds, stream, g);
         }
         return (int)hipGetLastError();
+    }
+    // gemm mode 1, latency-bound node-row linears (fewer 64x64 tiles than that): 32x32 tiles with a deep operand ring
+    if (prd_get_gemm_mode() == 1 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 && batches == 1) {
+        const int nch = g.K / 64;
+        dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
+        const bool many = (long)grid.x * grid.y > 1024;         // throughput regime: one group per workgroup, more workgroups per CU
+        if (nch <= 1) return launch_ring<1, 1>(g, grid, stream);
+        if (nch <= 2) return launch_ring<2, 1>(g, grid, stream);
+        if (nch <= 4) return launch_ring<4, 1>(g, grid, stream);
+        if (nch <= 8) return launch_ring<8, 1>(g, grid, stream);
+        if (!g.a_ln) {
+            if (many) return launch_ring<4, 1>(g, grid, stream);
+            if (nch <= 16) return launch_ring<8, 2>(g, grid, stream);
+            return launch_ring<4, 4>(g, grid, stream);
+        }
+        if (nch <= 16) return launch_ring<8, 2>(g, grid, stream);   // LayerNorm needs the whole row in the ring: K <= 1024 here
     }
     int tile = g.tile_hint;
     if (g.a_ln) {                                   // fused LayerNorm lives in the K-split kernel only; the K slice of a lane
