@@ -29,6 +29,7 @@ class PrdGemm(C.Structure):
         ("resid", vp), ("sr1", cll), ("sr2", cll), ("ldr", ci),
         ("tile_hint", ci),
         ("a_ln", ci),
+        ("ln_out", vp), ("ldlo", ci),
     ]
 
 

@@ -231,6 +231,13 @@ __global__ __launch_bounds__(NWK * 64) void gemm_skinny_kernel(PrdGemm g) {   //
         }
         const float rz = am / sqrtf(var / (float)g.K + 1e-5f);
         __syncthreads();                                  // red[] is reused by the K-split reduction below
+        if (g.ln_out && tile_n == 0 && mv) {              // the normalised rows themselves (first column tile only)
+            float* lo = g.ln_out + (size_t)(m0 + r) * g.ldlo + k0;
+#pragma unroll
+            for (int t = 0; t < LNG; ++t)
+                if (t < nk) *reinterpret_cast<float4*>(lo + 8 * t) = make_float4((av[t].x - mean) * rz, (av[t].y - mean) * rz,
+                                                                                 (av[t].z - mean) * rz, (av[t].w - mean) * rz);
+        }
 #pragma unroll
         for (int bt = 0; bt < LNG / BT; ++bt) {
 #pragma unroll
@@ -553,11 +560,14 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
         }
         rz = 1.0f / sqrtf(s2 / (float)g.K + 1e-5f);
     }
-#define PRD_GR_STAGE(SLOT, ST)                                                                           \
+#define PRD_GR_STAGE(SLOT, ST, CI)                                                                       \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
         float4 a = ra[SLOT][j];                                                                          \
         const float4 b = rb[SLOT][j];                                                                    \
-        if (LN) { a.x = (a.x - mean) * rz; a.y = (a.y - mean) * rz; a.z = (a.z - mean) * rz; a.w = (a.w - mean) * rz; } \
+        if (LN) {                                                                                        \
+            a.x = (a.x - mean) * rz; a.y = (a.y - mean) * rz; a.z = (a.z - mean) * rz; a.w = (a.w - mean) * rz; \
+            if (lo) *reinterpret_cast<float4*>(lo + (kg + KG * (CI)) * KCH + 32 * j) = a;               \
+        }                                                                                                \
         unsigned h0, l0, h1, l1;                                                                         \
         unsigned char* d_ = mysm + (ST) * STAGE + row * (KCH * 2) + (((4 * j + (seg >> 1)) ^ (row & 7)) << 4) + (seg & 1) * 8; \
         split2h(a.x, a.y, h0, l0); split2h(a.z, a.w, h1, l1);                                            \
@@ -567,6 +577,8 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
         *reinterpret_cast<u32x2*>(d_ + 2 * PL) = u32x2{h0, h1};                                          \
         *reinterpret_cast<u32x2*>(d_ + 3 * PL) = u32x2{l0, l1};                                          \
     }
+    // the normalised rows themselves, written by the first column tile (PrdGemm.ln_out)
+    float* lo = (LN && g.ln_out && tile_n == 0 && m0 + row < g.M) ? g.ln_out + (size_t)(m0 + row) * g.ldlo + 4 * seg : nullptr;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -588,7 +600,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
         for (int d = 0; d < D; ++d) {
             const int c = c0 + d;
             if (c < maxn) {
-                if (c < myn) { PRD_GR_STAGE(d, d & 1) }
+                if (c < myn) { PRD_GR_STAGE(d, d & 1, c) }
                 PRD_GR_LOAD(d, c + D)
                 __syncthreads();
                 if (c < myn) PRD_GR_MFMA(d & 1)
@@ -677,13 +689,12 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.G1 <= 0 || g.G2 <= 0) return PRD_ERR_ARG;
     if ((g.lda & 3) || (g.ldb & 3)) return PRD_ERR_ALIGN;
     const int batches = g.G1 * g.G2;
+    if (g.ln_out && (!g.a_ln || batches != 1 || (g.ldlo & 3) || g.ldlo < g.K)) return PRD_ERR_ARG;
     const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
-    // gemm mode 1: THROUGHPUT-bound linears (>= 512 tiles of 64x64: SPAttention's 512 -> 4 x 2048 projection) go to the fp16 x 2
-    // split kernel (41 -> 26 us).  The other single-track linears (20-160 tiles) are latency-bound: there the LDS-staged kernel
-    // measured SLOWER than the skinny fp32 kernel, which has all its operand loads in flight at once (512 -> 2048: 27 vs 20 us,
-    // 2048 -> 512: 31 vs 22, 512 -> 256: 27 vs 11; a two-chunk prefetch does not cover the ~2 us operand latency of a 0.25 us chunk).
+    // gemm mode 1: THROUGHPUT-bound linears (>= 512 tiles of 64x64: SPAttention's 512 -> 4 x 2048 projection, the transition at
+    // b = 8) go to the 64x64-tile fp16 x 2 kernel (41 -> 26 us); the latency-bound ones (20-160 tiles) to gemm_ring_kernel below.
     if (prd_get_gemm_mode() == 1 && g.tile_hint == 0 && !g.b_kn && (g.K % 32) == 0 && tiles64 >= 512 && g.G1 * g.G2 == 1 &&
-        (!g.a_ln || (g.K % 16) == 0)) {
+        (!g.a_ln || (g.K % 16) == 0) && !g.ln_out) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
         static std::once_flag once1, once4;
         if (g.K >= 1024) {

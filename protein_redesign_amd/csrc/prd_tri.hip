@@ -751,128 +751,141 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
 }
 
 // Single-track gated attention core (reference modules.py:216-223 with the pair bias of :300-304), heads of width 16:
-// o[b,q,h*16+c] = gate * softmax_k(q.k + bias[b,h,q,k], keys with mask < 0.5 filled with -2^15) v.  One workgroup per
-// (b, h, 64 queries): K_h / V_h^T of all N nodes are staged in LDS, each wave streams the keys for one 16-query tile
-// with the same swapped 16x16x4 MFMA scheme as the triangle attention.  Replaces three launches (logits GEMM, row
-// softmax, P*V GEMM) and the [b,H,N,N] logits round trip.
-__global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict__ o_out, const float* __restrict__ qkvg,
-                                                               const float* __restrict__ bias, const float* __restrict__ mask,
-                                                               int b, int N, int npad, int H) {
+// o[b,q,h*16+c] = gate * softmax_k(q.k + bias[b,h,q,k], keys with mask < 0.5 filled with -2^15) v.  Replaces three launches
+// (logits GEMM, row softmax, P*V GEMM) and the [b,H,N,N] logits round trip.
+// The kernel is pure latency (0.2 GF, 1.3 MB at N = 320), so it is laid out WIDE: one workgroup per (b, h, 16 queries), the
+// keys split in contiguous quarters over the four waves, every operand of a wave's first three 32-key blocks (K rows, V
+// columns, pair bias, key mask -- straight from global memory in the lane layout of the swapped 16x16x4 MFMA scheme of the
+// triangle attention) requested before the first MFMA; the four partial (max, sum, o) triples are merged through LDS in
+// wave order.  (The first form -- 64 queries per workgroup, K / V^T of all nodes staged in LDS, ten dependent key blocks
+// per wave -- took 14.9 us on 20 workgroups.)
+struct SaBlock {                      // one 32-key block in the lane layout (lane = (query ql | key row, quad g4))
+    float4 k[2];                      // K[key0 + 16 j + ql][4 g4 ..]
+    float v[2][4], bi[2][4], mk[2][4];   // V[key][ql], bias[q][key], mask[key] for key = key0 + 16 j + 4 g4 + e
+};
+
+PRD_DEV void sa_load(SaBlock& s, const float* __restrict__ base, const float* __restrict__ brow, const float* __restrict__ mrow,
+                     int N, int key0, int h, int ql, int g4) {
     constexpr int C = 16, HC = 64, L = 4 * HC;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Kl = smem;                          // [npad][KP]
-    float* Vt = Kl + npad * KP;                // [16][npad+4]
-    float* kadd = Vt + C * (npad + 4);         // [npad]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ql = lane & 15, g4 = lane >> 4;
-    const int qblocks = (N + 63) / 64;
-    const int qb = blockIdx.x % qblocks;
-    const int bh = blockIdx.x / qblocks;
-    const int h = bh % H, bb = bh / H;
-    const float* base = qkvg + (size_t)bb * N * L;
-    for (int idx = tid; idx < npad * 4; idx += 256) {          // K rows: 4 groups of 16 B per node
-        const int j = idx >> 2, f = idx & 3;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (j < N) {
-            kv = *reinterpret_cast<const float4*>(base + (size_t)j * L + HC + h * C + 4 * f);
-            vv = *reinterpret_cast<const float4*>(base + (size_t)j * L + 2 * HC + h * C + 4 * f);
-        }
-        *reinterpret_cast<float4*>(Kl + j * KP + 4 * f) = kv;
-        Vt[(4 * f + 0) * (npad + 4) + j] = vv.x;
-        Vt[(4 * f + 1) * (npad + 4) + j] = vv.y;
-        Vt[(4 * f + 2) * (npad + 4) + j] = vv.z;
-        Vt[(4 * f + 3) * (npad + 4) + j] = vv.w;
-    }
-    for (int k = tid; k < npad; k += 256) {
-        const bool inside = k < N;
-        const bool keep = inside && (!mask || mask[(size_t)bb * N + (inside ? k : 0)] >= 0.5f);
-        kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
-    }
-    __syncthreads();
-    const int q = qb * 64 + wave * 16 + ql;
-    const bool qok = q < N;
-    const int qq = qok ? q : 0;
-    const float4 qf = *reinterpret_cast<const float4*>(base + (size_t)qq * L + h * C + 4 * g4);   // already scaled by 1/sqrt(c)
-    const float* brow = bias + (((size_t)bb * H + h) * N + qq) * N;
-    float m_run = -1e30f, l_run = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    // the pair bias of the NEXT 32-key block is fetched while the current one is processed (unconditional loads with a
-    // clamped key: a load issued where it is needed costs one L2 round trip per block -- 10 of them were most of the
-    // kernel's 18 us at N = 320)
-    float bcur[2][4], bnxt[2][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+        const int kr = key0 + 16 * j + ql;
+        s.k[j] = *reinterpret_cast<const float4*>(base + (size_t)(kr < N ? kr : N - 1) * L + HC + h * C + 4 * g4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int key = 16 * j + 4 * g4 + e;
-            bcur[j][e] = brow[key < N ? key : N - 1];
+            const int key = key0 + 16 * j + 4 * g4 + e, kc = key < N ? key : N - 1;
+            s.v[j][e] = base[(size_t)kc * L + 2 * HC + h * C + ql];
+            s.bi[j][e] = brow[kc];
+            s.mk[j][e] = mrow ? mrow[kc] : 1.0f;
         }
-    for (int key0 = 0; key0 < npad; key0 += 32) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = key0 + 32 + 16 * j + 4 * g4 + e;
-                bnxt[j][e] = brow[key < N ? key : N - 1];
-            }
-        f32x4 s[2];
-        float4 ma[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float4 kf = *reinterpret_cast<const float4*>(Kl + (key0 + 16 * j + ql) * KP + 4 * g4);
-            ma[j] = *reinterpret_cast<const float4*>(kadd + key0 + 16 * j + 4 * g4);
-            f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            z4 = mfma16(kf.x, qf.x, z4);
-            z4 = mfma16(kf.y, qf.y, z4);
-            z4 = mfma16(kf.z, qf.z, z4);
-            z4 = mfma16(kf.w, qf.w, z4);
-            s[j] = z4;
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float mav[4] = {ma[j].x, ma[j].y, ma[j].z, ma[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = (s[j][e] + bcur[j][e]) * LOG2E;           // logits + bias, exp2 domain (keys >= N: overridden below)
-                s[j][e] = (mav[e] == 0.f) ? v : mav[e];
-                tmax = fmaxf(tmax, s[j][e]);
-            }
-        }
-        tmax = rows4_max(tmax);
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(s[j][e] - m_new);
-                s[j][e] = pe;
-                psum += pe;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] *= alpha;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float4 vf = *reinterpret_cast<const float4*>(Vt + ql * (npad + 4) + key0 + 16 * j + 4 * g4);
-            o = mfma16(vf.x, s[j][0], o);
-            o = mfma16(vf.y, s[j][1], o);
-            o = mfma16(vf.z, s[j][2], o);
-            o = mfma16(vf.w, s[j][3], o);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bcur[j][e] = bnxt[j][e];
     }
-    const float l_tot = rows4_sum(l_run);
-    if (qok) {
+}
+
+__global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict__ o_out, const float* __restrict__ qkvg,
+                                                               const float* __restrict__ bias, const float* __restrict__ mask,
+                                                               int b, int N, int H) {
+    constexpr int C = 16, HC = 64, L = 4 * HC, RD = 3;
+    __shared__ float part[4][6][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 15, g4 = lane >> 4;
+    const int qtiles = (N + 15) / 16;
+    const int qt = blockIdx.x % qtiles;
+    const int bh = blockIdx.x / qtiles;
+    const int h = bh % H, bb = bh / H;
+    const float* base = qkvg + (size_t)bb * N * L;
+    const int q = qt * 16 + ql;
+    const bool qok = q < N;
+    const int qq = qok ? q : 0;
+    const float* brow = bias + (((size_t)bb * H + h) * N + qq) * N;
+    const float* mrow = mask ? mask + (size_t)bb * N : nullptr;
+    const int nblk = (N + 31) / 32, per = (nblk + 3) / 4;
+    const int blk0 = wave * per;
+    const int nb = nblk - blk0 < per ? (nblk - blk0 > 0 ? nblk - blk0 : 0) : per;      // blocks of this wave (wave-uniform)
+    SaBlock ring[RD];
+    if (nb > 0) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) sa_load(ring[d], base, brow, mrow, N, (blk0 + (d < nb ? d : nb - 1)) * 32, h, ql, g4);
+    }
+    const float4 qf = *reinterpret_cast<const float4*>(base + (size_t)qq * L + h * C + 4 * g4);   // already scaled by 1/sqrt(c)
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < nb; i0 += RD) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) {
+            const int i = i0 + d;
+            if (i < nb) {                                          // wave-uniform
+                const int key0 = (blk0 + i) * 32;
+                const SaBlock& blk = ring[d];
+                f32x4 s[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    z4 = mfma16(blk.k[j].x, qf.x, z4);
+                    z4 = mfma16(blk.k[j].y, qf.y, z4);
+                    z4 = mfma16(blk.k[j].z, qf.z, z4);
+                    z4 = mfma16(blk.k[j].w, qf.w, z4);
+                    s[j] = z4;
+                }
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = key0 + 16 * j + 4 * g4 + e;
+                        const float v = (s[j][e] + blk.bi[j][e]) * LOG2E;         // logits + bias, exp2 domain
+                        s[j][e] = key >= N ? -INFINITY : (blk.mk[j][e] >= 0.5f ? v : -32768.0f * LOG2E);
+                        tmax = fmaxf(tmax, s[j][e]);
+                    }
+                tmax = rows4_max(tmax);
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(s[j][e] - m_new);
+                        s[j][e] = pe;
+                        psum += pe;
+                    }
+                l_run = l_run * alpha + psum;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool vin = key0 + 16 * j + 4 * g4 < N;                 // clamped V rows of keys >= N meet p = 0, but guard NaN payloads
+                    o = mfma16(vin ? blk.v[j][0] : 0.f, s[j][0], o);
+                    o = mfma16(key0 + 16 * j + 4 * g4 + 1 < N ? blk.v[j][1] : 0.f, s[j][1], o);
+                    o = mfma16(key0 + 16 * j + 4 * g4 + 2 < N ? blk.v[j][2] : 0.f, s[j][2], o);
+                    o = mfma16(key0 + 16 * j + 4 * g4 + 3 < N ? blk.v[j][3] : 0.f, s[j][3], o);
+                }
+                const int nx = i + RD;                              // refill the slot (clamped: the tail re-reads the last block)
+                sa_load(ring[d], base, brow, mrow, N, (blk0 + (nx < nb ? nx : nb - 1)) * 32, h, ql, g4);
+            }
+        }
+    }
+    const float l_w = rows4_sum(l_run);
+    part[wave][0][lane] = m_run;
+    part[wave][1][lane] = l_w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[wave][2 + e][lane] = o[e];
+    __syncthreads();
+    if (wave == 0 && qok) {
+        float m_all = part[0][0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m_all = fmaxf(m_all, part[w][0][lane]);
+        float l_tot = 0.f, ot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {                              // fixed order; a wave without keys has l = 0, o = 0
+            const float sc = __builtin_amdgcn_exp2f(part[w][0][lane] - m_all);
+            l_tot += part[w][1][lane] * sc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ot[e] += part[w][2 + e][lane] * sc;
+        }
         const float4 gf = *reinterpret_cast<const float4*>(base + (size_t)q * L + 3 * HC + h * C + 4 * g4);
         *reinterpret_cast<float4*>(o_out + ((size_t)bb * N + q) * HC + h * C + 4 * g4) =
-            make_float4(gf.x * (o[0] / l_tot), gf.y * (o[1] / l_tot), gf.z * (o[2] / l_tot), gf.w * (o[3] / l_tot));
+            make_float4(gf.x * (ot[0] / l_tot), gf.y * (ot[1] / l_tot), gf.z * (ot[2] / l_tot), gf.w * (ot[3] / l_tot));
     }
 }
 
@@ -2012,11 +2025,7 @@ extern "C" int prd_single_attn_core(float* o, const float* qkvg, const float* bi
                                     int b, int N, int H, int c, hipStream_t stream) {
     if (!o || !qkvg || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
-    const int npad = prd_round_up(N, 32);
-    const size_t lds = ((size_t)npad * KP + 16 * (npad + 4) + npad) * sizeof(float);
-    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
-    PRD_SET_LDS(single_attn_core_kernel, lds);
-    hipLaunchKernelGGL(single_attn_core_kernel, dim3(b * H * prd_ceil_div(N, 64)), dim3(256), lds, stream, o, qkvg, bias, mask, b, N, npad, H);
+    hipLaunchKernelGGL(single_attn_core_kernel, dim3(b * H * prd_ceil_div(N, 16)), dim3(256), 0, stream, o, qkvg, bias, mask, b, N, H);
     return (int)hipGetLastError();
 }
 

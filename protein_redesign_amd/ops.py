@@ -71,7 +71,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), b_kn=False, alpha=1.0, bias=None, act=0, act_from=0,
          addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
          mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0,
-         colscale=None, tile_hint=0, a_ln=False):
+         colscale=None, tile_hint=0, a_ln=False, ln_out=None):
     """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h)."""
     g = PrdGemm()
     g.A, g.B, g.C = _off(A, a_off), _off(B, b_off), _off(Cout, c_off)
@@ -88,6 +88,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.sr1, g.sr2, g.ldr = sr[0], sr[1], ldr
     g.colscale, g.tile_hint = dptr(colscale), tile_hint
     g.a_ln = 1 if a_ln else 0
+    g.ln_out, g.ldlo = dptr(ln_out), (ln_out.shape[-1] if ln_out is not None else 0)
     import ctypes
     check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
     return Cout

@@ -163,10 +163,14 @@ class OuterLinear(nn.Module):
 
     def run(self, single, pair, *, residual: bool, out=None):
         b, N, S = single.shape
-        x = ops.layer_norm(single)
         w = self.linear.weight
         u = torch.empty(b, N, self.pair_dim, device=single.device, dtype=torch.float32)
-        ops.gemm(x, w, u, b * N, self.pair_dim, S, S, 2 * S, self.pair_dim, b_off=S)      # u = x W2^T
+        if ops.ln_fusable(S):           # u = LN(single) W2^T with the LayerNorm inside the GEMM, which also writes x = LN(single)
+            x = torch.empty_like(single)
+            ops.gemm(single, w, u, b * N, self.pair_dim, S, S, 2 * S, self.pair_dim, b_off=S, a_ln=True, ln_out=x)
+        else:
+            x = ops.layer_norm(single)
+            ops.gemm(x, w, u, b * N, self.pair_dim, S, S, 2 * S, self.pair_dim, b_off=S)
         return ops.outer_linear_pair(pair, x, u, w, self.linear.bias, residual=residual, out=out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
