@@ -85,7 +85,9 @@ typedef struct PrdGemm {
     int tile_hint;                  /* 0 = automatic; 32 / 64 / 128 force the workgroup tile */
     int a_ln;                       /* 1: A rows are LayerNorm-ed over K on the fly (no affine, eps 1e-5, biased variance) --
                                        nn.LayerNorm(K, elementwise_affine=False) fused into the linear that follows it
-                                       (reference modules.py:296,306).  Needs !b_kn, K % 4 == 0, K <= 512; uses the 32x32 K-split tile. */
+                                       (reference modules.py:296,306).  Needs !b_kn, K % 4 == 0 and K <= 512 (32x32 K-split tile), or -- gemm mode 1,
+                                       fewer than 512 tiles of 64x64, one batch -- K % 64 == 0 and K <= 1024 (operand-ring kernel);
+                                       PRD_ERR_UNSUPPORTED otherwise. */
     float* ln_out; int ldlo;        /* optional, with a_ln and G1 = G2 = 1: the LayerNorm-ed A rows are also written here (row pitch
                                        ldlo floats) by the workgroups of the first column tile -- OuterLinear needs LN(single)
                                        itself next to the W2 projection of it (modules.py:283-287) */

@@ -29,8 +29,11 @@ int main(void) {
     EXPECT(prd_gemm(&g, s), PRD_ERR_ARG);                              /* null operands */
     g.A = g.B = p; g.C = p; g.M = g.N = g.K = 8; g.G1 = g.G2 = 1; g.lda = 6; g.ldb = 8; g.ldc = 8;
     EXPECT(prd_gemm(&g, s), PRD_ERR_ALIGN);                            /* lda not a multiple of 4 */
-    g.lda = 8; g.a_ln = 1; g.K = 1024; g.lda = g.ldb = 1024;
-    EXPECT(prd_gemm(&g, s), PRD_ERR_UNSUPPORTED);                      /* fused LayerNorm beyond K = 512 */
+    g.lda = 8; g.a_ln = 1; g.K = 4096; g.lda = g.ldb = 4096;
+    EXPECT(prd_gemm(&g, s), PRD_ERR_UNSUPPORTED);                      /* fused LayerNorm beyond the row the kernels keep in registers */
+    g.K = 8; g.lda = g.ldb = 8; g.a_ln = 0; g.ln_out = p; g.ldlo = 8;
+    EXPECT(prd_gemm(&g, s), PRD_ERR_ARG);                              /* ln_out without a_ln */
+    g.ln_out = 0;
     EXPECT(prd_ln_rows(0, p, 0, 0, 4, 4, 4, 4, s), PRD_ERR_ARG);
     EXPECT(prd_ln_rows(p, p, p, 0, 4, 4, 4, 4, s), PRD_ERR_ARG);       /* gamma without beta */
     EXPECT(prd_softmax_rows(p, 4, 8, 4, s), PRD_ERR_ARG);             /* ld < n */
