@@ -431,6 +431,100 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dx
     for (int c = lane; c < C; c += 64) { const float y = (xr[c] - mean) * rstd; dx[row * C + c] = rstd * (gr[c] - m1 - y * m2); }
 }
 
+
+// ---- weight gradient of a pair-position linear: dW[o][i] = sum_rows dy[row][o] * x[row][i] --------------------------------
+// rows = b N N (2e5 at N = 320), O, I <= 256: a reduction over a huge K with a tiny output, for which the BLAS picks an
+// 8-workgroup kernel (450 us per call, 35 % of the first-cut training step).  Here the rows are dealt to ~256 slabs; a
+// workgroup holds 64x64 blocks of dW in fp32 MFMA accumulators (v_mfma_f32_32x32x2_f32: two rows per instruction, lane r
+// supplies dy[row][o0 + 2r + ea] and x[row][i0 + 2r + eb], so a wave reads 256 contiguous bytes per row and operand), waves
+// that share a block interleave the rows and are merged in LDS; the slab partials are summed by a second kernel in slab
+// order (deterministic, no atomics).
+template <int NBLK>                                     // 64x64 blocks of dW per workgroup: 1, 2 or 4 (4 / NBLK waves per block)
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ part, const float* __restrict__ dy, const float* __restrict__ x,
+                                                           long rows, int O, int I, int lddy, int ldx, int rows_per_wg) {
+    constexpr int WPB = 4 / NBLK, U = 8;
+    __shared__ float red[WPB > 1 ? 4 : 1][64][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    const int ibn = I / 64;
+    const int blk = blockIdx.y * NBLK + wave / WPB, sub = wave % WPB;
+    const int ob = blk / ibn, ib = blk - ob * ibn;
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    const float* dyp = dy + ob * 64 + 2 * r;
+    const float* xp = x + ib * 64 + 2 * r;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[ea][eb][q] = 0.f;
+    float2 ca[U], cb[U], na[U], nb[U];
+    auto load = [&](float2 (&a)[U], float2 (&b)[U], long row) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = row + 2 * u + hi;
+            const long rc = rr < r1 ? rr : r1 - 1;          // clamped (rows past the slab are multiplied by zero)
+            const float z = rr < r1 ? 1.f : 0.f;
+            const float2 t = *reinterpret_cast<const float2*>(dyp + rc * lddy);
+            a[u] = make_float2(t.x * z, t.y * z);
+            b[u] = *reinterpret_cast<const float2*>(xp + rc * ldx);
+        }
+    };
+    const long step = 2L * U * WPB;
+    long row = r0 + 2L * U * sub;
+    if (row < r1) load(ca, cb, row);
+    for (; row < r1; row += step) {
+        const long nx = row + step;
+        load(na, nb, nx < r1 ? nx : row);                   // unconditional prefetch (the last one re-reads the current group)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0][0] = mfma32(ca[u].x, cb[u].x, acc[0][0]);
+            acc[0][1] = mfma32(ca[u].x, cb[u].y, acc[0][1]);
+            acc[1][0] = mfma32(ca[u].y, cb[u].x, acc[1][0]);
+            acc[1][1] = mfma32(ca[u].y, cb[u].y, acc[1][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { ca[u] = na[u]; cb[u] = nb[u]; }
+    }
+    if (WPB > 1) {                                          // merge the waves of a block (fixed order)
+        if (sub > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[wave][e * 16 + q][lane] = acc[e >> 1][e & 1][q];
+        }
+        __syncthreads();
+        if (sub == 0) {
+#pragma unroll
+            for (int w = 1; w < WPB; ++w)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[e >> 1][e & 1][q] += red[wave + w][e * 16 + q][lane];
+        }
+    }
+    if (sub == 0) {
+        float* pt = part + (size_t)blockIdx.x * O * I;
+#pragma unroll
+        for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = ob * 64 + 2 * drow32(q, hi) + ea;
+                *reinterpret_cast<float2*>(pt + (size_t)o * I + ib * 64 + 2 * r) = make_float2(acc[ea][0][q], acc[ea][1][q]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, int n, int slabs) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += part[(size_t)k * n + e];
+    dw[e] = s;
+}
+
 }  // namespace
 
 #define PRD_BWD_SET_LDS(kernel)                                                                                 \
@@ -512,5 +606,32 @@ extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float
 extern "C" int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream) {
     if (!dx || !dy || !x || rows <= 0 || C <= 0) return PRD_ERR_ARG;
     hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dx, dy, x, (long)rows, C);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t prd_linear_wgrad_workspace(long long rows, int O, int I) {
+    if (rows <= 0 || O <= 0 || I <= 0) return 0;
+    long slabs = rows / 512 < 256 ? (rows + 511) / 512 : 256;
+    if (slabs < 1) slabs = 1;
+    return (size_t)slabs * O * I * sizeof(float);
+}
+
+extern "C" int prd_linear_wgrad(float* dw, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
+                                float* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!dw || !dy || !x || !ws || rows <= 0 || O <= 0 || I <= 0) return PRD_ERR_ARG;
+    if ((O % 64) || (I % 64) || O > 256 || I > 256) return PRD_ERR_UNSUPPORTED;
+    if ((lddy & 1) || (ldx & 1) || lddy < O || ldx < I) return PRD_ERR_ALIGN;
+    if (ws_bytes < prd_linear_wgrad_workspace(rows, O, I)) return PRD_ERR_WORKSPACE;
+    const long slabs = (long)(prd_linear_wgrad_workspace(rows, O, I) / ((size_t)O * I * sizeof(float)));
+    const int rows_per_wg = (int)((rows + slabs - 1) / slabs);
+    const int nblk = (O / 64) * (I / 64);
+    const int per = (nblk % 4 == 0) ? 4 : ((nblk % 2 == 0) ? 2 : 1);     // 64x64 blocks per workgroup
+    dim3 grid((unsigned)slabs, nblk / per);
+    if (per == 4) hipLaunchKernelGGL(linear_wgrad_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
+    else if (per == 2) hipLaunchKernelGGL(linear_wgrad_kernel<2>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
+    else if (per == 1) hipLaunchKernelGGL(linear_wgrad_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
+    else return PRD_ERR_UNSUPPORTED;
+    const int n = O * I;
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dw, ws, n, (int)slabs);
     return (int)hipGetLastError();
 }

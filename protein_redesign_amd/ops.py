@@ -278,18 +278,20 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
     check(lib().prd_tri_mul_proj_bwd(dptr(dpair), dptr(dpp), dptr(dpg), dptr(dAB), dptr(dx1), dptr(pair), dptr(mask), dptr(wp),
                                      dptr(bp), dptr(wg), dptr(bg), dptr(wpT), dptr(wgT), int(incoming), b, N, P, stream()),
           "prd_tri_mul_proj_bwd")
-    # weight gradients: dW = dOut^T In over all rows (library GEMMs); LN(pair), LN(O) recomputed by the LayerNorm kernel
+    # weight gradients: dW = dOut^T In over all rows (linear_wgrad); LN(pair), LN(O) recomputed by the LayerNorm kernel
     x = layer_norm(pair.contiguous()).view(-1, P)
     lo = layer_norm(O[..., :N].permute(0, 2, 3, 1).contiguous()).view(-1, P)
     dz2, dgp2, dpp2, dpg2 = dz.view(-1, P), dgp.view(-1, P), dpp.view(-1, 2 * P), dpg.view(-1, 2 * P)
-    grads = (dpp2.t() @ x, dpp2.sum(0), dpg2.t() @ x, dpg2.sum(0), dz2.t() @ lo, dz2.sum(0), dgp2.t() @ x, dgp2.sum(0))
+    grads = (linear_wgrad(dpp2, x), dpp2.sum(0), linear_wgrad(dpg2, x), dpg2.sum(0), linear_wgrad(dz2, lo), dz2.sum(0),
+             linear_wgrad(dgp2, x), dgp2.sum(0))
     return dpair, grads
 
 
 def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool):
     """Gradients of the TriangleAttention update (ops.tri_attn with residual=False) with respect to ``pair`` and its seven weight
     tensors on the hand-written backward (csrc/prd_bwd.hip): out-projection backward (row GEMM) -> attention core backward per
-    (row, head) -> projections backward (row GEMM) -> LayerNorm backward.  Weight gradients: BLAS reductions over all N^2 rows."""
+    (row, head) -> projections backward (row GEMM) -> LayerNorm backward.  Weight gradients: slab reductions over all N^2 rows
+    (linear_wgrad)."""
     wq, wk, wv, wg, bg, wo, bo = wts
     b, N, _, P = pair.shape
     HC = H * c
@@ -307,8 +309,30 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool):
     x = layer_norm(pair.contiguous()).view(-1, P)
     d2 = dqkvg.view(-1, 4, HC)
     dy2 = dy.view(-1, P)
-    grads = (d2[:, 0].t() @ x, d2[:, 1].t() @ x, d2[:, 2].t() @ x, d2[:, 3].t() @ x, d2[:, 3].sum(0), dy2.t() @ og.view(-1, HC), dy2.sum(0))
+    dw4 = linear_wgrad(dqkvg.view(-1, 4 * HC), x)                                               # d W_q | W_k | W_v | W_g stacked [4 HC, P]
+    grads = (dw4[:HC], dw4[HC:2 * HC], dw4[2 * HC:3 * HC], dw4[3 * HC:], d2[:, 3].sum(0), linear_wgrad(dy2, og.view(-1, HC)), dy2.sum(0))
     return dpair, grads
+
+
+WGRAD_MIN_ROWS = 8192
+
+
+def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dW [O, I] = dy2^T x2 for row-major 2-D views dy2 [rows, O] and x2 [rows, I] (row stride = their stride(0), unit column
+    stride): the weight gradient of a linear applied at every pair position.  Hand-written slab reduction
+    (prd_linear_wgrad) for the shapes it covers -- rows >= 8192, O and I multiples of 64 up to 256 -- else a library GEMM."""
+    rows, O = dy2.shape
+    I = x2.shape[1]
+    if (rows >= WGRAD_MIN_ROWS and O % 64 == 0 and I % 64 == 0 and O <= 256 and I <= 256 and dy2.stride(1) == 1 and x2.stride(1) == 1
+            and dy2.stride(0) % 2 == 0 and x2.stride(0) % 2 == 0 and dy2.storage_offset() % 2 == 0 and x2.storage_offset() % 2 == 0):
+        dw = torch.empty(O, I, device=dy2.device, dtype=F32)
+        nbytes = lib().prd_linear_wgrad_workspace(rows, O, I)
+        ws = torch.empty(nbytes // 4, device=dy2.device, dtype=F32)
+        check(lib().prd_linear_wgrad(dptr(dw), dy2.data_ptr(), x2.data_ptr(), rows, O, I, dy2.stride(0), x2.stride(0), dptr(ws), nbytes, stream()),
+              "prd_linear_wgrad")
+        return dw
+    return dy2.t() @ x2
+
 
 
 def tri_attn_uses_long_rows(N: int, P: int) -> bool:

@@ -22,6 +22,36 @@ def ln(x, w=None, b=None):
     return F.layer_norm(x, x.shape[-1:], w, b, 1e-5)
 
 
+class _PairLinear(torch.autograd.Function):
+    """F.linear whose weight gradient over the b N N pair positions is the slab reduction of csrc/prd_bwd.hip
+    (ops.linear_wgrad) instead of the library's long-K GEMM (450 us per call at N = 320, 8 workgroups)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = (dy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_wgrad(dy2, x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """nn.Linear; at pair-position row counts with 64-multiple widths the backward takes the hand-written weight-gradient kernel."""
+    from . import ops
+    rows = x.numel() // x.shape[-1]
+    if x.is_cuda and rows >= ops.WGRAD_MIN_ROWS and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and max(w.shape) <= 256 and torch.is_grad_enabled():
+        return _PairLinear.apply(x, w, b)
+    return F.linear(x, w, b)
+
+
 def small_table_lookup(idx, table):
     """F.embedding for a table of a few rows over a huge index tensor, as one-hot @ table: the backward is then a dense
     [rows x positions] GEMM instead of a scatter-add with millions of collisions per row (4 ms per table at N = 320)."""
@@ -39,15 +69,15 @@ def gated_attention(x, mask, wq, wk, wv, wg, bg, wo, bo, heads: int, head_dim: i
     def split(t):
         return t.reshape(*lead, n, heads, head_dim).transpose(-2, -3)
 
-    q, k, v = split(F.linear(x, wq)), split(F.linear(x, wk)), split(F.linear(x, wv))
-    g = split(torch.sigmoid(F.linear(x, wg, bg)))
+    q, k, v = split(linear(x, wq)), split(linear(x, wk)), split(linear(x, wv))
+    g = split(torch.sigmoid(linear(x, wg, bg)))
     logits = torch.matmul((1.0 / math.sqrt(head_dim)) * q, k.transpose(-1, -2))
     if bias is not None:
         logits = logits + bias
     logits = logits.masked_fill(mask.unsqueeze(-2).unsqueeze(-2) < 0.5, -(2.0 ** 15))
     out = g * torch.matmul(torch.softmax(logits, dim=-1), v)
     out = out.transpose(-2, -3).reshape(*lead, n, heads * head_dim)
-    return F.linear(out, wo, bo)
+    return linear(out, wo, bo)
 
 
 def pair_bias(pair, w, b=None, gamma=None, beta=None):
@@ -70,10 +100,10 @@ def triangle_multiplication(pair, mask, wp, bp, wg, bg, wo, bo, wog, bog, incomi
     """modules.py:262-274."""
     x = ln(pair)
     m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
-    ab = m2 * torch.sigmoid(F.linear(x, wg, bg)) * F.linear(x, wp, bp)
+    ab = m2 * torch.sigmoid(linear(x, wg, bg)) * linear(x, wp, bp)
     a, b = torch.chunk(ab, 2, dim=-1)
     o = torch.einsum("bkid,bkjd->bijd" if incoming else "bikd,bjkd->bijd", a, b)
-    return torch.sigmoid(F.linear(x, wog, bog)) * F.linear(ln(o), wo, bo)
+    return torch.sigmoid(linear(x, wog, bog)) * linear(ln(o), wo, bo)
 
 
 def outer_linear(single, w, b):
@@ -88,7 +118,7 @@ def outer_linear(single, w, b):
 
 def transition(x, w1, b1, w2, b2):
     """single_fc / pair_fc: LN -> Linear -> ReLU -> Linear (modules.py:306-311, 321-326)."""
-    return F.linear(torch.relu(F.linear(ln(x), w1, b1)), w2, b2)
+    return linear(torch.relu(linear(ln(x), w1, b1)), w2, b2)
 
 
 def outer_product_update(single, mask, g, bta, w1, b1, w2, b2, wo, bo):
@@ -96,7 +126,7 @@ def outer_product_update(single, mask, g, bta, w1, b1, w2, b2, wo, bo):
     x = ln(single, g, bta)
     m = mask.unsqueeze(-1)
     a, b = F.linear(x, w1, b1) * m, F.linear(x, w2, b2) * m
-    outer = F.linear(a.unsqueeze(2) * b.unsqueeze(1), wo, bo)
+    outer = linear(a.unsqueeze(2) * b.unsqueeze(1), wo, bo)
     m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
     return m2 * (outer / (m2 + 1e-3))
 
@@ -152,7 +182,7 @@ def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int
 def heads(single, pair, z, mask, wr1, br1, wr2, ws1, bs1, ws2):
     """modules.py:403 (pair symmetrisation) + model.py:364-374: coordinate update and sequence logits."""
     pair = 0.5 * (pair + pair.transpose(1, 2))
-    w = F.linear(torch.relu(F.linear(ln(pair), wr1, br1)), wr2)
+    w = F.linear(torch.relu(linear(ln(pair), wr1, br1)), wr2)
     zij = z.unsqueeze(-2) - z.unsqueeze(-3)
     r = zij * torch.rsqrt(torch.sum(torch.square(zij), -1, keepdim=True) + 1e-4)
     m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)

@@ -42,8 +42,11 @@ def hip_model(args, params):
 
 
 @pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
-def test_training_step_gradients_vs_reference_and_oracle(golden, name, gemm_mode):
+def test_training_step_gradients_vs_reference_and_oracle(golden, name, gemm_mode, monkeypatch):
     case, z, args, params, pb = case_inputs(golden, name)
+    if name != "small32":       # the pair-position weight gradients through prd_linear_wgrad also at these small row counts
+        from protein_redesign_amd import ops
+        monkeypatch.setattr(ops, "WGRAD_MIN_ROWS", 1)
     t = torch.from_numpy(z["train_t"])
     nz, ns = torch.from_numpy(z["train_noise_z"]), torch.from_numpy(z["train_noise_seq"])
     want_loss, want = oracle_grads(args, params, pb, t, nz, ns)
@@ -155,3 +158,21 @@ def test_triangle_attention_backward_kernels(mode, P, gemm_mode):
     assert rel_l2(dpair.cpu(), pl.grad) < 1e-5
     for n, got in zip(names, grads):
         assert rel_l2(got.cpu(), leaf["ta." + n].grad) < 1e-5, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,O,I", [(40 * 40 * 2, 64, 64), (102400, 256, 64), (20000, 64, 256), (9001, 128, 128), (8192, 256, 256)])
+def test_linear_weight_gradient_kernel(rows, O, I):
+    """prd_linear_wgrad (slab partials on fp32 MFMA + ordered reduction) against a float64 reduction; also through strided views
+    (a column slice of a wider tensor, as the attention backward passes them)."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(rows + O)
+    wide = torch.randn(rows, O + 64, generator=g).cuda()
+    dy = wide[:, 64:]                                   # row stride O + 64, offset 64
+    x = torch.randn(rows, I, generator=g).cuda()
+    got = ops.linear_wgrad(dy, x)
+    want = (dy.double().t() @ x.double())
+    err = (got.double() - want).norm() / want.norm()
+    assert got.shape == (O, I) and err < 2e-6, err
+    if rows >= ops.WGRAD_MIN_ROWS:                      # bit-reproducible (no atomics)
+        assert torch.equal(got, ops.linear_wgrad(dy, x))
