@@ -224,29 +224,19 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
 // Triangle attention backward, core (reference modules.py:236-243 -> 185-225 under autograd).  One workgroup per (pair row, head),
 // persistent.  Given dog = d(gated per-head output) [b,N,N,64] (= W_o^T d(update), a row GEMM done by the caller) it recomputes
 // q, k, v, gate of the row (fp32 MFMA row GEMMs into LDS), then
-//   pass A (thread = query):  sweep 1 over the keys: softmax statistics m, l and o = P v;  delta = do . o;  d(gate pre-activation);
-//                             sweep 2: p = exp(s - m) / l,  dS = p (do . v_j - delta),  dq += dS k_j
-//   pass B (thread = key):    sweep over the queries: p and dS again from the stored m, l, delta;  dk += dS q,  dv += p do
-// on the fp32 VALU (the logits are recomputed three times; 16-wide dot products in registers, the other operand broadcast from
-// LDS).  Masked keys (mask_2d < 0.5) have their logit REPLACED by -2^15 in the forward: no gradient flows into q, k through them,
-// while v still receives p * do.  Output: dqkvg[b,N,N,4,64] by pair position = d(W_q x) | d(W_k x) | d(W_v x) | d(gate pre-act.),
-// channels head-major; the projections' input gradient, the LayerNorm backward and the weight gradients are row GEMMs / BLAS
-// reductions on the caller's side.
-constexpr int TB_PITCH = 20;        // LDS pitch (floats) of the [N][16] arrays: 16-byte aligned rows (float4 reads), conflict-free when thread = row
-PRD_DEV void tb_load16(const float* __restrict__ p, float (&v)[16]) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const float4 t = *reinterpret_cast<const float4*>(p + 4 * f);
-        v[4 * f] = t.x; v[4 * f + 1] = t.y; v[4 * f + 2] = t.z; v[4 * f + 3] = t.w;
-    }
-}
-PRD_DEV float tb_dot16(const float (&a)[16], const float (&b)[16]) {      // four independent chains
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 16; c += 4) { s0 += a[c] * b[c]; s1 += a[c + 1] * b[c + 1]; s2 += a[c + 2] * b[c + 2]; s3 += a[c + 3] * b[c + 3]; }
-    return (s0 + s1) + (s2 + s3);
-}
-
+//   pass A (wave = 16-query tile):  sweep 1 over the keys: softmax statistics m, l and o = P v;  delta = do . o;  d(gate
+//                                   pre-activation);  sweep 2: p = exp(s - m) / l,  dS = p (do . v_j - delta),  dq += dS k_j
+//   pass B (wave = 16-key tile):    sweep over the queries: p and dS again from the stored m, l, delta;  dk += dS q,  dv += p do
+// on v_mfma_f32_16x16x4_f32 in the "swapped" form of the forward kernels: a logit tile comes out as (keys in registers, query =
+// lane) in pass A and (queries in registers, key = lane) in pass B, which is the B-operand layout of the products that contract
+// over the tile's register index (P v, dS k, dS^T q, P^T do) -- no transposes; their A operands are read column-wise from the
+// same [position][16] LDS arrays (pitch 20: both the row-wise float4 reads and the column-wise scalar reads are conflict-free).
+// The logits are recomputed three times (sweep 1, sweep 2, pass B).  Masked keys (mask_2d < 0.5) have their logit REPLACED by
+// -2^15 in the forward: no gradient flows into q, k through them, while v still receives p * do.
+// Output: dqkvg[b,N,N,4,64] by pair position = d(W_q x) | d(W_k x) | d(W_v x) | d(gate pre-act.), channels head-major; the
+// projections' input gradient, the LayerNorm backward and the weight gradients are row GEMMs / slab reductions on the caller's side.
+constexpr int TB_PITCH = 20;        // LDS pitch (floats) of the [N][16] arrays
+constexpr float LOG2E = 1.4426950408889634f;
 template <int P>
 __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
     float* __restrict__ dqkvg, const float* __restrict__ dog, const float* __restrict__ pair, const float* __restrict__ mask,
@@ -299,111 +289,154 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
             zero_acc(a1);
             rowgemm<P, 1>(Wl, x, a0, r, hi);                         // [k; v]
             rowgemm<P, 1>(Wl + 2 * C * (P + 4), x, a1, r, hi);       // [q; g]
-            if (valid) {
-                // D rows of a 32-output block: channels {4hi+e} in registers 0-3, {8+4hi+e} in 4-7; second 16 outputs in 8-15
+            // D rows of a 32-output block: channels {4hi+e} in registers 0-3, {8+4hi+e} in 4-7; second 16 outputs in 8-15.
+            // Positions past N (the arrays are read in whole 16-position tiles) hold zeros: they meet p = 0 in the MFMAs.
+            const float z = valid ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Kl[v * TB_PITCH + 4 * hi + e] = z * a0[0][e];
+                Kl[v * TB_PITCH + 8 + 4 * hi + e] = z * a0[0][4 + e];
+                Vl[v * TB_PITCH + 4 * hi + e] = z * a0[0][8 + e];
+                Vl[v * TB_PITCH + 8 + 4 * hi + e] = z * a0[0][12 + e];
+                Ql[v * TB_PITCH + 4 * hi + e] = z * a1[0][e];
+                Ql[v * TB_PITCH + 8 + 4 * hi + e] = z * a1[0][4 + e];
+                Gl[v * TB_PITCH + 4 * hi + e] = z * sigmoidf_(a1[0][8 + e] + bg[h * C + 4 * hi + e]);
+                Gl[v * TB_PITCH + 8 + 4 * hi + e] = z * sigmoidf_(a1[0][12 + e] + bg[h * C + 8 + 4 * hi + e]);
+            }
+            if (hi == 0) kml[v] = (valid && mu * mask[(long)bb * N + v] >= 0.5f) ? 1.f : 0.f;
+        }
+        for (int idx = tid; idx < npad * C; idx += NT) {             // dog of this head, row by row (zeros past N)
+            const int v = idx >> 4, c = idx & 15;
+            Dl[v * TB_PITCH + c] = v < N ? dog[row_pos(v) * HC + h * C + c] : 0.f;
+        }
+        __syncthreads();
+        const int ql = lane & 15, g4 = lane >> 4;
+        const int ntile = (N + 15) / 16;
+        constexpr float FILL2 = -32768.0f * LOG2E;                   // the masked-key logit in the exp2 domain
+        // ---- pass A: a 16-query tile per wave; lane (ql, g4) = query ql, keys / channels 4 g4 + e in registers ----
+        for (int qt = wave; qt < ntile; qt += NWV) {
+            const int q = qt * 16 + ql;
+            const bool qok = q < N;
+            const float4 qf = *reinterpret_cast<const float4*>(Ql + q * TB_PITCH + 4 * g4);
+            float m_run = -1e30f, l_run = 0.f;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < ntile * 16; k0 += 16) {            // sweep 1: statistics and o = P v
+                const float4 kf = *reinterpret_cast<const float4*>(Kl + (k0 + ql) * TB_PITCH + 4 * g4);
+                const float4 km = *reinterpret_cast<const float4*>(kml + k0 + 4 * g4);
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+                sv = mfma16(kf.x, qf.x, sv);
+                sv = mfma16(kf.y, qf.y, sv);
+                sv = mfma16(kf.z, qf.z, sv);
+                sv = mfma16(kf.w, qf.w, sv);
+                const float kmv[4] = {km.x, km.y, km.z, km.w};
+                float tmax = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    Kl[v * TB_PITCH + 4 * hi + e] = a0[0][e];
-                    Kl[v * TB_PITCH + 8 + 4 * hi + e] = a0[0][4 + e];
-                    Vl[v * TB_PITCH + 4 * hi + e] = a0[0][8 + e];
-                    Vl[v * TB_PITCH + 8 + 4 * hi + e] = a0[0][12 + e];
-                    Ql[v * TB_PITCH + 4 * hi + e] = a1[0][e];
-                    Ql[v * TB_PITCH + 8 + 4 * hi + e] = a1[0][4 + e];
-                    Gl[v * TB_PITCH + 4 * hi + e] = sigmoidf_(a1[0][8 + e] + bg[h * C + 4 * hi + e]);
-                    Gl[v * TB_PITCH + 8 + 4 * hi + e] = sigmoidf_(a1[0][12 + e] + bg[h * C + 8 + 4 * hi + e]);
+                    sv[e] = (k0 + 4 * g4 + e >= N) ? -INFINITY : (kmv[e] != 0.f ? sv[e] * LOG2E : FILL2);
+                    tmax = fmaxf(tmax, sv[e]);
                 }
-                if (hi == 0) kml[v] = (mu * mask[(long)bb * N + v] >= 0.5f) ? 1.f : 0.f;
+                tmax = rows4_max(tmax);
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sv[e] = __builtin_amdgcn_exp2f(sv[e] - m_new);
+                    psum += sv[e];
+                    o[e] *= alpha;
+                }
+                l_run = l_run * alpha + psum;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o = mfma16(Vl[(k0 + 4 * g4 + e) * TB_PITCH + ql], sv[e], o);      // o^T[ch][query]
             }
-        }
-        for (int idx = tid; idx < N * C; idx += NT) {                // dog of this head, row by row
-            const int v = idx >> 4, c = idx & 15;
-            Dl[v * TB_PITCH + c] = dog[row_pos(v) * HC + h * C + c];
-        }
-        __syncthreads();
-        // ---- pass A: one query per thread ----
-        for (int q = tid; q < N; q += NT) {
-            float qv[C], dov[C], gv[C], o[C];
-            tb_load16(Ql + q * TB_PITCH, qv);
-            tb_load16(Gl + q * TB_PITCH, gv);
-            tb_load16(Dl + q * TB_PITCH, dov);
+            const float il = 1.0f / rows4_sum(l_run);
+            const float4 gv = *reinterpret_cast<const float4*>(Gl + q * TB_PITCH + 4 * g4);
+            const float4 dg = *reinterpret_cast<const float4*>(Dl + q * TB_PITCH + 4 * g4);
+            const float gvv[4] = {gv.x, gv.y, gv.z, gv.w}, dgv[4] = {dg.x, dg.y, dg.z, dg.w};
+            float dov[4], dgp[4], dsum = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) o[c] = 0.f;
-            float m = -INFINITY, l = 0.f;
-            for (int j = 0; j < N; ++j) {
-                float kj[C], vj[C];
-                tb_load16(Kl + j * TB_PITCH, kj);
-                tb_load16(Vl + j * TB_PITCH, vj);
-                float sdot = tb_dot16(qv, kj);
-                if (kml[j] == 0.f) sdot = -32768.0f;
-                const float mn = fmaxf(m, sdot);
-                const float alpha = expf(m - mn), pj = expf(sdot - mn);
-                l = l * alpha + pj;
-#pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = o[c] * alpha + pj * vj[c];
-                m = mn;
+            for (int e = 0; e < 4; ++e) {
+                const float oe = o[e] * il;
+                dgp[e] = dgv[e] * oe * gvv[e] * (1.0f - gvv[e]);      // d(gate pre-activation)
+                dov[e] = dgv[e] * gvv[e];                             // do = dog * gate
+                dsum += dov[e] * oe;
             }
-            const float il = 1.0f / l;
-            float delta = 0.f;
-            float* outp = dqkvg + row_pos(q) * (4 * HC) + h * C;
+            const float delta = rows4_sum(dsum);
+            float* outp = dqkvg + row_pos(qok ? q : 0) * (4 * HC) + h * C + 4 * g4;
+            if (qok) *reinterpret_cast<float4*>(outp + 3 * HC) = make_float4(dgp[0], dgp[1], dgp[2], dgp[3]);
+            *reinterpret_cast<float4*>(Dl + q * TB_PITCH + 4 * g4) = make_float4(dov[0], dov[1], dov[2], dov[3]);   // pass B reads do
+            if (g4 == 0) { Ml[q] = m_run; Ll[q] = il; El[q] = delta; }
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < ntile * 16; k0 += 16) {            // sweep 2: dS and dq
+                const float4 kf = *reinterpret_cast<const float4*>(Kl + (k0 + ql) * TB_PITCH + 4 * g4);
+                const float4 vf = *reinterpret_cast<const float4*>(Vl + (k0 + ql) * TB_PITCH + 4 * g4);
+                const float4 km = *reinterpret_cast<const float4*>(kml + k0 + 4 * g4);
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sv = mfma16(kf.x, qf.x, sv);
+                sv = mfma16(kf.y, qf.y, sv);
+                sv = mfma16(kf.z, qf.z, sv);
+                sv = mfma16(kf.w, qf.w, sv);
+                dp = mfma16(vf.x, dov[0], dp);                        // dP[key][query] = v_key . do_query
+                dp = mfma16(vf.y, dov[1], dp);
+                dp = mfma16(vf.z, dov[2], dp);
+                dp = mfma16(vf.w, dov[3], dp);
+                const float kmv[4] = {km.x, km.y, km.z, km.w};
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                o[c] *= il;
-                const float dogc = dov[c];
-                outp[3 * HC + c] = dogc * o[c] * gv[c] * (1.0f - gv[c]);     // d(gate pre-activation)
-                dov[c] = dogc * gv[c];                                         // do
-                delta += dov[c] * o[c];
+                for (int e = 0; e < 4; ++e) {
+                    const bool keep = kmv[e] != 0.f;                  // keys past N have kml = 0
+                    const float pe = __builtin_amdgcn_exp2f(sv[e] * LOG2E - m_run) * il;
+                    sv[e] = keep ? pe * (dp[e] - delta) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dq = mfma16(Kl[(k0 + 4 * g4 + e) * TB_PITCH + ql], sv[e], dq);    // dq^T[ch][query]
             }
-            float dq[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) dq[c] = 0.f;
-            for (int j = 0; j < N; ++j) {
-                float kj[C], vj[C];
-                tb_load16(Kl + j * TB_PITCH, kj);
-                tb_load16(Vl + j * TB_PITCH, vj);
-                float sdot = tb_dot16(qv, kj);
-                const float dp = tb_dot16(dov, vj);
-                const bool keep = kml[j] != 0.f;
-                if (!keep) sdot = -32768.0f;
-                const float pj = expf(sdot - m) * il;
-                const float ds = keep ? pj * (dp - delta) : 0.f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) dq[c] += ds * kj[c];
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) outp[c] = scale * dq[c];             // d(W_q x): q = scale * W_q x
-            Ml[q] = m;
-            Ll[q] = il;
-            El[q] = delta;
-        }
-        __syncthreads();                                                       // every thread is done reading dog before it becomes do
-        for (int q = tid; q < N; q += NT) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) Dl[q * TB_PITCH + c] *= Gl[q * TB_PITCH + c];      // pass B reads do = dog * gate
+            if (qok) *reinterpret_cast<float4*>(outp) = make_float4(scale * dq[0], scale * dq[1], scale * dq[2], scale * dq[3]);   // q = scale * W_q x
         }
         __syncthreads();
-        // ---- pass B: one key per thread ----
-        for (int j = tid; j < N; j += NT) {
-            float kv[C], vv[C], dk[C], dv[C];
-            tb_load16(Kl + j * TB_PITCH, kv);
-            tb_load16(Vl + j * TB_PITCH, vv);
-#pragma unroll
-            for (int c = 0; c < C; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+        // ---- pass B: a 16-key tile per wave; lane (ql, g4) = key ql, queries / channels 4 g4 + e in registers ----
+        for (int kt = wave; kt < ntile; kt += NWV) {
+            const int j = kt * 16 + ql;
+            const bool jok = j < N;
+            const float4 kf = *reinterpret_cast<const float4*>(Kl + j * TB_PITCH + 4 * g4);
+            const float4 vf = *reinterpret_cast<const float4*>(Vl + j * TB_PITCH + 4 * g4);
             const bool keep = kml[j] != 0.f;
-            for (int q = 0; q < N; ++q) {
-                float qq[C], dd[C];
-                tb_load16(Ql + q * TB_PITCH, qq);
-                tb_load16(Dl + q * TB_PITCH, dd);
-                float sdot = tb_dot16(qq, kv);
-                const float dp = tb_dot16(dd, vv);
-                if (!keep) sdot = -32768.0f;
-                const float pj = expf(sdot - Ml[q]) * Ll[q];
-                const float ds = keep ? pj * (dp - El[q]) : 0.f;
+            f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+            for (int q0 = 0; q0 < ntile * 16; q0 += 16) {
+                const float4 qa = *reinterpret_cast<const float4*>(Ql + (q0 + ql) * TB_PITCH + 4 * g4);
+                const float4 da = *reinterpret_cast<const float4*>(Dl + (q0 + ql) * TB_PITCH + 4 * g4);
+                const float4 m4 = *reinterpret_cast<const float4*>(Ml + q0 + 4 * g4);
+                const float4 l4 = *reinterpret_cast<const float4*>(Ll + q0 + 4 * g4);
+                const float4 e4 = *reinterpret_cast<const float4*>(El + q0 + 4 * g4);
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sv = mfma16(qa.x, kf.x, sv);                          // S[query][key]
+                sv = mfma16(qa.y, kf.y, sv);
+                sv = mfma16(qa.z, kf.z, sv);
+                sv = mfma16(qa.w, kf.w, sv);
+                dp = mfma16(da.x, vf.x, dp);                          // dP[query][key]
+                dp = mfma16(da.y, vf.y, dp);
+                dp = mfma16(da.z, vf.z, dp);
+                dp = mfma16(da.w, vf.w, dp);
+                const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+                f32x4 ds;
 #pragma unroll
-                for (int c = 0; c < C; ++c) { dk[c] += ds * qq[c]; dv[c] += pj * dd[c]; }
+                for (int e = 0; e < 4; ++e) {
+                    const bool qin = q0 + 4 * g4 + e < N;             // the statistics of queries past N are not defined
+                    const float pe = qin ? __builtin_amdgcn_exp2f((keep ? sv[e] * LOG2E : FILL2) - mv[e]) * lv[e] : 0.f;
+                    sv[e] = pe;
+                    ds[e] = (keep && qin) ? pe * (dp[e] - ev[e]) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dv = mfma16(Dl[(q0 + 4 * g4 + e) * TB_PITCH + ql], sv[e], dv);      // dv^T[ch][key] += do[query][ch] p
+                    dk = mfma16(Ql[(q0 + 4 * g4 + e) * TB_PITCH + ql], ds[e], dk);      // dk^T[ch][key] += q[query][ch] dS
+                }
             }
-            float* outp = dqkvg + row_pos(j) * (4 * HC) + h * C;
-#pragma unroll
-            for (int c = 0; c < C; ++c) { outp[HC + c] = dk[c]; outp[2 * HC + c] = dv[c]; }
+            if (jok) {
+                float* outp = dqkvg + row_pos(j) * (4 * HC) + h * C + 4 * g4;
+                *reinterpret_cast<float4*>(outp + HC) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+                *reinterpret_cast<float4*>(outp + 2 * HC) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            }
         }
     }
 }
