@@ -320,20 +320,28 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
             const float4 qf = *reinterpret_cast<const float4*>(Ql + q * TB_PITCH + 4 * g4);
             float m_run = -1e30f, l_run = 0.f;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            for (int k0 = 0; k0 < ntile * 16; k0 += 16) {            // sweep 1: statistics and o = P v
-                const float4 kf = *reinterpret_cast<const float4*>(Kl + (k0 + ql) * TB_PITCH + 4 * g4);
-                const float4 km = *reinterpret_cast<const float4*>(kml + k0 + 4 * g4);
-                f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-                sv = mfma16(kf.x, qf.x, sv);
-                sv = mfma16(kf.y, qf.y, sv);
-                sv = mfma16(kf.z, qf.z, sv);
-                sv = mfma16(kf.w, qf.w, sv);
-                const float kmv[4] = {km.x, km.y, km.z, km.w};
+            for (int k0 = 0; k0 < npad; k0 += 32) {                  // sweep 1: statistics and o = P v, two 16-key tiles per update
+                f32x4 sv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 kf = *reinterpret_cast<const float4*>(Kl + (k0 + 16 * j + ql) * TB_PITCH + 4 * g4);
+                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    z4 = mfma16(kf.x, qf.x, z4);
+                    z4 = mfma16(kf.y, qf.y, z4);
+                    z4 = mfma16(kf.z, qf.z, z4);
+                    z4 = mfma16(kf.w, qf.w, z4);
+                    sv[j] = z4;
+                }
                 float tmax = -INFINITY;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sv[e] = (k0 + 4 * g4 + e >= N) ? -INFINITY : (kmv[e] != 0.f ? sv[e] * LOG2E : FILL2);
-                    tmax = fmaxf(tmax, sv[e]);
+                for (int j = 0; j < 2; ++j) {
+                    const float4 km = *reinterpret_cast<const float4*>(kml + k0 + 16 * j + 4 * g4);
+                    const float kmv[4] = {km.x, km.y, km.z, km.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sv[j][e] = (k0 + 16 * j + 4 * g4 + e >= N) ? -INFINITY : (kmv[e] != 0.f ? sv[j][e] * LOG2E : FILL2);
+                        tmax = fmaxf(tmax, sv[j][e]);
+                    }
                 }
                 tmax = rows4_max(tmax);
                 const float m_new = fmaxf(m_run, tmax);
@@ -341,14 +349,19 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
                 m_run = m_new;
                 float psum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sv[e] = __builtin_amdgcn_exp2f(sv[e] - m_new);
-                    psum += sv[e];
-                    o[e] *= alpha;
-                }
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sv[j][e] = __builtin_amdgcn_exp2f(sv[j][e] - m_new);
+                        psum += sv[j][e];
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= alpha;
                 l_run = l_run * alpha + psum;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o = mfma16(Vl[(k0 + 4 * g4 + e) * TB_PITCH + ql], sv[e], o);      // o^T[ch][query]
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o = mfma16(Vl[(k0 + 16 * j + 4 * g4 + e) * TB_PITCH + ql], sv[j][e], o);      // o^T[ch][query]
             }
             const float il = 1.0f / rows4_sum(l_run);
             const float4 gv = *reinterpret_cast<const float4*>(Gl + q * TB_PITCH + 4 * g4);
@@ -368,28 +381,39 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
             *reinterpret_cast<float4*>(Dl + q * TB_PITCH + 4 * g4) = make_float4(dov[0], dov[1], dov[2], dov[3]);   // pass B reads do
             if (g4 == 0) { Ml[q] = m_run; Ll[q] = il; El[q] = delta; }
             f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-            for (int k0 = 0; k0 < ntile * 16; k0 += 16) {            // sweep 2: dS and dq
-                const float4 kf = *reinterpret_cast<const float4*>(Kl + (k0 + ql) * TB_PITCH + 4 * g4);
-                const float4 vf = *reinterpret_cast<const float4*>(Vl + (k0 + ql) * TB_PITCH + 4 * g4);
-                const float4 km = *reinterpret_cast<const float4*>(kml + k0 + 4 * g4);
-                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                sv = mfma16(kf.x, qf.x, sv);
-                sv = mfma16(kf.y, qf.y, sv);
-                sv = mfma16(kf.z, qf.z, sv);
-                sv = mfma16(kf.w, qf.w, sv);
-                dp = mfma16(vf.x, dov[0], dp);                        // dP[key][query] = v_key . do_query
-                dp = mfma16(vf.y, dov[1], dp);
-                dp = mfma16(vf.z, dov[2], dp);
-                dp = mfma16(vf.w, dov[3], dp);
-                const float kmv[4] = {km.x, km.y, km.z, km.w};
+            for (int k0 = 0; k0 < npad; k0 += 32) {                  // sweep 2: dS and dq
+                f32x4 sv[2], dp[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool keep = kmv[e] != 0.f;                  // keys past N have kml = 0
-                    const float pe = __builtin_amdgcn_exp2f(sv[e] * LOG2E - m_run) * il;
-                    sv[e] = keep ? pe * (dp[e] - delta) : 0.f;
+                for (int j = 0; j < 2; ++j) {
+                    const float4 kf = *reinterpret_cast<const float4*>(Kl + (k0 + 16 * j + ql) * TB_PITCH + 4 * g4);
+                    const float4 vf = *reinterpret_cast<const float4*>(Vl + (k0 + 16 * j + ql) * TB_PITCH + 4 * g4);
+                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+                    z4 = mfma16(kf.x, qf.x, z4);
+                    d4 = mfma16(vf.x, dov[0], d4);                    // dP[key][query] = v_key . do_query
+                    z4 = mfma16(kf.y, qf.y, z4);
+                    d4 = mfma16(vf.y, dov[1], d4);
+                    z4 = mfma16(kf.z, qf.z, z4);
+                    d4 = mfma16(vf.z, dov[2], d4);
+                    z4 = mfma16(kf.w, qf.w, z4);
+                    d4 = mfma16(vf.w, dov[3], d4);
+                    sv[j] = z4;
+                    dp[j] = d4;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dq = mfma16(Kl[(k0 + 4 * g4 + e) * TB_PITCH + ql], sv[e], dq);    // dq^T[ch][query]
+                for (int j = 0; j < 2; ++j) {
+                    const float4 km = *reinterpret_cast<const float4*>(kml + k0 + 16 * j + 4 * g4);
+                    const float kmv[4] = {km.x, km.y, km.z, km.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool keep = kmv[e] != 0.f;              // keys past N have kml = 0
+                        const float pe = __builtin_amdgcn_exp2f(sv[j][e] * LOG2E - m_run) * il;
+                        sv[j][e] = keep ? pe * (dp[j][e] - delta) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq = mfma16(Kl[(k0 + 16 * j + 4 * g4 + e) * TB_PITCH + ql], sv[j][e], dq);    // dq^T[ch][query]
             }
             if (qok) *reinterpret_cast<float4*>(outp) = make_float4(scale * dq[0], scale * dq[1], scale * dq[2], scale * dq[3]);   // q = scale * W_q x
         }
@@ -402,35 +426,45 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
             const float4 vf = *reinterpret_cast<const float4*>(Vl + j * TB_PITCH + 4 * g4);
             const bool keep = kml[j] != 0.f;
             f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-            for (int q0 = 0; q0 < ntile * 16; q0 += 16) {
-                const float4 qa = *reinterpret_cast<const float4*>(Ql + (q0 + ql) * TB_PITCH + 4 * g4);
-                const float4 da = *reinterpret_cast<const float4*>(Dl + (q0 + ql) * TB_PITCH + 4 * g4);
-                const float4 m4 = *reinterpret_cast<const float4*>(Ml + q0 + 4 * g4);
-                const float4 l4 = *reinterpret_cast<const float4*>(Ll + q0 + 4 * g4);
-                const float4 e4 = *reinterpret_cast<const float4*>(El + q0 + 4 * g4);
-                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                sv = mfma16(qa.x, kf.x, sv);                          // S[query][key]
-                sv = mfma16(qa.y, kf.y, sv);
-                sv = mfma16(qa.z, kf.z, sv);
-                sv = mfma16(qa.w, kf.w, sv);
-                dp = mfma16(da.x, vf.x, dp);                          // dP[query][key]
-                dp = mfma16(da.y, vf.y, dp);
-                dp = mfma16(da.z, vf.z, dp);
-                dp = mfma16(da.w, vf.w, dp);
-                const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
-                f32x4 ds;
+            for (int q0 = 0; q0 < npad; q0 += 32) {                  // two 16-query tiles per step (independent MFMA chains)
+                f32x4 sv[2], ds[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool qin = q0 + 4 * g4 + e < N;             // the statistics of queries past N are not defined
-                    const float pe = qin ? __builtin_amdgcn_exp2f((keep ? sv[e] * LOG2E : FILL2) - mv[e]) * lv[e] : 0.f;
-                    sv[e] = pe;
-                    ds[e] = (keep && qin) ? pe * (dp[e] - ev[e]) : 0.f;
+                for (int t = 0; t < 2; ++t) {
+                    const float4 qa = *reinterpret_cast<const float4*>(Ql + (q0 + 16 * t + ql) * TB_PITCH + 4 * g4);
+                    const float4 da = *reinterpret_cast<const float4*>(Dl + (q0 + 16 * t + ql) * TB_PITCH + 4 * g4);
+                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+                    z4 = mfma16(qa.x, kf.x, z4);                      // S[query][key]
+                    d4 = mfma16(da.x, vf.x, d4);                      // dP[query][key]
+                    z4 = mfma16(qa.y, kf.y, z4);
+                    d4 = mfma16(da.y, vf.y, d4);
+                    z4 = mfma16(qa.z, kf.z, z4);
+                    d4 = mfma16(da.z, vf.z, d4);
+                    z4 = mfma16(qa.w, kf.w, z4);
+                    d4 = mfma16(da.w, vf.w, d4);
+                    sv[t] = z4;
+                    ds[t] = d4;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dv = mfma16(Dl[(q0 + 4 * g4 + e) * TB_PITCH + ql], sv[e], dv);      // dv^T[ch][key] += do[query][ch] p
-                    dk = mfma16(Ql[(q0 + 4 * g4 + e) * TB_PITCH + ql], ds[e], dk);      // dk^T[ch][key] += q[query][ch] dS
+                for (int t = 0; t < 2; ++t) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(Ml + q0 + 16 * t + 4 * g4);
+                    const float4 l4 = *reinterpret_cast<const float4*>(Ll + q0 + 16 * t + 4 * g4);
+                    const float4 e4 = *reinterpret_cast<const float4*>(El + q0 + 16 * t + 4 * g4);
+                    const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool qin = q0 + 16 * t + 4 * g4 + e < N;         // the statistics of queries past N are not defined
+                        const float pe = qin ? __builtin_amdgcn_exp2f((keep ? sv[t][e] * LOG2E : FILL2) - mv[e]) * lv[e] : 0.f;
+                        sv[t][e] = pe;
+                        ds[t][e] = (keep && qin) ? pe * (ds[t][e] - ev[e]) : 0.f;
+                    }
                 }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dv = mfma16(Dl[(q0 + 16 * t + 4 * g4 + e) * TB_PITCH + ql], sv[t][e], dv);      // dv^T[ch][key] += do[query][ch] p
+                        dk = mfma16(Ql[(q0 + 16 * t + 4 * g4 + e) * TB_PITCH + ql], ds[t][e], dk);      // dk^T[ch][key] += q[query][ch] dS
+                    }
             }
             if (jok) {
                 float* outp = dqkvg + row_pos(j) * (4 * HC) + h * C + 4 * g4;
@@ -550,12 +584,28 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ p
     }
 }
 
+// 64 elements per workgroup, the slabs dealt in four contiguous quarters to the four waves (eight loads in flight per lane),
+// quarter sums combined in wave order: the summation order is fixed.
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, int n, int slabs) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    __shared__ float qs[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int per = (slabs + 3) / 4, k0 = wave * per, k1 = (k0 + per < slabs) ? k0 + per : slabs;
     float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += part[(size_t)k * n + e];
-    dw[e] = s;
+    if (e < n) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(k + u) * n + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; k < k1; ++k) s += part[(size_t)k * n + e];
+    }
+    qs[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && e < n) dw[e] = ((qs[0][lane] + qs[1][lane]) + qs[2][lane]) + qs[3][lane];
 }
 
 }  // namespace
@@ -623,9 +673,7 @@ extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;          // rows beyond N ~ 400: not in this first cut
     const long nwork = (long)b * N * H;
     const int grid = (int)(nwork < 256 ? nwork : 256);
-    int nthreads = prd_round_up(N, 64);                         // one query / key per thread in a single round where possible
-    if (nthreads > 512) nthreads = 512;
-    if (nthreads < 256) nthreads = 256;
+    const int nthreads = 512;                                   // 8 waves: two per SIMD cover each other's dependent MFMA chains
     if (P == 64) {
         PRD_BWD_SET_LDS(tri_attn_bwd_core_kernel<64>);
         hipLaunchKernelGGL(tri_attn_bwd_core_kernel<64>, dim3(grid), dim3(nthreads), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
@@ -665,6 +713,6 @@ extern "C" int prd_linear_wgrad(float* dw, const float* dy, const float* x, long
     else if (per == 1) hipLaunchKernelGGL(linear_wgrad_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
     else return PRD_ERR_UNSUPPORTED;
     const int n = O * I;
-    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dw, ws, n, (int)slabs);
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dw, ws, n, (int)slabs);
     return (int)hipGetLastError();
 }
