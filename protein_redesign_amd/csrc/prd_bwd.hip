@@ -584,6 +584,43 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ p
     }
 }
 
+// The same reduction for a NARROW output side (O <= 16: the attention-bias and coordinate-head linears, modules.py:300-304,
+// model.py:364-369): one lane per input column, the O values of dy per row broadcast, rows dealt to slabs and to the four waves.
+template <int OMAX>
+__global__ __launch_bounds__(256) void linear_wgrad_narrow_kernel(float* __restrict__ part, const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  long rows, int O, int I, int lddy, int ldx, int rows_per_wg) {
+    __shared__ float red[4][OMAX][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.y * 64 + lane;
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    float acc[OMAX];
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) acc[o] = 0.f;
+    constexpr int U = 8;
+    for (long row = r0 + (long)U * wave; row < r1; row += 4 * U) {
+        float xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = (row + u < r1) ? x[(row + u) * ldx + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* dr = dy + (row + u < r1 ? row + u : r1 - 1) * lddy;         // wave-uniform address: a broadcast load
+#pragma unroll
+            for (int o = 0; o < OMAX; ++o)
+                if (o < O) acc[o] += dr[o] * xv[u];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) red[wave][o][lane] = acc[o];
+    __syncthreads();
+    if (wave == 0) {
+        float* pt = part + (size_t)blockIdx.x * O * I;
+#pragma unroll
+        for (int o = 0; o < OMAX; ++o)
+            if (o < O) pt[(size_t)o * I + i] = ((red[0][o][lane] + red[1][o][lane]) + red[2][o][lane]) + red[3][o][lane];
+    }
+}
+
 // 64 elements per workgroup, the slabs dealt in four contiguous quarters to the four waves (eight loads in flight per lane),
 // quarter sums combined in wave order: the summation order is fixed.
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, int n, int slabs) {
@@ -700,11 +737,21 @@ extern "C" size_t prd_linear_wgrad_workspace(long long rows, int O, int I) {
 extern "C" int prd_linear_wgrad(float* dw, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
                                 float* ws, size_t ws_bytes, hipStream_t stream) {
     if (!dw || !dy || !x || !ws || rows <= 0 || O <= 0 || I <= 0) return PRD_ERR_ARG;
-    if ((O % 64) || (I % 64) || O > 256 || I > 256) return PRD_ERR_UNSUPPORTED;
-    if ((lddy & 1) || (ldx & 1) || lddy < O || ldx < I) return PRD_ERR_ALIGN;
+    const bool narrow = O <= 16;
+    if ((!narrow && (O % 64)) || (I % 64) || O > 256 || I > 256) return PRD_ERR_UNSUPPORTED;
+    if (!narrow && ((lddy & 1) || (ldx & 1))) return PRD_ERR_ALIGN;
+    if (lddy < O || ldx < I) return PRD_ERR_ARG;
     if (ws_bytes < prd_linear_wgrad_workspace(rows, O, I)) return PRD_ERR_WORKSPACE;
     const long slabs = (long)(prd_linear_wgrad_workspace(rows, O, I) / ((size_t)O * I * sizeof(float)));
     const int rows_per_wg = (int)((rows + slabs - 1) / slabs);
+    if (narrow) {
+        dim3 grid((unsigned)slabs, I / 64);
+        if (O <= 4) hipLaunchKernelGGL(linear_wgrad_narrow_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
+        else hipLaunchKernelGGL(linear_wgrad_narrow_kernel<16>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
+        const int n = O * I;
+        hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dw, ws, n, (int)slabs);
+        return (int)hipGetLastError();
+    }
     const int nblk = (O / 64) * (I / 64);
     const int per = (nblk % 4 == 0) ? 4 : ((nblk % 2 == 0) ? 2 : 1);     // 64x64 blocks per workgroup
     dim3 grid((unsigned)slabs, nblk / per);

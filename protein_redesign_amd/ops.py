@@ -320,11 +320,14 @@ WGRAD_MIN_ROWS = 8192
 def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """dW [O, I] = dy2^T x2 for row-major 2-D views dy2 [rows, O] and x2 [rows, I] (row stride = their stride(0), unit column
     stride): the weight gradient of a linear applied at every pair position.  Hand-written slab reduction
-    (prd_linear_wgrad) for the shapes it covers -- rows >= 8192, O and I multiples of 64 up to 256 -- else a library GEMM."""
+    (prd_linear_wgrad) for the shapes it covers -- rows >= 8192, I a multiple of 64, O a multiple of 64 or at most 16, both up to 256 --
+    else a library GEMM."""
     rows, O = dy2.shape
     I = x2.shape[1]
-    if (rows >= WGRAD_MIN_ROWS and O % 64 == 0 and I % 64 == 0 and O <= 256 and I <= 256 and dy2.stride(1) == 1 and x2.stride(1) == 1
-            and dy2.stride(0) % 2 == 0 and x2.stride(0) % 2 == 0 and dy2.storage_offset() % 2 == 0 and x2.storage_offset() % 2 == 0):
+    wide = (O % 64 == 0 and dy2.stride(0) % 2 == 0 and x2.stride(0) % 2 == 0 and dy2.storage_offset() % 2 == 0
+            and x2.storage_offset() % 2 == 0)
+    if (rows >= WGRAD_MIN_ROWS and (wide or O <= 16) and I % 64 == 0 and O <= 256 and I <= 256 and dy2.stride(1) == 1
+            and x2.stride(1) == 1):
         dw = torch.empty(O, I, device=dy2.device, dtype=F32)
         nbytes = lib().prd_linear_wgrad_workspace(rows, O, I)
         ws = torch.empty(nbytes // 4, device=dy2.device, dtype=F32)

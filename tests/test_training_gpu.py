@@ -161,7 +161,8 @@ def test_triangle_attention_backward_kernels(mode, P, gemm_mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,O,I", [(40 * 40 * 2, 64, 64), (102400, 256, 64), (20000, 64, 256), (9001, 128, 128), (8192, 256, 256)])
+@pytest.mark.parametrize("rows,O,I", [(40 * 40 * 2, 64, 64), (102400, 256, 64), (20000, 64, 256), (9001, 128, 128), (8192, 256, 256),
+                                      (102400, 4, 64), (20001, 1, 64), (9000, 12, 128)])
 def test_linear_weight_gradient_kernel(rows, O, I):
     """prd_linear_wgrad (slab partials on fp32 MFMA + ordered reduction) against a float64 reduction; also through strided views
     (a column slice of a wider tensor, as the attention backward passes them)."""
