@@ -65,7 +65,29 @@ def build_asan(verbose: bool = True) -> str:
     return exe
 
 
+def build_timing(verbose: bool = True) -> str:
+    """Diagnostic build with in-kernel cycle stamps (-DPRD_TIMING: tools/ta_timing.py, tools/phase_timing.py read them through
+    prd_debug_read); load it with PRD_LIB=<path>.  Never the shipped library: the stamps cost ~10 % of a wave's cycles."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(HERE, "csrc", "timing")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(HERE, "libprd_hip_timing.so")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(out_dir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-DPRD_TIMING", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 if __name__ == "__main__":
+    if "--timing" in sys.argv:
+        print(build_timing())
+        sys.exit(0)
     if "--asan" in sys.argv:
         exe = build_asan()
         sys.exit(subprocess.call([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")))

@@ -26,7 +26,9 @@
 
 #ifdef PRD_TIMING     // diagnostic builds only (tools/ta_timing.py, tools/phase_timing.py): in-kernel cycle stamps
 __device__ unsigned long long prd_dbg[256 * 16 * 8 * 4];
+__device__ int prd_dbg_sel;        // which kernel's PhaseTimer is recorded (0: every one, the last launch wins)
 extern "C" int prd_debug_read(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(prd_dbg), sizeof(prd_dbg)); }
+extern "C" int prd_debug_select(int id) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(prd_dbg_sel), &id, sizeof(int)); }
 // tri_attn_core: [wg][12 waves][8 iterations][4 stamps]
 #define PRD_STAMP(k) do { if (lane == 0 && it < 8) prd_dbg[((blockIdx.x * 12 + wave) * 8 + it) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
 // row kernels: cycles per phase summed over the tasks of a wave, [wg][16 waves][8 phases]
@@ -40,7 +42,8 @@ struct PhaseTimer {
         acc[k] += n - t;
         t = n;
     }
-    __device__ void flush() {
+    __device__ void flush(int id = 0) {
+        if (prd_dbg_sel != 0 && prd_dbg_sel != id) return;
         if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) prd_dbg[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k] = acc[k];
     }
 };
@@ -48,7 +51,7 @@ struct PhaseTimer {
 #define PRD_STAMP(k)
 struct PhaseTimer {
     __device__ void mark(int) {}
-    __device__ void flush() {}
+    __device__ void flush(int = 0) {}
 };
 #endif
 
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
         if (tb.ok) proj_compute<P, B3>(tb, xb, mub, mvb, AB, Wpl, Wgl, bpl, bgl, N, ldn, cstride, lane_off, r, hi, pt);
     }
     pt.mark(5);
-    pt.flush();
+    pt.flush(1);
 }
 
 // Triangle-multiplication contraction (reference modules.py:272, "ikd,jkd->ijd" / "kid,kjd->ijd" after the
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
     __shared__ __attribute__((aligned(16))) float bol[P];
     __shared__ __attribute__((aligned(16))) float bgl[P];
     constexpr float ASC = B3 ? H2_INV_WSCALE : 1.0f;     // accumulator scale of the split form
+    PhaseTimer pt;
     if (B3) {
         stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wol), wo, P, P, threadIdx.x, NW * 64, H2_WSCALE);
         stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wgl), wog, P, P, threadIdx.x, NW * 64, H2_WSCALE);
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
     stage_vec_cll(bol, bo, P, threadIdx.x, NW * 64);
     stage_vec_cll(bgl, bog, P, threadIdx.x, NW * 64);
     __syncthreads();
+    pt.mark(6);                                         // 6: prologue (weight staging, barrier)
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5, wave = threadIdx.x >> 6;
     const int nvb = (N + 31) / 32;
     const long ntask = (long)b * N * nvb;
@@ -476,7 +481,9 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
     // projection of LN(O) for the same halves (32 MFMAs each instead of 128 in one wave); the halves meet in LDS.
     const long slots = (long)gridDim.x * 4;
     const long left = ntask % slots;
-    const bool coop = queue == nullptr && NB == 2 && NW >= 4 && left > 0 && left <= 2 * (long)gridDim.x;
+    // (fp32 form only: the split form is bound by operand latency, not by the matrix pipe -- co-resident waves overlap, and a
+    // partial extra round on the second wave of a SIMD costs less than the cooperative pass)
+    const bool coop = !B3 && queue == nullptr && NB == 2 && NW >= 4 && left > 0 && left <= 2 * (long)gridDim.x;
     const long nwhole = coop ? ntask - left : ntask;
     WaveTasks tasks(queue, nwhole, NW);
     for (long task = tasks.next(); task >= 0; task = tasks.next()) {
@@ -487,29 +494,44 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
         const bool valid = j < N;
         const int jj = valid ? j : 0;
         const long off = (bi * N + jj) * P;
+        // Both operands of the task are requested up front: the contraction output of this (i,j) for the lane's channels
+        // (coalesced over j per channel; lanes past N read column 0 and are never stored) and the pair row -- one exposed
+        // memory latency per task instead of three (row, O, row again for the residual).
+        // Buffer addressing: one descriptor per operand and task, the lane part of the address computed once, the channel
+        // stride of O as a scalar offset -- 32 scattered 64-bit address computations per task were a third of a wave's cycles.
+        float x[KH], xr[KH];
+        {
+            const prd_rsrc ro = make_rsrc(O + (((long)bb * P) * N + i) * ldn + vb * 32);
+            const unsigned cbytes = (unsigned)N * (unsigned)ldn * 4u;              // channel stride of the contraction output
+            const unsigned lo = valid ? (unsigned)r * 4u + (unsigned)(4 * hi) * cbytes : BUF_OOB;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) x[s] = buf_load(ro, lo, (unsigned)(8 * (s >> 2) + (s & 3)) * cbytes);
+            const prd_rsrc rp = make_rsrc(pair + (bi * N + vb * 32) * P);
+            load_row_cll_buf<P>(rp, valid ? ((unsigned)r * P + 4 * hi) * 4u : BUF_OOB, xr);
+        }
+        pt.mark(0);                                     // 0: task decode, load issue
         float gate[KH];
         {
-            float x[KH];
-            load_row_cll<P>(pair + off, hi, valid, x);
-            ln_cll<KH>(x);
+            float xn[KH];
+#pragma unroll
+            for (int s = 0; s < KH; ++s) xn[s] = xr[s];
+            ln_cll<KH>(xn);
+            pt.mark(1);                                 // 1: wait for the pair row, LayerNorm
             f32x16 ag[NB];
             zero_acc(ag);
             if (B3) {
                 u32x4 xs[2][P / 16];
-                split2h_cll<KH>(x, xs);
+                split2h_cll<KH>(xn, xs);
                 rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wgl), P, 0, xs, ag, r, hi);
             } else {
-                rowgemm<P, NB>(Wgl, x, ag, r, hi);
+                rowgemm<P, NB>(Wgl, xn, ag, r, hi);
             }
 #pragma unroll
             for (int s = 0; s < KH; ++s) gate[s] = sigmoid_fast(ag[s >> 4][s & 15] * ASC + bgl[hi * KH + s]);
         }
-        float x[KH];
-        // contraction output of this (i,j) for the lane's channels (coalesced over j per channel)
-#pragma unroll
-        for (int s = 0; s < KH; ++s)
-            x[s] = valid ? O[(((long)bb * P + cll_ch(s, hi)) * N + i) * ldn + jj] : 0.f;
+        pt.mark(2);                                     // 2: gate GEMM + sigmoid
         ln_cll<KH>(x);
+        pt.mark(3);                                     // 3: wait for O, LayerNorm
         f32x16 ao[NB];
         zero_acc(ao);
         if (B3) {
@@ -519,11 +541,14 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_kernel(int* queue, float*
         } else {
             rowgemm<P, NB>(Wol, x, ao, r, hi);
         }
-        load_row_cll<P>(pair + off, hi, valid && residual, x);       // raw row again (cache hit) for the residual
+        pt.mark(4);                                     // 4: projection GEMM
 #pragma unroll
-        for (int s = 0; s < KH; ++s) x[s] = x[s] + gate[s] * (ao[s >> 4][s & 15] * ASC + bol[hi * KH + s]);
+        for (int s = 0; s < KH; ++s) x[s] = (residual ? xr[s] : 0.f) + gate[s] * (ao[s >> 4][s & 15] * ASC + bol[hi * KH + s]);
         store_row_cll<P>(out + off, hi, valid, x);
+        pt.mark(5);                                     // 5: epilogue + store issue
     }
+    pt.mark(7);                                         // 7: leaving the task loop (queue exhausted)
+    pt.flush(2);
     if (coop) {
         __shared__ float part[2][64][17];                     // LN(O) projections of waves 2 / 3, per lane 16 values
         for (long task = nwhole + blockIdx.x; task < ntask; task += gridDim.x) {     // uniform over the workgroup

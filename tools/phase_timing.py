@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-phase cycle totals of a row kernel from in-kernel stamps (library built with -DPRD_TIMING, PRD_LIB=...).
-usage: phase_timing.py tri_mul_proj [N]"""
+usage: phase_timing.py tri_mul_proj|tri_mul_out|tri_mul_contract [N [gemm_mode]]"""
 import ctypes
 import os
 import sys
@@ -16,7 +16,9 @@ from protein_redesign_amd.synthetic import deterministic_state_dict  # noqa: E40
 from protein_redesign_amd.weights import spec_tensors  # noqa: E402
 
 PHASES = {"tri_mul_contract": ["loads issue + LDS reads + MFMA", "vmcnt wait + LDS writes", "barrier"],
-          "tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"]}
+          "tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"],
+          "tri_mul_out": ["decode + load issue", "wait row + LN", "gate GEMM + sigmoid", "wait O + LN", "projection GEMM",
+                          "epilogue + stores", "prologue", "exit"]}
 
 
 def main():
@@ -33,6 +35,10 @@ def main():
     ws = torch.empty(m.Denoiser.ws_floats(1, N), device="cuda")
     L = _lib.lib()
     L.prd_debug_read.argtypes = [ctypes.c_void_p]
+    L.prd_debug_select.argtypes = [ctypes.c_int]
+    assert L.prd_debug_select({"tri_mul_proj": 1, "tri_mul_out": 2}.get(which, 0)) == 0
+    if len(sys.argv) > 3:
+        L.prd_set_gemm_mode(int(sys.argv[3]))
     with torch.inference_mode():
         for _ in range(3):
             blk.pair_mul_outgoing.run(pair, mask, residual=True, out=pair.clone(), ws=ws)
