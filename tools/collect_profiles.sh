@@ -35,6 +35,15 @@ python tools/pmc_summary.py $(db gpurun_out/${TAG}_n769_pmc_FETCH_SIZE) $(db gpu
 } > $OUT/${TAG}_bench_lines.jsonl
 python tools/op_bench.py > $OUT/${TAG}_op_bench.txt 2>&1
 python tools/train_bench.py > $OUT/${TAG}_train_bench.txt 2>&1
+# (e) training step: kernel stats of three optimisation steps
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_train_trace -o t -- python3 tools/train_bench.py --steps 3 --warmup 2 > gpurun_out/${TAG}_train_trace.log 2>&1
+python tools/rocprof_summary.py $(db gpurun_out/${TAG}_train_trace) $OUT/${TAG}_train_kernel_stats.txt > /dev/null
+# (f) the single-track GEMM study (tools/ubench/nodegemm_bench.hip, built by hipcc beforehand) and the row-kernel phase timers
+if [ -x tools/ubench/nodegemm_bench ]; then ./tools/ubench/nodegemm_bench 320 0 0 > $OUT/${TAG}_nodegemm_ubench.txt 2>&1; fi
+if [ -f protein_redesign_amd/libprd_hip_timing.so ]; then
+  { PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py tri_mul_out 320 1
+    PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py tri_mul_proj 320 1; } > $OUT/${TAG}_row_kernel_phases.txt 2>/dev/null
+fi
 ls -la $OUT
 # the raw rocpd databases are scratch (tens of MB): only the summaries travel back
-rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_pmc_* gpurun_out/${TAG}_n769_trace gpurun_out/${TAG}_n769_pmc_*
+rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_pmc_* gpurun_out/${TAG}_n769_trace gpurun_out/${TAG}_n769_pmc_* gpurun_out/${TAG}_train_trace
