@@ -134,16 +134,18 @@ def test_triangle_multiplication_backward_kernels(mode, P, gemm_mode):
 
 
 @pytest.mark.parametrize("mode", ["starting", "ending"])
-@pytest.mark.parametrize("P", [32, 64])
-def test_triangle_attention_backward_kernels(mode, P, gemm_mode):
+@pytest.mark.parametrize("P,b,N", [(32, 2, 45), (64, 2, 45), (64, 1, 100), (64, 1, 352)])
+def test_triangle_attention_backward_kernels(mode, P, b, N, gemm_mode):
     """The hand-written backward of TriangleAttention (prd_tri_attn_bwd_core + row GEMMs + prd_ln_rows_bwd) against the oracle's
-    autograd: gradient with respect to the pair input and all seven weight tensors; ragged masked batch, one fully masked row."""
-    from protein_redesign_amd import ops
+    autograd: gradient with respect to the pair input and all seven weight tensors; ragged masked batch, one fully masked row;
+    N = 352 is the longest row the kernel keeps in LDS (training.TRI_ATTN_BWD_MAX_N)."""
+    from protein_redesign_amd import ops, training
+    assert N <= training.TRI_ATTN_BWD_MAX_N
     g = torch.Generator().manual_seed(80 + P)
-    b, N, H, c = 2, 45, 4, 16
+    H, c = 4, 16
     pair = torch.randn(b, N, N, P, generator=g)
     mask = torch.ones(b, N)
-    mask[1, 38:] = 0
+    mask[b - 1, N - 7:] = 0
     names = ["attn.q_proj.weight", "attn.k_proj.weight", "attn.v_proj.weight", "attn.gate_proj.weight", "attn.gate_proj.bias",
              "attn.out_proj.weight", "attn.out_proj.bias"]
     shapes = [(64, P), (64, P), (64, P), (64, P), (64,), (P, 64), (P,)]
