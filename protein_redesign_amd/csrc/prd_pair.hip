@@ -7,6 +7,30 @@
 #include "../../include/prd_hip.h"
 #include <mutex>
 
+#ifdef PRD_TIMING     // diagnostic builds only (tools/phase_timing.py): cycles per phase summed over the tasks of a wave
+__device__ unsigned long long prd_dbg_pair[256 * 16 * 8];
+extern "C" int prd_debug_read_pair(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(prd_dbg_pair), sizeof(prd_dbg_pair)); }
+struct PairPhaseTimer {
+    unsigned long long t, acc[8];
+    __device__ PairPhaseTimer() { for (int k = 0; k < 8; ++k) acc[k] = 0; t = __builtin_readcyclecounter(); }
+    __device__ void mark(int k) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long n = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        acc[k] += n - t;
+        t = n;
+    }
+    __device__ void flush() {
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) prd_dbg_pair[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k] = acc[k];
+    }
+};
+#else
+struct PairPhaseTimer {
+    __device__ void mark(int) {}
+    __device__ void flush() {}
+};
+#endif
+
 namespace {
 
 constexpr int WG = 256;   // 4 waves
@@ -839,7 +863,8 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
                                                                const float* __restrict__ wb, const float* __restrict__ bb_,
                                                                float* __restrict__ bias_out, int H, long rows, long nn, int residual) {
     constexpr int KH = P / 2, HID = 4 * P, HH = HID / 2, NB = P / 32, HC = 64;
-    constexpr int PASSES = 4, HBP = HID / 32 / PASSES, HHP = HH / PASSES;     // hidden units per pass: 32 HBP, per lane HHP
+    constexpr int PASSES = P == 64 ? 8 : 4, HBP = HID / 32 / PASSES, HHP = HH / PASSES;   // hidden units per pass: 32 HBP, per lane HHP
+    // (P = 64: eight passes of one 32-unit block keep the kernel inside the 168 registers of a 12-wave workgroup)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
     u32x4* W1h = reinterpret_cast<u32x4*>(smem_h2);                 // [2][HID][P/8]
     u32x4* W2h = W1h + 2 * HID * (P / 8);                           // [2][P][HID/8]
@@ -849,6 +874,7 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
     float* bol = b2l + P;                                           // [P] CLL
     float* wbl = bol + P;                                           // [8][P] CLL (bias head)
     const int NT = NW * 64;
+    PairPhaseTimer pt;
     stage_weight_h2<P>(W1h, w1, HID, P, threadIdx.x, NT, H2_WSCALE);
     stage_weight_h2<HID>(W2h, w2, P, HID, threadIdx.x, NT, H2_WSCALE);
     if (og) stage_weight_h2<HC>(Woh, wo, P, HC, threadIdx.x, NT, H2_WSCALE);
@@ -858,16 +884,17 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
     if (bias_out)
         for (int h = 0; h < H; ++h) stage_vec_cll(wbl + h * P, wb + h * P, P, threadIdx.x, NT);
     __syncthreads();
+    pt.mark(6);                                         // 6: prologue (weight staging, barrier)
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const long ntask = (rows + 31) / 32;
     WaveTasks tasks(nullptr, ntask, NW);
-    // the first task's rows are in flight while the weights are staged; afterwards the loads of task i+1 are issued before
-    // task i is computed (vmcnt retires in order: a load issued after a task's stores would wait for all of them)
+    // (requesting the first task's rows before the weight staging was tried: the staging loop then spills, 38.7 -> 50.9 us)
     for (long task = tasks.next(); task >= 0; task = tasks.next()) {
         const long pos = task * 32 + r;
         const bool valid = pos < rows;
         float raw[KH];
         load_row_cll<P>(pair + pos * P, hi, valid, raw);
+        pt.mark(0);                                     // 0: decode + load issue
         if (og) {
             float xo[HC / 2];
             load_row_cll<HC>(og + pos * HC, hi, valid, xo);
@@ -879,12 +906,14 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
 #pragma unroll
             for (int s_ = 0; s_ < KH; ++s_) raw[s_] = raw[s_] + (acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bol[hi * KH + s_]);
         }
+        pt.mark(1);                                     // 1: wait for the rows + attention out-projection
         float x[KH];
 #pragma unroll
         for (int s_ = 0; s_ < KH; ++s_) x[s_] = raw[s_];
         ln_cll<KH>(x);
         u32x4 xs[2][P / 16];
         split2h_cll<KH>(x, xs);
+        pt.mark(2);                                     // 2: LayerNorm + split
         f32x16 acc2[NB];
         zero_acc(acc2);
 #define PRD_H2_PASS(Q)                                                                                              \
@@ -900,23 +929,33 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
             rowgemm_h2_part<HID, NB, (Q) * HHP / 8, ((Q) + 1) * HHP / 8>(W2h, P, 0, hs, acc2, r, hi);               \
         }
         PRD_H2_PASS(0) PRD_H2_PASS(1) PRD_H2_PASS(2) PRD_H2_PASS(3)
+        if constexpr (PASSES == 8) { PRD_H2_PASS(4) PRD_H2_PASS(5) PRD_H2_PASS(6) PRD_H2_PASS(7) }
 #undef PRD_H2_PASS
+        pt.mark(3);                                     // 3: transition GEMMs
 #pragma unroll
         for (int s_ = 0; s_ < KH; ++s_) raw[s_] = (residual ? raw[s_] : 0.f) + (acc2[s_ >> 4][s_ & 15] * H2_INV_WSCALE + b2l[hi * KH + s_]);
         store_row_cll<P>(out + pos * P, hi, valid, raw);
+        pt.mark(4);                                     // 4: epilogue + store issue
         if (bias_out) {
             ln_cll<KH>(raw);
             const long bb = pos / nn, rem = pos - bb * nn;
             for (int h = 0; h < H; ++h) {
-                float a = 0.f;
+                const float4* wv = reinterpret_cast<const float4*>(wbl + h * P + hi * KH);      // 16-byte LDS reads, two addresses per wave
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-                for (int s_ = 0; s_ < KH; ++s_) a += raw[s_] * wbl[h * P + hi * KH + s_];
-                a = xhalf_sum(a);
+                for (int s4 = 0; s4 < KH / 4; ++s4) {
+                    const float4 w = wv[s4];
+                    a0 += raw[4 * s4] * w.x; a1 += raw[4 * s4 + 1] * w.y; a2 += raw[4 * s4 + 2] * w.z; a3 += raw[4 * s4 + 3] * w.w;
+                }
+                float a = xhalf_sum((a0 + a1) + (a2 + a3));
                 if (bb_) a += bb_[h];
                 if (valid && hi == 0) bias_out[(bb * H + h) * nn + rem] = a;
             }
         }
+        pt.mark(5);                                     // 5: next block's attention bias
     }
+    pt.mark(7);
+    pt.flush();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1393,7 +1432,7 @@ template <int P>
 int launch_pair_tail_h2(float* out, const float* pair, const float* og, const float* wo, const float* bo, const float* w1,
                         const float* b1, const float* w2, const float* b2, const float* bias_w, const float* bias_b,
                         float* bias_out, int H, long rows, long nn, int residual, hipStream_t stream) {
-    constexpr int NWH = 8;
+    constexpr int NWH = 12;
     const size_t lds = ((size_t)2 * 4 * P * (P / 8) + (size_t)2 * P * (4 * P / 8) + (size_t)2 * P * 8) * 16 + (size_t)(4 * P + 2 * P + 8 * P) * 4;
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     const int grid = grid_for((rows + 31) / 32, 4, 256);

@@ -143,9 +143,17 @@ class _Ema:
             self.num_updates += 1
             decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
         with torch.no_grad():
-            for p, s in self._match(params):
-                if p.requires_grad:
-                    s.sub_((s - p.detach().to(s.device)) * (1.0 - decay))
+            pairs = [(p.detach(), s) for p, s in self._match(params) if p.requires_grad]
+            if pairs and all(p.device == s.device and p.is_cuda for p, s in pairs):
+                # the same arithmetic as the loop below (s -= (s - p) * (1 - decay)) in three multi-tensor launches
+                # instead of three launches per tensor (720 per optimisation step)
+                shadow = [s for _, s in pairs]
+                tmp = torch._foreach_sub(shadow, [p for p, _ in pairs])
+                torch._foreach_mul_(tmp, 1.0 - decay)
+                torch._foreach_sub_(shadow, tmp)
+            else:
+                for p, s in pairs:
+                    s.sub_((s - p.to(s.device)) * (1.0 - decay))
 
     def state_dict(self):
         return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow,

@@ -17,6 +17,8 @@ from protein_redesign_amd.weights import spec_tensors  # noqa: E402
 
 PHASES = {"tri_mul_contract": ["loads issue + LDS reads + MFMA", "vmcnt wait + LDS writes", "barrier"],
           "tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"],
+          "pair_tail": ["decode + load issue", "wait rows + out-projection", "LayerNorm + split", "transition GEMMs", "epilogue + stores",
+                        "next attention bias", "prologue", "exit"],
           "tri_mul_out": ["decode + load issue", "wait row + LN", "gate GEMM + sigmoid", "wait O + LN", "projection GEMM",
                           "epilogue + stores", "prologue", "exit"]}
 
@@ -39,12 +41,22 @@ def main():
     assert L.prd_debug_select({"tri_mul_proj": 1, "tri_mul_out": 2}.get(which, 0)) == 0
     if len(sys.argv) > 3:
         L.prd_set_gemm_mode(int(sys.argv[3]))
-    with torch.inference_mode():
-        for _ in range(3):
-            blk.pair_mul_outgoing.run(pair, mask, residual=True, out=pair.clone(), ws=ws)
-        torch.cuda.synchronize()
     buf = np.zeros(256 * 16 * 8 * 4, dtype=np.uint64)
-    assert L.prd_debug_read(buf.ctypes.data) == 0
+    with torch.inference_mode():
+        if which == "pair_tail":
+            nxt, ta, pf = m.Denoiser.folding_blocks[1], blk.pair_attn_ending.attn, blk.pair_fc
+            og = torch.randn(1, N, N, 64, generator=g).cuda()
+            for _ in range(3):
+                ops.block_tail_(pair.clone(), og, ta.out_proj.weight, ta.out_proj.bias, pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias,
+                                nxt.attn_bias[1].weight, nxt.attn_bias[1].bias)
+            torch.cuda.synchronize()
+            L.prd_debug_read_pair.argtypes = [ctypes.c_void_p]
+            assert L.prd_debug_read_pair(buf.ctypes.data) == 0
+        else:
+            for _ in range(3):
+                blk.pair_mul_outgoing.run(pair, mask, residual=True, out=pair.clone(), ws=ws)
+            torch.cuda.synchronize()
+            assert L.prd_debug_read(buf.ctypes.data) == 0
     t = buf[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64)
     if which == "tri_mul_contract":
         t = buf[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64)
