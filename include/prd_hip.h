@@ -50,10 +50,12 @@ int prd_version(void);
  *        - fp16 hi + lo (RTZ + one mixed-precision FMA, 22 bits), 3 products, 16/3 of the fp32 rate: the row GEMMs (tri_mul
  *          projection / output, attention projections and output projection, pair transition / block tail, outer-linear,
  *          pair_init, OPM), the triangle-multiplication contraction, P*V of the triangle attention, Q*K^T of long rows
- *          (N > 384) and SPAttention's large projection.  Weight images stay the size of the fp32 ones.  fp16 saturates at
- *          65504: LayerNorm-ed rows, their gated / ReLU-ed projections, probabilities and weights (staged x 16) are far inside;
+ *          (N > 384) and the node-row linears of the single track (prd_gemm with one batch, K a multiple of 64 or 32).
+ *          Weight images stay the size of the fp32 ones.  fp16 saturates at 65504: LayerNorm-ed rows, their gated / ReLU-ed
+ *          projections, probabilities and weights (staged x 16) are far inside;
  *        - bf16 x 3 by truncation (exact, 24 bits), 6 products, 16/6 of the fp32 rate: Q*K^T of short rows;
- *      the latency-bound single-track kernels, pair_bias and the coordinate head run fp32 MFMA in either mode.
+ *      the single-track attention core, SPAttention's batched logits / P*V GEMMs, pair_bias and the coordinate head run fp32
+ *      MFMA in either mode.
  * Both modes meet every parity tolerance of tests/ (the GPU suite runs its operator / step / trajectory / gradient tests in both). */
 int prd_set_gemm_mode(int mode);
 int prd_get_gemm_mode(void);

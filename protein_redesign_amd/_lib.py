@@ -102,9 +102,10 @@ def lib():
 def row_gemm_description(b3: bool) -> str:
     """What the GEMMs of the pair kernels compute in, for bench.py's JSON line (stated truthfully, not as a precision claim)."""
     if b3:
-        return ("split16: fp32 operands split into 16-bit parts -- fp16 hi+lo (22 bits, 3 products) in the row GEMMs, the "
-                "triangle-multiplication contraction and P*V; bf16 x3 (24 bits, 6 products) in Q*K^T of short rows -- multiplied "
-                "on the fp16/bf16 MFMA pipes with fp32 accumulation; the latency-bound single-track kernels run fp32 MFMA.  "
+        return ("split16: fp32 operands split into 16-bit parts -- fp16 hi+lo (22 bits, 3 products) in the row GEMMs of the pair "
+                "track, the node-row linears of the single track, the triangle-multiplication contraction and P*V; bf16 x3 "
+                "(24 bits, 6 products) in Q*K^T of short rows -- multiplied on the fp16/bf16 MFMA pipes with fp32 accumulation; "
+                "the single-track attention core, SPAttention's batched GEMMs, pair_bias and the coordinate head run fp32 MFMA.  "
                 "Parity tolerances are the same as in fp32 mode (PRD_GEMM_MODE=fp32)")
     return "fp32-mfma"
 
