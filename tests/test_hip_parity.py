@@ -135,6 +135,26 @@ def test_linear_with_fused_layer_norm(M, N, K):
             ops.gemm(cu(x), cu(w), torch.empty(M, N, device=DEV), M, N, K, K, K, N, a_ln=True)
 
 
+@pytest.mark.parametrize("M,N,K", [(320, 64, 512), (77, 33, 256), (50, 96, 1024), (320, 512, 2048), (90, 40, 128)])
+def test_operand_ring_gemm_edges(M, N, K, gemm_mode):
+    """The node-row linears in both arithmetic modes (gemm mode 1: gemm_ring_kernel -- ragged M / N tiles, 1 to 32 chunks of
+    64 k, one to four K groups), with the epilogue (bias, ReLU, residual) and -- where the fused LayerNorm applies (K <= 512
+    on the K-split kernel, K <= 1024 on the operand ring) -- the normalised rows as a side output (PrdGemm.ln_out)."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g) * 1.5 + 0.7
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    want = torch.relu(x.double() @ w.double().t() + b.double()) + res.double()
+    got = ops.linear(cu(x), cu(w), cu(b), act=1, resid=cu(res))
+    assert rel_l2(got.cpu(), want) < 2e-6
+    if K <= 512 or (gemm_mode == "split16" and K <= 1024):
+        xn = torch.empty(M, K, device=DEV)
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm(cu(x), cu(w), out, M, N, K, K, K, N, bias=cu(b), a_ln=True, ln_out=xn)
+        assert rel_l2(xn.cpu(), O.ln(x)) < 2e-6
+        assert rel_l2(out.cpu(), O.ln(x).double() @ w.double().t() + b.double()) < 5e-6
+
+
 # ---------------------------------------------------------------------------------------------------
 # operators vs the oracle (module-level API of the mirror classes)
 # ---------------------------------------------------------------------------------------------------
