@@ -155,6 +155,14 @@ int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w
  * AB[b][2P][N][ldn] (A = channels 0..P-1, B = channels P..2P-1, ldn = round_up(N,32), zero padded), O[b][P][N][ldn].
  * The backward calls it on transposed operands for dA and dB. */
 int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, hipStream_t stream);
+/* TriangleMultiplication "outgoing" followed by "incoming", in place on `pair` (both residual updates of modules.py:336-337),
+ * gemm mode 1 only (prd_tri_mul_chain_supported): five launches instead of six -- the output stage of the first module and the
+ * projection stage of the second run as one row pass down the columns (the outgoing contraction stores its result transposed
+ * for it).  w_outgoing / w_incoming: eight device pointers each, in prd_tri_mul's order (w_proj, b_proj, w_gate, b_gate, w_out,
+ * b_out, w_ogate, b_ogate).  Workspace as for prd_tri_mul.  Results equal two prd_tri_mul calls up to fp32 rounding. */
+int prd_tri_mul_chain_supported(int N, int P);
+int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outgoing, const float* const* w_incoming,
+                      int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream);
 /* Output stage backward.  dy = gradient of the update [b,N,N,P]; O = contraction output (channel-major, as left in prd_tri_mul's
  * workspace); w_*_t = the transposed weights [in][out].  Writes dz = dy * gate and dgp = d(pre-activation of the output gate)
  * (row layout [b,N,N,P]; dW_out = dz^T LN(O), dW_ogate = dgp^T LN(pair) are left to the caller's BLAS), dO (channel-major) and

@@ -198,6 +198,119 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_kernel(int* queue, float
     pt.flush(1);
 }
 
+// Output stage of the OUTGOING triangle multiplication fused with the projection stage of the INCOMING one that follows it
+// in the folding block (modules.py:336-337; gemm mode 1): both are row-local, so the updated pair row never leaves the
+// registers between them -- one launch and one pass over the pair tensor less per block (tri_mul_out 19 us + tri_mul_proj
+// 24 us, most of the latter launch / prologue / imbalance rather than arithmetic).  The incoming projection reads pair[v, u]
+// for 32 consecutive v (its operand layout is [channel][u][v]), so the tasks run DOWN the columns: (u, 32 rows v).  For
+// those tasks the contraction output must be contiguous in v, which the outgoing contraction provides by swapping its
+// operands (O^T = B A^T).  Per task: Ot[:, u, v-block] and pair[v-block, u] -> gate, projection of LN(O), residual ->
+// pair[v-block, u] (written back) -> LN -> a | b projections and gates of the incoming module, masked -> AB[:, u, v-block].
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_mul_out_proj_kernel(float* pair, const float* __restrict__ Ot, const float* __restrict__ mask,
+                                                                   const float* __restrict__ wo, const float* __restrict__ bo,
+                                                                   const float* __restrict__ wog, const float* __restrict__ bog,
+                                                                   const float* __restrict__ wp, const float* __restrict__ bp,
+                                                                   const float* __restrict__ wg, const float* __restrict__ bg,
+                                                                   float* __restrict__ AB, int b, int N, int ldn) {
+    constexpr int KH = P / 2, NB = P / 32, OUT = 2 * P, OB = OUT / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem_op[];
+    float* Wol = smem_op;                    // fp16 hi | lo planes (prd_common.h: stage_weight_h2), x 16
+    float* Wgol = Wol + P * P;
+    float* Wpl = Wgol + P * P;
+    float* Wgl = Wpl + OUT * P;
+    float* bol = Wgl + OUT * P;              // [P] CLL
+    float* bgol = bol + P;                   // [P] CLL
+    float* bpl = bgol + P;                   // [2P] CLL, x 16 (rides in the accumulators)
+    float* bgl = bpl + OUT;                  // [2P] CLL, x -log2(e) x 16
+    stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wol), wo, P, P, threadIdx.x, NW * 64, H2_WSCALE);
+    stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wgol), wog, P, P, threadIdx.x, NW * 64, H2_WSCALE);
+    stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wpl), wp, OUT, P, threadIdx.x, NW * 64, H2_WSCALE);
+    stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wgl), wg, OUT, P, threadIdx.x, NW * 64, NEG_LOG2E * H2_WSCALE);
+    stage_vec_cll(bol, bo, P, threadIdx.x, NW * 64);
+    stage_vec_cll(bgol, bog, P, threadIdx.x, NW * 64);
+    stage_vec_cll(bpl, bp, OUT, threadIdx.x, NW * 64, H2_WSCALE);
+    stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64, NEG_LOG2E * H2_WSCALE);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int nvb = ldn / 32;
+    const long ntask = (long)b * N * nvb;
+    const unsigned cbytes = (unsigned)N * (unsigned)ldn * 4u;              // channel stride of Ot and AB
+    const unsigned lane_off = (unsigned)(4 * hi) * cbytes + (unsigned)r * 4u;
+    WaveTasks tasks(nullptr, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        const int ti = (int)task;
+        const int vb = ti % nvb, bu = ti / nvb;            // bu = bb * N + u
+        const int bb = bu / N, u = bu - bb * N;
+        const int v = vb * 32 + r;
+        const bool valid = v < N;
+        const int vv = valid ? v : 0;
+        float x[KH], xr[KH];
+        {
+            const prd_rsrc ro = make_rsrc(Ot + (((long)bb * P) * N + u) * ldn + vb * 32);
+#pragma unroll
+            for (int s = 0; s < KH; ++s) x[s] = buf_load(ro, valid ? lane_off : BUF_OOB, (unsigned)(8 * (s >> 2) + (s & 3)) * cbytes);
+            const prd_rsrc rp = make_rsrc(pair + (long)bb * N * N * P);
+            load_row_cll_buf<P>(rp, valid ? (((unsigned)vv * N + u) * P + 4 * hi) * 4u : BUF_OOB, xr);
+        }
+        const float mu = mask[bu], mv = mask[bb * N + vv];
+        // ---- output stage of the outgoing module ----
+        float gate[KH];
+        {
+            float xn[KH];
+#pragma unroll
+            for (int s = 0; s < KH; ++s) xn[s] = xr[s];
+            ln_cll<KH>(xn);
+            f32x16 ag[NB];
+            zero_acc(ag);
+            u32x4 xs[2][P / 16];
+            split2h_cll<KH>(xn, xs);
+            rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wgol), P, 0, xs, ag, r, hi);
+#pragma unroll
+            for (int s = 0; s < KH; ++s) gate[s] = sigmoid_fast(ag[s >> 4][s & 15] * H2_INV_WSCALE + bgol[hi * KH + s]);
+        }
+        ln_cll<KH>(x);
+        {
+            f32x16 ao[NB];
+            zero_acc(ao);
+            u32x4 xs[2][P / 16];
+            split2h_cll<KH>(x, xs);
+            rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wol), P, 0, xs, ao, r, hi);
+#pragma unroll
+            for (int s = 0; s < KH; ++s) x[s] = xr[s] + gate[s] * (ao[s >> 4][s & 15] * H2_INV_WSCALE + bol[hi * KH + s]);
+        }
+        store_row_cll<P>(pair + (((long)bb * N + vv) * N + u) * P, hi, valid, x);          // the updated pair row
+        // ---- projection stage of the incoming module on the row still in registers ----
+        ln_cll<KH>(x);
+        u32x4 xs[2][P / 16];
+        split2h_cll<KH>(x, xs);
+        const float m2 = valid ? mu * mv : 0.f;
+        const bool plain = __all(m2 == 1.0f);
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+            f32x16 ap[1], ag[1];
+            bias_acc(ap, bpl + hi * P + 16 * ob);
+            bias_acc(ag, bgl + hi * P + 16 * ob);
+            rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, ob * 32, xs, ap, r, hi);
+            rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, ob * 32, xs, ag, r, hi);
+            // output channel of register q: 32 ob + (q & 3) + 8 (q >> 2) + 4 hi; the hi part sits in lane_off
+            const prd_rsrc cb = make_rsrc(AB + ((((long)bb * 2 * P) + 32 * ob) * N + u) * ldn + vb * 32);
+            if (plain) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float val = (ap[0][q] * H2_INV_WSCALE) * gate_from_scaled(ag[0][q] * H2_INV_WSCALE);
+                    buf_store(val, cb, lane_off, (unsigned)((q & 3) + 8 * (q >> 2)) * cbytes);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    buf_store(m2 * ((ap[0][q] * H2_INV_WSCALE) * gate_from_scaled(ag[0][q] * H2_INV_WSCALE)), cb, lane_off,
+                              (unsigned)((q & 3) + 8 * (q >> 2)) * cbytes);
+            }
+        }
+    }
+}
+
 // Triangle-multiplication contraction (reference modules.py:272, "ikd,jkd->ijd" / "kid,kjd->ijd" after the
 // operand transposition done by tri_mul_proj): nch = b*P independent K-contiguous GEMMs
 //   O[ch][i][j] = sum_k A[ch][i][k] * B[ch][j][k],   A/B/O rows of pitch ldn (zero padded to a multiple of 32).
@@ -321,7 +434,7 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
 // sixteen lanes of a ds_read_b128 group (rows distinct mod 16, same logical slot) hit sixteen different 4-bank groups.
 constexpr int TMS_T = 160, TMS_PLANE = TMS_T * 64, TMS_OPER = 2 * TMS_PLANE;       // bytes
 __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __restrict__ O, const float* __restrict__ AB,
-                                                                     int N, int ldn, int P, int nbatch, int tiles) {
+                                                                     int N, int ldn, int P, int nbatch, int tiles, int swap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tms[];          // [2 buffers][A | B][2 planes][160 rows][64 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
@@ -353,8 +466,10 @@ __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __re
         }
         const int bb = ch / P, d = ch - bb * P;
         const int m0 = (tile / tiles) * TMS_T, n0 = (tile % tiles) * TMS_T;
-        const float* __restrict__ A = AB + ((size_t)bb * 2 * P + d) * N * ldn;
-        const float* __restrict__ B = AB + ((size_t)bb * 2 * P + P + d) * N * ldn;
+        // swap: the operands change roles, i.e. the output is the TRANSPOSE O^T[j][i] (what the column-wise tasks of
+        // tri_mul_out_proj_kernel read contiguously)
+        const float* __restrict__ A = AB + ((size_t)bb * 2 * P + (swap ? P : 0) + d) * N * ldn;
+        const float* __restrict__ B = AB + ((size_t)bb * 2 * P + (swap ? 0 : P) + d) * N * ldn;
         const prd_rsrc ra = make_rsrc(A + (size_t)m0 * ldn), rb = make_rsrc(B + (size_t)n0 * ldn);
         const prd_rsrc rmid = mid_is_b ? rb : ra;
         unsigned off[5];
@@ -1957,7 +2072,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
             const int vb3 = b * P * tl * tl;
             const size_t lds3 = (size_t)4 * TMS_OPER;
             PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
-            hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl);
+            hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0);
         }
         else
             hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
@@ -1988,11 +2103,73 @@ extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int
         const int vb3 = b * P * tl * tl;
         const size_t lds3 = (size_t)4 * TMS_OPER;
         PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
-        hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl);
+        hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0);
     } else {
         const int tiles = prd_ceil_div(N, 64);
         const int vblocks = b * P * tiles * tiles;
         hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_tri_mul_chain_supported(int N, int P) {
+    return (N > 0 && (P == 32 || P == 64) && g_gemm_mode.load(std::memory_order_relaxed) == 1) ? 1 : 0;
+}
+
+extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outgoing, const float* const* w_incoming,
+                                 int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!pair || !mask || !w_outgoing || !w_incoming || !ws || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    for (int k = 0; k < 8; ++k)
+        if (!w_outgoing[k] || !w_incoming[k]) return PRD_ERR_ARG;
+    if (!prd_tri_mul_chain_supported(N, P)) return PRD_ERR_UNSUPPORTED;
+    if (ws_bytes < prd_workspace_bytes("tri_mul", b, N, 0, P)) return PRD_ERR_WORKSPACE;
+    const int ldn = prd_round_up(N, 32);
+    float* AB = ws;                                   // [b][2P][N][ldn]
+    float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
+    const float* const* wa = w_outgoing;              // proj w, b | gate w, b | out w, b | out-gate w, b
+    const float* const* wb = w_incoming;
+    const size_t ldsp = ((size_t)2 * 2 * P * P + 4 * P) * sizeof(float);
+    const long ptask = ((long)b * N * (ldn / 32) + 7) / 8 * 8 * (2 * P / 32);
+    const int pgrid = grid_for(ptask, 4, 256);
+    const int tl = prd_ceil_div(N, TMS_T);
+    const int vb3 = b * P * tl * tl;
+    const size_t lds3 = (size_t)4 * TMS_OPER;
+    const long rtask = (long)b * N * (ldn / 32);
+    const int rgrid = grid_for(rtask, 4, 256);
+    const size_t ldsf = ((size_t)2 * P * P + (size_t)2 * 2 * P * P + 6 * P) * sizeof(float);
+    // 1. a | b of the outgoing module
+    if (P == 64) {
+        PRD_SET_LDS((tri_mul_proj_kernel<64, 12, true>), ldsp);
+        hipLaunchKernelGGL((tri_mul_proj_kernel<64, 12, true>), dim3(pgrid), dim3(12 * 64), ldsp, stream, (int*)nullptr, AB, pair, mask,
+                           wa[0], wa[1], wa[2], wa[3], b, N, ldn, 0);
+    } else {
+        PRD_SET_LDS((tri_mul_proj_kernel<32, 12, true>), ldsp);
+        hipLaunchKernelGGL((tri_mul_proj_kernel<32, 12, true>), dim3(pgrid), dim3(12 * 64), ldsp, stream, (int*)nullptr, AB, pair, mask,
+                           wa[0], wa[1], wa[2], wa[3], b, N, ldn, 0);
+    }
+    // 2. its contraction, transposed: O^T[c][j][i]
+    PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
+    hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1);
+    // 3. output stage of the outgoing module + a | b of the incoming one
+    if (P == 64) {
+        PRD_SET_LDS((tri_mul_out_proj_kernel<64, 8>), ldsf);
+        hipLaunchKernelGGL((tri_mul_out_proj_kernel<64, 8>), dim3(rgrid), dim3(8 * 64), ldsf, stream, pair, O, mask, wa[4], wa[5], wa[6], wa[7],
+                           wb[0], wb[1], wb[2], wb[3], AB, b, N, ldn);
+    } else {
+        PRD_SET_LDS((tri_mul_out_proj_kernel<32, 8>), ldsf);
+        hipLaunchKernelGGL((tri_mul_out_proj_kernel<32, 8>), dim3(rgrid), dim3(8 * 64), ldsf, stream, pair, O, mask, wa[4], wa[5], wa[6], wa[7],
+                           wb[0], wb[1], wb[2], wb[3], AB, b, N, ldn);
+    }
+    // 4. contraction of the incoming module
+    hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0);
+    // 5. its output stage
+    {
+        const long ntask = (long)b * N * prd_ceil_div(N, 32);
+        const int grid = grid_for(ntask, 4, 256);
+        if (P == 64) hipLaunchKernelGGL((tri_mul_out_kernel<64, 8, true>), dim3(grid), dim3(8 * 64), 0, stream, (int*)nullptr, pair, pair, O,
+                                        wb[4], wb[5], wb[6], wb[7], b, N, ldn, 1);
+        else hipLaunchKernelGGL((tri_mul_out_kernel<32, 8, true>), dim3(grid), dim3(8 * 64), 0, stream, (int*)nullptr, pair, pair, O,
+                                wb[4], wb[5], wb[6], wb[7], b, N, ldn, 1);
     }
     return (int)hipGetLastError();
 }

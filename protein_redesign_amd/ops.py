@@ -234,6 +234,27 @@ def tri_mul(pair, mask, wts, *, incoming: bool, residual: bool, out=None, ws=Non
     return out
 
 
+def tri_mul_chain_supported(N: int, P: int) -> bool:
+    """True when the fused outgoing -> incoming chain (prd_tri_mul_chain) exists for this shape in the current arithmetic mode."""
+    return lib().prd_tri_mul_chain_supported(N, P) == 1
+
+
+def tri_mul_chain_(pair, mask, wts_outgoing, wts_incoming, ws=None) -> torch.Tensor:
+    """pair += TriMul_outgoing(pair); pair += TriMul_incoming(pair), in place (modules.py:336-337), with the output stage of the
+    first and the projection stage of the second fused into one row pass (prd_tri_mul_chain; gemm mode 1)."""
+    import ctypes
+    b, N, _, P = pair.shape
+    nbytes = workspace_bytes("tri_mul", b, N, 0, P)
+    if ws is None:
+        ws = torch.empty(nbytes // 4, device=pair.device, dtype=F32)
+    arr = ctypes.c_void_p * 8
+    wa = arr(*[dptr(w) for w in wts_outgoing])
+    wb = arr(*[dptr(w) for w in wts_incoming])
+    check(lib().prd_tri_mul_chain(dptr(pair), dptr(mask), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(wb, ctypes.c_void_p),
+                                  b, N, P, dptr(ws), ws.numel() * 4, stream()), "prd_tri_mul_chain")
+    return pair
+
+
 def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
     """Gradients of the TriangleMultiplication update (ops.tri_mul with residual=False) with respect to ``pair`` and its eight
     weight tensors, on the hand-written backward kernels (csrc/prd_bwd.hip): forward recompute (projection, contraction) ->

@@ -10,6 +10,8 @@ take the node mask itself, recovered here as the diagonal of ``mask_2d``.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from argparse import Namespace
 from typing import Mapping, Optional, Tuple
@@ -152,6 +154,9 @@ class TriangleMultiplication(nn.Module):
         return self.run(pair.contiguous(), _node_mask(mask_2d), residual=False)
 
 
+_TRI_MUL_CHAIN = os.environ.get("PRD_TRI_MUL_CHAIN", "1") != "0"      # 0: two prd_tri_mul calls (A/B measurements)
+
+
 class OuterLinear(nn.Module):
     """modules.py:277-287, without the [N,N,2S] concat: W1 (x_i*x_j) + W2 x_i - W2 x_j + b."""
 
@@ -231,8 +236,11 @@ class FoldingBlock(nn.Module):
         fc = self.single_fc
         single = ops.transition_single(single, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=True)
         self.outer_linear.run(single, pair, residual=True, out=pair)
-        self.pair_mul_outgoing.run(pair, mask, residual=True, out=pair, ws=ws)
-        self.pair_mul_incoming.run(pair, mask, residual=True, out=pair, ws=ws)
+        if _TRI_MUL_CHAIN and ops.tri_mul_chain_supported(N, pair.shape[-1]):      # gemm mode 1: out-stage of the first + projection of the second fused
+            ops.tri_mul_chain_(pair, mask, self.pair_mul_outgoing.weights(), self.pair_mul_incoming.weights(), ws=ws)
+        else:
+            self.pair_mul_outgoing.run(pair, mask, residual=True, out=pair, ws=ws)
+            self.pair_mul_incoming.run(pair, mask, residual=True, out=pair, ws=ws)
         self.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)
         # ending triangle attention: core kernel, then ONE fused row pass = its output projection + the pair
         # transition + (if there is a next block) that block's attention bias

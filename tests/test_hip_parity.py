@@ -236,6 +236,41 @@ def test_triangle_multiplication(setup, mode, gemm_mode):
     assert rel_l2(got.cpu(), want) < OP_TOL
 
 
+@pytest.mark.parametrize("P,b,N", [(64, 2, 40), (32, 1, 70), (64, 1, 192)])
+def test_triangle_multiplication_chain(P, b, N):
+    """prd_tri_mul_chain (gemm mode 1): pair += outgoing(pair); pair += incoming(pair) with the output stage of the first module
+    and the projection stage of the second fused into one column-wise row pass (transposed contraction output) -- against the
+    oracle's two residual updates and against two separate prd_tri_mul calls; ragged N, masked batch element."""
+    from protein_redesign_amd import _lib
+    from protein_redesign_amd.trunk import TriangleMultiplication
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(1) == 0
+    try:
+        assert ops.tri_mul_chain_supported(N, P)
+        g = torch.Generator().manual_seed(100 + N)
+        mods = {m: TriangleMultiplication(P, m) for m in ("outgoing", "incoming")}
+        params = {}
+        for m, mod in mods.items():
+            for k, v in mod.state_dict().items():
+                params[f"{m}.{k}"] = torch.randn(v.shape, generator=g) / (math.sqrt(v.shape[-1]) if v.dim() == 2 else 3.0)
+            mod.load_state_dict({k: params[f"{m}.{k}"] for k in mod.state_dict()})
+            mod.to(DEV)
+        pair = torch.randn(b, N, N, P, generator=g)
+        mask = torch.ones(b, N)
+        mask[b - 1, N - 5:] = 0
+        m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+        want = pair + O.triangle_multiplication(params, "outgoing", pair, m2, False)
+        want = want + O.triangle_multiplication(params, "incoming", want, m2, True)
+        got = ops.tri_mul_chain_(cu(pair).clone(), cu(mask), mods["outgoing"].weights(), mods["incoming"].weights())
+        assert rel_l2(got.cpu(), want) < OP_TOL
+        sep = cu(pair).clone()
+        mods["outgoing"].run(sep, cu(mask), residual=True, out=sep)
+        mods["incoming"].run(sep, cu(mask), residual=True, out=sep)
+        assert rel_l2(got.cpu(), sep.cpu()) < 2e-6
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+
+
 @pytest.mark.parametrize("mode", ["starting", "ending"])
 def test_triangle_attention(setup, mode, gemm_mode):
     s = setup
