@@ -61,6 +61,38 @@ int main(void) {
     EXPECT(prd_reverse_update(p, p, ibuf, p, p, p, p, 0, 1, 8, 21, 10, s), PRD_ERR_ARG);
     EXPECT(prd_static_pair(p, p, p, p, ibuf, ibuf, ibuf, ibuf, p, p, p, p, p, 7, 32, 1, 8, 62, s), PRD_ERR_ALIGN);
     EXPECT(prd_time_embed(p, ibuf, p, p, 10, 1, 64, 255, s), PRD_ERR_ARG);                    /* odd time_dim */
+    /* entries added in round 2: null / unsupported arguments are refused before any HIP call */
+    EXPECT(prd_atom_embed(0, ibuf, p, p, (const int*)ibuf, 9, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_single_init(0, p, p, p, p, 8, 64, 21, s), PRD_ERR_ARG);
+    EXPECT(prd_step_boundary(0, p, ibuf, p, p, p, p, p, p, p, p, p, p, p, p, (int*)ibuf, 1, 8, 21, 10, 64, 64, 256, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_transition(0, p, p, p, p, p, 1, 1, 8, 64, 0, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_transition(p, p, p, p, p, p, 1, 1, 8, 48, 0, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn_out(0, p, p, p, p, 1, 1, 8, 64, 0, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_contract(0, p, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_contract(p, p, 1, 8, 48, s), PRD_ERR_UNSUPPORTED);
+    {
+        const float* w8[8] = {p, p, p, p, p, p, p, p};
+        const float* w7[8] = {p, p, p, 0, p, p, p, p};
+        EXPECT(prd_tri_mul_chain_supported(320, 64), 1);
+        EXPECT(prd_tri_mul_chain_supported(320, 48), 0);
+        EXPECT(prd_tri_mul_chain(0, p, w8, w8, 1, 8, 64, p, 1 << 20, s), PRD_ERR_ARG);
+        EXPECT(prd_tri_mul_chain(p, p, w8, w7, 1, 8, 64, p, 1 << 20, s), PRD_ERR_ARG);          /* a missing weight pointer */
+        EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 16, s), PRD_ERR_WORKSPACE);
+        EXPECT(prd_set_gemm_mode(0), 0);
+        EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);  /* fp32 mode has no fused chain */
+        EXPECT(prd_set_gemm_mode(1), 0);
+    }
+    EXPECT(prd_tri_mul_out_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_attn_bwd_core(0, p, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_attn_bwd_core(p, p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row beyond the LDS */
+    EXPECT(prd_ln_rows_bwd(0, p, p, 8, 64, s), PRD_ERR_ARG);
+    EXPECT((int)(prd_linear_wgrad_workspace(102400, 256, 64) != (size_t)200 * 256 * 64 * 4), 0);
+    EXPECT((int)prd_linear_wgrad_workspace(0, 256, 64), 0);
+    EXPECT(prd_linear_wgrad(0, p, p, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
+    EXPECT(prd_linear_wgrad(p, p, p, 100, 96, 64, 96, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);       /* O neither <= 16 nor a multiple of 64 */
+    EXPECT(prd_linear_wgrad(p, p, p, 100, 64, 64, 65, 64, p, 1 << 20, s), PRD_ERR_ALIGN);            /* odd row pitch */
+    EXPECT(prd_linear_wgrad(p, p, p, 100, 64, 64, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
     EXPECT((int)(prd_workspace_bytes("tri_mul", 1, 320, 512, 64) != (size_t)3 * 64 * 320 * 320 * 4), 0);
     EXPECT((int)prd_workspace_bytes("nonsense", 1, 320, 512, 64), 0);
     EXPECT((int)prd_workspace_bytes(0, 1, 320, 512, 64), 0);
