@@ -11,6 +11,8 @@ fp32 throughout (the reference trains under fp16 autocast, train.py:37; parity i
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
@@ -169,9 +171,19 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
 # the whole network (model.py:254-316), differentiable with respect to every trainable parameter
 # ---------------------------------------------------------------------------------------------------
 
+# Per-block activation checkpointing (reference modules.py:399-401).  Every operator here already saves only its INPUT and
+# recomputes its forward in its own backward, so what a block keeps without checkpointing is six pair tensors (26 MB each per
+# complex at N = 320; peak memory of a 2-complex step 1.9 -> 2.6 GB) -- nothing against 288 GB, while the checkpoint replays the
+# whole block's forward a third time (56.8 -> 52.7 ms per step).  Off by default; PRD_TRAIN_CHECKPOINT=1 restores the reference's
+# memory behaviour (same gradients either way).
+USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
+
+
 def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch.Tensor, mask: torch.Tensor, t: torch.Tensor,
-            use_checkpoint: bool = True):
+            use_checkpoint: Optional[bool] = None):
     """(noise_pred [b,N,3], seq_pred [b,N,21]) with a backward; ``model`` is a ProteinReDiffModel."""
+    if use_checkpoint is None:
+        use_checkpoint = USE_CHECKPOINT
     mask = mask.contiguous()
     den = model.Denoiser
     H = den.num_heads
