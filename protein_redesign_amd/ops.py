@@ -308,7 +308,7 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
     return dpair, grads
 
 
-def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool):
+def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=None):
     """Gradients of the TriangleAttention update (ops.tri_attn with residual=False) with respect to ``pair`` and its seven weight
     tensors on the hand-written backward (csrc/prd_bwd.hip): out-projection backward (row GEMM) -> attention core backward per
     (row, head) -> projections backward (row GEMM) -> LayerNorm backward.  Weight gradients: slab reductions over all N^2 rows
@@ -318,7 +318,8 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool):
     HC = H * c
     dev = pair.device
     dy = dy.contiguous()
-    og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending)                  # forward recompute: gated head outputs
+    if og is None:                                                                              # forward recompute: gated head outputs
+        og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending)
     dog = linear(dy, wo.t().contiguous())                                                         # d og = dy W_o
     dqkvg = torch.empty(b, N, N, 4, HC, device=dev, dtype=F32)
     check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
@@ -451,6 +452,16 @@ def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> 
     check(lib().prd_tri_attn_core(dptr(og), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
                                   b, N, P, H, c, stream()), "prd_tri_attn_core")
     return og
+
+
+def tri_attn_out(pair, og, wo, bo, *, residual: bool, out=None) -> torch.Tensor:
+    """Second launch of tri_attn alone: (residual ? pair : 0) + og W_o^T + b_o."""
+    b, N, _, P = pair.shape
+    if out is None:
+        out = torch.empty_like(pair)
+    check(lib().prd_tri_attn_out(dptr(out), dptr(pair), dptr(og), dptr(wo), dptr(bo), int(residual), b, N, P,
+                                 task_queue(pair.device), stream()), "prd_tri_attn_out")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -23,6 +23,14 @@ from . import ops
 from . import torch_ref as R
 
 
+# Per-block activation checkpointing (reference modules.py:399-401).  Every operator here already saves only its INPUT and
+# recomputes its forward in its own backward, so what a block keeps without checkpointing is six pair tensors (26 MB each per
+# complex at N = 320; peak memory of a 2-complex step 1.9 -> 2.6 GB) -- nothing against 288 GB, while the checkpoint replays the
+# whole block's forward a third time (56.8 -> 52.7 ms per step).  Off by default; PRD_TRAIN_CHECKPOINT=1 restores the reference's
+# memory behaviour (same gradients either way).
+USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
+
+
 class HipOp(torch.autograd.Function):
     """``HipOp.apply(fwd, ref, *tensors)``: ``fwd(*tensors)`` runs HIP kernels (no autograd), ``ref(*tensors)`` is the same
     operator in differentiable torch ops and is only evaluated inside ``backward``.  Both return one tensor or a tuple."""
@@ -78,16 +86,24 @@ class TriAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pair, mask, ending: bool, H: int, c: int, *wts):
         ctx.cfg = (ending, H, c)
-        ctx.save_for_backward(pair, mask, *wts)
         with torch.no_grad():
-            return ops.tri_attn(pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, residual=False)
+            p, w = pair.detach().contiguous(), [x.detach() for x in wts]
+            og = ops.tri_attn_core(p, mask, w[:5], H, c, ending=ending)
+            out = ops.tri_attn_out(p, og, w[5], w[6], residual=False)
+        # without per-block checkpointing the gated head outputs (64 floats per pair position) are kept for the backward
+        # instead of being recomputed by a second core launch
+        ctx.keep_og = not USE_CHECKPOINT
+        ctx.save_for_backward(pair, mask, *wts, *([og] if ctx.keep_og else []))
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        pair, mask, *wts = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
+        og = saved.pop() if ctx.keep_og else None
+        pair, mask, *wts = saved
         ending, H, c = ctx.cfg
         with torch.no_grad():
-            dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending)
+            dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, og=og)
         return (dpair, None, None, None, None, *grads)
 
 
@@ -170,14 +186,6 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
 # ---------------------------------------------------------------------------------------------------
 # the whole network (model.py:254-316), differentiable with respect to every trainable parameter
 # ---------------------------------------------------------------------------------------------------
-
-# Per-block activation checkpointing (reference modules.py:399-401).  Every operator here already saves only its INPUT and
-# recomputes its forward in its own backward, so what a block keeps without checkpointing is six pair tensors (26 MB each per
-# complex at N = 320; peak memory of a 2-complex step 1.9 -> 2.6 GB) -- nothing against 288 GB, while the checkpoint replays the
-# whole block's forward a third time (56.8 -> 52.7 ms per step).  Off by default; PRD_TRAIN_CHECKPOINT=1 restores the reference's
-# memory behaviour (same gradients either way).
-USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
-
 
 def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch.Tensor, mask: torch.Tensor, t: torch.Tensor,
             use_checkpoint: Optional[bool] = None):
