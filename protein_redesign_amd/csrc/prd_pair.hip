@@ -583,9 +583,11 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out
     u32x4* Wh = reinterpret_cast<u32x4*>(smem_ol);          // [2 planes][P rows][S/8 slots]
     const int SL = S / 8;
     float* bl = reinterpret_cast<float*>(Wh + 2 * P * SL);  // [P] CLL
+    PairPhaseTimer pt;
     stage_weight_h2_nat(Wh, w, P, S, 2 * S, 0, threadIdx.x, NW * 64, H2_WSCALE);
     stage_vec_cll(bl, bias, P, threadIdx.x, NW * 64);
     __syncthreads();
+    pt.mark(6);                                             // 6: prologue (W1 staging, barrier)
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const int nvb = (N + 31) / 32;
     const int npairs = nvb * (nvb + 1) / 2;                // block pairs (ib <= jb)
@@ -609,6 +611,7 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out
         const float* xj = x + ((long)bb * N + jj) * S + 8 * hi;
         f32x16 acc[NB];
         zero_acc(acc);
+        pt.mark(0);                                         // 0: task decode
         // software pipeline: the operands of K step s+1 are in flight while step s is split and multiplied
         float4 ca0 = *reinterpret_cast<const float4*>(xi), ca1 = *reinterpret_cast<const float4*>(xi + 4);
         float4 cb0 = *reinterpret_cast<const float4*>(xj), cb1 = *reinterpret_cast<const float4*>(xj + 4);
@@ -623,6 +626,7 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out
             __builtin_amdgcn_sched_barrier(0);
             ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
         }
+        pt.mark(1);                                         // 1: K loop (x_i x_j products, splits, MFMAs)
         // epilogue: (i,j) for j >= i and the mirrored (j,i) for j > i (see outer_linear_res_kernel)
         float ui[KH], uj[KH], pr[KH];
         load_row_cll<P>(u + bi * P, hi, true, ui);
@@ -633,12 +637,16 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out
 #pragma unroll
         for (int s_ = 0; s_ < KH; ++s_) pr[s_] = pr[s_] + (((acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + ui[s_]) - uj[s_]) + bl[hi * KH + s_]);
         store_row_cll<P>(out + off, hi, upper, pr);
+        pt.mark(2);                                         // 2: u / pair rows, first store
         const long offm = (((long)bb * N + jj) * N + i) * P;
         load_row_cll<P>(pair + offm, hi, mirror && residual, pr);
 #pragma unroll
         for (int s_ = 0; s_ < KH; ++s_) pr[s_] = pr[s_] + (((acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + uj[s_]) - ui[s_]) + bl[hi * KH + s_]);
         store_row_cll<P>(out + offm, hi, mirror, pr);
+        pt.mark(3);                                         // 3: mirrored pair rows + store
     }
+    pt.mark(7);
+    pt.flush();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ from protein_redesign_amd.weights import spec_tensors  # noqa: E402
 
 PHASES = {"tri_mul_contract": ["loads issue + LDS reads + MFMA", "vmcnt wait + LDS writes", "barrier"],
           "tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"],
+          "outer_linear": ["task decode", "K loop", "u / pair rows + store", "mirrored rows + store", "-", "-", "prologue", "exit"],
           "pair_tail": ["decode + load issue", "wait rows + out-projection", "LayerNorm + split", "transition GEMMs", "epilogue + stores",
                         "next attention bias", "prologue", "exit"],
           "tri_mul_out": ["decode + load issue", "wait row + LN", "gate GEMM + sigmoid", "wait O + LN", "projection GEMM",
@@ -43,7 +44,14 @@ def main():
         L.prd_set_gemm_mode(int(sys.argv[3]))
     buf = np.zeros(256 * 16 * 8 * 4, dtype=np.uint64)
     with torch.inference_mode():
-        if which == "pair_tail":
+        if which == "outer_linear":
+            single = torch.randn(1, N, 512, generator=g).cuda()
+            for _ in range(3):
+                blk.outer_linear.run(single, pair.clone(), residual=True, out=pair.clone())
+            torch.cuda.synchronize()
+            L.prd_debug_read_pair.argtypes = [ctypes.c_void_p]
+            assert L.prd_debug_read_pair(buf.ctypes.data) == 0
+        elif which == "pair_tail":
             nxt, ta, pf = m.Denoiser.folding_blocks[1], blk.pair_attn_ending.attn, blk.pair_fc
             og = torch.randn(1, N, N, 64, generator=g).cuda()
             for _ in range(3):
