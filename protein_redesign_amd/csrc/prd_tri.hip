@@ -433,26 +433,41 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
 // LDS rows are 64 B (32 fp16) per plane without padding; the 16-byte slot j of row r sits at j ^ ((r >> 2) & 3), so the
 // sixteen lanes of a ds_read_b128 group (rows distinct mod 16, same logical slot) hit sixteen different 4-bank groups.
 constexpr int TMS_T = 160, TMS_PLANE = TMS_T * 64, TMS_OPER = 2 * TMS_PLANE;       // bytes
-__global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __restrict__ O, const float* __restrict__ AB,
-                                                                     int N, int ldn, int P, int nbatch, int tiles, int swap) {
+// waves per workgroup of the split contraction: 8 by default; 16 (PRD_TMS_NW=16) makes the kernel itself 1 us faster (18.8 vs
+// 19.8 us) but the whole step 15 us slower in the same run (1.932 vs 1.918 ms, twice) -- kept as a tuning knob only
+static int tms_nw() {
+    static const int v = [] { const char* e = getenv("PRD_TMS_NW"); return (e && atoi(e) == 16) ? 16 : 8; }();
+    return v;
+}
+template <int NWV>                                  // 8 or 16 waves: 25 sub-tiles dealt round-robin, 4 or 2 accumulators per wave
+__global__ __launch_bounds__(NWV * 64) void tri_mul_contract_split_kernel(float* __restrict__ O, const float* __restrict__ AB,
+                                                                          int N, int ldn, int P, int nbatch, int tiles, int swap) {
+    constexpr int NT = NWV * 64, NPT = (2560 + NT - 1) / NT, NSUB = (25 + NWV - 1) / NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char tms[];          // [2 buffers][A | B][2 planes][160 rows][64 B]
+    PhaseTimer pt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const int nch = nbatch * P;
     const int t2 = tiles * tiles;
-    // staging: 2 x 160 rows x 8 pieces of 4 floats per chunk = 2560 pieces, 5 per thread.  Piece p = tid + 512 i:
-    // i = 0, 1 -> A rows, i = 2 -> A (waves 0-3) or B (waves 4-7), i = 3, 4 -> B rows: the operand is wave-uniform.
-    unsigned srow[5], sdst[5], ssrc[5];
+    // staging: 2 x 160 rows x 8 pieces of 4 floats per chunk = 2560 pieces, NPT per thread.  Piece p = tid + NT i; pieces
+    // below 1280 are A rows, the others B rows: 1280 is a multiple of 64, so the operand (and whether the piece exists) is
+    // wave-uniform.
+    unsigned srow[NPT], sdst[NPT], ssrc[NPT];
+    bool sisb[NPT], sok[NPT];
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);     // scalar: operand / existence of a piece are decided per wave
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int p = tid + 512 * i;
-        const int oper = p >= 1280 ? 1 : 0, q = p - 1280 * oper;
+    for (int i = 0; i < NPT; ++i) {
+        const int pw = wbase + NT * i;
+        sok[i] = pw < 2560;
+        const int oper = (sok[i] && pw >= 1280) ? 1 : 0;
+        const int pc = sok[i] ? tid + NT * i : 0;
+        const int q = pc - 1280 * oper;
         const int row = q >> 3, f = q & 7;
+        sisb[i] = oper == 1;
         srow[i] = row;
         sdst[i] = oper * TMS_OPER + row * 64 + (((f >> 1) ^ ((row >> 2) & 3)) << 4) + (f & 1) * 8;
         ssrc[i] = ((unsigned)row * ldn + 4 * f) * 4u;
     }
-    const bool mid_is_b = wave >= 4;
     const unsigned swz = (unsigned)((r >> 2) & 3);
     for (int vblk = blockIdx.x; vblk < nch * t2; vblk += gridDim.x) {
         int ch, tile;
@@ -471,36 +486,31 @@ __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __re
         const float* __restrict__ A = AB + ((size_t)bb * 2 * P + (swap ? P : 0) + d) * N * ldn;
         const float* __restrict__ B = AB + ((size_t)bb * 2 * P + (swap ? 0 : P) + d) * N * ldn;
         const prd_rsrc ra = make_rsrc(A + (size_t)m0 * ldn), rb = make_rsrc(B + (size_t)n0 * ldn);
-        const prd_rsrc rmid = mid_is_b ? rb : ra;
-        unsigned off[5];
+        unsigned off[NPT];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const bool isb = i > 2 || (i == 2 && mid_is_b);
-            off[i] = ((isb ? n0 : m0) + (int)srow[i] < N) ? ssrc[i] : BUF_OOB;        // rows past the edge load zeros
-        }
-        // sub-tiles of this wave: s = wave + 8 k (k < 4) of the 5 x 5 grid, skipped when outside the matrix
-        int si[4], sj[4];
-        bool sv[4];
+        for (int i = 0; i < NPT; ++i)
+            off[i] = (sok[i] && (sisb[i] ? n0 : m0) + (int)srow[i] < N) ? ssrc[i] : BUF_OOB;      // rows past the edge load zeros
+        // sub-tiles of this wave: s = wave + NWV k (k < NSUB) of the 5 x 5 grid, skipped when outside the matrix
+        int si[NSUB], sj[NSUB];
+        bool sv[NSUB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int s_ = wave + 8 * k;
+        for (int k = 0; k < NSUB; ++k) {
+            const int s_ = wave + NWV * k;
             si[k] = s_ / 5;
             sj[k] = s_ - 5 * si[k];
             sv[k] = s_ < 25 && m0 + 32 * si[k] < N && n0 + 32 * sj[k] < N;
         }
-        f32x16 acc[4];
+        f32x16 acc[NSUB];
         zero_acc(acc);
         const int nchunk = ldn / 32;
-        u32x4 u[5], v[5];
+        u32x4 u[NPT], v[NPT];
 #define PRD_TMS_LOAD(R, C)                                                                                          \
-    R[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[0], (C) * 128, 0));              \
-    R[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[1], (C) * 128, 0));              \
-    R[2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rmid, off[2], (C) * 128, 0));            \
-    R[3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[3], (C) * 128, 0));              \
-    R[4] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[4], (C) * 128, 0));
+    _Pragma("unroll") for (int i = 0; i < NPT; ++i)                                                                 \
+        R[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sisb[i] ? rb : ra, off[i], (C) * 128, 0));
         // four fp32 values -> two planes of four fp16 (8 bytes each)
 #define PRD_TMS_STAGE(R, BUF)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NPT; ++i) {                                                               \
+        if (!sok[i]) continue;                                                                                      \
         unsigned h0, l0, h1, l1;                                                                                    \
         split2h(__uint_as_float(R[i][0]), __uint_as_float(R[i][1]), h0, l0);                                        \
         split2h(__uint_as_float(R[i][2]), __uint_as_float(R[i][3]), h1, l1);                                        \
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __re
         const unsigned char* base = tms + (CUR) * 2 * TMS_OPER;                                                     \
         _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                          \
             const unsigned col = (((unsigned)(2 * st + hi)) ^ swz) << 4;                                            \
-            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                         \
+            _Pragma("unroll") for (int k = 0; k < NSUB; ++k) {                                                      \
                 if (sv[k]) {                                                                                        \
                     const unsigned char* ap = base + (32 * si[k] + r) * 64 + col;                                   \
                     const unsigned char* bp = base + TMS_OPER + (32 * sj[k] + r) * 64 + col;                        \
@@ -531,9 +541,13 @@ __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __re
                 }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
+        pt.mark(0);                                     /* 0: load issue + LDS reads + MFMAs */                     \
         if ((C) + 1 < nchunk) { PRD_TMS_STAGE(R, (CUR) ^ 1) }                                                       \
+        pt.mark(1);                                     /* 1: wait for the next chunk + split + LDS writes */       \
         __syncthreads();                                                                                            \
+        pt.mark(2);                                     /* 2: barrier */                                            \
     }
+        pt.mark(6);                                     // 6: tile decode (and, for the first tile, kernel entry)
         PRD_TMS_LOAD(u, 0)
         PRD_TMS_STAGE(u, 0)
         {
@@ -541,6 +555,7 @@ __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __re
             PRD_TMS_LOAD(u, c1)
         }
         __syncthreads();
+        pt.mark(3);                                     // 3: first chunk: exposed load latency + staging
         for (int c = 0; c < nchunk; c += 2) {
             PRD_TMS_CHUNK(c, 0, u, v)
             if (c + 1 < nchunk) PRD_TMS_CHUNK(c + 1, 1, v, u)
@@ -550,7 +565,7 @@ __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __re
 #undef PRD_TMS_CHUNK
         float* __restrict__ Oc = O + (size_t)ch * N * ldn;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NSUB; ++k) {
             if (!sv[k]) continue;
             const int n = n0 + 32 * sj[k] + r;
             if (n < N) {
@@ -561,7 +576,9 @@ __global__ __launch_bounds__(512) void tri_mul_contract_split_kernel(float* __re
                 }
             }
         }
+        pt.mark(4);                                     // 4: output stores
     }   // virtual blocks
+    pt.flush(3);
 }
 
 template <int P, int NW, bool B3>
@@ -2071,8 +2088,8 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
             const int tl = prd_ceil_div(N, TMS_T);
             const int vb3 = b * P * tl * tl;
             const size_t lds3 = (size_t)4 * TMS_OPER;
-            PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
-            hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0);
+                        if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
         }
         else
             hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
@@ -2102,8 +2119,8 @@ extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int
         const int tl = prd_ceil_div(N, TMS_T);
         const int vb3 = b * P * tl * tl;
         const size_t lds3 = (size_t)4 * TMS_OPER;
-        PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
-        hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0);
+                if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     } else {
         const int tiles = prd_ceil_div(N, 64);
         const int vblocks = b * P * tiles * tiles;
@@ -2148,8 +2165,8 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
                            wa[0], wa[1], wa[2], wa[3], b, N, ldn, 0);
     }
     // 2. its contraction, transposed: O^T[c][j][i]
-    PRD_SET_LDS(tri_mul_contract_split_kernel, lds3);
-    hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1);
+        if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
+    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     // 3. output stage of the outgoing module + a | b of the incoming one
     if (P == 64) {
         PRD_SET_LDS((tri_mul_out_proj_kernel<64, 8>), ldsf);
@@ -2161,7 +2178,8 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
                            wb[0], wb[1], wb[2], wb[3], AB, b, N, ldn);
     }
     // 4. contraction of the incoming module
-    hipLaunchKernelGGL(tri_mul_contract_split_kernel, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0);
+    if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     // 5. its output stage
     {
         const long ntask = (long)b * N * prd_ceil_div(N, 32);

@@ -15,7 +15,8 @@ from protein_redesign_amd.diffusion_model import ProteinReDiffModel  # noqa: E40
 from protein_redesign_amd.synthetic import deterministic_state_dict  # noqa: E402
 from protein_redesign_amd.weights import spec_tensors  # noqa: E402
 
-PHASES = {"tri_mul_contract": ["loads issue + LDS reads + MFMA", "vmcnt wait + LDS writes", "barrier"],
+PHASES = {"tri_mul_contract": ["load issue + LDS reads + MFMA", "wait next chunk + split + LDS writes", "barrier", "first chunk (exposed)",
+                               "output stores", "-", "tile decode"],
           "tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"],
           "outer_linear": ["task decode", "K loop", "u / pair rows + store", "mirrored rows + store", "-", "-", "prologue", "exit"],
           "pair_tail": ["decode + load issue", "wait rows + out-projection", "LayerNorm + split", "transition GEMMs", "epilogue + stores",
@@ -39,7 +40,7 @@ def main():
     L = _lib.lib()
     L.prd_debug_read.argtypes = [ctypes.c_void_p]
     L.prd_debug_select.argtypes = [ctypes.c_int]
-    assert L.prd_debug_select({"tri_mul_proj": 1, "tri_mul_out": 2}.get(which, 0)) == 0
+    assert L.prd_debug_select({"tri_mul_proj": 1, "tri_mul_out": 2, "tri_mul_contract": 3}.get(which, 0)) == 0
     if len(sys.argv) > 3:
         L.prd_set_gemm_mode(int(sys.argv[3]))
     buf = np.zeros(256 * 16 * 8 * 4, dtype=np.uint64)
@@ -68,7 +69,7 @@ def main():
     t = buf[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64)
     if which == "tri_mul_contract":
         t = buf[: 256 * 16 * 8].reshape(256, 16, 8).astype(np.float64)
-    nw = 4 if which == "tri_mul_contract" else int((t.sum(axis=(0, 2)) > 0).sum())
+    nw = int((t.sum(axis=(0, 2)) > 0).sum())
     t = t[:, :nw, : len(PHASES[which])]
     tot = t.sum(axis=2)
     print(f"{which}: N={N}, {nw} waves/WG; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
