@@ -188,9 +188,10 @@ int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, 
 /* Weight gradient of a linear applied at every pair position (autograd of nn.Linear over [b,N,N,*] activations, e.g.
  * modules.py:262-274, 321-326): dw[O][I] = sum over rows of dy[row][0..O) (x) x[row][0..I); row pitches lddy / ldx floats (even).
  * I a multiple of 64, O a multiple of 64 or at most 16 (the attention-bias / coordinate-head linears), both at most 256.
+ * db (optional, NULL = skip): the bias gradient db[O] = sum over rows of dy, from the same pass over dy.
  * ws: prd_linear_wgrad_workspace(rows, O, I) bytes of slab partials. */
 size_t prd_linear_wgrad_workspace(long long rows, int O, int I);
-int prd_linear_wgrad(float* dw, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
+int prd_linear_wgrad(float* dw, float* db, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
                      float* ws, size_t ws_bytes, hipStream_t stream);
 
 /* TriangleAttention (modules.py:236-243 -> 185-225): out = (residual ? pair : 0) + update(pair).

@@ -59,7 +59,7 @@ SIGNATURES = {
     "prd_tri_attn_bwd_core": [vp] * 9 + [ci] * 6 + [vp],
     "prd_ln_rows_bwd": [vp, vp, vp, cll, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
-    "prd_linear_wgrad": [vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],
+    "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, vp],

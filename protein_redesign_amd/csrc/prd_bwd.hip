@@ -508,9 +508,11 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dx
 // order (deterministic, no atomics).
 template <int NBLK>                                     // 64x64 blocks of dW per workgroup: 1, 2 or 4 (4 / NBLK waves per block)
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ part, const float* __restrict__ dy, const float* __restrict__ x,
-                                                           long rows, int O, int I, int lddy, int ldx, int rows_per_wg) {
+                                                           long rows, int O, int I, int lddy, int ldx, int rows_per_wg, int want_db) {
     constexpr int WPB = 4 / NBLK, U = 8;
     __shared__ float red[WPB > 1 ? 4 : 1][64][64];
+    __shared__ float redb[4][2][32];                        // column sums of dy (the bias gradient) of the waves of a block
+    const int pn = O * I + (want_db ? O : 0);               // floats per slab partial: dW, then db
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
     const int ibn = I / 64;
     const int blk = blockIdx.y * NBLK + wave / WPB, sub = wave % WPB;
@@ -526,6 +528,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ p
         for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[ea][eb][q] = 0.f;
+    float sdb0 = 0.f, sdb1 = 0.f;                           // db partial of columns ob * 64 + 2 r, + 1 (rows of this lane's parity)
     float2 ca[U], cb[U], na[U], nb[U];
     auto load = [&](float2 (&a)[U], float2 (&b)[U], long row) {
 #pragma unroll
@@ -550,6 +553,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ p
             acc[0][1] = mfma32(ca[u].x, cb[u].y, acc[0][1]);
             acc[1][0] = mfma32(ca[u].y, cb[u].x, acc[1][0]);
             acc[1][1] = mfma32(ca[u].y, cb[u].y, acc[1][1]);
+            sdb0 += ca[u].x;
+            sdb1 += ca[u].y;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -572,8 +577,20 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ p
                     for (int q = 0; q < 16; ++q) acc[e >> 1][e & 1][q] += red[wave + w][e * 16 + q][lane];
         }
     }
+    if (want_db && ib == 0) {                               // block-uniform per wave; the waves of a block add up in wave order
+        sdb0 += __shfl_xor(sdb0, 32);
+        sdb1 += __shfl_xor(sdb1, 32);
+        if (hi == 0) { redb[wave][0][r] = sdb0; redb[wave][1][r] = sdb1; }
+    }
+    if (want_db) __syncthreads();
+    if (want_db && ib == 0 && sub == 0 && hi == 0) {
+        float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) { b0 += redb[wave + w][0][r]; b1 += redb[wave + w][1][r]; }
+        *reinterpret_cast<float2*>(part + (size_t)blockIdx.x * pn + (size_t)O * I + ob * 64 + 2 * r) = make_float2(b0, b1);
+    }
     if (sub == 0) {
-        float* pt = part + (size_t)blockIdx.x * O * I;
+        float* pt = part + (size_t)blockIdx.x * pn;
 #pragma unroll
         for (int ea = 0; ea < 2; ++ea)
 #pragma unroll
@@ -588,8 +605,13 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ p
 // model.py:364-369): one lane per input column, the O values of dy per row broadcast, rows dealt to slabs and to the four waves.
 template <int OMAX>
 __global__ __launch_bounds__(256) void linear_wgrad_narrow_kernel(float* __restrict__ part, const float* __restrict__ dy, const float* __restrict__ x,
-                                                                  long rows, int O, int I, int lddy, int ldx, int rows_per_wg) {
+                                                                  long rows, int O, int I, int lddy, int ldx, int rows_per_wg, int want_db) {
     __shared__ float red[4][OMAX][64];
+    __shared__ float redb[4][OMAX];
+    const int pn = O * I + (want_db ? O : 0);
+    float sdb[OMAX];
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) sdb[o] = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.y * 64 + lane;
     const long r0 = (long)blockIdx.x * rows_per_wg;
@@ -607,23 +629,34 @@ __global__ __launch_bounds__(256) void linear_wgrad_narrow_kernel(float* __restr
             const float* dr = dy + (row + u < r1 ? row + u : r1 - 1) * lddy;         // wave-uniform address: a broadcast load
 #pragma unroll
             for (int o = 0; o < OMAX; ++o)
-                if (o < O) acc[o] += dr[o] * xv[u];
+                if (o < O) {
+                    const float dv = dr[o];
+                    acc[o] += dv * xv[u];
+                    sdb[o] += (row + u < r1) ? dv : 0.f;        // the same value in every lane
+                }
         }
+    }
+    if (want_db && blockIdx.y == 0) {
+        if (lane == 0)
+#pragma unroll
+            for (int o = 0; o < OMAX; ++o) redb[wave][o] = sdb[o];
     }
 #pragma unroll
     for (int o = 0; o < OMAX; ++o) red[wave][o][lane] = acc[o];
     __syncthreads();
     if (wave == 0) {
-        float* pt = part + (size_t)blockIdx.x * O * I;
+        float* pt = part + (size_t)blockIdx.x * pn;
 #pragma unroll
         for (int o = 0; o < OMAX; ++o)
             if (o < O) pt[(size_t)o * I + i] = ((red[0][o][lane] + red[1][o][lane]) + red[2][o][lane]) + red[3][o][lane];
+        if (want_db && blockIdx.y == 0 && lane < O) pt[(size_t)O * I + lane] = ((redb[0][lane] + redb[1][lane]) + redb[2][lane]) + redb[3][lane];
     }
 }
 
 // 64 elements per workgroup, the slabs dealt in four contiguous quarters to the four waves (eight loads in flight per lane),
 // quarter sums combined in wave order: the summation order is fixed.
-__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, int n, int slabs) {
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ part,
+                                                                  int n, int nw, int slabs) {     // n floats per slab: nw of dW, then db
     __shared__ float qs[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
@@ -642,7 +675,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restr
     }
     qs[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && e < n) dw[e] = ((qs[0][lane] + qs[1][lane]) + qs[2][lane]) + qs[3][lane];
+    if (wave == 0 && e < n) {
+        const float v = ((qs[0][lane] + qs[1][lane]) + qs[2][lane]) + qs[3][lane];
+        if (e < nw) dw[e] = v;
+        else db[e - nw] = v;
+    }
 }
 
 }  // namespace
@@ -727,14 +764,17 @@ extern "C" int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long 
     return (int)hipGetLastError();
 }
 
-extern "C" size_t prd_linear_wgrad_workspace(long long rows, int O, int I) {
-    if (rows <= 0 || O <= 0 || I <= 0) return 0;
-    long slabs = rows / 512 < 256 ? (rows + 511) / 512 : 256;
-    if (slabs < 1) slabs = 1;
-    return (size_t)slabs * O * I * sizeof(float);
+static long wgrad_slabs(long long rows) {
+    long slabs = rows / 512 < 256 ? (long)((rows + 511) / 512) : 256;
+    return slabs < 1 ? 1 : slabs;
 }
 
-extern "C" int prd_linear_wgrad(float* dw, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
+extern "C" size_t prd_linear_wgrad_workspace(long long rows, int O, int I) {
+    if (rows <= 0 || O <= 0 || I <= 0) return 0;
+    return (size_t)wgrad_slabs(rows) * ((size_t)O * I + O) * sizeof(float);        // dW and db partials of every slab
+}
+
+extern "C" int prd_linear_wgrad(float* dw, float* db, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
                                 float* ws, size_t ws_bytes, hipStream_t stream) {
     if (!dw || !dy || !x || !ws || rows <= 0 || O <= 0 || I <= 0) return PRD_ERR_ARG;
     const bool narrow = O <= 16;
@@ -742,24 +782,22 @@ extern "C" int prd_linear_wgrad(float* dw, const float* dy, const float* x, long
     if (!narrow && ((lddy & 1) || (ldx & 1))) return PRD_ERR_ALIGN;
     if (lddy < O || ldx < I) return PRD_ERR_ARG;
     if (ws_bytes < prd_linear_wgrad_workspace(rows, O, I)) return PRD_ERR_WORKSPACE;
-    const long slabs = (long)(prd_linear_wgrad_workspace(rows, O, I) / ((size_t)O * I * sizeof(float)));
+    const long slabs = wgrad_slabs(rows);
     const int rows_per_wg = (int)((rows + slabs - 1) / slabs);
+    const int want_db = db ? 1 : 0;
+    const int nw = O * I, n = nw + (want_db ? O : 0);
     if (narrow) {
         dim3 grid((unsigned)slabs, I / 64);
-        if (O <= 4) hipLaunchKernelGGL(linear_wgrad_narrow_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
-        else hipLaunchKernelGGL(linear_wgrad_narrow_kernel<16>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
-        const int n = O * I;
-        hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dw, ws, n, (int)slabs);
-        return (int)hipGetLastError();
+        if (O <= 4) hipLaunchKernelGGL(linear_wgrad_narrow_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+        else hipLaunchKernelGGL(linear_wgrad_narrow_kernel<16>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+    } else {
+        const int nblk = (O / 64) * (I / 64);
+        const int per = (nblk % 4 == 0) ? 4 : ((nblk % 2 == 0) ? 2 : 1);     // 64x64 blocks per workgroup
+        dim3 grid((unsigned)slabs, nblk / per);
+        if (per == 4) hipLaunchKernelGGL(linear_wgrad_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+        else if (per == 2) hipLaunchKernelGGL(linear_wgrad_kernel<2>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+        else hipLaunchKernelGGL(linear_wgrad_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
     }
-    const int nblk = (O / 64) * (I / 64);
-    const int per = (nblk % 4 == 0) ? 4 : ((nblk % 2 == 0) ? 2 : 1);     // 64x64 blocks per workgroup
-    dim3 grid((unsigned)slabs, nblk / per);
-    if (per == 4) hipLaunchKernelGGL(linear_wgrad_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
-    else if (per == 2) hipLaunchKernelGGL(linear_wgrad_kernel<2>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
-    else if (per == 1) hipLaunchKernelGGL(linear_wgrad_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg);
-    else return PRD_ERR_UNSUPPORTED;
-    const int n = O * I;
-    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dw, ws, n, (int)slabs);
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dw, db, ws, n, nw, (int)slabs);
     return (int)hipGetLastError();
 }

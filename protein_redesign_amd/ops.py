@@ -303,8 +303,8 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
     x = layer_norm(pair.contiguous()).view(-1, P)
     lo = layer_norm(O[..., :N].permute(0, 2, 3, 1).contiguous()).view(-1, P)
     dz2, dgp2, dpp2, dpg2 = dz.view(-1, P), dgp.view(-1, P), dpp.view(-1, 2 * P), dpg.view(-1, 2 * P)
-    grads = (linear_wgrad(dpp2, x), dpp2.sum(0), linear_wgrad(dpg2, x), dpg2.sum(0), linear_wgrad(dz2, lo), dz2.sum(0),
-             linear_wgrad(dgp2, x), dgp2.sum(0))
+    grads = (*linear_wgrad(dpp2, x, bias=True), *linear_wgrad(dpg2, x, bias=True), *linear_wgrad(dz2, lo, bias=True),
+             *linear_wgrad(dgp2, x, bias=True))
     return dpair, grads
 
 
@@ -331,19 +331,19 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
     x = layer_norm(pair.contiguous()).view(-1, P)
     d2 = dqkvg.view(-1, 4, HC)
     dy2 = dy.view(-1, P)
-    dw4 = linear_wgrad(dqkvg.view(-1, 4 * HC), x)                                               # d W_q | W_k | W_v | W_g stacked [4 HC, P]
-    grads = (dw4[:HC], dw4[HC:2 * HC], dw4[2 * HC:3 * HC], dw4[3 * HC:], d2[:, 3].sum(0), linear_wgrad(dy2, og.view(-1, HC)), dy2.sum(0))
+    dw4, db4 = linear_wgrad(dqkvg.view(-1, 4 * HC), x, bias=True)                                # d W_q | W_k | W_v | W_g stacked [4 HC, P]
+    grads = (dw4[:HC], dw4[HC:2 * HC], dw4[2 * HC:3 * HC], dw4[3 * HC:], db4[3 * HC:], *linear_wgrad(dy2, og.view(-1, HC), bias=True))
     return dpair, grads
 
 
 WGRAD_MIN_ROWS = 8192
 
 
-def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor, bias: bool = False):
     """dW [O, I] = dy2^T x2 for row-major 2-D views dy2 [rows, O] and x2 [rows, I] (row stride = their stride(0), unit column
-    stride): the weight gradient of a linear applied at every pair position.  Hand-written slab reduction
-    (prd_linear_wgrad) for the shapes it covers -- rows >= 8192, I a multiple of 64, O a multiple of 64 or at most 16, both up to 256 --
-    else a library GEMM."""
+    stride): the weight gradient of a linear applied at every pair position; with ``bias`` also db [O] = column sums of dy2 from the
+    same pass -> (dW, db).  Hand-written slab reduction (prd_linear_wgrad) for the shapes it covers -- rows >= 8192, I a multiple of
+    64, O a multiple of 64 or at most 16, both up to 256 -- else a library GEMM."""
     rows, O = dy2.shape
     I = x2.shape[1]
     wide = (O % 64 == 0 and dy2.stride(0) % 2 == 0 and x2.stride(0) % 2 == 0 and dy2.storage_offset() % 2 == 0
@@ -351,13 +351,14 @@ def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     if (rows >= WGRAD_MIN_ROWS and (wide or O <= 16) and I % 64 == 0 and O <= 256 and I <= 256 and dy2.stride(1) == 1
             and x2.stride(1) == 1):
         dw = torch.empty(O, I, device=dy2.device, dtype=F32)
+        db = torch.empty(O, device=dy2.device, dtype=F32) if bias else None
         nbytes = lib().prd_linear_wgrad_workspace(rows, O, I)
         ws = torch.empty(nbytes // 4, device=dy2.device, dtype=F32)
-        check(lib().prd_linear_wgrad(dptr(dw), dy2.data_ptr(), x2.data_ptr(), rows, O, I, dy2.stride(0), x2.stride(0), dptr(ws), nbytes, stream()),
-              "prd_linear_wgrad")
-        return dw
-    return dy2.t() @ x2
-
+        check(lib().prd_linear_wgrad(dptr(dw), dptr(db), dy2.data_ptr(), x2.data_ptr(), rows, O, I, dy2.stride(0), x2.stride(0),
+                                     dptr(ws), nbytes, stream()), "prd_linear_wgrad")
+        return (dw, db) if bias else dw
+    dw = dy2.t() @ x2
+    return (dw, dy2.sum(0)) if bias else dw
 
 
 def tri_attn_uses_long_rows(N: int, P: int) -> bool:

@@ -38,8 +38,13 @@ class _PairLinear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         dx = (dy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_wgrad(dy2, x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
-        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            got = ops.linear_wgrad(dy2, x.reshape(-1, x.shape[-1]), bias=want_db)
+            dw, db = got if want_db else (got, None)
+        elif want_db:
+            db = dy2.sum(0)
         return dx, dw, db
 
 

@@ -87,12 +87,12 @@ int main(void) {
     EXPECT(prd_tri_attn_bwd_core(0, p, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(p, p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row beyond the LDS */
     EXPECT(prd_ln_rows_bwd(0, p, p, 8, 64, s), PRD_ERR_ARG);
-    EXPECT((int)(prd_linear_wgrad_workspace(102400, 256, 64) != (size_t)200 * 256 * 64 * 4), 0);
+    EXPECT((int)(prd_linear_wgrad_workspace(102400, 256, 64) != (size_t)200 * (256 * 64 + 256) * 4), 0);
     EXPECT((int)prd_linear_wgrad_workspace(0, 256, 64), 0);
-    EXPECT(prd_linear_wgrad(0, p, p, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
-    EXPECT(prd_linear_wgrad(p, p, p, 100, 96, 64, 96, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);       /* O neither <= 16 nor a multiple of 64 */
-    EXPECT(prd_linear_wgrad(p, p, p, 100, 64, 64, 65, 64, p, 1 << 20, s), PRD_ERR_ALIGN);            /* odd row pitch */
-    EXPECT(prd_linear_wgrad(p, p, p, 100, 64, 64, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_linear_wgrad(0, p, p, p, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
+    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 96, 64, 96, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);       /* O neither <= 16 nor a multiple of 64 */
+    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 65, 64, p, 1 << 20, s), PRD_ERR_ALIGN);            /* odd row pitch */
+    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
     EXPECT((int)(prd_workspace_bytes("tri_mul", 1, 320, 512, 64) != (size_t)3 * 64 * 320 * 320 * 4), 0);
     EXPECT((int)prd_workspace_bytes("nonsense", 1, 320, 512, 64), 0);
     EXPECT((int)prd_workspace_bytes(0, 1, 320, 512, 64), 0);

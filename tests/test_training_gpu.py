@@ -177,5 +177,8 @@ def test_linear_weight_gradient_kernel(rows, O, I):
     want = (dy.double().t() @ x.double())
     err = (got.double() - want).norm() / want.norm()
     assert got.shape == (O, I) and err < 2e-6, err
+    got2, db = ops.linear_wgrad(dy, x, bias=True)      # the bias gradient from the same pass
+    wantb = dy.double().sum(0)
+    assert db.shape == (O,) and (db.double() - wantb).norm() / wantb.norm() < 2e-6
     if rows >= ops.WGRAD_MIN_ROWS:                      # bit-reproducible (no atomics)
-        assert torch.equal(got, ops.linear_wgrad(dy, x))
+        assert torch.equal(got, ops.linear_wgrad(dy, x)) and torch.equal(got, got2)
