@@ -135,6 +135,12 @@ int prd_pair_init(float* pair, const float* static_pair, const float* z, const f
  * models/AF2_modules.py:406-411,454-459 with LN affine gamma/beta and no bias). */
 int prd_pair_bias(float* bias_out, const float* pair, const float* gamma, const float* beta,
                   const float* w, const float* bvec, int b, int N, int P, int H, hipStream_t stream);
+/* Two bias head sets from ONE pass over the pair tensor (same rows, same LayerNorm statistics): SPAttention's pair bias
+ * (AF2_modules.py:454-459) and the first folding block's attention bias (modules.py:300-304) both read the pair tensor that the
+ * outer-product update leaves.  Arguments as for prd_pair_bias, per set. */
+int prd_pair_bias2(float* bias_a, const float* pair, const float* gamma_a, const float* beta_a, const float* w_a,
+                   const float* bvec_a, int Ha, float* bias_b, const float* gamma_b, const float* beta_b, const float* w_b,
+                   const float* bvec_b, int Hb, int b, int N, int P, hipStream_t stream);
 /* OuterProductUpdate tail (models/AF2_modules.py:532-545 + modules.py:395-397):
  * out[i,j,:] = (flags&1 ? pair : 0) + (flags&2 ? m_i m_j : 1) * (W_o (a_i * b_j) + b_o) / (m_i m_j + 1e-3);
  * ab = [a | b] of shape [b,N,2C].  `out` may alias `pair` (in-place residual update), here and below. */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "prd_time_embed": [vp] * 4 + [ci] * 4 + [vp],
     "prd_pair_init": [vp] * 7 + [ci] * 4 + [vp],
     "prd_pair_bias": [vp] * 6 + [ci] * 4 + [vp],
+    "prd_pair_bias2": [vp] * 6 + [ci] + [vp] * 5 + [ci] * 4 + [vp],
     "prd_opm_pair": [vp] * 6 + [ci] * 5 + [vp],
     "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp, vp],
     "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, vp],

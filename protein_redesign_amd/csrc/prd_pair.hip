@@ -320,35 +320,51 @@ template <int P>
 __global__ __launch_bounds__(WG) void pair_bias_kernel(float* __restrict__ out, const float* __restrict__ pair,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ w, const float* __restrict__ bvec,
+                                                       float* __restrict__ out2, const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                       const float* __restrict__ w2, const float* __restrict__ bvec2, int H2,
                                                        int b, int N, int H) {
+    // (out2 != NULL: a second head set on the same normalised rows -- SPAttention's pair bias and the first folding block's
+    // attention bias are both functions of the pair tensor after the outer-product update)
     constexpr int KH = P / 2;
-    __shared__ __attribute__((aligned(16))) float wl[8 * P];
-    __shared__ __attribute__((aligned(16))) float gl[P];
-    __shared__ __attribute__((aligned(16))) float bl[P];
-    for (int h = 0; h < H; ++h) stage_vec_cll(wl + h * P, w + h * P, P, threadIdx.x, WG);
-    stage_vec_cll(gl, gamma, P, threadIdx.x, WG);
-    stage_vec_cll(bl, beta, P, threadIdx.x, WG);
+    __shared__ __attribute__((aligned(16))) float wl[2][8 * P];
+    __shared__ __attribute__((aligned(16))) float gl[2][P];
+    __shared__ __attribute__((aligned(16))) float bl[2][P];
+    for (int h = 0; h < H; ++h) stage_vec_cll(wl[0] + h * P, w + h * P, P, threadIdx.x, WG);
+    stage_vec_cll(gl[0], gamma, P, threadIdx.x, WG);
+    stage_vec_cll(bl[0], beta, P, threadIdx.x, WG);
+    if (out2) {
+        for (int h = 0; h < H2; ++h) stage_vec_cll(wl[1] + h * P, w2 + h * P, P, threadIdx.x, WG);
+        stage_vec_cll(gl[1], gamma2, P, threadIdx.x, WG);
+        stage_vec_cll(bl[1], beta2, P, threadIdx.x, WG);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const long nn = (long)N * N, rows = (long)b * nn, ntask = (rows + 31) / 32;
     for (long task = (long)blockIdx.x * 4 + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * 4) {
         const long pos = task * 32 + r;
         const bool valid = pos < rows;
-        float x[KH];
-        load_row_cll<P>(pair + pos * P, hi, valid, x);
-        ln_cll<KH>(x);
-        if (gamma) {
-#pragma unroll
-            for (int s = 0; s < KH; ++s) x[s] = x[s] * gl[hi * KH + s] + bl[hi * KH + s];
-        }
+        float xn[KH];
+        load_row_cll<P>(pair + pos * P, hi, valid, xn);
+        ln_cll<KH>(xn);
         const long bb = pos / nn, rem = pos - bb * nn;
-        for (int h = 0; h < H; ++h) {
-            float acc = 0.f;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) acc += x[s] * wl[h * P + hi * KH + s];
-            acc = xhalf_sum(acc);
-            if (bvec) acc += bvec[h];
-            if (valid && hi == 0) out[(bb * H + h) * nn + rem] = acc;
+        for (int set = 0; set < 2; ++set) {
+            if (set == 1 && !out2) break;
+            const float* ga = set ? gamma2 : gamma;
+            const float* bv = set ? bvec2 : bvec;
+            float* o = set ? out2 : out;
+            const int nh = set ? H2 : H;
+            float x[KH];
+#pragma unroll
+            for (int s = 0; s < KH; ++s) x[s] = ga ? xn[s] * gl[set][hi * KH + s] + bl[set][hi * KH + s] : xn[s];
+            for (int h = 0; h < nh; ++h) {
+                float acc = 0.f;
+#pragma unroll
+                for (int s = 0; s < KH; ++s) acc += x[s] * wl[set][h * P + hi * KH + s];
+                acc = xhalf_sum(acc);
+                if (bv) acc += bv[h];
+                if (valid && hi == 0) o[(bb * nh + h) * nn + rem] = acc;
+            }
         }
     }
 }
@@ -1356,8 +1372,24 @@ extern "C" int prd_pair_bias(float* bias_out, const float* pair, const float* ga
     PRD_CHECK_P(P);
     const long ntask = ((long)b * N * N + 31) / 32;
     const int grid = grid_for(ntask, 4, 2048);
-    if (P == 64) hipLaunchKernelGGL(pair_bias_kernel<64>, dim3(grid), dim3(WG), 0, stream, bias_out, pair, gamma, beta, w, bvec, b, N, H);
-    else hipLaunchKernelGGL(pair_bias_kernel<32>, dim3(grid), dim3(WG), 0, stream, bias_out, pair, gamma, beta, w, bvec, b, N, H);
+    const float* nul = nullptr;
+    if (P == 64) hipLaunchKernelGGL(pair_bias_kernel<64>, dim3(grid), dim3(WG), 0, stream, bias_out, pair, gamma, beta, w, bvec, (float*)nullptr, nul, nul, nul, nul, 0, b, N, H);
+    else hipLaunchKernelGGL(pair_bias_kernel<32>, dim3(grid), dim3(WG), 0, stream, bias_out, pair, gamma, beta, w, bvec, (float*)nullptr, nul, nul, nul, nul, 0, b, N, H);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_pair_bias2(float* bias_a, const float* pair, const float* gamma_a, const float* beta_a, const float* w_a,
+                              const float* bvec_a, int Ha, float* bias_b, const float* gamma_b, const float* beta_b, const float* w_b,
+                              const float* bvec_b, int Hb, int b, int N, int P, hipStream_t stream) {
+    if (!bias_a || !bias_b || !pair || !w_a || !w_b || b <= 0 || N <= 0 || Ha <= 0 || Ha > 8 || Hb <= 0 || Hb > 8 ||
+        (gamma_a && !beta_a) || (gamma_b && !beta_b)) return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    const long ntask = ((long)b * N * N + 31) / 32;
+    const int grid = grid_for(ntask, 4, 2048);
+    if (P == 64) hipLaunchKernelGGL(pair_bias_kernel<64>, dim3(grid), dim3(WG), 0, stream, bias_a, pair, gamma_a, beta_a, w_a, bvec_a,
+                                    bias_b, gamma_b, beta_b, w_b, bvec_b, Hb, b, N, Ha);
+    else hipLaunchKernelGGL(pair_bias_kernel<32>, dim3(grid), dim3(WG), 0, stream, bias_a, pair, gamma_a, beta_a, w_a, bvec_a,
+                            bias_b, gamma_b, beta_b, w_b, bvec_b, Hb, b, N, Ha);
     return (int)hipGetLastError();
 }
 

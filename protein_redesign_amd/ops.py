@@ -197,6 +197,18 @@ def pair_bias(pair, w, bvec=None, gamma=None, beta=None) -> torch.Tensor:
     return out
 
 
+def pair_bias2(pair, set_a, set_b):
+    """Two pair_bias results from one pass over ``pair``; each set = (w, bvec, gamma, beta) as in pair_bias."""
+    b, N, _, P = pair.shape
+    (wa, ba, ga, bea), (wb, bb, gb, beb) = set_a, set_b
+    Ha, Hb = wa.shape[0], wb.shape[0]
+    oa = torch.empty(b, Ha, N, N, device=pair.device, dtype=F32)
+    ob = torch.empty(b, Hb, N, N, device=pair.device, dtype=F32)
+    check(lib().prd_pair_bias2(dptr(oa), dptr(pair), dptr(ga), dptr(bea), dptr(wa), dptr(ba), Ha,
+                               dptr(ob), dptr(gb), dptr(beb), dptr(wb), dptr(bb), Hb, b, N, P, stream()), "prd_pair_bias2")
+    return oa, ob
+
+
 def opm_pair(pair, ab, mask, w_out, b_out, *, residual: bool, apply_mask: bool, out=None) -> torch.Tensor:
     b, N, _, P = pair.shape
     Cc = ab.shape[-1] // 2

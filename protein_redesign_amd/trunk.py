@@ -303,9 +303,14 @@ class Denoiser(nn.Module):
             join()
         self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair, ab=ab)
         spa = self.SPAAttnBlock
-        single = spa.attend(mn, qkvg, spa.bias_from_pair(pair))
-        bias = None
         blocks = list(self.folding_blocks)
+        if blocks:      # SPAttention's pair bias and the first block's attention bias: one pass over the pair tensor
+            ab0 = blocks[0].attn_bias[1]
+            spa_bias, bias = ops.pair_bias2(pair, (spa.linear_z[1].weight, None, spa.linear_z[0].weight, spa.linear_z[0].bias),
+                                            (ab0.weight, ab0.bias, None, None))
+        else:
+            spa_bias, bias = spa.bias_from_pair(pair), None
+        single = spa.attend(mn, qkvg, spa_bias)
         for i, block in enumerate(blocks):
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
             single, pair, bias = block.run_(single, pair, mask, ws=ws, bias=bias, next_block=nxt)

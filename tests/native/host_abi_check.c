@@ -41,6 +41,8 @@ int main(void) {
     EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 64, 100, s), PRD_ERR_UNSUPPORTED);       /* dist_dim % 8 */
     EXPECT(prd_pair_bias(p, p, p, 0, p, p, 1, 8, 64, 4, s), PRD_ERR_ARG);                    /* gamma without beta */
     EXPECT(prd_pair_bias(p, p, 0, 0, p, p, 1, 8, 64, 9, s), PRD_ERR_ARG);                    /* more than 8 heads */
+    EXPECT(prd_pair_bias2(p, p, 0, 0, p, p, 4, 0, 0, 0, p, p, 4, 1, 8, 64, s), PRD_ERR_ARG);     /* second output missing */
+    EXPECT(prd_pair_bias2(p, p, p, 0, p, p, 4, p, 0, 0, p, p, 4, 1, 8, 64, s), PRD_ERR_ARG);     /* gamma without beta */
     EXPECT(prd_opm_pair(p, p, p, p, p, p, 3, 1, 8, 64, 12, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_outer_linear(p, p, p, p, p, p, 1, 1, 8, 64, 36, 0, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, p, 16, 0, s), PRD_ERR_WORKSPACE);
