@@ -216,6 +216,16 @@ int prd_tri_attn_core(float* og, const float* pair, const float* mask, const flo
                       int b, int N, int P, int H, int c, hipStream_t stream);
 int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
                      int residual, int b, int N, int P, int* queue, hipStream_t stream);
+/* Triangle attention core whose input row is `pair + og_in W_o^T + b_o`: the residual update of the PREVIOUS triangle attention
+ * (its output projection, modules.py:339-340) is applied while the row is loaded, and written to `pair_out` -- which must not
+ * alias `pair` -- by the workgroups of head 0, instead of a separate prd_tri_attn_out launch.  gemm mode 1, short rows only
+ * (prd_tri_attn_core_fused_supported); og as prd_tri_attn_core.  Equal to prd_tri_attn_out(pair_out, pair, og_in, ...,
+ * residual = 1) followed by prd_tri_attn_core(og, pair_out, ...) up to fp32 rounding. */
+int prd_tri_attn_core_fused_supported(int N, int P);
+int prd_tri_attn_core_fused(float* og, float* pair_out, const float* pair, const float* og_in, const float* wo_in,
+                            const float* bo_in, const float* mask, const float* wq, const float* wk, const float* wv,
+                            const float* wg, const float* bg, int ending, int b, int N, int P, int H, int c,
+                            hipStream_t stream);
 /* single-track gated attention core for heads of width 16 (modules.py:216-223): qkvg = [q/sqrt(c) | k | v | sigmoid(gate)]
  * of shape [b,N,4*H*c] (one packed prd_gemm), bias [b,H,N,N], mask [b,N] or NULL -> o[b,N,H*c] = gate * softmax(qk + bias) v */
 int prd_single_attn_core(float* o, const float* qkvg, const float* bias, const float* mask,

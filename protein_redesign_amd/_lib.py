@@ -54,6 +54,8 @@ SIGNATURES = {
     "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, vp],
     "prd_tri_mul_contract": [vp, vp, ci, ci, ci, vp],
     "prd_tri_mul_chain_supported": [ci, ci],
+    "prd_tri_attn_core_fused_supported": [ci, ci],
+    "prd_tri_attn_core_fused": [vp] * 12 + [ci] * 6 + [vp],
     "prd_tri_mul_chain": [vp, vp, vp, vp, ci, ci, ci, vp, cz, vp],
     "prd_tri_mul_out_bwd": [vp] * 13 + [ci] * 3 + [vp],
     "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 4 + [vp],

@@ -1428,11 +1428,18 @@ PRD_DEV void ta_keyloop_split(const unsigned char* __restrict__ lds, const Split
     }
 }
 
-template <int P, int NW, int NTQ, bool PREFETCH>
+// FUSE: the row this kernel attends over is not `pair` itself but pair + og_in W_o^T + b_o -- the residual update of the
+// PREVIOUS triangle attention (its output projection, modules.py:339-340) applied while the row is loaded, instead of a
+// separate tri_attn_out launch and pass over the pair tensor.  The four head-workgroups of a row all apply it (24 MFMAs per
+// 32 positions, ~5 % of a row's cycles); the workgroup of head 0 writes the updated row to `pair_out`, which must be a
+// DIFFERENT buffer than `pair` (the other heads of the row read `pair` concurrently).
+template <int P, int NW, int NTQ, bool PREFETCH, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
-    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending) {
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int npad, int H, int ending,
+    const float* __restrict__ og_in = nullptr, const float* __restrict__ wo_in = nullptr, const float* __restrict__ bo_in = nullptr,
+    float* __restrict__ pair_out = nullptr) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     constexpr float VSCALE = H2_WSCALE;         // the projection weights are staged x 16 (rowgemm_h2): V stays x 16 (exact), so
                                                 // that its small components keep a normal fp16 lo part; k, q, gate are scaled back
@@ -1454,6 +1461,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
     float* Gl = reinterpret_cast<float*>(lds + L.gl);
     float* kadd = reinterpret_cast<float*>(lds + L.kadd);
     float* bqg = reinterpret_cast<float*>(lds + L.bqg);
+    float* bol = bqg + 32;                                             // FUSE: [P] CLL, then the W_o image (fp16 hi | lo planes, x 16)
+    u32x4* Wob = reinterpret_cast<u32x4*>(lds + L.bqg + 128 + P * 4);
     _Float16* Vh = reinterpret_cast<_Float16*>(lds + L.vh);
     _Float16* Vl = reinterpret_cast<_Float16*>(lds + L.vl);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1462,6 +1471,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
     const int nqb = (N + 31) / 32;
     const int ntile = (N + 15) / 16;
     const int rstride = gridDim.x / H;
+    if (FUSE) {
+        stage_weight_h2<HC>(Wob, wo_in, P, HC, tid, NT, H2_WSCALE);
+        stage_vec_cll(bol, bo_in, P, tid, NT);
+    }
     int h, slot;
     if ((rstride & 7) == 0) {                   // the H heads of one row on one XCD (see tri_attn_core_kernel)
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -1534,6 +1547,19 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_kernel(
                 for (int s_ = 0; s_ < KH; ++s_) x[s_] = xnext[PREFETCH ? s_ : 0];
             } else {
                 load_row_cll<P>(pair + row_pos(bu, valid ? v : 0) * P, hi, valid, x);
+            }
+            if (FUSE) {                         // x += og_in W_o^T + b_o: the previous attention's residual update of this row
+                const long pos = row_pos(bu, valid ? v : 0);
+                float xo[HC / 2];
+                load_row_cll<HC>(og_in + pos * HC, hi, valid, xo);
+                u32x4 os[2][HC / 16];
+                split2h_cll<HC / 2>(xo, os);
+                f32x16 ao[P / 32];
+                zero_acc(ao);
+                rowgemm_h2<HC, P / 32>(Wob, P, 0, os, ao, r, hi);
+#pragma unroll
+                for (int s_ = 0; s_ < KH; ++s_) x[s_] = x[s_] + (ao[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bol[hi * KH + s_]);
+                if (h == 0 && (halves & 1)) store_row_cll<P>(pair_out + pos * P, hi, valid, x);
             }
             ln_cll<KH>(x);
             u32x4 xs[2][P / 16];
@@ -2246,6 +2272,48 @@ extern "C" int prd_single_attn_core(float* o, const float* qkvg, const float* bi
     if (!o || !qkvg || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(single_attn_core_kernel, dim3(b * H * prd_ceil_div(N, 16)), dim3(256), 0, stream, o, qkvg, bias, mask, b, N, H);
+    return (int)hipGetLastError();
+}
+
+// LDS of the fused form: the short-row split kernel's layout + the W_o image and bias of the previous attention
+static size_t tri_attn_fused_lds(int N, int P) {
+    bool long_row;
+    const size_t lds = tri_attn_lds(N, P, true, &long_row);
+    if (long_row) return (size_t)1 << 30;
+    return lds + (size_t)P * 4 + (size_t)P * 256;
+}
+
+extern "C" int prd_tri_attn_core_fused_supported(int N, int P) {
+    return (N > 0 && (P == 32 || P == 64) && g_gemm_mode.load(std::memory_order_relaxed) == 1 &&
+            tri_attn_fused_lds(N, P) <= 160 * 1024) ? 1 : 0;
+}
+
+extern "C" int prd_tri_attn_core_fused(float* og, float* pair_out, const float* pair, const float* og_in, const float* wo_in,
+                                       const float* bo_in, const float* mask, const float* wq, const float* wk, const float* wv,
+                                       const float* wg, const float* bg, int ending, int b, int N, int P, int H, int c,
+                                       hipStream_t stream) {
+    if (!og || !pair_out || !pair || !og_in || !wo_in || !bo_in || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0 ||
+        pair_out == pair) return PRD_ERR_ARG;
+    if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
+    if (!prd_tri_attn_core_fused_supported(N, P)) return PRD_ERR_UNSUPPORTED;
+    const int npad = prd_round_up(N, 64);
+    const size_t lds = tri_attn_fused_lds(N, P);
+    const long rows_total = (long)b * N;
+    const long cap = 256 / H;
+    long per_head = cap < rows_total ? cap : rows_total;
+    if (per_head < 1) per_head = 1;
+    const long rounds = (rows_total + per_head - 1) / per_head;
+    per_head = (rows_total + rounds - 1) / rounds;
+    const int grid = (int)(per_head * H);
+    if (P == 64) {
+        PRD_SET_LDS((tri_attn_core_split_kernel<64, 8, 2, true, true>), lds);
+        hipLaunchKernelGGL((tri_attn_core_split_kernel<64, 8, 2, true, true>), dim3(grid), dim3(512), lds, stream, og, pair, mask, wq, wk, wv, wg,
+                           bg, b, N, npad, H, ending, og_in, wo_in, bo_in, pair_out);
+    } else {
+        PRD_SET_LDS((tri_attn_core_split_kernel<32, 8, 2, true, true>), lds);
+        hipLaunchKernelGGL((tri_attn_core_split_kernel<32, 8, 2, true, true>), dim3(grid), dim3(512), lds, stream, og, pair, mask, wq, wk, wv, wg,
+                           bg, b, N, npad, H, ending, og_in, wo_in, bo_in, pair_out);
+    }
     return (int)hipGetLastError();
 }
 

@@ -467,6 +467,22 @@ def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> 
     return og
 
 
+def tri_attn_core_fused_supported(N: int, P: int) -> bool:
+    """True when prd_tri_attn_core_fused exists for this shape in the current arithmetic mode."""
+    return lib().prd_tri_attn_core_fused_supported(N, P) == 1
+
+
+def tri_attn_core_fused(pair, og_in, wo_in, bo_in, mask, wts, H: int, c: int, *, ending: bool, pair_out, og=None) -> torch.Tensor:
+    """og of a triangle attention over the rows of ``pair + og_in W_o^T + b_o`` (the previous attention's residual update,
+    applied on the fly and written to ``pair_out``, a different buffer); wts = (q.w, k.w, v.w, gate.w, gate.b)."""
+    b, N, _, P = pair.shape
+    if og is None:
+        og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
+    check(lib().prd_tri_attn_core_fused(dptr(og), dptr(pair_out), dptr(pair), dptr(og_in), dptr(wo_in), dptr(bo_in), dptr(mask),
+                                        *[dptr(w) for w in wts], int(ending), b, N, P, H, c, stream()), "prd_tri_attn_core_fused")
+    return og
+
+
 def tri_attn_out(pair, og, wo, bo, *, residual: bool, out=None) -> torch.Tensor:
     """Second launch of tri_attn alone: (residual ? pair : 0) + og W_o^T + b_o."""
     b, N, _, P = pair.shape

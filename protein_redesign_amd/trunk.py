@@ -155,6 +155,10 @@ class TriangleMultiplication(nn.Module):
 
 
 _TRI_MUL_CHAIN = os.environ.get("PRD_TRI_MUL_CHAIN", "1") != "0"      # 0: two prd_tri_mul calls (A/B measurements)
+# 1: the starting attention's output projection rides in the row load of the ending core (prd_tri_attn_core_fused).  Measured
+# SLOWER (1.973 vs 1.931 ms per step, A/B in one run): each of the four head-workgroups of a row re-reads the previous og row
+# (4 x 26 MB instead of one pass) and repeats the projection.  Off by default; kept as a tested opt-in.
+_TRI_ATTN_FUSE = os.environ.get("PRD_TRI_ATTN_FUSE", "0") == "1"
 
 
 class OuterLinear(nn.Module):
@@ -220,8 +224,9 @@ class FoldingBlock(nn.Module):
             Linear(pair_dim * transition_factor, pair_dim, init="final"),
         )
 
-    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, bias=None, next_block=None):
-        """In place on ``pair``.  ``bias``: this block's attention bias if the previous block's fused tail
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, bias=None, next_block=None, spare_holder=None):
+        """In place on ``pair`` or -- fused attention form, gemm mode 1 -- ending in another buffer: use the RETURNED pair tensor.
+        ``bias``: this block's attention bias if the previous block's fused tail
         already produced it; ``next_block``: the following FoldingBlock, whose attention bias is then computed
         by this block's fused tail.  Returns (single, pair, next_bias or None)."""
         sa = self.single_attn
@@ -241,12 +246,28 @@ class FoldingBlock(nn.Module):
         else:
             self.pair_mul_outgoing.run(pair, mask, residual=True, out=pair, ws=ws)
             self.pair_mul_incoming.run(pair, mask, residual=True, out=pair, ws=ws)
-        self.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)
-        # ending triangle attention: core kernel, then ONE fused row pass = its output projection + the pair
-        # transition + (if there is a next block) that block's attention bias
         ta = self.pair_attn_ending.attn
-        og = ops.tri_attn_core(pair, mask, ta.weights()[:5], ta.num_heads, ta.head_dim, ending=True,
-                               og=ws[: b * N * N * 64].view(b, N, N, 64))
+        nog = b * N * N * 64
+        if _TRI_ATTN_FUSE and ops.tri_attn_core_fused_supported(N, pair.shape[-1]) and ws.numel() >= 2 * nog:
+            # starting attention: core only; its output projection + residual ride in the row load of the ending core, which
+            # writes the updated pair tensor to the spare buffer (the residual stream changes buffers here)
+            ts = self.pair_attn_starting.attn
+            og_s = ops.tri_attn_core(pair, mask, ts.weights()[:5], ts.num_heads, ts.head_dim, ending=False,
+                                     og=ws[:nog].view(b, N, N, 64))
+            spare = spare_holder[0] if spare_holder else None
+            if spare is None:
+                spare = torch.empty_like(pair)
+            og = ops.tri_attn_core_fused(pair, og_s, ts.out_proj.weight, ts.out_proj.bias, mask, ta.weights()[:5], ta.num_heads,
+                                         ta.head_dim, ending=True, pair_out=spare, og=ws[nog: 2 * nog].view(b, N, N, 64))
+            pair, spare = spare, pair
+            if spare_holder is not None:
+                spare_holder[0] = spare          # the buffer the residual stream just left: the next block's target
+        else:
+            self.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)
+            # ending triangle attention: core kernel, then ONE fused row pass = its output projection + the pair
+            # transition + (if there is a next block) that block's attention bias
+            og = ops.tri_attn_core(pair, mask, ta.weights()[:5], ta.num_heads, ta.head_dim, ending=True,
+                                   og=ws[:nog].view(b, N, N, 64))
         pf = self.pair_fc
         nb_w = next_block.attn_bias[1].weight if next_block is not None else None
         nb_b = next_block.attn_bias[1].bias if next_block is not None else None
@@ -311,9 +332,10 @@ class Denoiser(nn.Module):
         else:
             spa_bias, bias = spa.bias_from_pair(pair), None
         single = spa.attend(mn, qkvg, spa_bias)
+        holder = [None]             # spare pair buffer of the fused attention form (the residual stream alternates between two)
         for i, block in enumerate(blocks):
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-            single, pair, bias = block.run_(single, pair, mask, ws=ws, bias=bias, next_block=nxt)
+            single, pair, bias = block.run_(single, pair, mask, ws=ws, bias=bias, next_block=nxt, spare_holder=holder)
         return single, pair
 
     def forward(self, batch, z, t, single, pair, cache):

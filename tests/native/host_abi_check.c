@@ -84,6 +84,9 @@ int main(void) {
         EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);  /* fp32 mode has no fused chain */
         EXPECT(prd_set_gemm_mode(1), 0);
     }
+    EXPECT(prd_tri_attn_core_fused_supported(320, 64), 1);
+    EXPECT(prd_tri_attn_core_fused_supported(769, 64), 0);      /* long rows: no fused form */
+    EXPECT(prd_tri_attn_core_fused(p, p, p, p, p, p, p, p, p, p, p, p, 1, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);   /* pair_out aliases pair */
     EXPECT(prd_tri_mul_out_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(0, p, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);

@@ -271,6 +271,35 @@ def test_triangle_multiplication_chain(P, b, N):
         assert _lib.lib().prd_set_gemm_mode(prev) == 0
 
 
+@pytest.mark.parametrize("ending", [False, True])
+@pytest.mark.parametrize("P,b,N", [(64, 2, 40), (32, 1, 70), (64, 1, 130)])
+def test_triangle_attention_core_with_fused_previous_update(P, b, N, ending):
+    """prd_tri_attn_core_fused (gemm mode 1): the previous attention's output projection + residual applied while the row is
+    loaded -- pair_out and og against prd_tri_attn_out followed by prd_tri_attn_core; ragged N, masked batch element, leftover
+    blocks shared by two waves."""
+    from protein_redesign_amd import _lib
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(1) == 0
+    try:
+        assert ops.tri_attn_core_fused_supported(N, P)
+        g = torch.Generator().manual_seed(7 * N + P)
+        pair = cu(torch.randn(b, N, N, P, generator=g))
+        og_in = cu(torch.randn(b, N, N, 64, generator=g))
+        mask = torch.ones(b, N)
+        mask[b - 1, N - 6:] = 0
+        mask = cu(mask)
+        wo, bo = cu(torch.randn(P, 64, generator=g) / 8.0), cu(torch.randn(P, generator=g) / 4.0)
+        wts = [cu(torch.randn(64, P, generator=g) / math.sqrt(P)) for _ in range(4)] + [cu(torch.randn(64, generator=g) / 4.0)]
+        want_pair = ops.tri_attn_out(pair, og_in, wo, bo, residual=True)
+        want_og = ops.tri_attn_core(want_pair, mask, wts, 4, 16, ending=ending)
+        pair_out = torch.empty_like(pair)
+        og = ops.tri_attn_core_fused(pair, og_in, wo, bo, mask, wts, 4, 16, ending=ending, pair_out=pair_out)
+        assert rel_l2(pair_out.cpu(), want_pair.cpu()) < 1e-6
+        assert rel_l2(og.cpu(), want_og.cpu()) < 2e-6
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+
+
 @pytest.mark.parametrize("mode", ["starting", "ending"])
 def test_triangle_attention(setup, mode, gemm_mode):
     s = setup
