@@ -267,7 +267,7 @@ def tri_mul_chain_(pair, mask, wts_outgoing, wts_incoming, ws=None) -> torch.Ten
     return pair
 
 
-def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
+def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
     """Gradients of the TriangleMultiplication update (ops.tri_mul with residual=False) with respect to ``pair`` and its eight
     weight tensors, on the hand-written backward kernels (csrc/prd_bwd.hip): forward recompute (projection, contraction) ->
     output-stage backward -> the two gradient contractions on the forward contraction kernel -> projection-stage backward.
@@ -277,10 +277,11 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool):
     ldn = round_up(N, 32)
     dev = pair.device
     unit = b * P * N * ldn
-    ws = torch.empty(3 * unit, device=dev, dtype=F32)
-    scratch = torch.empty_like(pair)
-    check(lib().prd_tri_mul(dptr(scratch), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(incoming), 0, b, N, P,
-                            dptr(ws), ws.numel() * 4, 0, stream()), "prd_tri_mul (recompute)")
+    if ws is None:                                       # forward recompute of the operands and the contraction output
+        ws = torch.empty(3 * unit, device=dev, dtype=F32)
+        scratch = torch.empty_like(pair)
+        check(lib().prd_tri_mul(dptr(scratch), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(incoming), 0, b, N, P,
+                                dptr(ws), ws.numel() * 4, 0, stream()), "prd_tri_mul (recompute)")
     AB = ws[:2 * unit].view(b, 2 * P, N, ldn)
     O = ws[2 * unit:].view(b, P, N, ldn)
     dy = dy.contiguous()

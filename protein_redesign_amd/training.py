@@ -1,11 +1,11 @@
 """Differentiable network for the optimisation step (reference model.py:490-549, modules.py:391-404) -- SURVEY.md §8f "next" #1.
 
-Every operator of the trunk becomes one ``torch.autograd.Function`` (``HipOp``): its FORWARD is the HIP operator of the
-inference path (ops.py -> libprd_hip.so, out of place), its BACKWARD recomputes that operator with the differentiable
-torch-op restatement in torch_ref.py on the GPU and lets autograd produce the gradients of its inputs and weights (the
-survey's first cut; operators with hand-written backward kernels bypass torch_ref).  Like the reference
-(modules.py:399-401) every FoldingBlock runs under ``torch.utils.checkpoint``: between blocks only (single, pair) are kept and
-a block's forward is re-run -- on the HIP kernels again -- inside the backward pass.
+Every operator of the trunk becomes one ``torch.autograd.Function``: its FORWARD is the HIP operator of the inference path
+(ops.py -> libprd_hip.so, out of place); its BACKWARD is a hand-written HIP backward (TriMulFn, TriAttnFn; csrc/prd_bwd.hip) or
+-- ``HipOp``, the survey's first cut -- recomputes the operator with the differentiable torch-op restatement in torch_ref.py on
+the GPU and lets autograd produce the gradients of its inputs and weights (the weight gradients of the pair-position linears
+again on a HIP kernel).  The reference's per-block ``torch.utils.checkpoint`` (modules.py:399-401) is available
+(``USE_CHECKPOINT``) but off by default.
 
 fp32 throughout (the reference trains under fp16 autocast, train.py:37; parity is defined against its fp32 arithmetic).
 """
@@ -23,11 +23,12 @@ from . import ops
 from . import torch_ref as R
 
 
-# Per-block activation checkpointing (reference modules.py:399-401).  Every operator here already saves only its INPUT and
-# recomputes its forward in its own backward, so what a block keeps without checkpointing is six pair tensors (26 MB each per
-# complex at N = 320; peak memory of a 2-complex step 1.9 -> 2.6 GB) -- nothing against 288 GB, while the checkpoint replays the
-# whole block's forward a third time (56.8 -> 52.7 ms per step).  Off by default; PRD_TRAIN_CHECKPOINT=1 restores the reference's
-# memory behaviour (same gradients either way).
+# Per-block activation checkpointing (reference modules.py:399-401).  With it, between blocks only (single, pair) are kept, a
+# block's forward is re-run on the HIP kernels inside the backward pass, and every operator recomputes what its backward needs.
+# Without it the operators' inputs stay alive (six pair tensors per block, 26 MB each per complex at N = 320) and the triangle
+# operators also keep their intermediates (operands a | b and the contraction output; the gated head outputs) instead of
+# recomputing them: peak memory of a 2-complex step 1.9 -> 3.9 GB -- nothing against 288 GB -- and 56.8 -> 47.9 ms per step.
+# Off by default; PRD_TRAIN_CHECKPOINT=1 restores the reference's memory behaviour (same gradients either way).
 USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
 
 
@@ -66,15 +67,22 @@ class TriMulFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pair, mask, incoming: bool, *wts):
         ctx.incoming = incoming
-        ctx.save_for_backward(pair, mask, *wts)
+        ctx.keep_ws = not USE_CHECKPOINT           # the operands a | b and the contraction output (3 pair-sized tensors) stay for the backward
         with torch.no_grad():
-            return ops.tri_mul(pair.detach().contiguous(), mask, [w.detach() for w in wts], incoming=incoming, residual=False)
+            p = pair.detach().contiguous()
+            b, N, _, P = p.shape
+            ws = torch.empty(ops.workspace_bytes("tri_mul", b, N, 0, P) // 4, device=p.device, dtype=torch.float32) if ctx.keep_ws else None
+            out = ops.tri_mul(p, mask, [w.detach() for w in wts], incoming=incoming, residual=False, ws=ws)
+        ctx.save_for_backward(pair, mask, *wts, *([ws] if ctx.keep_ws else []))
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        pair, mask, *wts = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
+        ws = saved.pop() if ctx.keep_ws else None
+        pair, mask, *wts = saved
         with torch.no_grad():
-            dpair, grads = ops.tri_mul_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], incoming=ctx.incoming)
+            dpair, grads = ops.tri_mul_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], incoming=ctx.incoming, ws=ws)
         return (dpair, None, None, *grads)
 
 
