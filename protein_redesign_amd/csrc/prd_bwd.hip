@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
     }
 }
 
-template <int P, int NW>
+template <int P, int NW, bool B3>                   // B3: the eight row GEMMs in the fp16 x 2 split form (gemm mode 1), weights x 16
 __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
     float* __restrict__ dpair, float* __restrict__ dpp_out, float* __restrict__ dpg_out,
     const float* __restrict__ dAB, const float* __restrict__ dx1, const float* __restrict__ pair, const float* __restrict__ mask,
@@ -149,17 +149,26 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
     const float* __restrict__ wpT, const float* __restrict__ wgT, int b, int N, int ldn, int incoming) {
     constexpr int KH = P / 2, NB = P / 32, OUT = 2 * P;
     extern __shared__ __attribute__((aligned(16))) float smem_b3[];
-    float* Wpl = smem_b3;                        // [2P][P+4]
-    float* Wgl = Wpl + OUT * (P + 4);
-    float* WpTl = Wgl + OUT * (P + 4);           // [P][2P+4]: rows = input channels of the projection, K = its 2P outputs
-    float* WgTl = WpTl + P * (OUT + 4);
-    float* bpl = WgTl + P * (OUT + 4);           // [2P] CLL
+    constexpr int WSZ = B3 ? OUT * P : OUT * (P + 4), WTSZ = B3 ? P * OUT : P * (OUT + 4);      // floats per staged matrix
+    float* Wpl = smem_b3;                        // [2P][P+4] (fp32) or fp16 hi | lo planes of the same size as the fp32 matrix
+    float* Wgl = Wpl + WSZ;
+    float* WpTl = Wgl + WSZ;                     // [P][2P+4]: rows = input channels of the projection, K = its 2P outputs
+    float* WgTl = WpTl + WTSZ;
+    float* bpl = WgTl + WTSZ;                    // [2P] CLL
     float* bgl = bpl + OUT;
     const int NT = NW * 64;
-    stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NT);
-    stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NT);
-    stage_weight_cll<OUT>(WpTl, wpT, P, OUT, threadIdx.x, NT);
-    stage_weight_cll<OUT>(WgTl, wgT, P, OUT, threadIdx.x, NT);
+    constexpr float ASC = B3 ? H2_INV_WSCALE : 1.0f;
+    if (B3) {
+        stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wpl), wp, OUT, P, threadIdx.x, NT, H2_WSCALE);
+        stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wgl), wg, OUT, P, threadIdx.x, NT, H2_WSCALE);
+        stage_weight_h2<OUT>(reinterpret_cast<u32x4*>(WpTl), wpT, P, OUT, threadIdx.x, NT, H2_WSCALE);
+        stage_weight_h2<OUT>(reinterpret_cast<u32x4*>(WgTl), wgT, P, OUT, threadIdx.x, NT, H2_WSCALE);
+    } else {
+        stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NT);
+        stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NT);
+        stage_weight_cll<OUT>(WpTl, wpT, P, OUT, threadIdx.x, NT);
+        stage_weight_cll<OUT>(WgTl, wgT, P, OUT, threadIdx.x, NT);
+    }
     stage_vec_cll(bpl, bp, OUT, threadIdx.x, NT);
     stage_vec_cll(bgl, bg, OUT, threadIdx.x, NT);
     __syncthreads();
@@ -182,20 +191,27 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
         const float m2 = valid ? mask[bu] * mask[(long)bb * N + vv] : 0.f;
         f32x16 adx[NB];
         zero_acc(adx);
+        u32x4 xs[2][P / 16];
+        if (B3) split2h_cll<KH>(x, xs);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {            // h = 0: the a operand (output channels 0 .. P-1), h = 1: the b operand
             f32x16 ap[NB], ag[NB];
             zero_acc(ap);
             zero_acc(ag);
-            rowgemm<P, NB>(Wpl + h * P * (P + 4), x, ap, r, hi);
-            rowgemm<P, NB>(Wgl + h * P * (P + 4), x, ag, r, hi);
+            if (B3) {
+                rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wpl), OUT, h * P, xs, ap, r, hi);
+                rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wgl), OUT, h * P, xs, ag, r, hi);
+            } else {
+                rowgemm<P, NB>(Wpl + h * P * (P + 4), x, ap, r, hi);
+                rowgemm<P, NB>(Wgl + h * P * (P + 4), x, ag, r, hi);
+            }
             float dpp[KH], dpg[KH];
 #pragma unroll
             for (int s = 0; s < KH; ++s) {
                 const int ch = h * P + cll_ch(s, hi);
                 const float dab = valid ? dAB[(((long)bb * OUT + ch) * N + u) * ldn + vv] : 0.f;
-                const float pp = ap[s >> 4][s & 15] + bpl[hi * P + h * KH + s];
-                const float sg = sigmoidf_(ag[s >> 4][s & 15] + bgl[hi * P + h * KH + s]);
+                const float pp = ap[s >> 4][s & 15] * ASC + bpl[hi * P + h * KH + s];
+                const float sg = sigmoidf_(ag[s >> 4][s & 15] * ASC + bgl[hi * P + h * KH + s]);
                 dpp[s] = dab * m2 * sg;
                 dpg[s] = dab * m2 * pp * sg * (1.0f - sg);
             }
@@ -203,7 +219,18 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
             store_row_cll<P>(dpp_out + prow * OUT + h * P, hi, valid, dpp);
             store_row_cll<P>(dpg_out + prow * OUT + h * P, hi, valid, dpg);
             // dx += Wp[h]^T dpp + Wg[h]^T dpg: the half is CLL elements [32 h, 32 h + 32) of the 2P-wide K axis = groups [8h, 8h+8)
-            if (h == 0) {
+            if (B3) {                            // K steps of 16 (8 per lane): the half is steps [KH/8 h, KH/8 (h + 1)) of the 2P-wide K axis
+                u32x4 ps[2][KH / 8], gs[2][KH / 8];
+                split2h_cll<KH>(dpp, ps);
+                split2h_cll<KH>(dpg, gs);
+                if (h == 0) {
+                    rowgemm_h2_part<OUT, NB, 0, KH / 8>(reinterpret_cast<const u32x4*>(WpTl), P, 0, ps, adx, r, hi);
+                    rowgemm_h2_part<OUT, NB, 0, KH / 8>(reinterpret_cast<const u32x4*>(WgTl), P, 0, gs, adx, r, hi);
+                } else {
+                    rowgemm_h2_part<OUT, NB, KH / 8, KH / 4>(reinterpret_cast<const u32x4*>(WpTl), P, 0, ps, adx, r, hi);
+                    rowgemm_h2_part<OUT, NB, KH / 8, KH / 4>(reinterpret_cast<const u32x4*>(WgTl), P, 0, gs, adx, r, hi);
+                }
+            } else if (h == 0) {
                 rowgemm_part<OUT, NB, 0, KH / 4>(WpTl, dpp, adx, r, hi);
                 rowgemm_part<OUT, NB, 0, KH / 4>(WgTl, dpg, adx, r, hi);
             } else {
@@ -214,7 +241,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
         float dx[KH];
         load_row_cll<P>(dx1 + prow * P, hi, valid, dx);
 #pragma unroll
-        for (int s = 0; s < KH; ++s) dx[s] += adx[s >> 4][s & 15];
+        for (int s = 0; s < KH; ++s) dx[s] += adx[s >> 4][s & 15] * ASC;
         ln_cll_bwd<KH>(dx, x, rstd_x);
         store_row_cll<P>(dpair + prow * P, hi, valid, dx);
     }
@@ -722,18 +749,20 @@ extern "C" int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const 
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     constexpr int NWB = 8;
     const int ldn = prd_round_up(N, 32);
-    const size_t lds = ((size_t)2 * 2 * P * (P + 4) + (size_t)2 * P * (2 * P + 4) + 4 * P) * sizeof(float);
+    const bool b3 = prd_get_gemm_mode() == 1;
+    const size_t lds = b3 ? ((size_t)8 * P * P + 4 * P) * sizeof(float)
+                          : ((size_t)2 * 2 * P * (P + 4) + (size_t)2 * P * (2 * P + 4) + 4 * P) * sizeof(float);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     const int grid = grid_for((long)b * N * prd_ceil_div(N, 32), 4, 256);
-    if (P == 64) {
-        PRD_BWD_SET_LDS((tri_mul_proj_bwd_kernel<64, NWB>));
-        hipLaunchKernelGGL((tri_mul_proj_bwd_kernel<64, NWB>), dim3(grid), dim3(NWB * 64), lds, stream, dpair, dpp, dpg, dAB, dx1, pair, mask,
-                           w_proj, b_proj, w_gate, b_gate, w_proj_t, w_gate_t, b, N, ldn, incoming);
-    } else {
-        PRD_BWD_SET_LDS((tri_mul_proj_bwd_kernel<32, NWB>));
-        hipLaunchKernelGGL((tri_mul_proj_bwd_kernel<32, NWB>), dim3(grid), dim3(NWB * 64), lds, stream, dpair, dpp, dpg, dAB, dx1, pair, mask,
-                           w_proj, b_proj, w_gate, b_gate, w_proj_t, w_gate_t, b, N, ldn, incoming);
-    }
+#define PRD_PBW(PP, BB)                                                                                              \
+    do {                                                                                                             \
+        PRD_BWD_SET_LDS((tri_mul_proj_bwd_kernel<PP, NWB, BB>));                                                     \
+        hipLaunchKernelGGL((tri_mul_proj_bwd_kernel<PP, NWB, BB>), dim3(grid), dim3(NWB * 64), lds, stream, dpair, dpp, dpg, dAB, dx1, pair, \
+                           mask, w_proj, b_proj, w_gate, b_gate, w_proj_t, w_gate_t, b, N, ldn, incoming);           \
+    } while (0)
+    if (P == 64) { if (b3) PRD_PBW(64, true); else PRD_PBW(64, false); }
+    else { if (b3) PRD_PBW(32, true); else PRD_PBW(32, false); }
+#undef PRD_PBW
     return (int)hipGetLastError();
 }
 
