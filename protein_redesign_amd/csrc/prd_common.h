@@ -474,15 +474,24 @@ PRD_DEV void h2_nat_step(const u32x4* Wh, int nout, int SL, int st, const float 
         ph[q] = a;
         pl[q] = b;
     }
+    // rows 32 nb + r of both planes share the swizzle (o & 15 = r & 15): one slot per step, the row bases are loop invariants
+    // (the K loops of the outer-linear / OPM / pair-init kernels are VALU-issue bound: every address instruction counts)
+    const unsigned slot = (unsigned)(2 * st + hi) ^ (unsigned)(r & 15);
+    const u32x4* wh0 = Wh + (unsigned)r * (unsigned)SL + slot;
+    const u32x4* wl0 = Wh + ((unsigned)nout + (unsigned)r) * (unsigned)SL + slot;
+    u32x4 wh[NB], wl[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int o = nb * 32 + r;
-        const int slot = (2 * st + hi) ^ (o & 15);
-        const u32x4 wh = Wh[(size_t)o * SL + slot], wl = Wh[(size_t)(nout + o) * SL + slot];
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh), __builtin_bit_cast(f16x8_t, pl), acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wl), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
-    }
+    for (int nb = 0; nb < NB; ++nb) { wh[nb] = wh0[nb * 32 * SL]; wl[nb] = wl0[nb * 32 * SL]; }
+    // the three products of an accumulator are issued NB accumulators apart (no back-to-back dependent MFMAs)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh[nb]), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh[nb]), __builtin_bit_cast(f16x8_t, pl), acc[nb], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wl[nb]), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
 }
 // acc[nb] += W[row0 + 32 nb .. +31][16 S0 .. 16 S1) * x for the split row p (K-steps S0 .. S1 of the image's K)
 template <int K, int NB, int S0, int S1>
