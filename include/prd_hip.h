@@ -199,6 +199,12 @@ int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, 
 size_t prd_linear_wgrad_workspace(long long rows, int O, int I);
 int prd_linear_wgrad(float* dw, float* db, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
                      float* ws, size_t ws_bytes, hipStream_t stream);
+/* Gradient of a small embedding table applied at every pair position (modules.py:35-71: bond-type, bond-distance and
+ * relative-position tables): dtable[card][C] = sum over rows of dy[row][0..C) into row idx[row] (int64; indices outside
+ * [0, card) are ignored).  card <= 128, C <= 64.  ws: prd_embed_wgrad_workspace(rows, card, C) bytes. */
+size_t prd_embed_wgrad_workspace(long long rows, int card, int C);
+int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, long long rows, int card, int C, int lddy,
+                    float* ws, size_t ws_bytes, hipStream_t stream);
 
 /* TriangleAttention (modules.py:236-243 -> 185-225): out = (residual ? pair : 0) + update(pair).
  * ws: b * N * N * 64 floats. */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "prd_ln_rows_bwd": [vp, vp, vp, cll, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
     "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],
+    "prd_embed_wgrad_workspace": [cll, ci, ci],
+    "prd_embed_wgrad": [vp, vp, vp, cll, ci, ci, ci, vp, cz, vp],
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, vp],
@@ -94,7 +96,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes
-            fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace") else ci
+            fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace") else ci
         mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)      # prd_hip.h: prd_set_gemm_mode
         if os.environ.get("PRD_BF16X3"):                               # older spelling of PRD_GEMM_MODE=bf16x3
             mode = "bf16x3"

@@ -680,6 +680,40 @@ __global__ __launch_bounds__(256) void linear_wgrad_narrow_kernel(float* __restr
     }
 }
 
+// Gradient of a small embedding table looked up at every pair position (bond-type / bond-distance / relative-position tables of
+// the input stage, modules.py:35-71): dtable[c][:] = sum of dy over the rows with idx == c.  The BLAS form (one-hot^T dy) is the
+// same long-K, tiny-output GEMM as the linear weight gradients (475 us per table); here a wave keeps a private [card][C] table in
+// LDS (lane = channel, one row at a time: no conflicts, fixed order), the four waves and then the slabs are summed in order.
+__global__ __launch_bounds__(256) void embed_wgrad_kernel(float* __restrict__ part, const long long* __restrict__ idx, const float* __restrict__ dy,
+                                                          long rows, int card, int C, int lddy, int rows_per_wg) {
+    extern __shared__ float etab[];                          // [4 waves][card][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = etab + (size_t)wave * card * 64;
+    for (int e = lane; e < card * 64; e += 64) mine[e] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    constexpr int U = 8;
+    for (long row = r0 + (long)U * wave; row < r1; row += 4 * U) {
+        float v[U];
+        int c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = row + u < r1 ? row + u : r1 - 1;
+            c[u] = (int)idx[rr];                             // wave-uniform
+            v[u] = (row + u < r1 && lane < C) ? dy[rr * lddy + lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c[u] >= 0 && c[u] < card) mine[c[u] * 64 + lane] += v[u];
+    }
+    __syncthreads();
+    float* pt = part + (size_t)blockIdx.x * card * C;
+    for (int e = threadIdx.x; e < card * 64; e += 256) {
+        const int cc = e >> 6, ch = e & 63;
+        if (ch < C) pt[cc * C + ch] = ((etab[e] + etab[(size_t)card * 64 + e]) + etab[(size_t)2 * card * 64 + e]) + etab[(size_t)3 * card * 64 + e];
+    }
+}
+
 // 64 elements per workgroup, the slabs dealt in four contiguous quarters to the four waves (eight loads in flight per lane),
 // quarter sums combined in wave order: the summation order is fixed.
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ part,
@@ -828,5 +862,26 @@ extern "C" int prd_linear_wgrad(float* dw, float* db, const float* dy, const flo
         else hipLaunchKernelGGL(linear_wgrad_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
     }
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dw, db, ws, n, nw, (int)slabs);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t prd_embed_wgrad_workspace(long long rows, int card, int C) {
+    if (rows <= 0 || card <= 0 || C <= 0) return 0;
+    return (size_t)wgrad_slabs(rows) * card * C * sizeof(float);
+}
+
+extern "C" int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, long long rows, int card, int C, int lddy,
+                               float* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!dtable || !idx || !dy || !ws || rows <= 0 || card <= 0 || C <= 0 || lddy < C) return PRD_ERR_ARG;
+    if (C > 64 || card > 128) return PRD_ERR_UNSUPPORTED;
+    if (ws_bytes < prd_embed_wgrad_workspace(rows, card, C)) return PRD_ERR_WORKSPACE;
+    const long slabs = wgrad_slabs(rows);
+    const int rows_per_wg = (int)((rows + slabs - 1) / slabs);
+    const size_t lds = (size_t)4 * card * 64 * sizeof(float);
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)embed_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    hipLaunchKernelGGL(embed_wgrad_kernel, dim3((unsigned)slabs), dim3(256), lds, stream, ws, idx, dy, (long)rows, card, C, lddy, rows_per_wg);
+    const int n = card * C;
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dtable, (float*)nullptr, ws, n, n, (int)slabs);
     return (int)hipGetLastError();
 }

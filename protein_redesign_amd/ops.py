@@ -374,6 +374,17 @@ def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor, bias: bool = False):
     return (dw, dy2.sum(0)) if bias else dw
 
 
+def embed_wgrad(idx: torch.Tensor, dy2: torch.Tensor, card: int) -> torch.Tensor:
+    """dtable [card, C] = scatter-sum of the rows of dy2 [rows, C] by idx [rows] (int64): the gradient of a small embedding table
+    looked up at every pair position (prd_embed_wgrad; card <= 128, C <= 64, contiguous inputs)."""
+    rows, Cn = dy2.shape
+    dt = torch.empty(card, Cn, device=dy2.device, dtype=F32)
+    nbytes = lib().prd_embed_wgrad_workspace(rows, card, Cn)
+    ws = torch.empty(nbytes // 4, device=dy2.device, dtype=F32)
+    check(lib().prd_embed_wgrad(dptr(dt), dptr(idx, torch.int64), dptr(dy2), rows, card, Cn, Cn, dptr(ws), nbytes, stream()), "prd_embed_wgrad")
+    return dt
+
+
 def tri_attn_uses_long_rows(N: int, P: int) -> bool:
     """True when rows of N positions take the re-projecting long-row core kernel (prd_hip.h: prd_tri_attn_variant)."""
     return tri_attn_variant(N, P) >= 1

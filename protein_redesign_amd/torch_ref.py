@@ -58,11 +58,31 @@ def linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
+class _SmallTable(torch.autograd.Function):
+    """F.embedding whose table gradient is the slab reduction of csrc/prd_bwd.hip (ops.embed_wgrad): torch's scatter-add has
+    millions of collisions per table row (4 ms per table at N = 320), and the one-hot GEMM form is the BLAS's 8-workgroup long-K
+    kernel (475 us)."""
+
+    @staticmethod
+    def forward(ctx, idx, table):
+        ctx.save_for_backward(idx)
+        ctx.card = table.shape[0]
+        return F.embedding(idx, table)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        (idx,) = ctx.saved_tensors
+        return None, ops.embed_wgrad(idx.reshape(-1).contiguous(), dy.reshape(-1, dy.shape[-1]).contiguous(), ctx.card)
+
+
 def small_table_lookup(idx, table):
-    """F.embedding for a table of a few rows over a huge index tensor, as one-hot @ table: the backward is then a dense
-    [rows x positions] GEMM instead of a scatter-add with millions of collisions per row (4 ms per table at N = 320)."""
+    """F.embedding for a table of a few rows over a huge index tensor: hand-written table gradient on the GPU at pair-position
+    row counts; elsewhere as one-hot @ table (a dense GEMM backward instead of a scatter-add)."""
     if table.shape[0] > 128:
         return F.embedding(idx, table)
+    if idx.is_cuda and idx.numel() >= 8192 and table.shape[1] <= 64 and torch.is_grad_enabled() and idx.dtype == torch.int64:
+        return _SmallTable.apply(idx, table)
     return F.one_hot(idx, table.shape[0]).to(table.dtype) @ table
 
 

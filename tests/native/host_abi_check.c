@@ -98,6 +98,10 @@ int main(void) {
     EXPECT(prd_linear_wgrad(p, p, p, p, 100, 96, 64, 96, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);       /* O neither <= 16 nor a multiple of 64 */
     EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 65, 64, p, 1 << 20, s), PRD_ERR_ALIGN);            /* odd row pitch */
     EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_embed_wgrad(0, (const long long*)ibuf, p, 100, 8, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
+    EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 200, 64, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);   /* more than 128 table rows */
+    EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 8, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
+    EXPECT((int)(prd_embed_wgrad_workspace(102400, 65, 64) != (size_t)200 * 65 * 64 * 4), 0);
     EXPECT((int)(prd_workspace_bytes("tri_mul", 1, 320, 512, 64) != (size_t)3 * 64 * 320 * 320 * 4), 0);
     EXPECT((int)prd_workspace_bytes("nonsense", 1, 320, 512, 64), 0);
     EXPECT((int)prd_workspace_bytes(0, 1, 320, 512, 64), 0);

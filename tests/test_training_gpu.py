@@ -182,3 +182,17 @@ def test_linear_weight_gradient_kernel(rows, O, I):
     assert db.shape == (O,) and (db.double() - wantb).norm() / wantb.norm() < 2e-6
     if rows >= ops.WGRAD_MIN_ROWS:                      # bit-reproducible (no atomics)
         assert torch.equal(got, ops.linear_wgrad(dy, x)) and torch.equal(got, got2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,card,C", [(102400, 65, 64), (20011, 5, 64), (9000, 128, 32)])
+def test_embedding_table_gradient_kernel(rows, card, C):
+    """prd_embed_wgrad against index_add in float64; bit-reproducible."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(rows + card)
+    idx = torch.randint(0, card, (rows,), generator=g)
+    dy = torch.randn(rows, C, generator=g)
+    want = torch.zeros(card, C, dtype=torch.float64).index_add_(0, idx, dy.double())
+    got = ops.embed_wgrad(idx.cuda(), dy.cuda(), card)
+    assert got.shape == (card, C) and (got.double().cpu() - want).norm() / want.norm() < 2e-6
+    assert torch.equal(got, ops.embed_wgrad(idx.cuda(), dy.cuda(), card))
