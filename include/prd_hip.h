@@ -222,6 +222,14 @@ int prd_tri_attn_core(float* og, const float* pair, const float* mask, const flo
                       int b, int N, int P, int H, int c, hipStream_t stream);
 int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
                      int residual, int b, int N, int P, int* queue, hipStream_t stream);
+/* Second-generation core for short rows (N <= 352, split-16 arithmetic; csrc/prd_tri2.hip): same contract as
+ * prd_tri_attn_core, everything on the 32x32x16 fp16 MFMA (Q K^T with fp16 hi+lo operands rounded to nearest: 24 bits),
+ * the (query block, key tile) work of a row cut into equal contiguous ranges per wave.  prd_tri_attn_core dispatches to
+ * it when prd_tri_attn_v2_supported(N, P) and the gemm mode is split-16 (PRD_TA_VARIANT=10 keeps the first generation). */
+int prd_tri_attn_v2_supported(int N, int P);
+int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
+                         const float* wv, const float* wg, const float* bg, int ending,
+                         int b, int N, int P, int H, int c, hipStream_t stream);
 /* Triangle attention core whose input row is `pair + og_in W_o^T + b_o`: the residual update of the PREVIOUS triangle attention
  * (its output projection, modules.py:339-340) is applied while the row is loaded, and written to `pair_out` -- which must not
  * alias `pair` -- by the workgroups of head 0, instead of a separate prd_tri_attn_out launch.  gemm mode 1, short rows only

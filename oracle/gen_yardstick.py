@@ -1,0 +1,142 @@
+"""Reference-derived yardstick for LONG reverse-diffusion loops (build container only; test infrastructure).
+
+    python oracle/gen_yardstick.py cfg1_t200 cfg1_t200_random cfg1_t1000     # fp64 twins of the existing fp32 trajectory fixtures
+    python oracle/gen_yardstick.py cfg2_t1000 --dtype f32                    # BASELINE configs[1] at its own shape AND length
+    python oracle/gen_yardstick.py cfg2_t1000 --dtype f64
+
+Why: a T = 1000 loop of a denoiser amplifies round-off.  How much of a deviation between two fp32 implementations is
+"the same result" can only be answered by the reference itself: this script runs the IMPORTED reference
+(/root/reference/ProteinReDiff/model.py:377-422 `sample`) twice on the same complex, weights, redesign mask and injected
+noise -- once in fp32 (what gen_golden.py stores as `seg_z`, `traj_pos`, ...) and once with `model.double()` -- and stores
+the fp64 state entering every `traj_every`-th step.  delta_ref(step) = rel-L2(fp32 reference, fp64 reference) is the
+reference's own sensitivity to fp32 round-off along this very trajectory; an fp32 implementation is held to a small
+multiple of it (tests/test_hip_parity.py::test_free_running_trajectory_vs_yardstick).
+
+The schedule scalars (model.py:172-190) are computed in fp32 in BOTH runs (the same 16 fp32 vectors), so the two runs
+differ only in the arithmetic of the network forward and of the reverse update.
+
+Writes tests/golden/<case>_f64.npz (fp64 run) and, for cases gen_golden.py does not know (cfg2_*), tests/golden/<case>.npz
+(fp32 run, same keys as gen_golden's trajectory fixtures).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import gen_golden as G  # noqa: E402
+from ref_import import import_reference  # noqa: E402
+
+from protein_redesign_amd.synthetic import NoiseSource, clone_batch, synthetic_batch  # noqa: E402
+
+CASES = {k: v for k, v in G.CASES.items() if v.get("traj_only")}
+# BASELINE.json configs[1]: 256 residues + 64 ligand atoms, 512 / 64, 4 blocks, T = 1000, one sample
+CASES["cfg2_t1000"] = dict(
+    args=dict(single_dim=512, pair_dim=64, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
+              num_steps=1000, mask_prob=0.3),
+    sizes=[(64, 256)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(64, 256), traj_only=True,
+    weight_style="near_init", traj_every=25)
+
+
+class _Injected32(G._Injected):
+    """gen_golden's RNG routing, drawing the SAME fp32 numbers whatever the default dtype is."""
+
+    def __enter__(self):
+        super().__enter__()
+        patched_randn_like, patched_randperm = torch.randn_like, torch.randperm
+
+        def randn_like(x, **kw):
+            prev = torch.get_default_dtype()
+            torch.set_default_dtype(torch.float32)
+            try:
+                return patched_randn_like(x, **kw)
+            finally:
+                torch.set_default_dtype(prev)
+
+        torch.randn_like = randn_like
+        return self
+
+
+@torch.inference_mode()
+def run(name, case, ref_model, dtype, threads, max_steps=None):
+    torch.set_default_dtype(torch.float32)
+    model, args = G.build_reference(ref_model, case)          # fp32 weights, fp32 schedule tables
+    if dtype == "f64":
+        model = model.double()                                  # same weight VALUES; schedule attributes stay fp32 tensors
+    every = case["traj_every"]
+    one = synthetic_batch([case["traj_sample"]], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500)
+    if dtype == "f64":
+        one = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in one.items()}
+    states = []
+    inner = model.sample_step
+    t0 = time.time()
+
+    class _Stop(Exception):
+        pass
+
+    def spy(batch, z, seq_t, mask, t):
+        step = args["num_steps"] - 1 - int(t[0])
+        if step % every == 0:
+            states.append((step, z.clone(), seq_t.clone()))
+            print(f"[{name} {dtype}] step {step} t={time.time() - t0:.0f}s |z|={float(z.norm()):.4f}", flush=True)
+        if max_steps is not None and step >= max_steps:
+            raise _Stop
+        return inner(batch, z, seq_t, mask, t)
+
+    model.sample_step = spy
+    pos = logits = None
+    if dtype == "f64":
+        torch.set_default_dtype(torch.float64)                 # prepare_batch's one_hot * 2. - 1. must come out fp64
+    try:
+        with _Injected32([NoiseSource(G.NOISE_SEED, 0)]):
+            pos, logits = model.sample(clone_batch(one))
+    except _Stop:
+        pass
+    finally:
+        torch.set_default_dtype(torch.float32)
+    out = {"case": np.array(json.dumps(dict(case, name=name, dtype=dtype))),
+           "seg_step": np.array([s[0] for s in states])}
+    if dtype == "f64":
+        assert states[0][1].dtype == torch.float64
+        out.update(seg_z_f64=torch.cat([s[1] for s in states]).numpy(),                       # float64
+                   seg_seq_t_f64=torch.cat([s[2] for s in states]).float().numpy())           # rounded to fp32 (size)
+        if pos is not None:
+            out.update(traj_pos_f64=pos.numpy(), traj_logits_f64=logits.numpy())
+    else:
+        out["state_dict_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in model.state_dict().items()}))
+        out.update(seg_z=torch.cat([s[1] for s in states]).numpy(), seg_seq_t=torch.cat([s[2] for s in states]).numpy())
+        if pos is not None:
+            out.update(traj_pos=pos.numpy(), traj_logits=logits.numpy())
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="+")
+    ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
+    ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--max-steps", type=int, default=None, help="stop after this many steps (partial fixture)")
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    ref_model, _ = import_reference()
+    for name in a.cases:
+        torch.manual_seed(0)
+        res = run(name, CASES[name], ref_model, a.dtype, a.threads, a.max_steps)
+        suffix = "_f64" if a.dtype == "f64" else ""
+        if a.dtype == "f32" and name in G.CASES:
+            raise SystemExit(f"{name}: the fp32 fixture belongs to gen_golden.py")
+        path = os.path.join(ROOT, "tests", "golden", f"{name}{suffix}.npz")
+        np.savez_compressed(path, **res)
+        print(name, a.dtype, "->", path, f"{os.path.getsize(path) / 1024:.1f} KiB", flush=True)
+
+
+if __name__ == "__main__":
+    main()

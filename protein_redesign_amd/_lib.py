@@ -74,6 +74,8 @@ SIGNATURES = {
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
     "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 6 + [vp],
+    "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 6 + [vp],
+    "prd_tri_attn_v2_supported": [ci, ci],
     "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
 }

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprd_hip.so")
-SOURCES = ["prd_gemm.hip", "prd_pair.hip", "prd_tri.hip", "prd_bwd.hip"]
+SOURCES = ["prd_gemm.hip", "prd_pair.hip", "prd_tri.hip", "prd_tri2.hip", "prd_bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -2253,6 +2253,8 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     else if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
     else if (b3) {
         static const int variant = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;     // tuning only
+        if (variant == 0 && prd_tri_attn_v2_supported(N, P))
+            return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
         if (P == 64) {
             if (variant == 1) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 16, 64, 16, 1, false);
             else if (variant == 2) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 12, 64, 12, 1, false);

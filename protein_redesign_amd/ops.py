@@ -479,6 +479,21 @@ def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> 
     return og
 
 
+def tri_attn_v2_supported(N: int, P: int) -> bool:
+    """True when the second-generation core (csrc/prd_tri2.hip) serves rows of N positions."""
+    return lib().prd_tri_attn_v2_supported(N, P) == 1
+
+
+def tri_attn_core_v2(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> torch.Tensor:
+    """The second-generation core called directly (split-16 arithmetic whatever the gemm mode); arguments as tri_attn_core."""
+    b, N, _, P = pair.shape
+    if og is None:
+        og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
+    check(lib().prd_tri_attn_core_v2(dptr(og), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
+                                     b, N, P, H, c, stream()), "prd_tri_attn_core_v2")
+    return og
+
+
 def tri_attn_core_fused_supported(N: int, P: int) -> bool:
     """True when prd_tri_attn_core_fused exists for this shape in the current arithmetic mode."""
     return lib().prd_tri_attn_core_fused_supported(N, P) == 1

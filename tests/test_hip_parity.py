@@ -311,6 +311,49 @@ def test_triangle_attention(setup, mode, gemm_mode):
     assert rel_l2(got.cpu(), want) < OP_TOL
 
 
+@pytest.mark.parametrize("ending", [False, True])
+@pytest.mark.parametrize("b,N,valid", [(1, 320, 320), (2, 140, 131), (1, 33, 33), (1, 97, 64), (3, 200, 200), (1, 352, 340), (1, 31, 17)])
+def test_triangle_attention_core_v2(setup, b, N, valid, ending):
+    """Second-generation core (prd_tri2.hip: 32x32x16 MFMA, fp16 hi+lo rounded to nearest, work cut into contiguous ranges per
+    wave) called directly: the whole og tensor against the first-generation core in fp32-MFMA mode (a different kernel, exact
+    fp32 arithmetic), and a subset of rows against the oracle's gated attention.  Shapes: the bench shape (10 x 10 iterations on
+    8 waves: every query block is shared by two waves), ragged rows with masked tails, rows shorter than one tile, rows whose
+    padding reaches into the last tile, more waves than iterations (N = 31, 33), the longest row the kernel takes (352)."""
+    from protein_redesign_amd import _lib
+    s = setup
+    P = s["P"]
+    H, c = s["args"]["num_heads"], s["args"]["head_dim"]
+    assert ops.tri_attn_v2_supported(N, P)
+    g = torch.Generator().manual_seed(1000 + N + b)
+    pair = torch.randn(b, N, N, P, generator=g)
+    mask = torch.ones(b, N)
+    mask[-1, valid:] = 0
+    mod = s["model"].Denoiser.folding_blocks[0].pair_attn_ending if ending else s["model"].Denoiser.folding_blocks[0].pair_attn_starting
+    wts = [t.clone() for t in mod.attn.weights()][:5]
+    got = ops.tri_attn_core_v2(cu(pair), cu(mask), wts, H, c, ending=ending)
+    prev = _lib.lib().prd_get_gemm_mode()
+    try:
+        assert _lib.lib().prd_set_gemm_mode(0) == 0
+        ref = ops.tri_attn_core(cu(pair), cu(mask), wts, H, c, ending=ending)
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+    assert torch.isfinite(got).all()
+    assert rel_l2(got.cpu(), ref.cpu()) < OP_TOL
+    # rows against the oracle: og W_o^T + b_o is what the oracle returns, so project with torch on the CPU
+    rows = sorted({0, N // 2, valid - 1, N - 1} | set(torch.randint(0, N, (3,), generator=g).tolist()))
+    pfx = f"Denoiser.folding_blocks.0.pair_attn_{'ending' if ending else 'starting'}"
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    with torch.inference_mode():
+        if not ending:
+            sub, msub = pair[:, rows], m2[:, rows]
+        else:
+            sub, msub = pair[:, :, rows].transpose(1, 2), m2[:, :, rows].transpose(1, 2)
+        want = O.gated_attention(s["params"], pfx + ".attn", sub, msub, H, c)
+        gsub = got.cpu()[:, rows] if not ending else got.cpu()[:, :, rows].transpose(1, 2)
+        proj = gsub @ s["params"][pfx + ".attn.out_proj.weight"].T + s["params"][pfx + ".attn.out_proj.bias"]
+    assert rel_l2(proj, want) < OP_TOL
+
+
 def test_pair_transition(setup, gemm_mode):
     s = setup
     pf = s["model"].Denoiser.folding_blocks[0].pair_fc

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Tuning helper: time tri_attn_core (gemm mode 1) at the bench shape; run once per PRD_TA_VARIANT value."""
+"""Tuning helper: time tri_attn_core (gemm mode 1) at the bench shape; run once per PRD_TA_VARIANT value
+(unset / 0: second-generation core prd_tri2.hip; 10: first generation, 8 waves x 2 tiles; 1-3: its other variants)."""
 import os
 import sys
 
