@@ -8,6 +8,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprd_hip.so")
 SOURCES = ["prd_gemm.hip", "prd_pair.hip", "prd_tri.hip", "prd_tri2.hip", "prd_bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# per-source extras.  prd_tri2: the softmax arithmetic is placed by hand between the MFMAs of the key loop; the SLP vectoriser
+# would pack its scalar fp32 adds into v_pk_add_f32 (slower beside MFMAs on gfx950) and move them out of their slots
+EXTRA_FLAGS = {"prd_tri2.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(out, deps):
@@ -27,7 +30,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise FileNotFoundError(f"HIP source listed in build.py is missing: {spath}")
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(obj, [spath] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", spath, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", spath, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -52,7 +55,7 @@ def build_asan(verbose: bool = True) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(out_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-g", "-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-g", "-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -75,7 +78,7 @@ def build_timing(verbose: bool = True) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(out_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-DPRD_TIMING", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-DPRD_TIMING", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -35,10 +35,10 @@
 #include "../../include/prd_hip.h"
 #include <mutex>
 
-#ifdef PRD_TIMING     // diagnostic builds only (tools/ta2_timing.py): cycle stamps [workgroup][8 waves][8 rows][8 stamps]
-__device__ unsigned long long prd_dbg2[256 * 8 * 8 * 8];
+#ifdef PRD_TIMING     // diagnostic builds only (tools/ta2_timing.py): cycle stamps [workgroup][8 waves][8 rows][16 stamps]
+__device__ unsigned long long prd_dbg2[256 * 8 * 8 * 16];
 extern "C" int prd_debug_read2(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(prd_dbg2), sizeof(prd_dbg2)); }
-#define PRD2_STAMP(k) do { if (lane == 0 && it < 8) prd_dbg2[((blockIdx.x * 8 + wave) * 8 + it) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define PRD2_STAMP(k) do { if (lane == 0 && it < 8) prd_dbg2[((blockIdx.x * 8 + wave) * 8 + it) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PRD2_STAMP(k)
 #endif
@@ -47,7 +47,7 @@ namespace {
 
 constexpr float LOG2E_2 = 1.4426950408889634f;
 constexpr float P_SHIFT = 4.0f;                 // probabilities are 2^(s - max + P_SHIFT)
-constexpr int V2_MAXN = 352;
+constexpr int V2_MAXN = 384;
 
 PRD_DEV f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -57,12 +57,18 @@ PRD_DEV f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
 // signed), same three instructions per pair
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 PRD_DEV void split2h_rn(float a, float b, unsigned& hi, unsigned& lo) {
-    // the conversion is left to the compiler (it selects v_cvt_pk_f16_f32): as the FIRST reader of a value that may come
+    // Measured on gfx950 (tools/ubench/valu_rate_bench.hip, SIMD cycles per wave64 instruction at >= 2 waves per SIMD):
+    // v_cvt_pk_f16_f32 and v_fma_mix_f32 4.6, v_fma_mixlo/hi_f16 8.4 (the rate of a transcendental).  So the residuals are
+    // formed in fp32 (v_fma_mix_f32: fp16 source half * -1 + fp32 source, exact) and packed by a second conversion:
+    // 4 x 4.6 cycles per pair instead of 4.6 + 2 x 8.4.
+    // The first conversion is left to the compiler (it selects v_cvt_pk_f16_f32): as the FIRST reader of a value that may come
     // straight out of an MFMA or a transcendental it must be an instruction whose hazards hipcc pads (an asm statement's
     // reads are not padded)
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, h16x2));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, h16x2));
 }
 // 8 consecutive registers of an MFMA fragment -> hi / lo operand registers (element jj in half-word jj)
 PRD_DEV void split8_rn(const f32x16& v, int base, u32x4& h, u32x4& l) {
@@ -135,7 +141,7 @@ PRD_DEV V2Lds v2_layout(int P, int NP) {
     L.qh = off; off += 2 * L.plane;
     L.ql = off; off += 2 * L.plane;
     L.v = off; off += (unsigned)NP * 64u;              // [tile][a][hi][m = plane * 16 + c][8 fp16]
-    L.g = off; off += (unsigned)NP * 64u;              // [c][NP] fp32
+    L.g = off; off += (unsigned)NP * 64u;              // [position][hi][8] fp32: the 8 gate channels {4hi+e, 8+4hi+e} of a lane
     L.kadd = off; off += (unsigned)NP * 4u;
     L.flag = off; off += 64u;
     L.bias = off; off += 64u;
@@ -143,14 +149,42 @@ PRD_DEV V2Lds v2_layout(int P, int NP) {
     return L;
 }
 
+// LayerNorm without affine over a CLL row (ln_cll of prd_common.h with the cross-half sums on v_permlane32_swap instead of
+// ds_bpermute: no LDS round trip in the middle of the projection phase)
+template <int KH>
+PRD_DEV void ln_cll_p(float (&x)[KH]) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KH; k += 2) { s0 += x[k]; s1 += x[k + 1]; }
+    const float mean = xhalf_add(s0 + s1) * (1.0f / (2 * KH));
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KH; k += 2) {
+        x[k] -= mean;
+        x[k + 1] -= mean;
+        v0 = __builtin_fmaf(x[k], x[k], v0);
+        v1 = __builtin_fmaf(x[k + 1], x[k + 1], v1);
+    }
+    const float rstd = 1.0f / sqrtf(xhalf_add(v0 + v1) * (1.0f / (2 * KH)) + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) x[k] *= rstd;
+}
+
+struct KOp { u32x4 h, l; };                            // K hi | lo operands of one 32-key tile
+struct PBuf { u32x4 ph0, pl0, ph1, pl1, va0, va1; };   // probabilities of a tile (fp16 hi | lo, 2 x 16 keys) + its V operands
+
+PRD_DEV KOp load_k(const unsigned char* lds, unsigned kaddr, unsigned kl_off) {
+    KOp k;
+    k.h = *reinterpret_cast<const u32x4*>(lds + kaddr);
+    k.l = *reinterpret_cast<const u32x4*>(lds + kaddr + kl_off);
+    return k;
+}
+
 // S^T tile: 32 keys x 32 queries; C = cinit (all registers)
-PRD_DEV f32x16 qk_tile(const unsigned char* lds, const V2Lds& L, int T, int r, int hi, u32x4 qh, u32x4 ql, const f32x16& cinit) {
-    const unsigned ko = (unsigned)hi * L.plane + (unsigned)(32 * T + r) * 16u;
-    const u32x4 kh = *reinterpret_cast<const u32x4*>(lds + L.kh + ko);
-    const u32x4 kl = *reinterpret_cast<const u32x4*>(lds + L.kl + ko);
-    f32x16 s = mfma_h(kh, qh, cinit);
-    s = mfma_h(kh, ql, s);
-    s = mfma_h(kl, qh, s);
+PRD_DEV f32x16 qk_tile(const KOp& k, u32x4 qh, u32x4 ql, const f32x16& cinit) {
+    f32x16 s = mfma_h(k.h, qh, cinit);
+    s = mfma_h(k.h, ql, s);
+    s = mfma_h(k.l, qh, s);
     return s;
 }
 
@@ -167,12 +201,8 @@ PRD_DEV void mask_tile(const unsigned char* lds, const V2Lds& L, int T, int hi, 
     }
 }
 
-// p = 2^s (s already relative to the reference), row-sum, split, O += [V_hi; V_lo] P
-PRD_DEV void exp_pv_tile(const unsigned char* lds, const V2Lds& L, int T, int r, int hi, f32x16& s, float& lsum, bool& big,
-                         f32x16& o0, f32x16& o1) {
-    const unsigned vo = L.v + (unsigned)(T * 4 + hi) * 512u + (unsigned)r * 16u;
-    const u32x4 va0 = *reinterpret_cast<const u32x4*>(lds + vo);
-    const u32x4 va1 = *reinterpret_cast<const u32x4*>(lds + vo + 1024u);
+// p = 2^s (s already relative to the reference), row-sum, split into the B operands of P V
+PRD_DEV void exp_split(f32x16& s, float& lsum, bool& big, PBuf& p) {
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
@@ -184,13 +214,86 @@ PRD_DEV void exp_pv_tile(const unsigned char* lds, const V2Lds& L, int T, int r,
     const float ts = t0 + t1;
     big |= !(ts < 30000.0f);                           // a probability near the fp16 range (or inf / NaN)
     lsum += ts;
-    u32x4 ph0, pl0, ph1, pl1;
-    split8_rn(s, 0, ph0, pl0);
-    split8_rn(s, 8, ph1, pl1);
-    o0 = mfma_h(va0, ph0, o0);
-    o1 = mfma_h(va1, ph1, o1);
-    o0 = mfma_h(va0, pl0, o0);
-    o1 = mfma_h(va1, pl1, o1);
+    split8_rn(s, 0, p.ph0, p.pl0);
+    split8_rn(s, 8, p.ph1, p.pl1);
+}
+PRD_DEV void load_v(const unsigned char* lds, unsigned vaddr, PBuf& p) {
+    p.va0 = *reinterpret_cast<const u32x4*>(lds + vaddr);
+    p.va1 = *reinterpret_cast<const u32x4*>(lds + vaddr + 1024u);
+}
+// O += [V_hi; V_lo] P for both 16-key halves of a tile
+PRD_DEV void pv_tile(const PBuf& p, f32x16& o0, f32x16& o1) {
+    o0 = mfma_h(p.va0, p.ph0, o0);
+    o1 = mfma_h(p.va1, p.ph1, o1);
+    o0 = mfma_h(p.va0, p.pl0, o0);
+    o1 = mfma_h(p.va1, p.pl1, o1);
+}
+
+#define PRD2_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Priority = fraction of the wave's own key-loop work (tiles) still to do.  The waves of a SIMD are arbitrated oldest first:
+// without this the older wave of a SIMD runs its tiles at full speed and the younger one then finishes alone, at the VALU
+// issue rate of a single wave (measured: 14.0k vs 20.3k cycles per row for equal work; the SIMD is done when the slower is).
+PRD_DEV void v2_prio(int rem, int tot) {
+    if (4 * rem > 3 * tot) __builtin_amdgcn_s_setprio(3);
+    else if (2 * rem > tot) __builtin_amdgcn_s_setprio(2);
+    else if (4 * rem > tot) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+// One steady-state step of the key loop, written in ISSUE ORDER.  The seven MFMAs of a step -- P V of tile t-1 (operands p,
+// produced by the previous step) and Q K^T of tile t+1 (operands k, into sn) -- do not depend on the softmax arithmetic of
+// tile t (sc -> p), so the ~60 VALU instructions of that arithmetic are dealt into the seven 32-cycle gaps behind the MFMAs
+// (a wave issues in order: an MFMA occupies the matrix pipe for 32 cycles while the instructions behind it issue).  The P V
+// MFMAs come first: once they are issued, their operand registers take the probabilities of tile t and the V operands of tile
+// t (loaded for the next step); likewise the K registers take tile t+2 after the Q K^T MFMAs.  The scheduling fences keep
+// hipcc from regrouping the MFMAs into one cluster.
+PRD_DEV void pipe_step(const unsigned char* lds, unsigned kaddr_next, unsigned kl_off, unsigned vaddr, f32x16& sc, f32x16& sn,
+                       const f32x16& negm, u32x4 qh, u32x4 ql, KOp& k, PBuf& p, f32x16& o0, f32x16& o1, float& lsum, bool& big) {
+    float t0, t1;
+    o0 = mfma_h(p.va0, p.ph0, o0);
+    PRD2_FENCE();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
+    t0 = sc[0] + sc[2];
+    t1 = sc[1] + sc[3];
+    PRD2_FENCE();
+    o1 = mfma_h(p.va1, p.ph1, o1);
+    PRD2_FENCE();
+#pragma unroll
+    for (int j = 4; j < 8; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
+    t0 += sc[4]; t1 += sc[5]; t0 += sc[6]; t1 += sc[7];
+    PRD2_FENCE();
+    o0 = mfma_h(p.va0, p.pl0, o0);
+    PRD2_FENCE();
+#pragma unroll
+    for (int j = 8; j < 12; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
+    t0 += sc[8]; t1 += sc[9]; t0 += sc[10]; t1 += sc[11];
+    PRD2_FENCE();
+    o1 = mfma_h(p.va1, p.pl1, o1);
+    PRD2_FENCE();
+    load_v(lds, vaddr, p);                              // V of tile t: operands of the NEXT step's P V
+#pragma unroll
+    for (int j = 12; j < 16; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
+    t0 += sc[12]; t1 += sc[13]; t0 += sc[14]; t1 += sc[15];
+    PRD2_FENCE();
+    sn = mfma_h(k.h, qh, negm);
+    PRD2_FENCE();
+    split8_rn(sc, 0, p.ph0, p.pl0);
+    PRD2_FENCE();
+    sn = mfma_h(k.h, ql, sn);
+    PRD2_FENCE();
+    split8_rn(sc, 8, p.ph1, p.pl1);
+    PRD2_FENCE();
+    sn = mfma_h(k.l, qh, sn);
+    PRD2_FENCE();
+    k = load_k(lds, kaddr_next, kl_off);                // K of tile t+2
+    {
+        const float ts = t0 + t1;
+        big |= !(ts < 30000.0f);
+        lsum += ts;
+    }
+    PRD2_FENCE();
 }
 
 template <int P, int NW>
@@ -225,161 +328,269 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     const float sc = 0.25f * LOG2E_2;
     stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
     stage_weight_h2_rows<P>(Wb, 64, C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
-    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
-    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
-    if (tid < 16) biasl[tid] = H2_WSCALE * NEG_LOG2E * bg[h * C + tid];
-    const long nrows = (long)b * N;
-    auto row_pos = [&](long bu, int v) -> long {
-        const long bb = bu / N;
-        const long u = bu - bb * N;
-        return ending ? ((bb * N + v) * N + u) : (bu * N + v);
-    };
+    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    if (tid < 16) {                                     // gate bias in the register order of a lane: [hi][8]
+        const int hh = tid >> 3, e = tid & 7;
+        biasl[tid] = H2_WSCALE * NEG_LOG2E * bg[h * C + 4 * hh + (e & 3) + 8 * (e >> 2)];
+    }
+    const int nrows = b * N;                            // (the host checks that b * N * N fits an int)
+    struct RowIx { int bu, bb, u; };
+    auto make_row = [&](int bu) { RowIx x; x.bu = bu; x.bb = bu / N; x.u = bu - x.bb * N; return x; };       // 32-bit, once per row
+    auto row_pos = [&](const RowIx& x, int v) -> long { return ending ? (long)((x.bb * N + v) * N + x.u) : (long)(x.bu * N + v); };
     // ---- static work split ----
-    // phase 1: half-items i = 2 * block + kind dealt round-robin (kind 0 = [K|Q], 1 = [V|G])
-    const int nitem = 2 * nqb;
-    // phase 2: iterations (query block, key tile) cut into NW contiguous ranges
-    const int niter = nqb * nqb;
-    const int it_begin = (int)((long)niter * wave / NW), it_end = (int)((long)niter * (wave + 1) / NW);
+    // phase 1: block w (all four projections) by wave w; the blocks past the NW-th as half-items (kind 0 = [K|Q], 1 = [V|G])
+    // dealt round-robin
+    const int nfullblk = nqb < NW ? nqb : NW;
+    const int nextra = 2 * (nqb - nfullblk);
+    // phase 2: query blocks [0, wholeq) belong to one wave each (w, w + NW, ...); the (query block, key tile) iterations of the
+    // remaining R blocks are cut into NW contiguous ranges
+    const int wholeq = (nqb / NW) * NW;
+    const int R = nqb - wholeq;
+    const int rem_iter = R * nqb;
+    const int it_begin = (int)((long)rem_iter * wave / NW), it_end = (int)((long)rem_iter * (wave + 1) / NW);
     const float inv16 = H2_INV_WSCALE;
+    const unsigned kl_off = L.kl - L.kh;
+    const unsigned kbase = L.kh + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
+    const unsigned vbase = L.v + (unsigned)hi * 512u + (unsigned)r * 16u;          // + 2048 t
 
-    float xnext[KH];                                    // the wave's first phase-1 block of the NEXT row
+    float xnext[KH];                                    // the wave's own block of the NEXT row
+    float mknext = 0.f, munext = 0.f;                   // ... and its mask values (own block's positions; the row itself)
+    RowIx rnext = make_row(slot < nrows ? slot : 0);
     {
-        const int blk = wave >> 1;
-        const int v = blk * 32 + r;
-        const bool ok = slot < nrows && wave < nitem && v < N;
-        load_row_cll<P>(pair + row_pos(ok ? slot : 0, ok ? v : 0) * P, hi, ok, xnext);
+        const int v = wave * 32 + r;
+        const bool ok = slot < nrows && wave < nfullblk && v < N;
+        load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
+        if (ok) mknext = mask[rnext.bb * N + v];
+        if (slot < nrows) munext = mask[slot];
     }
     int it = 0;
-    for (long bu = slot; bu < nrows; bu += rstride, ++it) {
-        const int bb = (int)(bu / N);
+    for (int bu = slot; bu < nrows; bu += rstride, ++it) {
+        const RowIx row = rnext;
+        const int bb = row.bb;
         __syncthreads();                                // previous row's LDS consumed (and the weight image staged)
         PRD2_STAMP(0);
-        const float mu = mask[bu];
+        const float mu = munext;
         // ================= phase 1 =================
         {
-            // one half-item: LayerNorm + split of the block's rows (in place), one row GEMM, stores
-            auto do_item = [&](int item, float (&x)[KH]) {
-                const int blk = item >> 1, kind = item & 1;
+            auto key_override = [&](int blk, float mk) {           // logit override + tile flag of block blk
                 const int v = blk * 32 + r;
                 const bool valid = v < N;
-                ln_cll<KH>(x);
-                u32x4 xs[2][P / 16];
-                split2h_rn_cll<KH>(x, xs);
-                if (kind == 0) {
-                    {
-                        const bool keep = valid && (mu * mask[(long)bb * N + (valid ? v : 0)] >= 0.5f);
-                        if (hi == 0) kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
-                        const bool any_override = __any(!keep);
-                        if (lane == 0) tflag[blk] = any_override ? 1 : 0;
-                    }
-                    f32x16 acc[1];
-                    zero_acc(acc);
-                    rowgemm_h2<P, 1>(Wb, 64, 0, xs, acc, r, hi);
+                const bool keep = valid && (mu * mk >= 0.5f);
+                if (hi == 0) kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
+                const bool any_override = __any(!keep);
+                if (lane == 0) tflag[blk] = any_override ? 1 : 0;
+            };
+            // image rows: K 0-15 | Q 16-31 | G 32-47 | V 48-63.  Three row GEMMs per block:
+            //   kq: unswapped (A = rows r of the image): lane (pos, hi) registers 0-7 = K, 8-15 = Q channels {4hi+e, 8+4hi+e}
+            //   g : unswapped, A = G rows 32 + (r & 15) (lanes 16-31 repeat them): registers 0-7 = gate channels {4hi+e, 8+4hi+e}
+            //   v : SWAPPED, B = V rows 48 + (r & 15): lane (n, hi) register j = V channel n & 15 of position drow32(j, hi);
+            //       lanes 0-15 keep the fp16 hi part, lanes 16-31 the lo part = rows 0-15 / 16-31 of the P V A operand
+            auto wop = [&](int row, int s_, u32x4& wh, u32x4& wl) {
+                const int slot_ = h2_slot<P>(row, 2 * s_ + hi);
+                wh = Wb[(size_t)row * (P / 8) + slot_];
+                wl = Wb[(size_t)(64 + row) * (P / 8) + slot_];
+            };
+            auto gemm_kq = [&](const u32x4 (&xs)[2][P / 16], f32x16& acc) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[0][e] *= inv16;
-                    u32x4 kh4, kl4, qh4, ql4;
-                    split8_rn(acc[0], 0, kh4, kl4);
-                    split8_rn(acc[0], 8, qh4, ql4);
-                    const unsigned po = (unsigned)hi * L.plane + (unsigned)v * 16u;
-                    *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
-                    *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
-                    *reinterpret_cast<u32x4*>(lds + L.qh + po) = qh4;
-                    *reinterpret_cast<u32x4*>(lds + L.ql + po) = ql4;
-                } else {
-                    f32x16 acc;
-                    {
-                        const float b0 = r >= 16 ? biasl[r - 16] : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[e] = b0;
-                    }
-                    rowgemm_h2_swapped<P>(Wb, 64, 32, xs, acc, r, hi);
-                    if (r < 16) {                       // V channel r (x 16): hi | lo planes of positions drow32(j, hi)
-                        u32x4 vh0, vl0, vh1, vl1;
-                        split8_rn(acc, 0, vh0, vl0);
-                        split8_rn(acc, 8, vh1, vl1);
-                        const unsigned vo = L.v + (unsigned)(blk * 4 + hi) * 512u;
-                        *reinterpret_cast<u32x4*>(lds + vo + (unsigned)r * 16u) = vh0;
-                        *reinterpret_cast<u32x4*>(lds + vo + (unsigned)(16 + r) * 16u) = vl0;
-                        *reinterpret_cast<u32x4*>(lds + vo + 1024u + (unsigned)r * 16u) = vh1;
-                        *reinterpret_cast<u32x4*>(lds + vo + 1024u + (unsigned)(16 + r) * 16u) = vl1;
-                    } else {                            // gate channel r - 16
-                        float* gp = Gl + (r - 16) * NP + blk * 32 + 4 * hi;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<float4*>(gp + 8 * g) =
-                                make_float4(gate_from_scaled(acc[4 * g] * inv16), gate_from_scaled(acc[4 * g + 1] * inv16),
-                                            gate_from_scaled(acc[4 * g + 2] * inv16), gate_from_scaled(acc[4 * g + 3] * inv16));
-                    }
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 wh, wl;
+                    wop(r, s_, wh, wl);
+                    acc = mfma_h(wh, xs[0][s_], acc);
+                    acc = mfma_h(wh, xs[1][s_], acc);
+                    acc = mfma_h(wl, xs[0][s_], acc);
                 }
             };
-            auto fetch = [&](int item, float (&x)[KH]) {
-                const int v = (item >> 1) * 32 + r;
-                const bool ok = item < nitem && v < N;
-                load_row_cll<P>(pair + row_pos(bu, ok ? v : 0) * P, hi, ok, x);
+            auto gemm_gv = [&](const u32x4 (&xs)[2][P / 16], f32x16& ag, f32x16& av) {
+#pragma unroll
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 gh, gl, vh, vl;
+                    wop(32 + (r & 15), s_, gh, gl);
+                    wop(48 + (r & 15), s_, vh, vl);
+                    ag = mfma_h(gh, xs[0][s_], ag);
+                    av = mfma_h(xs[0][s_], vh, av);
+                    ag = mfma_h(gh, xs[1][s_], ag);
+                    av = mfma_h(xs[1][s_], vh, av);
+                    ag = mfma_h(gl, xs[0][s_], ag);
+                    av = mfma_h(xs[0][s_], vl, av);
+                }
             };
-            // the rows of item k + 1 are requested before item k is computed (item 0 came in during the previous key loops)
-            float xb[KH];
-            fetch(wave + NW, xb);
-            if (wave < nitem) do_item(wave, xnext);
-            if (wave + NW < nitem) {
-                fetch(wave + 2 * NW, xnext);
-                do_item(wave + NW, xb);
-                if (wave + 2 * NW < nitem) do_item(wave + 2 * NW, xnext);
+            auto store_kq = [&](int blk, f32x16& acc) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+                u32x4 kh4, kl4, qh4, ql4;
+                split8_rn(acc, 0, kh4, kl4);
+                split8_rn(acc, 8, qh4, ql4);
+                const unsigned po = (unsigned)hi * L.plane + (unsigned)(blk * 32 + r) * 16u;
+                *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
+                *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
+                *reinterpret_cast<u32x4*>(lds + L.qh + po) = qh4;
+                *reinterpret_cast<u32x4*>(lds + L.ql + po) = ql4;
+            };
+            auto g_init = [&](f32x16& ag) {
+                const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi + 4);
+                ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
+#pragma unroll
+                for (int e = 8; e < 16; ++e) ag[e] = 0.f;
+            };
+            auto store_gv = [&](int blk, const f32x16& ag, const f32x16& av) {
+                float* gp = Gl + (size_t)((blk * 32 + r) * 2 + hi) * 8;
+                *reinterpret_cast<float4*>(gp) = make_float4(gate_from_scaled(ag[0] * inv16), gate_from_scaled(ag[1] * inv16),
+                                                             gate_from_scaled(ag[2] * inv16), gate_from_scaled(ag[3] * inv16));
+                *reinterpret_cast<float4*>(gp + 4) = make_float4(gate_from_scaled(ag[4] * inv16), gate_from_scaled(ag[5] * inv16),
+                                                                 gate_from_scaled(ag[6] * inv16), gate_from_scaled(ag[7] * inv16));
+                u32x4 vh0, vl0, vh1, vl1;               // V stays x 16
+                split8_rn(av, 0, vh0, vl0);
+                split8_rn(av, 8, vh1, vl1);
+                const bool lo_lane = r >= 16;
+                u32x4 s0, s1;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
+                const unsigned vo = L.v + (unsigned)(blk * 4 + hi) * 512u + (unsigned)r * 16u;
+                *reinterpret_cast<u32x4*>(lds + vo) = s0;
+                *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+            };
+            // extra half-items of this wave: rows requested before the own block is computed
+            float xe[KH];
+            float mke = 0.f;
+            const int e0 = wave;                        // first extra half-item (block nfullblk + e0 / 2, kind e0 & 1)
+            {
+                const int v = (nfullblk + (e0 >> 1)) * 32 + r;
+                const bool ok = e0 < nextra && v < N;
+                load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi, ok, xe);
+                if (ok) mke = mask[bb * N + v];
+            }
+            if (wave < nfullblk) {                      // the wave's own block: LayerNorm + split once, three row GEMMs
+                key_override(wave, mknext);
+                PRD2_STAMP(6);
+                ln_cll_p<KH>(xnext);
+                u32x4 xs[2][P / 16];
+                split2h_rn_cll<KH>(xnext, xs);
+                f32x16 akq, ag, av;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { akq[e] = 0.f; av[e] = 0.f; }
+                g_init(ag);
+                PRD2_STAMP(7);
+                gemm_kq(xs, akq);
+                gemm_gv(xs, ag, av);
+                PRD2_STAMP(8);
+                store_kq(wave, akq);
+                store_gv(wave, ag, av);
+                PRD2_STAMP(9);
+            }
+            for (int e = e0; e < nextra; e += NW) {
+                const int blk = nfullblk + (e >> 1), kind = e & 1;
+                if (e != e0) {
+                    const int v = blk * 32 + r;
+                    const bool ok = v < N;
+                    load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi, ok, xe);
+                    mke = ok ? mask[bb * N + v] : 0.f;
+                }
+                ln_cll_p<KH>(xe);
+                u32x4 xs[2][P / 16];
+                split2h_rn_cll<KH>(xe, xs);
+                if (kind == 0) {
+                    key_override(blk, mke);
+                    f32x16 akq;
+#pragma unroll
+                    for (int q_ = 0; q_ < 16; ++q_) akq[q_] = 0.f;
+                    gemm_kq(xs, akq);
+                    store_kq(blk, akq);
+                } else {
+                    f32x16 ag, av;
+#pragma unroll
+                    for (int q_ = 0; q_ < 16; ++q_) av[q_] = 0.f;
+                    g_init(ag);
+                    gemm_gv(xs, ag, av);
+                    store_gv(blk, ag, av);
+                }
             }
         }
         PRD2_STAMP(1);
         __syncthreads();
         PRD2_STAMP(2);
-        {   // the wave's first block of the next row: in flight during the key loops
-            const long bun = bu + rstride;
-            const int v = (wave >> 1) * 32 + r;
-            const bool ok = bun < nrows && wave < nitem && v < N;
-            load_row_cll<P>(pair + row_pos(ok ? bun : 0, ok ? v : 0) * P, hi, ok, xnext);
+        {   // the wave's own block of the next row: in flight during the key loops
+            const int bun = bu + rstride;
+            rnext = make_row(bun < nrows ? bun : 0);
+            const int v = wave * 32 + r;
+            const bool ok = bun < nrows && wave < nfullblk && v < N;
+            load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
+            mknext = ok ? mask[rnext.bb * N + v] : 0.f;
+            munext = bun < nrows ? mask[bun] : 0.f;
         }
         // ================= phase 2 =================
-        unsigned long long fmask;
+        unsigned fmask;
         {
             const int f = lane < nqb ? tflag[lane] : 0;
-            fmask = __ballot(f != 0);
+            fmask = (unsigned)__ballot(f != 0);
         }
-        for (int i0 = it_begin; i0 < it_end;) {
-            const int qb = i0 / nqb;
-            const int T0 = i0 - qb * nqb;
-            const int T1 = (it_end - qb * nqb) < nqb ? (it_end - qb * nqb) : nqb;       // exclusive
-            i0 += T1 - T0;
+        // this wave's key-loop work of the row, in tiles (priority = share still to do)
+        const int work_tot = ((wholeq - wave + NW - 1) / NW) * nqb + (it_end - it_begin);
+        int work_rem = work_tot;
+        // key tiles [T0, T1) for query block qb: o8 = O (x 16, relative to mref), lsum = the lane's part of the row sum
+        auto run_piece = [&](int qb, int T0, int T1, float (&o8)[8], float& lsum, float& mref) {
+            v2_prio(work_rem, work_tot);
             const unsigned qo = (unsigned)hi * L.plane + (unsigned)(32 * qb + r) * 16u;
             const u32x4 qh = *reinterpret_cast<const u32x4*>(lds + L.qh + qo);
             const u32x4 ql = *reinterpret_cast<const u32x4*>(lds + L.ql + qo);
             f32x16 o0, o1, zero;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; zero[e] = 0.f; }
-            float lsum = 0.f, mref;
+            lsum = 0.f;
             bool big = false;
-            {
-                // first tile: fixes the reference
-                f32x16 sA = qk_tile(lds, L, T0, r, hi, qh, ql, zero);
-                if ((fmask >> T0) & 1) mask_tile(lds, L, T0, hi, 0.f, sA);
+            const unsigned range_bits = (T1 >= 32 ? 0xffffffffu : ((1u << T1) - 1u)) & ~((1u << T0) - 1u);
+            if ((fmask & range_bits) == 0) {
+                // ---- fast path: no masked / padded key in the piece; software-pipelined steps ----
+                const int tl = T1 - 1;                  // tiles past the piece are clamped to its last one (results unused)
+                KOp k = load_k(lds, kbase + 512u * T0, kl_off);
+                f32x16 sA = qk_tile(k, qh, ql, zero), sB;
+                k = load_k(lds, kbase + 512u * (T0 + 1 < tl ? T0 + 1 : tl), kl_off);
                 const float tmax = xhalf_max(max16(sA));
                 mref = tmax - P_SHIFT;
                 f32x16 negm;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) negm[e] = -mref;
-                f32x16 sB;
-                int t = T0 + 1;
-                if (t < T1) sB = qk_tile(lds, L, t, r, hi, qh, ql, negm);
+                sB = qk_tile(k, qh, ql, negm);                                   // tile T0 + 1 (or a clamped repeat)
+                k = load_k(lds, kbase + 512u * (T0 + 2 < tl ? T0 + 2 : tl), kl_off);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sA[e] -= mref;
-                exp_pv_tile(lds, L, T0, r, hi, sA, lsum, big, o0, o1);
+                PBuf p;
+                exp_split(sA, lsum, big, p);
+                load_v(lds, vbase + 2048u * T0, p);
+                // invariant at the top of a step for tile t: s? = logits of tile t, p = tile t - 1, k = K of tile t + 1
+                int t = T0 + 1;
                 while (t < T1) {
-                    if (t + 1 < T1) sA = qk_tile(lds, L, t + 1, r, hi, qh, ql, negm);
-                    if ((fmask >> t) & 1) mask_tile(lds, L, t, hi, mref, sB);
-                    exp_pv_tile(lds, L, t, r, hi, sB, lsum, big, o0, o1);
+                    v2_prio(work_rem - (t - T0), work_tot);
+                    pipe_step(lds, kbase + 512u * (t + 2 < tl ? t + 2 : tl), kl_off, vbase + 2048u * t, sB, sA, negm, qh, ql, k, p,
+                              o0, o1, lsum, big);
                     ++t;
                     if (t >= T1) break;
-                    if (t + 1 < T1) sB = qk_tile(lds, L, t + 1, r, hi, qh, ql, negm);
-                    if ((fmask >> t) & 1) mask_tile(lds, L, t, hi, mref, sA);
-                    exp_pv_tile(lds, L, t, r, hi, sA, lsum, big, o0, o1);
+                    pipe_step(lds, kbase + 512u * (t + 2 < tl ? t + 2 : tl), kl_off, vbase + 2048u * t, sA, sB, negm, qh, ql, k, p,
+                              o0, o1, lsum, big);
                     ++t;
+                }
+                pv_tile(p, o0, o1);                     // P V of the last tile
+            } else {
+                // ---- pieces with masked / padded keys: one tile at a time ----
+                KOp k0 = load_k(lds, kbase + 512u * T0, kl_off);
+                f32x16 s0 = qk_tile(k0, qh, ql, zero);
+                if ((fmask >> T0) & 1) mask_tile(lds, L, T0, hi, 0.f, s0);
+                const float tmax = xhalf_max(max16(s0));
+                mref = tmax - P_SHIFT;
+                f32x16 negm;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
+                PBuf p;
+                exp_split(s0, lsum, big, p);
+                load_v(lds, vbase + 2048u * T0, p);
+                pv_tile(p, o0, o1);
+                for (int t = T0 + 1; t < T1; ++t) {
+                    const KOp k = load_k(lds, kbase + 512u * t, kl_off);
+                    f32x16 s = qk_tile(k, qh, ql, negm);
+                    if ((fmask >> t) & 1) mask_tile(lds, L, t, hi, mref, s);
+                    exp_split(s, lsum, big, p);
+                    load_v(lds, vbase + 2048u * t, p);
+                    pv_tile(p, o0, o1);
                 }
             }
             if (__any(big || !(lsum < 3.0e38f))) {
@@ -390,7 +601,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 lsum = 0.f;
                 float m_run = -1e30f;
                 for (int t = T0; t < T1; ++t) {
-                    f32x16 s = qk_tile(lds, L, t, r, hi, qh, ql, zero);
+                    const KOp k = load_k(lds, kbase + 512u * t, kl_off);
+                    f32x16 s = qk_tile(k, qh, ql, zero);
                     if ((fmask >> t) & 1) mask_tile(lds, L, t, hi, 0.f, s);
                     const float m_new = max2f(m_run, xhalf_max(max16(s)));
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -400,59 +612,91 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; s[e] -= mref; }
                     bool dummy = false;
-                    exp_pv_tile(lds, L, t, r, hi, s, lsum, dummy, o0, o1);
+                    PBuf p;
+                    exp_split(s, lsum, dummy, p);
+                    load_v(lds, vbase + 2048u * t, p);
+                    pv_tile(p, o0, o1);
                 }
             }
-            // partial of this piece: slot wave + qb
-            float* pp = part + (size_t)(wave + qb) * 640 + lane;
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) pp[jj * 64] = (o0[jj] + o0[jj + 8]) + (o1[jj] + o1[jj + 8]);
-            pp[8 * 64] = lsum;
-            pp[9 * 64] = mref;
-        }
-        PRD2_STAMP(3);
-        __syncthreads();
-        PRD2_STAMP(4);
-        // ================= merge, gate, store =================
-        for (int qb = wave; qb < nqb; qb += NW) {
-            const int lo_it = qb * nqb, hi_it = lo_it + nqb - 1;
-            // waves whose range meets [lo_it, hi_it]: w_first = wave holding lo_it, w_last = wave holding hi_it
-            int wf = 0, wl = 0;
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const int st = (int)((long)niter * w / NW);
-                if (st <= lo_it) wf = w;
-                if (st <= hi_it) wl = w;
-            }
-            // (a wave between the two whose own range is empty left no partial)
-            auto has_piece = [&](int w) { return (int)((long)niter * (w + 1) / NW) > (int)((long)niter * w / NW); };
-            float M = -INFINITY;
-            for (int w = wf; w <= wl; ++w)
-                if (has_piece(w)) M = max2f(M, part[(size_t)(w + qb) * 640 + 9 * 64 + lane]);
-            float o[8], l = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
-            for (int w = wf; w <= wl; ++w) {
-                if (!has_piece(w)) continue;
-                const float* pp = part + (size_t)(w + qb) * 640 + lane;
-                const float scl = __builtin_amdgcn_exp2f(pp[9 * 64] - M);
-                l += scl * pp[8 * 64];
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
-            }
+            for (int jj = 0; jj < 8; ++jj) o8[jj] = (o0[jj] + o0[jj + 8]) + (o1[jj] + o1[jj + 8]);
+            work_rem -= T1 - T0;
+        };
+        // gate, normalise, store the 32 queries of block qb (l = the lane's part of the row sum)
+        auto finish = [&](int qb, const float (&o)[8], float l) {
             const float ltot = xhalf_add(l);
             const int v = 32 * qb + r;
             if (v < N) {
                 const float il = 1.0f / (VSCALE * ltot);
-                float res[8];
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int c = 4 * hi + (jj & 3) + 8 * (jj >> 2);
-                    res[jj] = Gl[c * NP + v] * (o[jj] * il);
-                }
-                float* dst = og + row_pos(bu, v) * HC + h * C + 4 * hi;
+                const float* gp = Gl + (size_t)(v * 2 + hi) * 8;
+                const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+                const float res[8] = {g0.x * (o[0] * il), g0.y * (o[1] * il), g0.z * (o[2] * il), g0.w * (o[3] * il),
+                                      g1.x * (o[4] * il), g1.y * (o[5] * il), g1.z * (o[6] * il), g1.w * (o[7] * il)};
+                float* dst = og + row_pos(row, v) * HC + h * C + 4 * hi;
                 *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
                 *reinterpret_cast<float4*>(dst + 8) = make_float4(res[4], res[5], res[6], res[7]);
+            }
+        };
+        for (int qb = wave; qb < wholeq; qb += NW) {    // whole query blocks: no partials, no merge
+            float o8[8], lsum, mref;
+            run_piece(qb, 0, nqb, o8, lsum, mref);
+            PRD2_STAMP(10);
+            finish(qb, o8, lsum);
+            PRD2_STAMP(11);
+        }
+        for (int i0 = it_begin; i0 < it_end;) {         // this wave's range of the shared blocks
+            const int rq = i0 / nqb;
+            const int T0 = i0 - rq * nqb;
+            const int T1 = (it_end - rq * nqb) < nqb ? (it_end - rq * nqb) : nqb;       // exclusive
+            i0 += T1 - T0;
+            float o8[8], lsum, mref;
+            run_piece(wholeq + rq, T0, T1, o8, lsum, mref);
+            float* pp = part + (size_t)(wave + rq) * 640 + lane;               // partial of this piece: slot wave + rq
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pp[jj * 64] = o8[jj];
+            pp[8 * 64] = lsum;
+            pp[9 * 64] = mref;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PRD2_STAMP(3);
+        if (R > 0) {
+            __syncthreads();
+            PRD2_STAMP(4);
+            // ================= merge of the shared blocks =================
+            for (int rq = wave; rq < R; rq += NW) {
+                const int lo_it = rq * nqb, hi_it = lo_it + nqb - 1;
+                // waves whose range meets [lo_it, hi_it]: w_first = wave holding lo_it, w_last = wave holding hi_it
+                int wf = 0, wl = 0;
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const int st = (int)((long)rem_iter * w / NW);
+                    if (st <= lo_it) wf = w;
+                    if (st <= hi_it) wl = w;
+                }
+                // (a wave between the two whose own range is empty left no partial).  Straight-line over the NW possible
+                // pieces so that the LDS reads of different pieces are in flight together
+                float mm[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const bool has = w >= wf && w <= wl && (int)((long)rem_iter * (w + 1) / NW) > (int)((long)rem_iter * w / NW);
+                    mm[w] = has ? part[(size_t)(w + rq) * 640 + 9 * 64 + lane] : -INFINITY;
+                }
+                float M = mm[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) M = max2f(M, mm[w]);
+                float o[8], l = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    if (mm[w] == -INFINITY) continue;              // wave-uniform: a piece exists for all lanes or for none
+                    const float* pp = part + (size_t)(w + rq) * 640 + lane;
+                    const float scl = __builtin_amdgcn_exp2f(mm[w] - M);
+                    l += scl * pp[8 * 64];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
+                }
+                finish(wholeq + rq, o, l);
             }
         }
         PRD2_STAMP(5);
@@ -460,9 +704,9 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
 }
 
 size_t v2_lds_bytes(int N, int P, int NW) {
-    const int NP = prd_round_up(N, 32);
+    const int NP = prd_round_up(N, 32), nqb = NP / 32;
     const size_t base = (size_t)64 * P * 4 + (size_t)NP * (4 * 32 + 64 + 64 + 4) + 128;
-    return base + (size_t)(NP / 32 + NW) * 2560;
+    return base + (size_t)(NW + nqb % NW) * 2560;      // partials: slot = wave + shared-block index
 }
 
 }  // namespace
@@ -487,6 +731,7 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     if (!prd_tri_attn_v2_supported(N, P)) return PRD_ERR_UNSUPPORTED;
+    if ((long)b * N * N > 0x7fffffffL / 2) return PRD_ERR_UNSUPPORTED;      // 32-bit position arithmetic in the kernel
     const int NP = prd_round_up(N, 32);
     const size_t lds = v2_lds_bytes(N, P, 8);
     const long rows_total = (long)b * N;
