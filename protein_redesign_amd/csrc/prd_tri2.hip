@@ -1,44 +1,53 @@
-// Triangle attention core, second generation (split-16 arithmetic, rows of up to 352 positions).
+// Triangle attention core, second generation (split-16 arithmetic, rows of up to 384 positions).
 //
 // Replaces the reference's TriangleAttention -> Attention.forward chain (modules.py:236-243 -> 185-225) up to the gated
 // per-head output `og`; the output projection stays in tri_attn_out / pair_tail (prd_tri.hip, prd_pair.hip).
 //
-// One PERSISTENT workgroup (8 waves) per CU serves one head for a strided set of pair rows, like the first-generation
-// kernel (tri_attn_core_split_kernel), but everything inside a row is laid out for the 32x32x16 fp16 MFMA:
+// One PERSISTENT workgroup of 12 waves (three per SIMD) per CU serves one head for a strided set of pair rows, like the
+// first-generation kernel (tri_attn_core_split_kernel), but everything inside a row is laid out for the 32x32x16 fp16 MFMA:
 //
-//   phase 1  per 32-position block of the row, two half-items dealt to the waves:
-//            [K|Q]: unswapped row GEMM (A = weights, B = the lane's LayerNorm-ed row, fp16 x 2): lane (pos, hi) ends up with
-//                   the 8 K channels {4hi+e, 8+4hi+e} and the same 8 Q channels of ITS position -- exactly the 8 contraction
-//                   values an A / B operand lane of the QK^T MFMA holds.  K and Q go to LDS as fp16 hi | lo planes with one
-//                   16-byte store per plane; no transposition, no three-way split.
-//            [V|G]: SWAPPED row GEMM (A = the rows, B = weights): lane (channel, hi) ends up with 16 positions of ONE
-//                   channel, which is the key-major order the P V MFMA wants from its A operand: V hi | lo planes are
-//                   stored with 16-byte stores (the first generation scattered 2-byte values), the gate (lanes 16-31)
-//                   goes to a [channel][position] fp32 tile.
+//   phase 1  per 32-position block of the row, three row GEMMs on the LayerNorm-ed, fp16 hi|lo split rows:
+//            [K|Q]: unswapped (A = weights, B = the lane's row): lane (pos, hi) ends up with the 8 K channels {4hi+e, 8+4hi+e}
+//                   and the same 8 Q channels of ITS position -- exactly the 8 contraction values an A / B operand lane of
+//                   the QK^T MFMA holds.  K and Q go to LDS as fp16 hi | lo planes with one 16-byte store per plane; no
+//                   transposition, no three-way split.
+//            [G]  : unswapped: the 8 gate channels of the lane's position, kept in fp32 for the epilogue.
+//            [V]  : SWAPPED (A = the rows, B = weights): lane (channel, hi) ends up with 16 positions of ONE channel, which is
+//                   the key-major order the P V MFMA wants from its A operand; lanes 0-15 keep the fp16 hi part, lanes 16-31
+//                   (the same 16 channels again) the lo part: two 16-byte stores per lane (the first generation scattered
+//                   2-byte values).
 //   phase 2  S^T = K Q^T for 32 keys x 32 queries per MFMA triple (kh qh + kh ql + kl qh; the contraction is the head width
 //            16 = the K of the instruction, nothing is padded), so a lane holds 16 logits of ONE query: softmax statistics
 //            are lane-local plus one cross-half exchange.  The probabilities, split into fp16 hi | lo, are directly the B
 //            operand of O^T = [V_hi; V_lo] P^T (M = 32 = both planes of the 16 channels: hi*hi, lo*hi, hi*lo, lo*lo in two
 //            MFMAs per 16 keys), because V was stored in the key order of the S^T register layout.
-//            The (query block, key tile) iterations of a row are cut into 8 CONTIGUOUS ranges, one per wave ("stream-K"):
-//            every wave gets the same number of tiles +-1 whatever N is; a wave's range crosses at most two query-block
-//            boundaries, every piece leaves a partial (reference, sum, O) in LDS and the partials of a query block are
-//            merged after one barrier (flash-decoding merge), gated and stored.
+//            Work split: query block q belongs to wave q (its keys in one sweep, result gated and stored directly).  When
+//            the number of blocks is not a multiple of 4, the SIMDs that own one block more shed key tiles of that block to
+//            the idle waves of the other SIMDs (every shed piece is a quarter of the row's keys); those blocks are merged
+//            from partials (reference, sum, O) in LDS after one barrier (flash-decoding merge).
 //            The reference maximum of a piece is fixed by its first tile (later tiles: accumulator preloaded with
 //            -reference, one v_exp_f32 per logit); should a probability leave the fp16 range the piece is redone with the
-//            online update in every tile.  QK^T of tile t+1 is issued before the softmax arithmetic of tile t.
+//            online update in every tile.
 //
-// Arithmetic: operands hi = RN_fp16(x), lo = RN_fp16(x - hi) (v_cvt_pk_f16_f32 + v_fma_mix): |x - hi - lo| <= 2^-24 |x|
-// while lo is a normal fp16 number, an absolute 2^-25 below that; products accumulate in fp32.  Probabilities are kept
-// x 2^4 relative to the reference maximum so that small probabilities keep a normal lo part.
+// Why this shape (tools/ubench/{valu_rate,overlap,tile_step}_bench.hip, MI355X): the kernel is VALU-bound, not MFMA-bound.
+// Per 32 x 32 logits a wave issues 7 MFMAs (224 matrix-pipe cycles) against 16 v_exp_f32 (8.4 SIMD cycles each), 32
+// conversion-class instructions for the split (4.6 each) and 16 adds (2.9): ~330 VALU cycles, of which an MFMA only hides
+// about 40 % of its own duration.  So the design minimises VALU instructions per logit (fp32 residuals + two packed
+// conversions instead of v_fma_mix*_f16, which issues at the transcendental rate; no transposition work; LayerNorm and split
+// of a block done once) and keeps three waves per SIMD resident to fill each other's stalls.
+//
+// Arithmetic: operands hi = RN_fp16(x), lo = RN_fp16(x - hi): |x - hi - lo| <= 2^-24 |x| while lo is a normal fp16 number, an
+// absolute 2^-25 below that; products accumulate in fp32.  Probabilities are kept x 2^4 relative to the reference maximum
+// so that small probabilities keep a normal lo part.
 #include "prd_common.h"
 #include "../../include/prd_hip.h"
+#include <cstdlib>
 #include <mutex>
 
-#ifdef PRD_TIMING     // diagnostic builds only (tools/ta2_timing.py): cycle stamps [workgroup][8 waves][8 rows][16 stamps]
-__device__ unsigned long long prd_dbg2[256 * 8 * 8 * 16];
+#ifdef PRD_TIMING     // diagnostic builds only (tools/ta2_timing.py): cycle stamps [workgroup][12 waves][8 rows][16 stamps]
+__device__ unsigned long long prd_dbg2[256 * 12 * 8 * 16];
 extern "C" int prd_debug_read2(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(prd_dbg2), sizeof(prd_dbg2)); }
-#define PRD2_STAMP(k) do { if (lane == 0 && it < 8) prd_dbg2[((blockIdx.x * 8 + wave) * 8 + it) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define PRD2_STAMP(k) do { if (lane == 0 && it < 8) prd_dbg2[((blockIdx.x * 12 + wave) * 8 + it) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PRD2_STAMP(k)
 #endif
@@ -222,18 +231,17 @@ PRD_DEV void load_v(const unsigned char* lds, unsigned vaddr, PBuf& p) {
     p.va1 = *reinterpret_cast<const u32x4*>(lds + vaddr + 1024u);
 }
 // O += [V_hi; V_lo] P for both 16-key halves of a tile
-PRD_DEV void pv_tile(const PBuf& p, f32x16& o0, f32x16& o1) {
+PRD_DEV void pv_tile(const PBuf& p, f32x16& o0) {
+    // one accumulator: an accumulate chain issues back to back, and the other waves of the SIMD fill the pipe anyway
     o0 = mfma_h(p.va0, p.ph0, o0);
-    o1 = mfma_h(p.va1, p.ph1, o1);
+    o0 = mfma_h(p.va1, p.ph1, o0);
     o0 = mfma_h(p.va0, p.pl0, o0);
-    o1 = mfma_h(p.va1, p.pl1, o1);
+    o0 = mfma_h(p.va1, p.pl1, o0);
 }
 
-#define PRD2_FENCE() __builtin_amdgcn_sched_barrier(0)
-
 // Priority = fraction of the wave's own key-loop work (tiles) still to do.  The waves of a SIMD are arbitrated oldest first:
-// without this the older wave of a SIMD runs its tiles at full speed and the younger one then finishes alone, at the VALU
-// issue rate of a single wave (measured: 14.0k vs 20.3k cycles per row for equal work; the SIMD is done when the slower is).
+// without this the older wave runs its tiles at full speed and the younger ones then finish alone, at the VALU issue rate
+// of a single wave (measured with two waves: 14.0k vs 20.3k cycles per row for equal work; the SIMD is done when the slowest is).
 PRD_DEV void v2_prio(int rem, int tot) {
     if (4 * rem > 3 * tot) __builtin_amdgcn_s_setprio(3);
     else if (2 * rem > tot) __builtin_amdgcn_s_setprio(2);
@@ -241,66 +249,20 @@ PRD_DEV void v2_prio(int rem, int tot) {
     else __builtin_amdgcn_s_setprio(0);
 }
 
-// One steady-state step of the key loop, written in ISSUE ORDER.  The seven MFMAs of a step -- P V of tile t-1 (operands p,
-// produced by the previous step) and Q K^T of tile t+1 (operands k, into sn) -- do not depend on the softmax arithmetic of
-// tile t (sc -> p), so the ~60 VALU instructions of that arithmetic are dealt into the seven 32-cycle gaps behind the MFMAs
-// (a wave issues in order: an MFMA occupies the matrix pipe for 32 cycles while the instructions behind it issue).  The P V
-// MFMAs come first: once they are issued, their operand registers take the probabilities of tile t and the V operands of tile
-// t (loaded for the next step); likewise the K registers take tile t+2 after the Q K^T MFMAs.  The scheduling fences keep
-// hipcc from regrouping the MFMAs into one cluster.
-PRD_DEV void pipe_step(const unsigned char* lds, unsigned kaddr_next, unsigned kl_off, unsigned vaddr, f32x16& sc, f32x16& sn,
-                       const f32x16& negm, u32x4 qh, u32x4 ql, KOp& k, PBuf& p, f32x16& o0, f32x16& o1, float& lsum, bool& big) {
-    float t0, t1;
-    o0 = mfma_h(p.va0, p.ph0, o0);
-    PRD2_FENCE();
+// maximum of the 16 registers of a fresh MFMA result: compiler-visible v_max (hipcc pads the MFMA -> VALU read hazard; it does
+// not for the reads of an asm statement)
+PRD_DEV float max16_mfma(const f32x16& s) {
+    float m0 = __builtin_fmaxf(s[0], s[1]), m1 = __builtin_fmaxf(s[2], s[3]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
-    t0 = sc[0] + sc[2];
-    t1 = sc[1] + sc[3];
-    PRD2_FENCE();
-    o1 = mfma_h(p.va1, p.ph1, o1);
-    PRD2_FENCE();
-#pragma unroll
-    for (int j = 4; j < 8; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
-    t0 += sc[4]; t1 += sc[5]; t0 += sc[6]; t1 += sc[7];
-    PRD2_FENCE();
-    o0 = mfma_h(p.va0, p.pl0, o0);
-    PRD2_FENCE();
-#pragma unroll
-    for (int j = 8; j < 12; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
-    t0 += sc[8]; t1 += sc[9]; t0 += sc[10]; t1 += sc[11];
-    PRD2_FENCE();
-    o1 = mfma_h(p.va1, p.pl1, o1);
-    PRD2_FENCE();
-    load_v(lds, vaddr, p);                              // V of tile t: operands of the NEXT step's P V
-#pragma unroll
-    for (int j = 12; j < 16; ++j) sc[j] = __builtin_amdgcn_exp2f(sc[j]);
-    t0 += sc[12]; t1 += sc[13]; t0 += sc[14]; t1 += sc[15];
-    PRD2_FENCE();
-    sn = mfma_h(k.h, qh, negm);
-    PRD2_FENCE();
-    split8_rn(sc, 0, p.ph0, p.pl0);
-    PRD2_FENCE();
-    sn = mfma_h(k.h, ql, sn);
-    PRD2_FENCE();
-    split8_rn(sc, 8, p.ph1, p.pl1);
-    PRD2_FENCE();
-    sn = mfma_h(k.l, qh, sn);
-    PRD2_FENCE();
-    k = load_k(lds, kaddr_next, kl_off);                // K of tile t+2
-    {
-        const float ts = t0 + t1;
-        big |= !(ts < 30000.0f);
-        lsum += ts;
-    }
-    PRD2_FENCE();
+    for (int j = 4; j < 16; j += 2) { m0 = __builtin_fmaxf(m0, s[j]); m1 = __builtin_fmaxf(m1, s[j + 1]); }
+    return __builtin_fmaxf(m0, m1);
 }
 
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
-    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending) {
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     constexpr float VSCALE = H2_WSCALE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -314,7 +276,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hi = lane >> 5;
-    const int nqb = NP / 32;                            // query blocks = key tiles
+    const int nqb = NP / 32;                            // query blocks = key tiles (<= NW)
     const int rstride = gridDim.x / H;
     int h, slot;
     if ((rstride & 7) == 0) {                           // the H heads of one row on one XCD
@@ -325,6 +287,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
         h = blockIdx.x % H;
         slot = blockIdx.x / H;
     }
+    // image rows: K 0-15 | Q 16-31 | G 32-47 | V 48-63 (fp16 hi | lo planes, x 16 so that small weights keep a normal lo part)
     const float sc = 0.25f * LOG2E_2;
     stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
     stage_weight_h2_rows<P>(Wb, 64, C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
@@ -338,28 +301,35 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     struct RowIx { int bu, bb, u; };
     auto make_row = [&](int bu) { RowIx x; x.bu = bu; x.bb = bu / N; x.u = bu - x.bb * N; return x; };       // 32-bit, once per row
     auto row_pos = [&](const RowIx& x, int v) -> long { return ending ? (long)((x.bb * N + v) * N + x.u) : (long)(x.bu * N + v); };
-    // ---- static work split ----
-    // phase 1: block w (all four projections) by wave w; the blocks past the NW-th as half-items (kind 0 = [K|Q], 1 = [V|G])
-    // dealt round-robin
-    const int nfullblk = nqb < NW ? nqb : NW;
-    const int nextra = 2 * (nqb - nfullblk);
-    // phase 2: query blocks [0, wholeq) belong to one wave each (w, w + NW, ...); the (query block, key tile) iterations of the
-    // remaining R blocks are cut into NW contiguous ranges
-    const int wholeq = (nqb / NW) * NW;
-    const int R = nqb - wholeq;
-    const int rem_iter = R * nqb;
-    const int it_begin = (int)((long)rem_iter * wave / NW), it_end = (int)((long)rem_iter * (wave + 1) / NW);
+
+    // ---- static work split (wave w sits on SIMD w & 3: only the balance depends on it) ----
+    // m = nqb mod 4 "group" blocks G_i = nqb - m + i are owned by waves on SIMDs 0 .. m-1, which therefore carry one block more
+    // than the others.  Helper wave j = nqb + j (j < 4 - m, on SIMD m + j) takes a quarter of the keys of EVERY group block;
+    // the owner keeps the first m quarters.  Phase 1: helper j < m also computes the [G, V] projections of group block j.
+    const int m4 = nqb & 3, gbase = nqb - m4, nhelp = m4 ? 4 - m4 : 0;
+    const bool owner = wave < nqb, helper = wave >= nqb && wave < nqb + nhelp;
+    const int hj = wave - nqb;                          // helper index
+    const bool group_owner = owner && wave >= gbase;    // owns a block that is shared with the helpers
+    const int gi = wave - gbase;                        // its index in the group
+    // phase 1 item: block + kinds (bit 0 = [K|Q], bit 1 = [G, V])
+    int p1_blk = -1, p1_kinds = 0;
+    if (owner) { p1_blk = wave; p1_kinds = (group_owner && gi < nhelp) ? 1 : 3; }
+    else if (helper && hj < m4) { p1_blk = gbase + hj; p1_kinds = 2; }
+    // quarter boundaries of the key tiles
+    auto qtile = [&](int k) { return (nqb * k) >> 2; };
+    const int own_t1 = group_owner ? qtile(m4) : nqb;   // the owner's key tiles [0, own_t1)
+    const int work_tot = owner ? own_t1 : (helper ? m4 * (qtile(m4 + hj + 1) - qtile(m4 + hj)) : 0);
     const float inv16 = H2_INV_WSCALE;
     const unsigned kl_off = L.kl - L.kh;
     const unsigned kbase = L.kh + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
     const unsigned vbase = L.v + (unsigned)hi * 512u + (unsigned)r * 16u;          // + 2048 t
 
-    float xnext[KH];                                    // the wave's own block of the NEXT row
-    float mknext = 0.f, munext = 0.f;                   // ... and its mask values (own block's positions; the row itself)
+    float xnext[KH];                                    // the rows of the wave's phase-1 block of the NEXT row
+    float mknext = 0.f, munext = 0.f;                   // ... and its mask values (the block's positions; the row itself)
     RowIx rnext = make_row(slot < nrows ? slot : 0);
     {
-        const int v = wave * 32 + r;
-        const bool ok = slot < nrows && wave < nfullblk && v < N;
+        const int v = p1_blk * 32 + r;
+        const bool ok = slot < nrows && p1_blk >= 0 && v < N;
         load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
         if (ok) mknext = mask[rnext.bb * N + v];
         if (slot < nrows) munext = mask[slot];
@@ -367,31 +337,34 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     int it = 0;
     for (int bu = slot; bu < nrows; bu += rstride, ++it) {
         const RowIx row = rnext;
-        const int bb = row.bb;
         __syncthreads();                                // previous row's LDS consumed (and the weight image staged)
         PRD2_STAMP(0);
         const float mu = munext;
         // ================= phase 1 =================
-        {
-            auto key_override = [&](int blk, float mk) {           // logit override + tile flag of block blk
-                const int v = blk * 32 + r;
-                const bool valid = v < N;
-                const bool keep = valid && (mu * mk >= 0.5f);
-                if (hi == 0) kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
-                const bool any_override = __any(!keep);
-                if (lane == 0) tflag[blk] = any_override ? 1 : 0;
+        if (p1_blk >= 0) {
+            const int blk = p1_blk;
+            auto wop = [&](int wrow, int s_, u32x4& wh, u32x4& wl) {
+                const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi);
+                wh = Wb[(size_t)wrow * (P / 8) + slot_];
+                wl = Wb[(size_t)(64 + wrow) * (P / 8) + slot_];
             };
-            // image rows: K 0-15 | Q 16-31 | G 32-47 | V 48-63.  Three row GEMMs per block:
-            //   kq: unswapped (A = rows r of the image): lane (pos, hi) registers 0-7 = K, 8-15 = Q channels {4hi+e, 8+4hi+e}
-            //   g : unswapped, A = G rows 32 + (r & 15) (lanes 16-31 repeat them): registers 0-7 = gate channels {4hi+e, 8+4hi+e}
-            //   v : SWAPPED, B = V rows 48 + (r & 15): lane (n, hi) register j = V channel n & 15 of position drow32(j, hi);
-            //       lanes 0-15 keep the fp16 hi part, lanes 16-31 the lo part = rows 0-15 / 16-31 of the P V A operand
-            auto wop = [&](int row, int s_, u32x4& wh, u32x4& wl) {
-                const int slot_ = h2_slot<P>(row, 2 * s_ + hi);
-                wh = Wb[(size_t)row * (P / 8) + slot_];
-                wl = Wb[(size_t)(64 + row) * (P / 8) + slot_];
-            };
-            auto gemm_kq = [&](const u32x4 (&xs)[2][P / 16], f32x16& acc) {
+            ln_cll_p<KH>(xnext);
+            u32x4 xs[2][P / 16];
+            split2h_rn_cll<KH>(xnext, xs);
+            PRD2_STAMP(6);
+            if (p1_kinds & 1) {
+                {   // logit override of masked / padded keys + tile flag
+                    const int v = blk * 32 + r;
+                    const bool valid = v < N;
+                    const bool keep = valid && (mu * mknext >= 0.5f);
+                    if (hi == 0) kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
+                    const bool any_override = __any(!keep);
+                    if (lane == 0) tflag[blk] = any_override ? 1 : 0;
+                }
+                // [K|Q]: lane (pos, hi) registers 0-7 = K, 8-15 = Q channels {4hi+e, 8+4hi+e}
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
                 for (int s_ = 0; s_ < P / 16; ++s_) {
                     u32x4 wh, wl;
@@ -400,8 +373,29 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                     acc = mfma_h(wh, xs[1][s_], acc);
                     acc = mfma_h(wl, xs[0][s_], acc);
                 }
-            };
-            auto gemm_gv = [&](const u32x4 (&xs)[2][P / 16], f32x16& ag, f32x16& av) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+                u32x4 kh4, kl4, qh4, ql4;
+                split8_rn(acc, 0, kh4, kl4);
+                split8_rn(acc, 8, qh4, ql4);
+                const unsigned po = (unsigned)hi * L.plane + (unsigned)(blk * 32 + r) * 16u;
+                *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
+                *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
+                *reinterpret_cast<u32x4*>(lds + L.qh + po) = qh4;
+                *reinterpret_cast<u32x4*>(lds + L.ql + po) = ql4;
+            }
+            if (p1_kinds & 2) {
+                // [G]: A = G rows 32 + (r & 15) (lanes 16-31 repeat them): registers 0-7 = gate channels {4hi+e, 8+4hi+e}
+                // [V]: SWAPPED, B = V rows 48 + (r & 15): lane (n, hi) register j = V channel n & 15 of position drow32(j, hi)
+                f32x16 ag, av;
+                {
+                    const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi + 4);
+                    ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
+#pragma unroll
+                    for (int e = 8; e < 16; ++e) ag[e] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) av[e] = 0.f;
+                }
 #pragma unroll
                 for (int s_ = 0; s_ < P / 16; ++s_) {
                     u32x4 gh, gl, vh, vl;
@@ -414,26 +408,6 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                     ag = mfma_h(gl, xs[0][s_], ag);
                     av = mfma_h(xs[0][s_], vl, av);
                 }
-            };
-            auto store_kq = [&](int blk, f32x16& acc) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] *= inv16;
-                u32x4 kh4, kl4, qh4, ql4;
-                split8_rn(acc, 0, kh4, kl4);
-                split8_rn(acc, 8, qh4, ql4);
-                const unsigned po = (unsigned)hi * L.plane + (unsigned)(blk * 32 + r) * 16u;
-                *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
-                *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
-                *reinterpret_cast<u32x4*>(lds + L.qh + po) = qh4;
-                *reinterpret_cast<u32x4*>(lds + L.ql + po) = ql4;
-            };
-            auto g_init = [&](f32x16& ag) {
-                const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi + 4);
-                ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
-#pragma unroll
-                for (int e = 8; e < 16; ++e) ag[e] = 0.f;
-            };
-            auto store_gv = [&](int blk, const f32x16& ag, const f32x16& av) {
                 float* gp = Gl + (size_t)((blk * 32 + r) * 2 + hi) * 8;
                 *reinterpret_cast<float4*>(gp) = make_float4(gate_from_scaled(ag[0] * inv16), gate_from_scaled(ag[1] * inv16),
                                                              gate_from_scaled(ag[2] * inv16), gate_from_scaled(ag[3] * inv16));
@@ -449,71 +423,16 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 const unsigned vo = L.v + (unsigned)(blk * 4 + hi) * 512u + (unsigned)r * 16u;
                 *reinterpret_cast<u32x4*>(lds + vo) = s0;
                 *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
-            };
-            // extra half-items of this wave: rows requested before the own block is computed
-            float xe[KH];
-            float mke = 0.f;
-            const int e0 = wave;                        // first extra half-item (block nfullblk + e0 / 2, kind e0 & 1)
-            {
-                const int v = (nfullblk + (e0 >> 1)) * 32 + r;
-                const bool ok = e0 < nextra && v < N;
-                load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi, ok, xe);
-                if (ok) mke = mask[bb * N + v];
-            }
-            if (wave < nfullblk) {                      // the wave's own block: LayerNorm + split once, three row GEMMs
-                key_override(wave, mknext);
-                PRD2_STAMP(6);
-                ln_cll_p<KH>(xnext);
-                u32x4 xs[2][P / 16];
-                split2h_rn_cll<KH>(xnext, xs);
-                f32x16 akq, ag, av;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { akq[e] = 0.f; av[e] = 0.f; }
-                g_init(ag);
-                PRD2_STAMP(7);
-                gemm_kq(xs, akq);
-                gemm_gv(xs, ag, av);
-                PRD2_STAMP(8);
-                store_kq(wave, akq);
-                store_gv(wave, ag, av);
-                PRD2_STAMP(9);
-            }
-            for (int e = e0; e < nextra; e += NW) {
-                const int blk = nfullblk + (e >> 1), kind = e & 1;
-                if (e != e0) {
-                    const int v = blk * 32 + r;
-                    const bool ok = v < N;
-                    load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi, ok, xe);
-                    mke = ok ? mask[bb * N + v] : 0.f;
-                }
-                ln_cll_p<KH>(xe);
-                u32x4 xs[2][P / 16];
-                split2h_rn_cll<KH>(xe, xs);
-                if (kind == 0) {
-                    key_override(blk, mke);
-                    f32x16 akq;
-#pragma unroll
-                    for (int q_ = 0; q_ < 16; ++q_) akq[q_] = 0.f;
-                    gemm_kq(xs, akq);
-                    store_kq(blk, akq);
-                } else {
-                    f32x16 ag, av;
-#pragma unroll
-                    for (int q_ = 0; q_ < 16; ++q_) av[q_] = 0.f;
-                    g_init(ag);
-                    gemm_gv(xs, ag, av);
-                    store_gv(blk, ag, av);
-                }
             }
         }
         PRD2_STAMP(1);
         __syncthreads();
         PRD2_STAMP(2);
-        {   // the wave's own block of the next row: in flight during the key loops
+        {   // the wave's phase-1 block of the next row: in flight during the key loops
             const int bun = bu + rstride;
             rnext = make_row(bun < nrows ? bun : 0);
-            const int v = wave * 32 + r;
-            const bool ok = bun < nrows && wave < nfullblk && v < N;
+            const int v = p1_blk * 32 + r;
+            const bool ok = bun < nrows && p1_blk >= 0 && v < N;
             load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
             mknext = ok ? mask[rnext.bb * N + v] : 0.f;
             munext = bun < nrows ? mask[bun] : 0.f;
@@ -524,102 +443,74 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
             const int f = lane < nqb ? tflag[lane] : 0;
             fmask = (unsigned)__ballot(f != 0);
         }
-        // this wave's key-loop work of the row, in tiles (priority = share still to do)
-        const int work_tot = ((wholeq - wave + NW - 1) / NW) * nqb + (it_end - it_begin);
         int work_rem = work_tot;
+        if (flags & 6) {                                // stagger the waves of a SIMD (w, w + 4, w + 8) so that their MFMA and VALU
+            const int j = wave >> 2;                    // segments do not coincide
+            if (j == 1) { if ((flags & 6) == 2) __builtin_amdgcn_s_sleep(3); else if ((flags & 6) == 4) __builtin_amdgcn_s_sleep(5); else __builtin_amdgcn_s_sleep(8); }
+            else if (j == 2) { if ((flags & 6) == 2) __builtin_amdgcn_s_sleep(6); else if ((flags & 6) == 4) __builtin_amdgcn_s_sleep(10); else __builtin_amdgcn_s_sleep(16); }
+        }
         // key tiles [T0, T1) for query block qb: o8 = O (x 16, relative to mref), lsum = the lane's part of the row sum
         auto run_piece = [&](int qb, int T0, int T1, float (&o8)[8], float& lsum, float& mref) {
-            v2_prio(work_rem, work_tot);
             const unsigned qo = (unsigned)hi * L.plane + (unsigned)(32 * qb + r) * 16u;
             const u32x4 qh = *reinterpret_cast<const u32x4*>(lds + L.qh + qo);
             const u32x4 ql = *reinterpret_cast<const u32x4*>(lds + L.ql + qo);
-            f32x16 o0, o1, zero;
+            f32x16 o0, zero;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; zero[e] = 0.f; }
+            for (int e = 0; e < 16; ++e) { o0[e] = 0.f; zero[e] = 0.f; }
             lsum = 0.f;
             bool big = false;
-            const unsigned range_bits = (T1 >= 32 ? 0xffffffffu : ((1u << T1) - 1u)) & ~((1u << T0) - 1u);
-            if ((fmask & range_bits) == 0) {
-                // ---- fast path: no masked / padded key in the piece; software-pipelined steps ----
-                const int tl = T1 - 1;                  // tiles past the piece are clamped to its last one (results unused)
+            if (flags & 1) v2_prio(work_rem, work_tot);
+            {
                 KOp k = load_k(lds, kbase + 512u * T0, kl_off);
-                f32x16 sA = qk_tile(k, qh, ql, zero), sB;
-                k = load_k(lds, kbase + 512u * (T0 + 1 < tl ? T0 + 1 : tl), kl_off);
-                const float tmax = xhalf_max(max16(sA));
-                mref = tmax - P_SHIFT;
-                f32x16 negm;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) negm[e] = -mref;
-                sB = qk_tile(k, qh, ql, negm);                                   // tile T0 + 1 (or a clamped repeat)
-                k = load_k(lds, kbase + 512u * (T0 + 2 < tl ? T0 + 2 : tl), kl_off);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sA[e] -= mref;
-                PBuf p;
-                exp_split(sA, lsum, big, p);
-                load_v(lds, vbase + 2048u * T0, p);
-                // invariant at the top of a step for tile t: s? = logits of tile t, p = tile t - 1, k = K of tile t + 1
-                int t = T0 + 1;
-                while (t < T1) {
-                    v2_prio(work_rem - (t - T0), work_tot);
-                    pipe_step(lds, kbase + 512u * (t + 2 < tl ? t + 2 : tl), kl_off, vbase + 2048u * t, sB, sA, negm, qh, ql, k, p,
-                              o0, o1, lsum, big);
-                    ++t;
-                    if (t >= T1) break;
-                    pipe_step(lds, kbase + 512u * (t + 2 < tl ? t + 2 : tl), kl_off, vbase + 2048u * t, sA, sB, negm, qh, ql, k, p,
-                              o0, o1, lsum, big);
-                    ++t;
-                }
-                pv_tile(p, o0, o1);                     // P V of the last tile
-            } else {
-                // ---- pieces with masked / padded keys: one tile at a time ----
-                KOp k0 = load_k(lds, kbase + 512u * T0, kl_off);
-                f32x16 s0 = qk_tile(k0, qh, ql, zero);
+                f32x16 s0 = qk_tile(k, qh, ql, zero);
+                if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_off);
                 if ((fmask >> T0) & 1) mask_tile(lds, L, T0, hi, 0.f, s0);
-                const float tmax = xhalf_max(max16(s0));
+                const float tmax = xhalf_max(max16_mfma(s0));
                 mref = tmax - P_SHIFT;
                 f32x16 negm;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
                 PBuf p;
-                exp_split(s0, lsum, big, p);
                 load_v(lds, vbase + 2048u * T0, p);
-                pv_tile(p, o0, o1);
+                exp_split(s0, lsum, big, p);
+                pv_tile(p, o0);
                 for (int t = T0 + 1; t < T1; ++t) {
-                    const KOp k = load_k(lds, kbase + 512u * t, kl_off);
+                    if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
                     f32x16 s = qk_tile(k, qh, ql, negm);
+                    if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_off);
+                    load_v(lds, vbase + 2048u * t, p);
                     if ((fmask >> t) & 1) mask_tile(lds, L, t, hi, mref, s);
                     exp_split(s, lsum, big, p);
-                    load_v(lds, vbase + 2048u * t, p);
-                    pv_tile(p, o0, o1);
+                    pv_tile(p, o0);
                 }
             }
             if (__any(big || !(lsum < 3.0e38f))) {
                 // rare: a later logit exceeded the reference by more than the fp16 range of the probabilities allows --
                 // redo the piece with the online update in every tile (probabilities <= 2^P_SHIFT)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+                for (int e = 0; e < 16; ++e) o0[e] = 0.f;
                 lsum = 0.f;
                 float m_run = -1e30f;
                 for (int t = T0; t < T1; ++t) {
                     const KOp k = load_k(lds, kbase + 512u * t, kl_off);
                     f32x16 s = qk_tile(k, qh, ql, zero);
                     if ((fmask >> t) & 1) mask_tile(lds, L, t, hi, 0.f, s);
-                    const float m_new = max2f(m_run, xhalf_max(max16(s)));
+                    const float m_new = max2f(m_run, xhalf_max(max16_mfma(s)));
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
                     mref = m_new - P_SHIFT;
                     lsum *= alpha;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; s[e] -= mref; }
+                    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; s[e] -= mref; }
                     bool dummy = false;
                     PBuf p;
-                    exp_split(s, lsum, dummy, p);
                     load_v(lds, vbase + 2048u * t, p);
-                    pv_tile(p, o0, o1);
+                    exp_split(s, lsum, dummy, p);
+                    pv_tile(p, o0);
                 }
             }
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o8[jj] = (o0[jj] + o0[jj + 8]) + (o1[jj] + o1[jj + 8]);
+            for (int jj = 0; jj < 8; ++jj) o8[jj] = o0[jj] + o0[jj + 8];
             work_rem -= T1 - T0;
         };
         // gate, normalise, store the 32 queries of block qb (l = the lane's part of the row sum)
@@ -630,83 +521,76 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 const float il = 1.0f / (VSCALE * ltot);
                 const float* gp = Gl + (size_t)(v * 2 + hi) * 8;
                 const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
-                const float res[8] = {g0.x * (o[0] * il), g0.y * (o[1] * il), g0.z * (o[2] * il), g0.w * (o[3] * il),
-                                      g1.x * (o[4] * il), g1.y * (o[5] * il), g1.z * (o[6] * il), g1.w * (o[7] * il)};
                 float* dst = og + row_pos(row, v) * HC + h * C + 4 * hi;
-                *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-                *reinterpret_cast<float4*>(dst + 8) = make_float4(res[4], res[5], res[6], res[7]);
+                *reinterpret_cast<float4*>(dst) = make_float4(g0.x * (o[0] * il), g0.y * (o[1] * il), g0.z * (o[2] * il), g0.w * (o[3] * il));
+                *reinterpret_cast<float4*>(dst + 8) = make_float4(g1.x * (o[4] * il), g1.y * (o[5] * il), g1.z * (o[6] * il), g1.w * (o[7] * il));
             }
         };
-        for (int qb = wave; qb < wholeq; qb += NW) {    // whole query blocks: no partials, no merge
-            float o8[8], lsum, mref;
-            run_piece(qb, 0, nqb, o8, lsum, mref);
-            PRD2_STAMP(10);
-            finish(qb, o8, lsum);
-            PRD2_STAMP(11);
-        }
-        for (int i0 = it_begin; i0 < it_end;) {         // this wave's range of the shared blocks
-            const int rq = i0 / nqb;
-            const int T0 = i0 - rq * nqb;
-            const int T1 = (it_end - rq * nqb) < nqb ? (it_end - rq * nqb) : nqb;       // exclusive
-            i0 += T1 - T0;
-            float o8[8], lsum, mref;
-            run_piece(wholeq + rq, T0, T1, o8, lsum, mref);
-            float* pp = part + (size_t)(wave + rq) * 640 + lane;               // partial of this piece: slot wave + rq
+        auto put_partial = [&](int pslot, const float (&o8)[8], float lsum, float mref) {
+            float* pp = part + (size_t)pslot * 640 + lane;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pp[jj * 64] = o8[jj];
             pp[8 * 64] = lsum;
             pp[9 * 64] = mref;
+        };
+        // partial slots of group block i: (nhelp + 1) * i + {0: owner, 1 + j: helper j}
+        if (owner) {
+            float o8[8], lsum, mref;
+            if (own_t1 > 0) run_piece(wave, 0, own_t1, o8, lsum, mref);
+            if (!group_owner) finish(wave, o8, lsum);
+            else if (own_t1 > 0) put_partial((nhelp + 1) * gi, o8, lsum, mref);
+        } else if (helper) {
+            const int T0 = qtile(m4 + hj), T1 = qtile(m4 + hj + 1);
+            for (int i = 0; i < m4; ++i) {
+                if (T1 <= T0) break;
+                float o8[8], lsum, mref;
+                run_piece(gbase + i, T0, T1, o8, lsum, mref);
+                put_partial((nhelp + 1) * i + 1 + hj, o8, lsum, mref);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         PRD2_STAMP(3);
-        if (R > 0) {
+        if (m4 > 0) {
             __syncthreads();
             PRD2_STAMP(4);
-            // ================= merge of the shared blocks =================
-            for (int rq = wave; rq < R; rq += NW) {
-                const int lo_it = rq * nqb, hi_it = lo_it + nqb - 1;
-                // waves whose range meets [lo_it, hi_it]: w_first = wave holding lo_it, w_last = wave holding hi_it
-                int wf = 0, wl = 0;
+            // ================= merge of the shared blocks (by their owners) =================
+            if (group_owner) {
+                // partials of the owner (k = 0) and of the helpers (k = 1 ..): a missing piece reads a valid slot with weight 0,
+                // so that all LDS reads are in flight together
+                const int s0 = (nhelp + 1) * gi;
+                float mm[5];
+                bool has[5];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) {
-                    const int st = (int)((long)rem_iter * w / NW);
-                    if (st <= lo_it) wf = w;
-                    if (st <= hi_it) wl = w;
-                }
-                // (a wave between the two whose own range is empty left no partial).  Straight-line over the NW possible
-                // pieces so that the LDS reads of different pieces are in flight together
-                float mm[NW];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const bool has = w >= wf && w <= wl && (int)((long)rem_iter * (w + 1) / NW) > (int)((long)rem_iter * w / NW);
-                    mm[w] = has ? part[(size_t)(w + rq) * 640 + 9 * 64 + lane] : -INFINITY;
+                for (int k = 0; k < 5; ++k) {
+                    has[k] = k == 0 ? own_t1 > 0 : (k - 1 < nhelp && qtile(m4 + k) > qtile(m4 + k - 1));
+                    const float v_ = part[(size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + 9 * 64 + lane];
+                    mm[k] = has[k] ? v_ : -INFINITY;
                 }
                 float M = mm[0];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) M = max2f(M, mm[w]);
+                for (int k = 1; k < 5; ++k) M = max2f(M, mm[k]);
                 float o[8], l = 0.f;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    if (mm[w] == -INFINITY) continue;              // wave-uniform: a piece exists for all lanes or for none
-                    const float* pp = part + (size_t)(w + rq) * 640 + lane;
-                    const float scl = __builtin_amdgcn_exp2f(mm[w] - M);
+                for (int k = 0; k < 5; ++k) {
+                    const float* pp = part + (size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + lane;
+                    const float scl = has[k] ? __builtin_amdgcn_exp2f(mm[k] - M) : 0.f;
                     l += scl * pp[8 * 64];
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
                 }
-                finish(wholeq + rq, o, l);
+                finish(wave, o, l);
             }
         }
         PRD2_STAMP(5);
     }
 }
 
-size_t v2_lds_bytes(int N, int P, int NW) {
-    const int NP = prd_round_up(N, 32), nqb = NP / 32;
+size_t v2_lds_bytes(int N, int P) {
+    const int NP = prd_round_up(N, 32), nqb = NP / 32, m4 = nqb & 3;
     const size_t base = (size_t)64 * P * 4 + (size_t)NP * (4 * 32 + 64 + 64 + 4) + 128;
-    return base + (size_t)(NW + nqb % NW) * 2560;      // partials: slot = wave + shared-block index
+    return base + (size_t)(m4 ? m4 * (5 - m4) : 0) * 2560;      // partials: (owner + helpers) of every shared block
 }
 
 }  // namespace
@@ -722,7 +606,7 @@ size_t v2_lds_bytes(int N, int P, int NW) {
 // 1 when the second-generation core serves rows of N positions (split-16 arithmetic only)
 extern "C" int prd_tri_attn_v2_supported(int N, int P) {
     if (N <= 0 || (P != 32 && P != 64)) return 0;
-    return (N <= V2_MAXN && v2_lds_bytes(N, P, 8) <= 160 * 1024) ? 1 : 0;
+    return (N <= V2_MAXN && v2_lds_bytes(N, P) <= 160 * 1024) ? 1 : 0;
 }
 
 extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
@@ -733,7 +617,7 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     if (!prd_tri_attn_v2_supported(N, P)) return PRD_ERR_UNSUPPORTED;
     if ((long)b * N * N > 0x7fffffffL / 2) return PRD_ERR_UNSUPPORTED;      // 32-bit position arithmetic in the kernel
     const int NP = prd_round_up(N, 32);
-    const size_t lds = v2_lds_bytes(N, P, 8);
+    const size_t lds = v2_lds_bytes(N, P);
     const long rows_total = (long)b * N;
     const long cap = 256 / H;
     long per_head = cap < rows_total ? cap : rows_total;
@@ -741,14 +625,16 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     const long rounds = (rows_total + per_head - 1) / per_head;
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
+    constexpr int NWV = 12;                             // nqb <= 12 query blocks, one wave each
+    static const int flags = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : 1;      // tuning only
     if (P == 64) {
-        PRD2_SET_LDS((tri_attn_core_v2_kernel<64, 8>));
-        hipLaunchKernelGGL((tri_attn_core_v2_kernel<64, 8>), dim3(grid), dim3(512), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, NP, H,
-                           ending);
+        PRD2_SET_LDS((tri_attn_core_v2_kernel<64, NWV>));
+        hipLaunchKernelGGL((tri_attn_core_v2_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
+                           NP, H, ending, flags);
     } else {
-        PRD2_SET_LDS((tri_attn_core_v2_kernel<32, 8>));
-        hipLaunchKernelGGL((tri_attn_core_v2_kernel<32, 8>), dim3(grid), dim3(512), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N, NP, H,
-                           ending);
+        PRD2_SET_LDS((tri_attn_core_v2_kernel<32, NWV>));
+        hipLaunchKernelGGL((tri_attn_core_v2_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
+                           NP, H, ending, flags);
     }
     return (int)hipGetLastError();
 }

@@ -26,9 +26,9 @@ for ending in (False, True):
     for _ in range(3):
         ops.tri_attn_core_v2(pair, mask, wts, 4, 16, ending=ending, og=og)
     torch.cuda.synchronize()
-    buf = np.zeros(256 * 8 * 8 * 16, dtype=np.uint64)
+    buf = np.zeros(256 * 12 * 8 * 16, dtype=np.uint64)
     assert L.prd_debug_read2(buf.ctypes.data) == 0
-    full = buf.reshape(256, 8, 8, 16).astype(np.int64)
+    full = buf.reshape(256, 12, 8, 16).astype(np.int64)
     nit = int((full[0, 0, :, 0] > 0).sum())
     full = full[:, :, :nit]
     t = full[..., :6]
@@ -42,10 +42,7 @@ for ending in (False, True):
     print(f"  top-of-loop wait        per wave mean {top.mean():8.0f}")
     span = t[..., 5].max(axis=1) - t[..., 0].min(axis=1)
     print(f"  row span per WG: mean {span.mean():.0f} min {span.min()} max {span.max()};  by wave, phase 2: " +
-          " ".join(f"{(t[:, w, :, 3] - t[:, w, :, 2]).mean():.0f}" for w in range(8)))
-    # finer stamps: 6 after the key override (row mask value arrived), 7 after LayerNorm + split, 8 after the row GEMMs,
-    # 9 after the K/Q/V/gate stores, 10 end of the whole-block key loop, 11 after its gate + store
-    def d(a, b):
-        return (full[..., a] - full[..., b]).mean()
-    print(f"  own block: override {d(6, 0):.0f}  LN+split {d(7, 6):.0f}  GEMMs {d(8, 7):.0f}  stores {d(9, 8):.0f}  rest of phase 1 {d(1, 9):.0f}")
-    print(f"  phase 2: whole-block loop {d(10, 2):.0f}  finish {d(11, 10):.0f}  shared pieces {d(3, 11):.0f}")
+          " ".join(f"{(t[:, w, :, 3] - t[:, w, :, 2]).mean():.0f}" for w in range(12)))
+    # finer stamp: 6 after LayerNorm + split of the wave's block
+    print(f"  phase 1: LN + split {(full[..., 6] - full[..., 0]).mean():.0f}  by wave, phase 1: " +
+          " ".join(f"{(t[:, w, :, 1] - t[:, w, :, 0]).mean():.0f}" for w in range(12)))
