@@ -606,7 +606,50 @@ def test_trajectory_vs_reference_golden(golden, name, gemm_mode):
     assert rel_l2(logits.cpu(), z["traj_logits"]) < TRAJ_TOL
 
 
-@pytest.mark.parametrize("name", ["cfg1_t200", "cfg1_t1000", "cfg1_t200_random"])
+@pytest.mark.parametrize("name", ["cfg1_t200", "cfg1_t200_random", "cfg1_t1000", "cfg2_t1000"])
+def test_free_running_trajectory_vs_yardstick(golden, name, gemm_mode):
+    """FREE-RUNNING T = 200 / T = 1000 loops (no restarts) held to the reference's own sensitivity to fp32 round-off.
+
+    The yardstick is reference-derived (oracle/gen_yardstick.py): the imported reference run in fp32 (<name>.npz) and with
+    model.double() (<name>_f64.npz) on the same complex, weights, mask and injected noise; delta_ref(step) = rel-L2 between the
+    two at every stored step.  With untrained weights the loop amplifies round-off: delta_ref grows from 3e-7 (10 steps) to
+    3e-3 ... 3e-2 at the end, i.e. the reference cannot reproduce ITSELF to 1e-4 across precisions, so 1e-4 against the fp32
+    run is not a meaningful bar for a free-running loop of this length (it is for segments: the test below).  What is
+    required of the HIP path, in both arithmetic modes, measured against the fp64 run:
+      * before the amplification sets in (delta_ref <= 1e-5): within 3 x delta_ref at EVERY stored step;
+      * over the whole loop: geometric mean of (HIP vs fp64) / delta_ref <= 2 and no stored step above 16 x (in the amplified
+        regime the two fp32 runs are independent draws of the same chaotic growth; observed: geometric mean 0.9-1.3, isolated
+        steps up to 10 x in either mode, profiles/r03_trajectory.txt);
+      * final positions and logits within 4 x delta_ref of the fp64 run."""
+    import os
+    from tools.trajectory_conditioning import GOLDEN, free_run, rel
+    if not (os.path.exists(os.path.join(GOLDEN, name + ".npz")) and os.path.exists(os.path.join(GOLDEN, name + "_f64.npz"))):
+        pytest.skip(f"{name}: yardstick fixture not generated (oracle/gen_yardstick.py)")
+    case, f32 = golden(name)
+    _, f64 = golden(name + "_f64")
+    steps = [int(v) for v in f64["seg_step"]]
+    zs, pos, logits = free_run(case, gemm_mode)
+    assert len(zs) >= len(steps)
+    ratios = []
+    for k, st in enumerate(steps):
+        ref32, ref64 = f32["seg_z"][k].astype(np.float64), f64["seg_z_f64"][k]
+        dref = rel(ref32, ref64)
+        dev = rel(zs[k][0], ref64)
+        if k == 0:
+            assert dev < 1e-6, "initial state differs"
+            continue
+        ratios.append(dev / dref)
+        if dref <= 1e-5:
+            assert dev <= 3 * dref + 1e-7, (name, st, dev, dref)
+        assert dev <= 16 * dref, (name, st, dev, dref)
+    gmean = math.exp(sum(math.log(max(r_, 1e-12)) for r_ in ratios) / len(ratios))
+    assert gmean <= 2.0, (name, gmean)
+    if "traj_pos_f64" in f64:
+        assert rel(pos, f64["traj_pos_f64"]) <= 4 * rel(f32["traj_pos"], f64["traj_pos_f64"])
+        assert rel(logits, f64["traj_logits_f64"]) <= 4 * rel(f32["traj_logits"], f64["traj_logits_f64"])
+
+
+@pytest.mark.parametrize("name", ["cfg1_t200", "cfg1_t1000", "cfg1_t200_random", "cfg2_t1000"])
 def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
     """T = 200 and T = 1000 (BASELINE configs[1]'s num_steps): every stretch of the loop, each restarted from the REFERENCE's own
     state (stored every 10 / 25 steps); the state the HIP path reaches at the next stored step must agree to 1e-4.  With
@@ -615,7 +658,10 @@ def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
     weights: the point cloud collapses and the unit directions z_ij / |z_ij| of the coordinate head lose their meaning) away
     from its own unperturbed run after 200 steps (DESIGN.md §2).  Segment-wise agreement is the statement that survives;
     the free-running deviation is printed for the record."""
+    import os
     from protein_redesign_amd.diffusion_model import ReverseDiffusion
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")):
+        pytest.skip(f"{name}: fixture not generated (oracle/gen_yardstick.py; BASELINE configs[1] at its own shape and length)")
     case, z, args, model, params = golden_case(golden, name)
     one = batch_to(synthetic_batch([tuple(case["traj_sample"])], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500), DEV)
     loop = ReverseDiffusion(model, one, [NoiseSource(NOISE_SEED, 0)])
