@@ -367,13 +367,22 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef __fp16 f16x2_t __attribute__((ext_vector_type(2)));
 constexpr float H2_WSCALE = 16.0f, H2_INV_WSCALE = 1.0f / 16.0f;
 
-// hi = RTZ_fp16(x); lo = fp16(x - hi) in ONE mixed-precision FMA per element (v_fma_mixlo/hi_f16: fp16 source half * -1 + fp32
-// source, result rounded once to fp16 into the low / high half of the destination): 3 VALU instructions per PAIR of values
-// instead of 6 (cvt_pkrtz, 2 x cvt_f32_f16, 2 x sub, cvt_pkrtz) -- VALU issue time is what the split kernels are bound by.
+// hi = RN_fp16(x), lo = RN_fp16(x - hi): the residual is formed in fp32 by v_fma_mix_f32 (fp16 source half * -1 + fp32 source:
+// exact) and the pair of residuals packed by a second v_cvt_pk_f16_f32.  Measured on gfx950 (tools/ubench/valu_rate_bench.hip,
+// SIMD cycles per wave64 instruction): v_cvt_pk_f16_f32 / v_fma_mix_f32 4.6, v_fma_mixlo/hi_f16 8.4 (the rate of a
+// transcendental) -- so 4 x 4.6 per pair of values beats the round-2 form (v_cvt_pkrtz + v_fma_mixlo_f16 + v_fma_mixhi_f16 =
+// 4.6 + 2 x 8.4) although it is one instruction longer, and rounding hi to nearest leaves a signed residual: hi + lo carries
+// 24 bits instead of 23.  VALU issue time is what the split kernels are bound by.
+// Range: an operand of magnitude >= 65520 rounds to +-inf (the RTZ form saturated at 65504; either is wrong, this one loudly).
+// The first conversion is left to the compiler: as the FIRST reader of a value that may come straight out of an MFMA or a
+// transcendental it must be an instruction whose hazards hipcc pads (an asm statement's reads are not padded).
+typedef _Float16 prd_h16x2 __attribute__((ext_vector_type(2)));
 PRD_DEV void split2h(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, prd_h16x2));
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, prd_h16x2));
 }
 // NE CLL elements x[0 .. NE) (NE a multiple of 8) -> 2 planes x NE/8 operand registers of 8 fp16
 template <int NE>

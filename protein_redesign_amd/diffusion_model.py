@@ -334,6 +334,11 @@ class ProteinReDiffModel(_Base):
         if not self.setup_schedule:
             self.run_setup_schedule()
             self.setup_schedule = True
+        if sources is None:
+            # the reference draws a fresh torch.randperm at every optimisation step (model.py:460 -> mask_utils.py:87), so the
+            # redesign mask of a complex differs from epoch to epoch: key the draw on a running count of training steps
+            # (batch_idx restarts every epoch; keyed determinism on batch_idx is for validation / predict only)
+            sources = self._sources(batch["atom_mask"].shape[0], None)
         batch = self.prepare_batch(batch, batch_idx, sources=sources)
         x, mask = batch["x"], batch["residue_and_atom_mask"]
         num_nodes = (mask > 0.5).sum(-1)

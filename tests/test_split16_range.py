@@ -1,0 +1,132 @@
+"""Operand RANGE of the split-16 arithmetic (gemm mode 1): fp32 operands travel as fp16 hi + lo, so un-normalised operands
+(outputs of projections with large or tiny weights, ReLU hidden units, gated a | b of the triangle multiplication, large
+attention logits) must stay accurate well away from O(1).  Every case is compared with the oracle evaluated in fp64; the
+bar is the operator tolerance of the suite (1e-5), or -- where fp32 arithmetic itself cannot reach it on such inputs --
+three times the error of the fp32 oracle against the same fp64 result.  Both arithmetic modes run."""
+import pytest
+import torch
+
+import prd_oracle as O
+from conftest import rel_l2
+from protein_redesign_amd import ops
+from test_hip_parity import DEV, OP_TOL, cu, gemm_mode, setup  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def to64(params):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in params.items()}
+
+
+def check(got, want32, want64, what):
+    e_ref = rel_l2(want32, want64)
+    e_hip = rel_l2(got.cpu(), want64)
+    assert torch.isfinite(got).all(), what
+    assert e_hip <= max(OP_TOL, 3 * e_ref), (what, e_hip, e_ref)
+
+
+@pytest.mark.parametrize("mode", ["outgoing", "incoming"])
+@pytest.mark.parametrize("scale", [50.0, 1e-3, 1.0])
+def test_triangle_multiplication_operand_scale(setup, mode, scale, gemm_mode):
+    """ab_proj weights and bias x 50 and x 1e-3: the operands a | b of the contraction are NOT LayerNorm-ed (modules.py:263-270);
+    their product runs over N keys, and the result is normalised only afterwards."""
+    s = setup
+    pfx = f"Denoiser.folding_blocks.0.pair_mul_{mode}"
+    params = dict(s["params"])
+    params[pfx + ".ab_proj.weight"] = s["params"][pfx + ".ab_proj.weight"] * scale
+    params[pfx + ".ab_proj.bias"] = s["params"][pfx + ".ab_proj.bias"] * scale
+    m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
+    with torch.inference_mode():
+        want32 = O.triangle_multiplication(params, pfx, s["pair"], m2, mode == "incoming")
+        want64 = O.triangle_multiplication(to64(params), pfx, s["pair"].double(), m2.double(), mode == "incoming")
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_mul_{mode}")
+    w = [t.clone() for t in mod.weights()]
+    w[0] = w[0] * scale
+    w[1] = w[1] * scale
+    got = ops.tri_mul(cu(s["pair"]), cu(s["mask"]), w, incoming=mode == "incoming", residual=False)
+    check(got, want32, want64, (mode, scale))
+
+
+@pytest.mark.parametrize("N", [200, 449, 769])
+@pytest.mark.parametrize("scale", [30.0, 400.0])
+def test_triangle_attention_large_logits(setup, N, scale, gemm_mode):
+    """q_proj x 30 / x 400 on the short-row kernel (N = 200), the split long-row kernel (N = 449, 769): logits of magnitude
+    10^2 .. 10^3, far above those of the first key tile, masked tail.  Row subset against the oracle in fp64."""
+    s = setup
+    P = s["P"]
+    H, c = s["args"]["num_heads"], s["args"]["head_dim"]
+    pfx = "Denoiser.folding_blocks.0.pair_attn_starting"
+    params = dict(s["params"])
+    params[pfx + ".attn.q_proj.weight"] = s["params"][pfx + ".attn.q_proj.weight"] * scale
+    g = torch.Generator().manual_seed(N)
+    pair = torch.randn(1, N, N, P, generator=g)
+    mask = torch.ones(1, N)
+    mask[0, N - 9:] = 0
+    rows = sorted({0, 31, N // 2, N - 10, N - 1} | set(torch.randint(0, N, (3,), generator=g).tolist()))
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    with torch.inference_mode():
+        want32 = O.gated_attention(params, pfx + ".attn", pair[:, rows], m2[:, rows], H, c)
+        want64 = O.gated_attention(to64(params), pfx + ".attn", pair[:, rows].double(), m2[:, rows].double(), H, c)
+    mod = s["model"].Denoiser.folding_blocks[0].pair_attn_starting
+    w = [t.clone() for t in mod.attn.weights()]
+    w[0] = w[0] * scale
+    got = ops.tri_attn(cu(pair), cu(mask), w, H, c, ending=False, residual=False)[:, rows]
+    check(got, want32, want64, (N, scale))
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1e4])
+def test_pair_operators_input_scale(setup, scale, gemm_mode):
+    """Pair tensor x 1e-4 / x 1e4: every pair operator starts with a LayerNorm, so the split sees the same normalised rows (up
+    to the eps of the norm): transition, triangle multiplication, triangle attention, attention bias."""
+    s = setup
+    pair = s["pair"] * scale
+    m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
+    blk = s["model"].Denoiser.folding_blocks[0]
+    p64 = to64(s["params"])
+    pf = blk.pair_fc
+    with torch.inference_mode():
+        w32 = O.transition(s["params"], "Denoiser.folding_blocks.0.pair_fc", pair)
+        w64 = O.transition(p64, "Denoiser.folding_blocks.0.pair_fc", pair.double())
+    check(ops.pair_transition(cu(pair), pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias, residual=False), w32, w64, ("pair_fc", scale))
+    with torch.inference_mode():
+        w32 = O.triangle_multiplication(s["params"], "Denoiser.folding_blocks.0.pair_mul_outgoing", pair, m2, False)
+        w64 = O.triangle_multiplication(p64, "Denoiser.folding_blocks.0.pair_mul_outgoing", pair.double(), m2.double(), False)
+    check(blk.pair_mul_outgoing(cu(pair), cu(m2)), w32, w64, ("tri_mul", scale))
+    with torch.inference_mode():
+        w32 = O.triangle_attention(s["params"], "Denoiser.folding_blocks.0.pair_attn_ending", pair, m2, s["args"]["num_heads"], s["args"]["head_dim"], True)
+        w64 = O.triangle_attention(p64, "Denoiser.folding_blocks.0.pair_attn_ending", pair.double(), m2.double(), s["args"]["num_heads"], s["args"]["head_dim"], True)
+    check(blk.pair_attn_ending(cu(pair), cu(m2)), w32, w64, ("tri_attn", scale))
+
+
+@pytest.mark.parametrize("scale", [30.0, 1e-3])
+def test_pair_transition_hidden_scale(setup, scale, gemm_mode):
+    """First-layer weights and bias of pair_fc x 30 / x 1e-3: large / tiny ReLU hidden units (the operand of the second GEMM is not
+    normalised)."""
+    s = setup
+    pfx = "Denoiser.folding_blocks.0.pair_fc"
+    params = dict(s["params"])
+    params[pfx + ".1.weight"] = s["params"][pfx + ".1.weight"] * scale
+    params[pfx + ".1.bias"] = s["params"][pfx + ".1.bias"] * scale
+    with torch.inference_mode():
+        w32 = O.transition(params, pfx, s["pair"])
+        w64 = O.transition(to64(params), pfx, s["pair"].double())
+    pf = s["model"].Denoiser.folding_blocks[0].pair_fc
+    got = ops.pair_transition(cu(s["pair"]), pf[1].weight * scale, pf[1].bias * scale, pf[3].weight, pf[3].bias, residual=False)
+    check(got, w32, w64, scale)
+
+
+@pytest.mark.parametrize("scale", [30.0, 1e-3])
+def test_single_transition_hidden_scale(setup, scale, gemm_mode):
+    """The same on the single track (gemm_ring: node-row linears with fused LayerNorm)."""
+    s = setup
+    pfx = "Denoiser.folding_blocks.0.single_fc"
+    params = dict(s["params"])
+    params[pfx + ".1.weight"] = s["params"][pfx + ".1.weight"] * scale
+    params[pfx + ".1.bias"] = s["params"][pfx + ".1.bias"] * scale
+    with torch.inference_mode():
+        w32 = O.transition(params, pfx, s["single"])
+        w64 = O.transition(to64(params), pfx, s["single"].double())
+    sf = s["model"].Denoiser.folding_blocks[0].single_fc
+    h = ops.linear(cu(s["single"]), (sf[1].weight * scale).contiguous(), (sf[1].bias * scale).contiguous(), act=1, ln_a=True)
+    got = ops.linear(h, sf[3].weight, sf[3].bias)
+    check(got, w32, w64, scale)

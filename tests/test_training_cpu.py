@@ -129,12 +129,19 @@ def _ddp_worker(rank, world, port, out_dir):
     torch.manual_seed(0)
     lin = torch.nn.Linear(5, 3)
     frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
-    unused = torch.nn.Parameter(torch.zeros(4))                  # never touched on rank 1: still part of the reduced layout
+    extra = torch.nn.Parameter(torch.zeros(4))                   # gradient 1 on rank 0, 0 on rank 1 -> 0.5 after averaging
+    unused = torch.nn.Parameter(torch.zeros(3))                  # never touched: like DDP(find_unused_parameters=False) an error
     x = torch.arange(10.0).view(2, 5) + rank
-    loss = lin(x).square().sum() + (unused.sum() if rank == 0 else 0.0)
+    loss = lin(x).square().sum() + extra.sum() * (1.0 if rank == 0 else 0.0)
     loss.backward()
-    training.all_reduce_gradients([lin.weight, lin.bias, frozen, unused])
-    torch.save({"w": lin.weight.grad, "b": lin.bias.grad, "u": unused.grad}, os.path.join(out_dir, f"g{rank}.pt"))
+    training.all_reduce_gradients([lin.weight, lin.bias, frozen, extra])
+    training.all_reduce_gradients([lin.weight, lin.bias, frozen, extra])      # persistent flat buffer: a second call averages equal values
+    raised = False
+    try:
+        training.all_reduce_gradients([lin.weight, unused])
+    except RuntimeError:
+        raised = True
+    torch.save({"w": lin.weight.grad, "b": lin.bias.grad, "u": extra.grad, "raised": raised}, os.path.join(out_dir, f"g{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -151,3 +158,4 @@ def test_gradient_average_over_two_ranks(tmp_path):
         want_w += lin.weight.grad / 2
     assert torch.allclose(g0["w"], want_w, rtol=1e-6) and torch.equal(g0["w"], g1["w"]) and torch.equal(g0["b"], g1["b"])
     assert torch.allclose(g0["u"], torch.full((4,), 0.5)) and torch.equal(g0["u"], g1["u"])
+    assert g0["raised"] and g1["raised"]

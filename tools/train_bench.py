@@ -25,9 +25,11 @@ def main():
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run, also with one rank
+    if world > 1 or launched:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)                  # "nccl" is RCCL on ROCm
     from protein_redesign_amd import training
     from protein_redesign_amd.constants import make_args
     from protein_redesign_amd.diffusion_model import ProteinReDiffModel
@@ -55,7 +57,10 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "optimisation micro-steps/s per complex (q-noising + fwd + bwd + Adam + EMA)", "value": round(world * a.batch / dt, 3),
                           "ms_per_step": round(dt * 1e3, 2), "n_gpus": world, "batch_per_gpu": a.batch, "N": a.atoms + a.residues,
-                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "losses": [round(x, 4) for x in losses]}))
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "losses": [round(x, 4) for x in losses],
+                          "backend": "nccl (RCCL), one flat gradient all-reduce per step" if (world > 1 or launched) else "single process"}))
+    if world > 1 or launched:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
