@@ -42,23 +42,29 @@ typedef struct ihipStream_t* hipStream_t;
 
 int prd_version(void);
 
-/* Arithmetic of the GEMMs inside the pair-track operators.  PROCESS-WIDE (the single piece of global state of the library):
- * set it before launching, not concurrently with launches whose arithmetic matters; every call reads it once.
- *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): plain fp32 FMA chains;
- *   1  (default) "split16": fp32 operands are split into 16-bit parts and multiplied on the fp16 / bf16 matrix pipes with fp32
- *      accumulation, every product whose weight exceeds 2^-22 included:
- *        - fp16 hi + lo (RTZ + one mixed-precision FMA, 22 bits), 3 products, 16/3 of the fp32 rate: the row GEMMs (tri_mul
- *          projection / output, attention projections and output projection, pair transition / block tail, outer-linear,
- *          pair_init, OPM), the triangle-multiplication contraction, P*V of the triangle attention, Q*K^T of long rows
- *          (N > 384) and the node-row linears of the single track (prd_gemm with one batch, K a multiple of 64 or 32).
- *          Weight images stay the size of the fp32 ones.  fp16 saturates at 65504: LayerNorm-ed rows, their gated / ReLU-ed
- *          projections, probabilities and weights (staged x 16) are far inside;
- *        - bf16 x 3 by truncation (exact, 24 bits), 6 products, 16/6 of the fp32 rate: Q*K^T of short rows;
- *      the single-track attention core, SPAttention's batched logits / P*V GEMMs, pair_bias and the coordinate head run fp32
- *      MFMA in either mode.
- * Both modes meet every parity tolerance of tests/ (the GPU suite runs its operator / step / trajectory / gradient tests in both). */
-int prd_set_gemm_mode(int mode);
-int prd_get_gemm_mode(void);
+/* Arithmetic of the GEMMs inside the operators.  The library keeps NO state: every entry point whose kernels depend on the
+ * arithmetic takes it as its `arith` argument (the last one before `stream`; PrdGemm carries it as a field), so calls with
+ * different arithmetics may run concurrently on different streams / threads.  (The Python host side keeps the process default:
+ * protein_redesign_amd._lib.set_gemm_mode, env PRD_GEMM_MODE.)
+ *   PRD_ARITH_FP32 (0)     fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): plain fp32 FMA chains;
+ *   PRD_ARITH_SPLIT16 (1)  fp32 operands are split into fp16 hi + lo -- hi = RN_fp16(x), lo = RN_fp16(x - hi): 24 bits while lo is
+ *      a normal fp16 number -- and multiplied on the fp16 matrix pipe with fp32 accumulation: hi*hi + hi*lo + lo*hi, 16/3 of
+ *      the fp32 rate.  Used by the row GEMMs (tri_mul projection / output, attention projections and output projection, pair
+ *      transition / block tail, outer-linear, pair_init, OPM), the triangle-multiplication contraction, Q*K^T and P*V of the
+ *      triangle attention and the node-row linears of the single track (prd_gemm with one batch, K a multiple of 64 or 32).
+ *      Weight images stay the size of the fp32 ones.  The first-generation short-row attention core (PRD_TA_VARIANT=10) uses
+ *      bf16 x 3 by truncation (24 bits, 6 products) for Q*K^T.  The single-track attention core, SPAttention's batched
+ *      logits / P*V GEMMs, pair_bias and the coordinate head run fp32 MFMA in either mode.
+ *      OPERAND RANGE: fp16 holds magnitudes up to 65504 (a larger operand becomes +-inf, the result NaN -- loudly wrong, never
+ *      silently saturated) and keeps a normal lo part down to |x| ~ 0.25 (2^-12 |x| >= 6.1e-5); below that the lo part is
+ *      subnormal and the operand carries an ABSOLUTE error of 2^-25 ~ 3e-8 instead of a relative 2^-24.  LayerNorm-ed rows
+ *      (|x| <= sqrt(C)), their gated / ReLU-ed projections, probabilities (kept x 2^4) and weights (staged x 16) are well
+ *      inside; tests/test_split16_range.py drives weights x 50 / x 1e-3 (triangle multiplication), x 30 / x 1e-3 (ReLU hidden
+ *      units), logits x 30 / x 400 and inputs x 1e-4 / x 1e4 through both arithmetics.  Activations or weights beyond ~1e4 / below
+ *      ~1e-4 in an un-normalised position are out of range for PRD_ARITH_SPLIT16: use PRD_ARITH_FP32.
+ * Both arithmetics meet every parity tolerance of tests/ (the GPU suite runs its operator / step / trajectory / gradient tests in both). */
+#define PRD_ARITH_FP32 0
+#define PRD_ARITH_SPLIT16 1
 
 /* ---- generic batched GEMM:  C[g] = epilogue(A[g] * B[g]^T)  (b_kn = 1: A[g] * B[g]) -------------
  * Replaces aten::linear / bmm / matmul on the single track (modules.py:185-225, 306-311;
@@ -93,6 +99,7 @@ typedef struct PrdGemm {
     float* ln_out; int ldlo;        /* optional, with a_ln and G1 = G2 = 1: the LayerNorm-ed A rows are also written here (row pitch
                                        ldlo floats) by the workgroups of the first column tile -- OuterLinear needs LN(single)
                                        itself next to the W2 projection of it (modules.py:283-287) */
+    int arith;                      /* PRD_ARITH_FP32 / PRD_ARITH_SPLIT16 */
 } PrdGemm;
 int prd_gemm(const PrdGemm* args, hipStream_t stream);
 
@@ -124,7 +131,7 @@ int prd_time_embed(float* ebeta, const int64_t* t, const float* freqs, const flo
 /* pair = static_pair + m_i m_j (W_d rbf(|z_i - z_j|) + ebeta)  (model.py:339-340, 359-361; modules.py:73-82) */
 int prd_pair_init(float* pair, const float* static_pair, const float* z, const float* mask,
                   const float* centers, const float* w_dist, const float* ebeta,
-                  int b, int N, int P, int dist_dim, hipStream_t stream);
+                  int b, int N, int P, int dist_dim, int arith, hipStream_t stream);
 
 /* ---- trunk operators ------------------------------------------------------------------------------
  * `queue` (where present): device pointer to 256 int32 (one counter per XCD, 128 B apart), zero before the first use, owned by the
@@ -145,28 +152,28 @@ int prd_pair_bias2(float* bias_a, const float* pair, const float* gamma_a, const
  * out[i,j,:] = (flags&1 ? pair : 0) + (flags&2 ? m_i m_j : 1) * (W_o (a_i * b_j) + b_o) / (m_i m_j + 1e-3);
  * ab = [a | b] of shape [b,N,2C].  `out` may alias `pair` (in-place residual update), here and below. */
 int prd_opm_pair(float* out, const float* pair, const float* ab, const float* mask, const float* w_out,
-                 const float* b_out, int flags, int b, int N, int P, int C, hipStream_t stream);
+                 const float* b_out, int flags, int b, int N, int P, int C, int arith, hipStream_t stream);
 /* OuterLinear (modules.py:283-287): out[i,j,:] = (residual ? pair : 0) + W1 (x_i * x_j) + u_i - u_j + bias,
  * x = LN(single), u = x W2^T [b,N,P] (computed by prd_gemm), w = [W1 | W2] of shape [P, 2S]. */
 int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
-                     const float* bias, int residual, int b, int N, int P, int S, int* queue, hipStream_t stream);
+                     const float* bias, int residual, int b, int N, int P, int S, int* queue, int arith, hipStream_t stream);
 /* TriangleMultiplication (modules.py:262-274): out = (residual ? pair : 0) + update(pair).
  * ws: 3 * b * P * N * round_up(N,32) floats (query prd_workspace_bytes). */
 int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w_proj, const float* b_proj,
                 const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
                 const float* w_ogate, const float* b_ogate, int incoming, int residual,
-                int b, int N, int P, float* ws, size_t ws_bytes, int* queue, hipStream_t stream);
+                int b, int N, int P, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream);
 /* ---- backward of TriangleMultiplication (autograd of modules.py:262-274; used by training.py) -------------------------------
  * The contraction of prd_tri_mul alone: O[b][d][i][j] = sum_k A[b][d][i][k] B[b][d][j][k], operands channel-major
  * AB[b][2P][N][ldn] (A = channels 0..P-1, B = channels P..2P-1, ldn = round_up(N,32), zero padded), O[b][P][N][ldn].
  * The backward calls it on transposed operands for dA and dB. */
-int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, hipStream_t stream);
+int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, int arith, hipStream_t stream);
 /* TriangleMultiplication "outgoing" followed by "incoming", in place on `pair` (both residual updates of modules.py:336-337),
- * gemm mode 1 only (prd_tri_mul_chain_supported): five launches instead of six -- the output stage of the first module and the
+ * PRD_ARITH_SPLIT16 only (prd_tri_mul_chain_supported): five launches instead of six -- the output stage of the first module and the
  * projection stage of the second run as one row pass down the columns (the outgoing contraction stores its result transposed
  * for it).  w_outgoing / w_incoming: eight device pointers each, in prd_tri_mul's order (w_proj, b_proj, w_gate, b_gate, w_out,
  * b_out, w_ogate, b_ogate).  Workspace as for prd_tri_mul.  Results equal two prd_tri_mul calls up to fp32 rounding. */
-int prd_tri_mul_chain_supported(int N, int P);
+int prd_tri_mul_chain_supported(int N, int P, int arith);
 int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outgoing, const float* const* w_incoming,
                       int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream);
 /* Output stage backward.  dy = gradient of the update [b,N,N,P]; O = contraction output (channel-major, as left in prd_tri_mul's
@@ -181,7 +188,7 @@ int prd_tri_mul_out_bwd(float* dz, float* dgp, float* dO, float* dx1, const floa
  * [b,N,N,2P] by pair position (dW_proj = dpp^T LN(pair), dW_gate = dpg^T LN(pair) are left to the caller's BLAS). */
 int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const float* dAB, const float* dx1, const float* pair,
                          const float* mask, const float* w_proj, const float* b_proj, const float* w_gate, const float* b_gate,
-                         const float* w_proj_t, const float* w_gate_t, int incoming, int b, int N, int P, hipStream_t stream);
+                         const float* w_proj_t, const float* w_gate_t, int incoming, int b, int N, int P, int arith, hipStream_t stream);
 
 /* ---- backward of TriangleAttention (autograd of modules.py:236-243 -> 185-225; used by training.py) -------------------------
  * Core: dog = W_out^T d(update) [b,N,N,64] (a row GEMM by the caller) -> dqkvg[b,N,N,4,64] by pair position =
@@ -210,18 +217,18 @@ int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, long l
  * ws: b * N * N * 64 floats. */
 int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
                  const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
-                 int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, hipStream_t stream);
-/* which core kernel prd_tri_attn uses for rows of N positions under the current gemm mode: 0 = short rows (K, V, Q and gate
+                 int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream);
+/* which core kernel prd_tri_attn uses for rows of N positions under arithmetic `arith`: 0 = short rows (K, V, Q and gate
  * of a row resident in LDS: N <= 448 in fp32 mode, N <= 384 with split operands), 1 = long rows on the fp32 kernel (Q / gate
  * re-projected per query block), 2 = long rows on the split-operand kernel (gemm mode 1, N <= 832),
  * PRD_ERR_UNSUPPORTED = N too large (beyond ~1000). */
-int prd_tri_attn_variant(int N, int P);
+int prd_tri_attn_variant(int N, int P, int arith);
 /* the two launches of prd_tri_attn, exposed separately (og = gated per-head output [b,N,N,64]) */
 int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                       const float* wv, const float* wg, const float* bg, int ending,
-                      int b, int N, int P, int H, int c, hipStream_t stream);
+                      int b, int N, int P, int H, int c, int arith, hipStream_t stream);
 int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
-                     int residual, int b, int N, int P, int* queue, hipStream_t stream);
+                     int residual, int b, int N, int P, int* queue, int arith, hipStream_t stream);
 /* Second-generation core for short rows (N <= 352, split-16 arithmetic; csrc/prd_tri2.hip): same contract as
  * prd_tri_attn_core, everything on the 32x32x16 fp16 MFMA (Q K^T with fp16 hi+lo operands rounded to nearest: 24 bits),
  * the (query block, key tile) work of a row cut into equal contiguous ranges per wave.  prd_tri_attn_core dispatches to
@@ -235,7 +242,7 @@ int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const 
  * alias `pair` -- by the workgroups of head 0, instead of a separate prd_tri_attn_out launch.  gemm mode 1, short rows only
  * (prd_tri_attn_core_fused_supported); og as prd_tri_attn_core.  Equal to prd_tri_attn_out(pair_out, pair, og_in, ...,
  * residual = 1) followed by prd_tri_attn_core(og, pair_out, ...) up to fp32 rounding. */
-int prd_tri_attn_core_fused_supported(int N, int P);
+int prd_tri_attn_core_fused_supported(int N, int P, int arith);
 int prd_tri_attn_core_fused(float* og, float* pair_out, const float* pair, const float* og_in, const float* wo_in,
                             const float* bo_in, const float* mask, const float* wq, const float* wk, const float* wv,
                             const float* wg, const float* bg, int ending, int b, int N, int P, int H, int c,
@@ -246,13 +253,13 @@ int prd_single_attn_core(float* o, const float* qkvg, const float* bias, const f
                          int b, int N, int H, int c, hipStream_t stream);
 /* pair transition (modules.py:321-326): out = (residual ? pair : 0) + W2 relu(W1 LN(pair) + b1) + b2, hidden = 4P */
 int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
-                        const float* b2, int residual, int b, int N, int P, int* queue, hipStream_t stream);
+                        const float* b2, int residual, int b, int N, int P, int* queue, int arith, hipStream_t stream);
 /* fused tail of a folding block, in place on `pair`: output projection of the ENDING triangle attention
  * (og from prd_tri_attn_core; modules.py:341), pair transition (modules.py:342), and optionally the next block's
  * attention bias Linear(LN(pair)) -> bias_out[b,H,N,N] (modules.py:300-304; bias_out NULL = skip). */
 int prd_block_tail(float* pair, const float* og, const float* wo, const float* bo, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* bias_w, const float* bias_b, float* bias_out,
-                   int b, int N, int P, int H, int* queue, hipStream_t stream);
+                   int b, int N, int P, int H, int* queue, int arith, hipStream_t stream);
 /* coordinate head (modules.py:403 + model.py:364-372): symmetrise, LN -> Linear -> ReLU -> Linear(1),
  * eps_raw[b,N,3] = sum_j m_i m_j w_ij (z_i - z_j) rsqrt(|z_i - z_j|^2 + 1e-4)  (mean not yet removed) */
 int prd_coord_head(float* eps_raw, const float* pair, const float* z, const float* mask,

@@ -30,15 +30,14 @@ class PrdGemm(C.Structure):
         ("tile_hint", ci),
         ("a_ln", ci),
         ("ln_out", vp), ("ldlo", ci),
+        ("arith", ci),
     ]
 
 
 # name -> argtypes (every entry point of include/prd_hip.h; tests check the export list against the header)
 SIGNATURES = {
     "prd_version": [],
-    "prd_set_gemm_mode": [ci],
-    "prd_get_gemm_mode": [],
-    "prd_tri_attn_variant": [ci, ci],
+    "prd_tri_attn_variant": [ci, ci, ci],
     "prd_gemm": [C.POINTER(PrdGemm), vp],
     "prd_ln_rows": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "prd_softmax_rows": [vp, ci, ci, ci, vp],
@@ -46,42 +45,84 @@ SIGNATURES = {
     "prd_atom_embed": [vp] * 5 + [ci] * 4 + [vp],
     "prd_single_init": [vp] * 5 + [ci] * 3 + [vp],
     "prd_time_embed": [vp] * 4 + [ci] * 4 + [vp],
-    "prd_pair_init": [vp] * 7 + [ci] * 4 + [vp],
+    "prd_pair_init": [vp] * 7 + [ci] * 5 + [vp],
     "prd_pair_bias": [vp] * 6 + [ci] * 4 + [vp],
     "prd_pair_bias2": [vp] * 6 + [ci] + [vp] * 5 + [ci] * 4 + [vp],
-    "prd_opm_pair": [vp] * 6 + [ci] * 5 + [vp],
-    "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp, vp],
-    "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, vp],
-    "prd_tri_mul_contract": [vp, vp, ci, ci, ci, vp],
-    "prd_tri_mul_chain_supported": [ci, ci],
-    "prd_tri_attn_core_fused_supported": [ci, ci],
+    "prd_opm_pair": [vp] * 6 + [ci] * 6 + [vp],
+    "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp, ci, vp],
+    "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, ci, vp],
+    "prd_tri_mul_contract": [vp, vp, ci, ci, ci, ci, vp],
+    "prd_tri_mul_chain_supported": [ci, ci, ci],
+    "prd_tri_attn_core_fused_supported": [ci, ci, ci],
     "prd_tri_attn_core_fused": [vp] * 12 + [ci] * 6 + [vp],
     "prd_tri_mul_chain": [vp, vp, vp, vp, ci, ci, ci, vp, cz, vp],
     "prd_tri_mul_out_bwd": [vp] * 13 + [ci] * 3 + [vp],
-    "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 4 + [vp],
+    "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 5 + [vp],
     "prd_tri_attn_bwd_core": [vp] * 9 + [ci] * 6 + [vp],
     "prd_ln_rows_bwd": [vp, vp, vp, cll, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
     "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],
     "prd_embed_wgrad_workspace": [cll, ci, ci],
     "prd_embed_wgrad": [vp, vp, vp, cll, ci, ci, ci, vp, cz, vp],
-    "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, vp],
-    "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, vp],
-    "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, vp],
+    "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, ci, vp],
+    "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, ci, vp],
+    "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, ci, vp],
     "prd_single_attn_core": [vp] * 4 + [ci] * 4 + [vp],
     "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
     "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
-    "prd_tri_attn_core": [vp] * 8 + [ci] * 6 + [vp],
+    "prd_tri_attn_core": [vp] * 8 + [ci] * 7 + [vp],
     "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 6 + [vp],
     "prd_tri_attn_v2_supported": [ci, ci],
-    "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, vp],
+    "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, ci, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
 }
 
 GEMM_MODES = {"fp32": 0, "split16": 1, "bf16x3": 1}      # "bf16x3": earlier name of the split-operand mode
-DEFAULT_GEMM_MODE = "split16"       # arithmetic the library is switched to when it is loaded (env PRD_GEMM_MODE overrides)
+DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (env PRD_GEMM_MODE overrides)
+
+# entry points that take the arithmetic as their last argument before the stream ...
+_ARITH_BEFORE_STREAM = ("prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
+                        "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail")
+# ... and the queries that take it as their last argument
+_ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported")
+
+
+class _Library:
+    """The loaded C library plus the ONE piece of state of the host side: the arithmetic (prd_hip.h: PRD_ARITH_*) that the
+    Python operators pass to every call.  The C ABI itself is stateless; ``prd_set_gemm_mode`` / ``prd_get_gemm_mode`` live
+    here, in the host language, with the names round 2 used so that callers and tests read the same."""
+
+    def __init__(self, cdll, mode: int):
+        self._cdll = cdll
+        self._mode = mode
+        self._wrapped = {}
+
+    def prd_set_gemm_mode(self, mode: int) -> int:
+        if mode not in (0, 1):
+            return -1
+        self._mode = int(mode)
+        return 0
+
+    def prd_get_gemm_mode(self) -> int:
+        return self._mode
+
+    def __getattr__(self, name):
+        fn = self._wrapped.get(name)
+        if fn is None:
+            raw = getattr(self._cdll, name)
+            if name in _ARITH_BEFORE_STREAM:
+                def fn(*args, _raw=raw):
+                    return _raw(*args[:-1], self._mode, args[-1])
+            elif name in _ARITH_LAST:
+                def fn(*args, _raw=raw):
+                    return _raw(*args, self._mode)
+            else:
+                fn = raw
+            self._wrapped[name] = fn
+        return fn
+
 
 _lib = None
 
@@ -94,18 +135,23 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m protein_redesign_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path.")
-        _lib = C.CDLL(LIB_PATH)
+        cdll = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
-            fn = getattr(_lib, name)
+            fn = getattr(cdll, name)
             fn.argtypes = argtypes
             fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace") else ci
-        mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)      # prd_hip.h: prd_set_gemm_mode
+        mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)
         if os.environ.get("PRD_BF16X3"):                               # older spelling of PRD_GEMM_MODE=bf16x3
             mode = "bf16x3"
         if mode not in GEMM_MODES:
             raise RuntimeError(f"PRD_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got {mode!r}")
-        _lib.prd_set_gemm_mode(GEMM_MODES[mode])
+        _lib = _Library(cdll, GEMM_MODES[mode])
     return _lib
+
+
+def arith() -> int:
+    """The arithmetic the operators pass to the library (PRD_ARITH_FP32 = 0 / PRD_ARITH_SPLIT16 = 1)."""
+    return lib().prd_get_gemm_mode()
 
 
 def row_gemm_description(b3: bool) -> str:

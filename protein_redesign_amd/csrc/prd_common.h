@@ -609,5 +609,8 @@ struct WaveTasks {
     }
 };
 
+// every entry point whose kernels depend on the arithmetic takes it as an argument (prd_hip.h: PRD_ARITH_*); the library keeps no state
+#define PRD_CHECK_ARITH(a) do { if ((a) != 0 && (a) != 1) return -1; } while (0)
+
 static inline int prd_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int prd_round_up(int a, int b) { return prd_ceil_div(a, b) * b; }

@@ -1337,7 +1337,8 @@ extern "C" int prd_time_embed(float* ebeta, const int64_t* t, const float* freqs
 
 extern "C" int prd_pair_init(float* pair, const float* static_pair, const float* z, const float* mask,
                              const float* centers, const float* w_dist, const float* ebeta,
-                             int b, int N, int P, int dist_dim, hipStream_t stream) {
+                             int b, int N, int P, int dist_dim, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!pair || !static_pair || !z || !mask || !centers || !w_dist || !ebeta || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (dist_dim <= 0 || (dist_dim & 7)) return PRD_ERR_UNSUPPORTED;
@@ -1345,7 +1346,7 @@ extern "C" int prd_pair_init(float* pair, const float* static_pair, const float*
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     const long ntask = ((long)b * N * N + 31) / 32;
     const int grid = grid_for(ntask, 4, 512);
-    if (prd_get_gemm_mode() == 1 && (dist_dim % 128) == 0) {        // fp16 x 2 split operands
+    if (arith == PRD_ARITH_SPLIT16 && (dist_dim % 128) == 0) {        // fp16 x 2 split operands
         const size_t lds2 = (size_t)4 * P * dist_dim + (size_t)dist_dim * 4;
         if (P == 64) {
             PRD_SET_LDS(pair_init_h2_kernel<64>, lds2);
@@ -1394,7 +1395,8 @@ extern "C" int prd_pair_bias2(float* bias_a, const float* pair, const float* gam
 }
 
 extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, const float* mask, const float* w_out,
-                            const float* b_out, int flags, int b, int N, int P, int C, hipStream_t stream) {
+                            const float* b_out, int flags, int b, int N, int P, int C, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!out || !pair || !ab || !mask || !w_out || !b_out || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (C <= 0 || (C & 7)) return PRD_ERR_UNSUPPORTED;
@@ -1402,7 +1404,7 @@ extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, cons
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const int grid = grid_for(ntask, 4, 1024);
-    if (prd_get_gemm_mode() == 1 && (C % 128) == 0) {               // fp16 x 2 split operands
+    if (arith == PRD_ARITH_SPLIT16 && (C % 128) == 0) {               // fp16 x 2 split operands
         const size_t lds2 = (size_t)4 * P * C + (size_t)P * 4;
         if (P == 64) {
             PRD_SET_LDS(opm_pair_h2_kernel<64>, lds2);
@@ -1424,13 +1426,14 @@ extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, cons
 }
 
 extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
-                                const float* bias, int residual, int b, int N, int P, int S, int* queue, hipStream_t stream) {
+                                const float* bias, int residual, int b, int N, int P, int S, int* queue, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!out || !pair || !x || !u || !w || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const size_t lds = ((size_t)P * (S + 4) + P) * sizeof(float);
-    if (prd_get_gemm_mode() == 1 && (S % 128) == 0 && (size_t)4 * P * S + 4 * P <= 160 * 1024) {   // fp16 x 2 split operands
+    if (arith == PRD_ARITH_SPLIT16 && (S % 128) == 0 && (size_t)4 * P * S + 4 * P <= 160 * 1024) {   // fp16 x 2 split operands
         constexpr int NWL = 8;
         const int nvb = prd_ceil_div(N, 32);
         const long nsym = (long)b * (nvb * (nvb + 1) / 2) * 32;
@@ -1484,10 +1487,11 @@ int launch_pair_tail_h2(float* out, const float* pair, const float* og, const fl
 }  // namespace
 
 extern "C" int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
-                                   const float* b2, int residual, int b, int N, int P, int* queue, hipStream_t stream) {
+                                   const float* b2, int residual, int b, int N, int P, int* queue, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!out || !pair || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
-    if (prd_get_gemm_mode() == 1) {             // split 16-bit operands (fp16 x 2), see pair_tail_h2_kernel
+    if (arith == PRD_ARITH_SPLIT16) {             // split 16-bit operands (fp16 x 2), see pair_tail_h2_kernel
         const long rows_ = (long)b * N * N;
         return P == 64 ? launch_pair_tail_h2<64>(out, pair, nullptr, nullptr, nullptr, w1, b1, w2, b2, nullptr, nullptr, nullptr, 0, rows_, (long)N * N, residual, stream)
                        : launch_pair_tail_h2<32>(out, pair, nullptr, nullptr, nullptr, w1, b1, w2, b2, nullptr, nullptr, nullptr, 0, rows_, (long)N * N, residual, stream);
@@ -1508,11 +1512,12 @@ extern "C" int prd_pair_transition(float* out, const float* pair, const float* w
 
 extern "C" int prd_block_tail(float* pair, const float* og, const float* wo, const float* bo, const float* w1, const float* b1,
                               const float* w2, const float* b2, const float* bias_w, const float* bias_b, float* bias_out,
-                              int b, int N, int P, int H, int* queue, hipStream_t stream) {
+                              int b, int N, int P, int H, int* queue, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!pair || !og || !wo || !bo || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (bias_out && (!bias_w || H <= 0 || H > 8)) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
-    if (prd_get_gemm_mode() == 1) {             // split 16-bit operands (fp16 x 2), see pair_tail_h2_kernel
+    if (arith == PRD_ARITH_SPLIT16) {             // split 16-bit operands (fp16 x 2), see pair_tail_h2_kernel
         const long rows_ = (long)b * N * N;
         return P == 64 ? launch_pair_tail_h2<64>(pair, pair, og, wo, bo, w1, b1, w2, b2, bias_w, bias_b, bias_out, H, rows_, (long)N * N, 1, stream)
                        : launch_pair_tail_h2<32>(pair, pair, og, wo, bo, w1, b1, w2, b2, bias_w, bias_b, bias_out, H, rows_, (long)N * N, 1, stream);

@@ -2004,9 +2004,6 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float
     }
 }
 
-// The ONE piece of process-wide state of the library (documented in prd_hip.h): relaxed atomic, read once per call.
-std::atomic<int> g_gemm_mode{1};
-
 int grid_for(long tasks, int per_wg, int cap) {
     long g = (tasks + per_wg - 1) / per_wg;
     if (g > cap) g = cap;
@@ -2027,14 +2024,6 @@ int grid_for(long tasks, int per_wg, int cap) {
         (void)(bytes);                                                                                          \
     } while (0)
 
-extern "C" int prd_set_gemm_mode(int mode) {
-    if (mode != 0 && mode != 1) return PRD_ERR_ARG;
-    g_gemm_mode.store(mode, std::memory_order_relaxed);
-    return 0;
-}
-
-extern "C" int prd_get_gemm_mode(void) { return g_gemm_mode.load(std::memory_order_relaxed); }
-
 namespace {
 // LDS bytes of the triangle-attention core for rows of N positions; long_row: the re-projecting variant is needed
 size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
@@ -2054,11 +2043,12 @@ size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
 }
 }  // namespace
 
-extern "C" int prd_tri_attn_variant(int N, int P) {
+extern "C" int prd_tri_attn_variant(int N, int P, int arith) {
+    PRD_CHECK_ARITH(arith);
     if (N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     bool long_row;
-    const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;
+    const bool b3 = arith == PRD_ARITH_SPLIT16;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
     if (!long_row) return 0;
@@ -2078,7 +2068,8 @@ extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P
 extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w_proj, const float* b_proj,
                            const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
                            const float* w_ogate, const float* b_ogate, int incoming, int residual,
-                           int b, int N, int P, float* ws, size_t ws_bytes, int* queue, hipStream_t stream) {
+                           int b, int N, int P, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!out || !pair || !mask || !w_proj || !b_proj || !w_gate || !b_gate || !w_out || !b_out || !w_ogate || !b_ogate || !ws ||
         b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
@@ -2086,7 +2077,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     const int ldn = prd_round_up(N, 32);
     float* AB = ws;                                   // [b][2P][N][ldn]
     float* O = ws + (size_t)2 * b * P * N * ldn;      // [b][P][N][ldn]
-    const bool b3m = g_gemm_mode.load(std::memory_order_relaxed) == 1;
+    const bool b3m = arith == PRD_ARITH_SPLIT16;
     {
         constexpr int NWP = 16;                      // one persistent 16-wave workgroup per CU (4 waves / SIMD)
         const bool b3 = b3m;                        // bf16 x 3 row GEMM (prd_set_gemm_mode)
@@ -2137,11 +2128,12 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
     return (int)hipGetLastError();
 }
 
-extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, hipStream_t stream) {
+extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!O || !AB || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     const int ldn = prd_round_up(N, 32);
-    if (g_gemm_mode.load(std::memory_order_relaxed) == 1) {
+    if (arith == PRD_ARITH_SPLIT16) {
         const int tl = prd_ceil_div(N, TMS_T);
         const int vb3 = b * P * tl * tl;
         const size_t lds3 = (size_t)4 * TMS_OPER;
@@ -2155,8 +2147,8 @@ extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int
     return (int)hipGetLastError();
 }
 
-extern "C" int prd_tri_mul_chain_supported(int N, int P) {
-    return (N > 0 && (P == 32 || P == 64) && g_gemm_mode.load(std::memory_order_relaxed) == 1) ? 1 : 0;
+extern "C" int prd_tri_mul_chain_supported(int N, int P, int arith) {
+    return (N > 0 && (P == 32 || P == 64) && arith == PRD_ARITH_SPLIT16) ? 1 : 0;
 }
 
 extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outgoing, const float* const* w_incoming,
@@ -2164,7 +2156,7 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     if (!pair || !mask || !w_outgoing || !w_incoming || !ws || b <= 0 || N <= 0) return PRD_ERR_ARG;
     for (int k = 0; k < 8; ++k)
         if (!w_outgoing[k] || !w_incoming[k]) return PRD_ERR_ARG;
-    if (!prd_tri_mul_chain_supported(N, P)) return PRD_ERR_UNSUPPORTED;
+    if (!prd_tri_mul_chain_supported(N, P, PRD_ARITH_SPLIT16)) return PRD_ERR_UNSUPPORTED;
     if (ws_bytes < prd_workspace_bytes("tri_mul", b, N, 0, P)) return PRD_ERR_WORKSPACE;
     const int ldn = prd_round_up(N, 32);
     float* AB = ws;                                   // [b][2P][N][ldn]
@@ -2220,12 +2212,13 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
 
 extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                                  const float* wv, const float* wg, const float* bg, int ending,
-                                 int b, int N, int P, int H, int c, hipStream_t stream) {
+                                 int b, int N, int P, int H, int c, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
-    const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;   // bf16 x 3 projections (short-row kernel only)
+    const bool b3 = arith == PRD_ARITH_SPLIT16;   // split 16-bit operands
     bool long_row;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
@@ -2285,8 +2278,8 @@ static size_t tri_attn_fused_lds(int N, int P) {
     return lds + (size_t)P * 4 + (size_t)P * 256;
 }
 
-extern "C" int prd_tri_attn_core_fused_supported(int N, int P) {
-    return (N > 0 && (P == 32 || P == 64) && g_gemm_mode.load(std::memory_order_relaxed) == 1 &&
+extern "C" int prd_tri_attn_core_fused_supported(int N, int P, int arith) {
+    return (N > 0 && (P == 32 || P == 64) && arith == PRD_ARITH_SPLIT16 &&
             tri_attn_fused_lds(N, P) <= 160 * 1024) ? 1 : 0;
 }
 
@@ -2297,7 +2290,7 @@ extern "C" int prd_tri_attn_core_fused(float* og, float* pair_out, const float* 
     if (!og || !pair_out || !pair || !og_in || !wo_in || !bo_in || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0 ||
         pair_out == pair) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
-    if (!prd_tri_attn_core_fused_supported(N, P)) return PRD_ERR_UNSUPPORTED;
+    if (!prd_tri_attn_core_fused_supported(N, P, PRD_ARITH_SPLIT16)) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const size_t lds = tri_attn_fused_lds(N, P);
     const long rows_total = (long)b * N;
@@ -2320,13 +2313,14 @@ extern "C" int prd_tri_attn_core_fused(float* og, float* pair_out, const float* 
 }
 
 extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
-                                int residual, int b, int N, int P, int* queue, hipStream_t stream) {
+                                int residual, int b, int N, int P, int* queue, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!out || !pair || !og || !wo || !bo || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     constexpr int NWA = 12;
     const long rows = (long)b * N * N;
     const int grid2 = grid_for((rows + 31) / 32, 4, 256);
-    const bool b3 = g_gemm_mode.load(std::memory_order_relaxed) == 1;
+    const bool b3 = arith == PRD_ARITH_SPLIT16;
 #define PRD_TAO(PP, BB) hipLaunchKernelGGL((tri_attn_out_kernel<PP, NWA, BB>), dim3(grid2), dim3(NWA * 64), 0, stream, queue, out, pair, og, wo, bo, rows, residual)
     if (P == 64) { if (b3) PRD_TAO(64, true); else PRD_TAO(64, false); }
     else { if (b3) PRD_TAO(32, true); else PRD_TAO(32, false); }
@@ -2336,10 +2330,11 @@ extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, 
 
 extern "C" int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
                             const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
-                            int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, hipStream_t stream) {
+                            int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream) {
+    PRD_CHECK_ARITH(arith);
     if (!ws) return PRD_ERR_ARG;
     if (ws_bytes < prd_workspace_bytes("tri_attn", b, N, 0, P)) return PRD_ERR_WORKSPACE;
-    int e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
+    int e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, arith, stream);
     if (e) return e;
-    return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, queue, stream);
+    return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, queue, arith, stream);
 }

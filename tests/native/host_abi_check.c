@@ -20,14 +20,13 @@ int main(void) {
     float* p = buf;
     hipStream_t s = 0;
     EXPECT(prd_version(), PRD_VERSION);
-    EXPECT(prd_set_gemm_mode(7), PRD_ERR_ARG);
-    EXPECT(prd_set_gemm_mode(0), 0);
-    EXPECT(prd_get_gemm_mode(), 0);
-    EXPECT(prd_set_gemm_mode(1), 0);
+    const int A1 = PRD_ARITH_SPLIT16, A0 = PRD_ARITH_FP32;     /* the arithmetic is an argument of every call: no library state */
     PrdGemm g;
     memset(&g, 0, sizeof g);
     EXPECT(prd_gemm(&g, s), PRD_ERR_ARG);                              /* null operands */
-    g.A = g.B = p; g.C = p; g.M = g.N = g.K = 8; g.G1 = g.G2 = 1; g.lda = 6; g.ldb = 8; g.ldc = 8;
+    g.A = g.B = p; g.C = p; g.M = g.N = g.K = 8; g.G1 = g.G2 = 1; g.lda = 6; g.ldb = 8; g.ldc = 8; g.arith = 7;
+    EXPECT(prd_gemm(&g, s), PRD_ERR_ARG);                              /* unknown arithmetic */
+    g.arith = A1;
     EXPECT(prd_gemm(&g, s), PRD_ERR_ALIGN);                            /* lda not a multiple of 4 */
     g.lda = 8; g.a_ln = 1; g.K = 4096; g.lda = g.ldb = 4096;
     EXPECT(prd_gemm(&g, s), PRD_ERR_UNSUPPORTED);                      /* fused LayerNorm beyond the row the kernels keep in registers */
@@ -37,27 +36,30 @@ int main(void) {
     EXPECT(prd_ln_rows(0, p, 0, 0, 4, 4, 4, 4, s), PRD_ERR_ARG);
     EXPECT(prd_ln_rows(p, p, p, 0, 4, 4, 4, 4, s), PRD_ERR_ARG);       /* gamma without beta */
     EXPECT(prd_softmax_rows(p, 4, 8, 4, s), PRD_ERR_ARG);             /* ld < n */
-    EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 48, 256, s), PRD_ERR_UNSUPPORTED);        /* pair_dim 48 */
-    EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 64, 100, s), PRD_ERR_UNSUPPORTED);       /* dist_dim % 8 */
+    EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 48, 256, A1, s), PRD_ERR_UNSUPPORTED);        /* pair_dim 48 */
+    EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 64, 100, A1, s), PRD_ERR_UNSUPPORTED);       /* dist_dim % 8 */
+    EXPECT(prd_pair_init(p, p, p, p, p, p, p, 1, 8, 64, 256, 5, s), PRD_ERR_ARG);               /* unknown arithmetic */
     EXPECT(prd_pair_bias(p, p, p, 0, p, p, 1, 8, 64, 4, s), PRD_ERR_ARG);                    /* gamma without beta */
     EXPECT(prd_pair_bias(p, p, 0, 0, p, p, 1, 8, 64, 9, s), PRD_ERR_ARG);                    /* more than 8 heads */
     EXPECT(prd_pair_bias2(p, p, 0, 0, p, p, 4, 0, 0, 0, p, p, 4, 1, 8, 64, s), PRD_ERR_ARG);     /* second output missing */
     EXPECT(prd_pair_bias2(p, p, p, 0, p, p, 4, p, 0, 0, p, p, 4, 1, 8, 64, s), PRD_ERR_ARG);     /* gamma without beta */
-    EXPECT(prd_opm_pair(p, p, p, p, p, p, 3, 1, 8, 64, 12, s), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_outer_linear(p, p, p, p, p, p, 1, 1, 8, 64, 36, 0, s), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, p, 16, 0, s), PRD_ERR_WORKSPACE);
-    EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 40, p, 1 << 20, 0, s), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_tri_attn(p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, 4, 16, 0, 0, 0, s), PRD_ERR_ARG);   /* no workspace */
-    EXPECT(prd_tri_attn(p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, 4, 16, p, 16, 0, s), PRD_ERR_WORKSPACE);
-    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 8, 64, 2, 32, s), PRD_ERR_UNSUPPORTED);        /* head_dim 32 */
-    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row too long for LDS */
-    EXPECT(prd_tri_attn_variant(320, 64), 0);
-    EXPECT(prd_tri_attn_variant(769, 64), 2);       /* gemm mode 1: the split-operand long-row kernel */
-    EXPECT(prd_tri_attn_variant(900, 64), 1);
-    EXPECT(prd_tri_attn_variant(100000, 64), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_tri_attn_variant(320, 48), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_opm_pair(p, p, p, p, p, p, 3, 1, 8, 64, 12, A1, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_outer_linear(p, p, p, p, p, p, 1, 1, 8, 64, 36, 0, A1, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, p, 16, 0, A1, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 40, p, 1 << 20, 0, A0, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn(p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, 4, 16, 0, 0, 0, A1, s), PRD_ERR_ARG);   /* no workspace */
+    EXPECT(prd_tri_attn(p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, 4, 16, p, 16, 0, A1, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 8, 64, 2, 32, A1, s), PRD_ERR_UNSUPPORTED);        /* head_dim 32 */
+    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, A1, s), PRD_ERR_UNSUPPORTED);   /* row too long for LDS */
+    EXPECT(prd_tri_attn_variant(320, 64, A1), 0);
+    EXPECT(prd_tri_attn_variant(769, 64, A1), 2);       /* split-16: the split-operand long-row kernel */
+    EXPECT(prd_tri_attn_variant(769, 64, A0), 1);
+    EXPECT(prd_tri_attn_variant(900, 64, A1), 1);
+    EXPECT(prd_tri_attn_variant(100000, 64, A1), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn_variant(320, 48, A1), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn_variant(320, 64, 2), PRD_ERR_ARG);
     EXPECT(prd_single_attn_core(p, p, p, p, 1, 8, 2, 32, s), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_block_tail(p, p, p, p, p, p, p, p, 0, 0, p, 1, 8, 64, 4, 0, s), PRD_ERR_ARG);   /* bias_out without bias weights */
+    EXPECT(prd_block_tail(p, p, p, p, p, p, p, p, 0, 0, p, 1, 8, 64, 4, 0, A1, s), PRD_ERR_ARG);   /* bias_out without bias weights */
     EXPECT(prd_coord_head(p, p, p, p, p, p, 0, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_remove_mean(p, p, p, 1, 8, 65, s), PRD_ERR_ARG);
     EXPECT(prd_reverse_update(p, p, ibuf, p, p, p, p, 0, 1, 8, 21, 10, s), PRD_ERR_ARG);
@@ -67,28 +69,30 @@ int main(void) {
     EXPECT(prd_atom_embed(0, ibuf, p, p, (const int*)ibuf, 9, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_single_init(0, p, p, p, p, 8, 64, 21, s), PRD_ERR_ARG);
     EXPECT(prd_step_boundary(0, p, ibuf, p, p, p, p, p, p, p, p, p, p, p, p, (int*)ibuf, 1, 8, 21, 10, 64, 64, 256, s), PRD_ERR_ARG);
-    EXPECT(prd_pair_transition(0, p, p, p, p, p, 1, 1, 8, 64, 0, s), PRD_ERR_ARG);
-    EXPECT(prd_pair_transition(p, p, p, p, p, p, 1, 1, 8, 48, 0, s), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_tri_attn_out(0, p, p, p, p, 1, 1, 8, 64, 0, s), PRD_ERR_ARG);
-    EXPECT(prd_tri_mul_contract(0, p, 1, 8, 64, s), PRD_ERR_ARG);
-    EXPECT(prd_tri_mul_contract(p, p, 1, 8, 48, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_pair_transition(0, p, p, p, p, p, 1, 1, 8, 64, 0, A1, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_transition(p, p, p, p, p, p, 1, 1, 8, 48, 0, A0, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn_out(0, p, p, p, p, 1, 1, 8, 64, 0, A1, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_contract(0, p, 1, 8, 64, A1, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_contract(p, p, 1, 8, 48, A0, s), PRD_ERR_UNSUPPORTED);
     {
         const float* w8[8] = {p, p, p, p, p, p, p, p};
         const float* w7[8] = {p, p, p, 0, p, p, p, p};
-        EXPECT(prd_tri_mul_chain_supported(320, 64), 1);
-        EXPECT(prd_tri_mul_chain_supported(320, 48), 0);
+        EXPECT(prd_tri_mul_chain_supported(320, 64, A1), 1);
+        EXPECT(prd_tri_mul_chain_supported(320, 48, A1), 0);
+        EXPECT(prd_tri_mul_chain_supported(320, 64, A0), 0);        /* fp32 arithmetic has no fused chain */
         EXPECT(prd_tri_mul_chain(0, p, w8, w8, 1, 8, 64, p, 1 << 20, s), PRD_ERR_ARG);
         EXPECT(prd_tri_mul_chain(p, p, w8, w7, 1, 8, 64, p, 1 << 20, s), PRD_ERR_ARG);          /* a missing weight pointer */
         EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 16, s), PRD_ERR_WORKSPACE);
-        EXPECT(prd_set_gemm_mode(0), 0);
-        EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);  /* fp32 mode has no fused chain */
-        EXPECT(prd_set_gemm_mode(1), 0);
     }
-    EXPECT(prd_tri_attn_core_fused_supported(320, 64), 1);
-    EXPECT(prd_tri_attn_core_fused_supported(769, 64), 0);      /* long rows: no fused form */
+    EXPECT(prd_tri_attn_core_fused_supported(320, 64, A1), 1);
+    EXPECT(prd_tri_attn_core_fused_supported(769, 64, A1), 0);      /* long rows: no fused form */
+    EXPECT(prd_tri_attn_v2_supported(320, 64), 1);
+    EXPECT(prd_tri_attn_v2_supported(400, 64), 0);                  /* more than 12 query blocks */
+    EXPECT(prd_tri_attn_core_v2(0, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_attn_core_v2(p, p, p, p, p, p, p, p, 0, 1, 400, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_core_fused(p, p, p, p, p, p, p, p, p, p, p, p, 1, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);   /* pair_out aliases pair */
     EXPECT(prd_tri_mul_out_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 1, 8, 64, s), PRD_ERR_ARG);
-    EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, A1, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(0, p, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(p, p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row beyond the LDS */
     EXPECT(prd_ln_rows_bwd(0, p, p, 8, 64, s), PRD_ERR_ARG);
