@@ -108,6 +108,115 @@ class PDBDataset(torch.utils.data.Dataset):
         return {"pdb_id": pdb_id, **ligand, **protein}
 
 
+class BucketBatchSampler(torch.utils.data.Sampler):
+    """Batches of complexes of SIMILAR size for data-parallel training.
+
+    The reference shuffles complexes freely (data.py:238-246: ``DataLoader(shuffle=True)``), so a batch is padded to its
+    longest complex and, under DDP, every optimisation step lasts as long as the rank that drew the largest one (N ranges over
+    100 .. 384 in PDBbind: the pair track costs O(N^3)).  This sampler keeps the reference's statistics -- every complex once per
+    epoch, order reshuffled every epoch -- but draws each batch from one size bucket and hands the ranks of a step batches of
+    the SAME bucket:
+
+    * ``sizes[i]`` = num_atoms + num_residues of complex i; complexes are sorted into buckets ``bucket_width`` nodes wide;
+    * per epoch (``set_epoch``) the members of every bucket are shuffled, cut into batches of ``batch_size``, the batches of a
+      bucket grouped into steps of ``world_size`` batches (an incomplete last group is completed by wrapping around inside the
+      bucket, as DistributedSampler pads), and the steps shuffled; rank r takes batch r of every step;
+    * deterministic in ``(seed, epoch)``, identical on every rank, no communication.
+
+    Use as ``DataLoader(dataset, batch_sampler=BucketBatchSampler(...), collate_fn=collate_fn)``."""
+
+    def __init__(self, sizes: Sequence[int], batch_size: int, world_size: int = 1, rank: int = 0, bucket_width: int = 32,
+                 seed: int = 0, shuffle: bool = True):
+        if not 0 <= rank < world_size:
+            raise ValueError(f"rank {rank} outside world of {world_size}")
+        if batch_size < 1 or bucket_width < 1:
+            raise ValueError("batch_size and bucket_width must be positive")
+        self.sizes = [int(v) for v in sizes]
+        self.batch_size, self.world_size, self.rank = batch_size, world_size, rank
+        self.bucket_width, self.seed, self.shuffle, self.epoch = bucket_width, seed, shuffle, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def _steps(self) -> List[List[List[int]]]:
+        g = torch.Generator().manual_seed((self.seed * 1_000_003 + self.epoch) & 0x7FFFFFFF)
+        buckets: Dict[int, List[int]] = {}
+        for i, n in enumerate(self.sizes):
+            buckets.setdefault(n // self.bucket_width, []).append(i)
+        steps: List[List[List[int]]] = []
+        for key in sorted(buckets):
+            members = buckets[key]
+            if self.shuffle:
+                members = [members[j] for j in torch.randperm(len(members), generator=g).tolist()]
+            batches = [members[k:k + self.batch_size] for k in range(0, len(members), self.batch_size)]
+            while len(batches) % self.world_size:                 # complete the last step with batches of the same bucket
+                batches.append(batches[len(batches) % max(1, len(batches) - 1)] if len(batches) > 1 else batches[0])
+            steps.extend(batches[k:k + self.world_size] for k in range(0, len(batches), self.world_size))
+        if self.shuffle:
+            steps = [steps[j] for j in torch.randperm(len(steps), generator=g).tolist()]
+        return steps
+
+    def __iter__(self):
+        for step in self._steps():
+            yield step[self.rank]
+
+    def __len__(self) -> int:
+        return len(self._steps())
+
+    def padding_waste(self) -> Tuple[float, float]:
+        """(this sampler, free shuffling with the same seed): fraction of the O(N^2) pair positions of an epoch that are
+        padding or idle time of a rank waiting for the largest batch of its step."""
+        def waste(steps):
+            used = total = 0
+            for step in steps:
+                nmax = max(self.sizes[i] for bt in step for i in bt)
+                for bt in step:
+                    total += len(bt) * nmax * nmax
+                    used += sum(self.sizes[i] ** 2 for i in bt)
+            return 1.0 - used / max(total, 1)
+        g = torch.Generator().manual_seed((self.seed * 1_000_003 + self.epoch) & 0x7FFFFFFF)
+        order = torch.randperm(len(self.sizes), generator=g).tolist()
+        free = [order[k:k + self.batch_size] for k in range(0, len(order), self.batch_size)]
+        free_steps = [free[k:k + self.world_size] for k in range(0, len(free), self.world_size)]
+        return waste(self._steps()), waste(free_steps)
+
+
+class PDBDataModule:
+    """data.py:206-259 without Lightning: the three id lists under ``data_dir`` and loaders over the preprocessed cache.
+    ``bucket_width`` > 0 makes the TRAINING loader draw size-bucketed batches (BucketBatchSampler; sizes are read once from
+    the cache); 0 reproduces the reference's free shuffling."""
+
+    def __init__(self, data_dir: Union[str, Path] = "data", batch_size: int = 1, num_workers: int = 1, bucket_width: int = 32,
+                 world_size: int = 1, rank: int = 0, seed: int = 0):
+        self.data_dir = Path(data_dir)
+        self.cache_dir = self.data_dir / "PDB_processed_cache"
+        self.batch_size, self.num_workers, self.bucket_width = batch_size, num_workers, bucket_width
+        self.world_size, self.rank, self.seed = world_size, rank, seed
+        self.train_sampler: Optional[BucketBatchSampler] = None
+
+    def setup(self, stage: Optional[str] = None) -> None:
+        def ids(name):
+            with open(self.data_dir / name, "r") as f:
+                return [line.strip() for line in f if line.strip()]
+        self.train_pdb_ids, self.val_pdb_ids, self.test_pdb_ids = ids("PRD_train_pdb_ids"), ids("PRD_val_pdb_ids"), ids("PRD_test_pdb_ids")
+
+    def train_dataloader(self):
+        ds = PDBDataset(self.cache_dir, self.train_pdb_ids)
+        if self.bucket_width <= 0:
+            return torch.utils.data.DataLoader(ds, batch_size=self.batch_size, shuffle=True, num_workers=self.num_workers, collate_fn=collate_fn)
+        sizes = [int(d["num_atoms"]) + int(d["num_residues"]) for d in (ds[i] for i in range(len(ds)))]
+        self.train_sampler = BucketBatchSampler(sizes, self.batch_size, self.world_size, self.rank, self.bucket_width, self.seed)
+        return torch.utils.data.DataLoader(ds, batch_sampler=self.train_sampler, num_workers=self.num_workers, collate_fn=collate_fn)
+
+    def val_dataloader(self):
+        return torch.utils.data.DataLoader(PDBDataset(self.cache_dir, self.val_pdb_ids), batch_size=self.batch_size,
+                                           num_workers=self.num_workers, collate_fn=collate_fn)
+
+    def test_dataloader(self):
+        return torch.utils.data.DataLoader(PDBDataset(self.cache_dir, self.test_pdb_ids), batch_size=self.batch_size,
+                                           num_workers=self.num_workers, collate_fn=collate_fn)
+
+
 # ---------------------------------------------------------------------------------------------------
 # proteins and output handling (protein.py:50-202, generate.py:65-91)
 # ---------------------------------------------------------------------------------------------------
