@@ -128,20 +128,20 @@ def dominant_kernel(model, mask, bpg, N, dev, reps):
 
 
 def measure_traffic(a):
-    """HBM-side bytes per launch of the dominant kernel, measured NOW: two child ``rocprofv3 --kernel-trace --pmc`` passes
-    (FETCH_SIZE and WRITE_SIZE need separate passes: 3 + 2 of the 4 TCC slots) of ``python3 bench.py --kernel-only``.
-    Units / corrections per MI355X_MICROARCH.md §HBM: both counters are KiB; on gfx950 FETCH_SIZE reports half the bytes
-    of wide (16 B / lane) coalesced reads -> x2; WRITE_SIZE matched the byte count of this kernel's output exactly
-    (profiles/README.md) and is used as is.  Returns (bytes or None, note)."""
+    """Counters of the dominant kernel, measured NOW: three child ``rocprofv3 --kernel-trace --pmc`` passes of
+    ``python3 bench.py --kernel-only`` (FETCH_SIZE and WRITE_SIZE need separate passes: 3 + 2 of the 4 TCC slots; the SQ / GRBM
+    counters ride in a third).  Units / corrections per MI355X_MICROARCH.md §HBM: both TCC counters are KiB; on gfx950 FETCH_SIZE
+    reports half the bytes of wide (16 B / lane) coalesced reads -> x2; WRITE_SIZE matched the byte count of this kernel's
+    output exactly (profiles/README.md) and is used as is.  Returns (bytes or None, note, {counter fractions})."""
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", {}
     vals = {}
     tmp = tempfile.mkdtemp(prefix="prd_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "t", "--",
+        for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]):
+            out = os.path.join(tmp, counters[0])
+            cmd = [prof, "--kernel-trace", "--pmc"] + counters + ["-d", out, "-o", "t", "--",
                    "python3", os.path.abspath(__file__), "--kernel-only", "--residues", str(a.residues), "--atoms", str(a.atoms),
                    "--samples-per-gpu", str(a.samples_per_gpu)]
             env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
@@ -149,20 +149,25 @@ def measure_traffic(a):
             r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not dbs:
-                return None, f"{counter} pass failed (exit {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
+                return None, f"{counters[0]} pass failed (exit {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}", {}
             db = sqlite3.connect(dbs[0])
-            rows = list(db.execute("select dispatch_id, sum(value) from counters_collection where counter_name = ? "
-                                   "and kernel_name like '%tri_attn_core%' group by dispatch_id", (counter,)))
-            if not rows:
-                return None, f"{counter}: no tri_attn_core dispatch in the counter database"
-            vals[counter] = sum(v for _, v in rows) / len(rows)
+            for counter in counters:
+                rows = list(db.execute("select dispatch_id, sum(value) from counters_collection where counter_name = ? "
+                                       "and kernel_name like '%tri_attn_core%' group by dispatch_id", (counter,)))
+                if not rows:
+                    return None, f"{counter}: no tri_attn_core dispatch in the counter database", {}
+                vals[counter] = sum(v for _, v in rows) / len(rows)
     except Exception as e:      # profiling is evidence, never a reason to lose the bench line
-        return None, f"PMC pass error: {e!r}"
+        return None, f"PMC pass error: {e!r}", {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     traffic = int(2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
+    cyc = vals["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
+    pipes = {"mfma_busy_frac": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),       # 1024 SIMDs
+             "valu_active_frac": round(4 * vals["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 4),      # the counter ticks in quad-cycles
+             "kernel_cycles_profiled": int(cyc)}
     return traffic, (f"measured in this run: child rocprofv3 --pmc passes, FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB x2 (gfx950 wide-read "
-                     f"correction) + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB per launch")
+                     f"correction) + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB per launch"), pipes
 
 
 def cpu_baseline(a, N, margs, params):
@@ -304,25 +309,64 @@ def main():
         kus = dominant_kernel(model, loop.mask, bpg, N, dev, reps=20)
         kfl = tri_attn_core_flops(bpg, N, P)
         ach = kfl / (kus * 1e-6) / 1e12
-        traffic, note = (None, "not measured (--no-traffic or N > 1)")
+        split_mode_now = _lib.lib().prd_get_gemm_mode() == 1
+        traffic, note, pipes = (None, "not measured (--no-traffic or N > 1)", {})
         if world == 1 and not a.no_traffic:
-            traffic, note = measure_traffic(a)
+            traffic, note, pipes = measure_traffic(a)
+        split_mode = _lib.lib().prd_get_gemm_mode() == 1
         variant = ops.tri_attn_variant(N, P)
-        split = _lib.lib().prd_get_gemm_mode() == 1 and variant in (0, 2)
-        kname = {0: "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel", 1: "tri_attn_core_long_kernel",
-                 2: "tri_attn_core_split_long_kernel"}[variant]
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
+        v2 = split_mode and variant == 0 and ops.tri_attn_v2_supported(N, P) and not os.environ.get("PRD_TA_VARIANT", "0").strip("0")
+        split = split_mode and variant in (0, 2)
+        kname = "tri_attn_core_v2_kernel" if v2 else {0: "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel",
+                                                        1: "tri_attn_core_long_kernel", 2: "tri_attn_core_split_long_kernel"}[variant]
+        # peak: the kernel issues on the 16-bit matrix pipe, where an fp32-accurate MAC costs three split products (hi*hi + hi*lo +
+        # lo*hi): 2.5 PF/s / 3.  In fp32 mode (fp32 MFMA kernels) the peak is the fp32 MFMA rate.
+        peak = PEAK_16BIT_TFLOPS / 3.0 if split_mode_now else FP32_PEAK_TFLOPS
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "frac_of_fp32_mfma_peak": round(ach / FP32_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "traffic_note": note,
                     "algorithmic_bytes_per_launch": tri_attn_core_bytes(bpg, N, P),
                     "kernel": kname, "launches_per_step": 2 * NB,
                     "flops_per_launch": kfl, "avg_launch_us": round(kus, 2),
-                    "peak_note": "achieved = ALGORITHMIC fp32 flops of the launch / its duration; peak = the dense fp32 MFMA rate the "
-                                 "reference arithmetic (fp32) is priced against"}
-        if split:      # what the split-operand kernel actually issues: 3 fp16 products per projection / P*V MAC, 6 bf16 products per Q*K^T MAC
-            ex = bpg * (3 * 8 * N * N * P * 64 + ((6 if variant == 0 else 4) + 3) * 2 * 64 * N ** 3)   # long rows: fp16 x 2 QK^T in 2 MFMAs
+                    "peak_note": "achieved = ALGORITHMIC fp32 flops of the launch / its duration; peak = the rate at which the pipe the kernel "
+                                 "issues on delivers fp32-accurate MACs: 2.5 PF/s dense fp16 MFMA / 3 split products per MAC (fp32 mode: "
+                                 "157.3 TF/s fp32 MFMA).  frac_of_fp32_mfma_peak is round 1-2's pricing (SURVEY 8d), kept for continuity: "
+                                 "above 1 it only says the 16-bit pipe is in use.  frac_of_16bit_peak prices what the kernel EXECUTES "
+                                 "(MFMA instructions x 32768 flops) against 2.5 PF/s; mfma_busy_frac / valu_active_frac are the measured "
+                                 "pipe occupancies (eager launches under the profiler).  The kernel is VALU-bound, not MFMA-bound: one "
+                                 "v_exp_f32 and one fp16 hi|lo split per logit (DESIGN.md 4.3; profiles/r03_roofline.txt covers every "
+                                 "kernel of the step)"}
+        if v2:         # every MFMA is a 32x32x16 (32768 flops): 36 per 32-position block of a row (3 row GEMMs x 4 k-steps x 3
+            nqb = (N + 31) // 32                                     # products), 7 per 32 x 32 logit tile (3 QK^T + 4 PV)
+            ex = bpg * N * 4 * (36 * nqb + 7 * nqb * nqb) * 32768
+        elif split:    # first generation: 3 fp16 products per projection / P*V MAC, 6 bf16 products per Q*K^T MAC (long rows: 4)
+            ex = bpg * (3 * 8 * N * N * P * 64 + ((6 if variant == 0 else 4) + 3) * 2 * 64 * N ** 3)
+        else:
+            ex = None
+        if ex:
             roofline.update({"executed_16bit_mfma_flops_per_launch": ex,
                              "executed_16bit_tflops": round(ex / (kus * 1e-6) / 1e12, 1), "peak_16bit_tflops": PEAK_16BIT_TFLOPS,
                              "frac_of_16bit_peak": round(ex / (kus * 1e-6) / 1e12 / PEAK_16BIT_TFLOPS, 4)})
+        roofline.update(pipes)
+
+    # ---- the same loop in the other arithmetic (rank 0, single process): one line shows both ----
+    other_ms = None
+    if rank == 0 and world == 1 and not a.no_traffic:
+        cur = _lib.lib().prd_get_gemm_mode()
+        _lib.lib().prd_set_gemm_mode(1 - cur)
+        try:
+            model2, _, _ = build_model(dev, graph=not a.no_graph)
+            loop2 = ReverseDiffusion(model2, batch_to(batch, dev), [NoiseSource(0, k) for k in range(bpg)])
+            for _ in range(2 + a.warmup):
+                loop2.step()
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            for _ in range(min(a.steps, 100)):
+                loop2.step()
+            torch.cuda.synchronize()
+            other_ms = round((time.perf_counter() - c0) / min(a.steps, 100) * 1e3, 4)
+        finally:
+            _lib.lib().prd_set_gemm_mode(cur)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -344,6 +388,7 @@ def main():
                                    f"of the samples at the end of the timed region)",
                        "samples_per_gpu": bpg, "hip_graph": not a.no_graph, "outputs_finite": finite,
                        "row_gemm": _lib.row_gemm_description(b3),
+                       ("fp32_mode_ms_per_step" if b3 else "split16_mode_ms_per_step"): other_ms,
                        "backend": "nccl (RCCL)" if dist is not None else "single process", "sharded_sample_check": shard_check},
             "step_gflop": round(flops / 1e9, 1),
             "step_tflops": round(flops * bpg / (dt / a.steps) / 1e12, 2),

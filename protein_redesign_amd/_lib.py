@@ -157,9 +157,9 @@ def arith() -> int:
 def row_gemm_description(b3: bool) -> str:
     """What the GEMMs of the pair kernels compute in, for bench.py's JSON line (stated truthfully, not as a precision claim)."""
     if b3:
-        return ("split16: fp32 operands split into 16-bit parts -- fp16 hi+lo (22 bits, 3 products) in the row GEMMs of the pair "
-                "track, the node-row linears of the single track, the triangle-multiplication contraction and P*V; bf16 x3 "
-                "(24 bits, 6 products) in Q*K^T of short rows -- multiplied on the fp16/bf16 MFMA pipes with fp32 accumulation; "
+        return ("split16: fp32 operands split into fp16 hi + lo (both rounded to nearest: 24 bits; 3 products hi*hi + hi*lo + lo*hi) "
+                "and multiplied on the fp16 MFMA pipe with fp32 accumulation -- the row GEMMs of the pair track, the node-row "
+                "linears of the single track, the triangle-multiplication contraction, Q*K^T and P*V of the triangle attention; "
                 "the single-track attention core, SPAttention's batched GEMMs, pair_bias and the coordinate head run fp32 MFMA.  "
                 "Parity tolerances are the same as in fp32 mode (PRD_GEMM_MODE=fp32)")
     return "fp32-mfma"

@@ -343,8 +343,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
         // ================= phase 1 =================
         if (p1_blk >= 0) {
             const int blk = p1_blk;
+            // lane coordinates made opaque per row: otherwise hipcc hoists the ~30 lane-invariant LDS addresses of this phase (weight
+            // operands of 12 k-steps, K / Q / V / gate stores) out of the row loop, where they sit in registers through the key
+            // loops and spill (measured: 9.4 MB of scratch writes per launch)
+            int r1 = r, hi1 = hi;
+            asm volatile("" : "+v"(r1), "+v"(hi1));
             auto wop = [&](int wrow, int s_, u32x4& wh, u32x4& wl) {
-                const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi);
+                const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi1);
                 wh = Wb[(size_t)wrow * (P / 8) + slot_];
                 wl = Wb[(size_t)(64 + wrow) * (P / 8) + slot_];
             };
@@ -354,21 +359,21 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
             PRD2_STAMP(6);
             if (p1_kinds & 1) {
                 {   // logit override of masked / padded keys + tile flag
-                    const int v = blk * 32 + r;
+                    const int v = blk * 32 + r1;
                     const bool valid = v < N;
                     const bool keep = valid && (mu * mknext >= 0.5f);
-                    if (hi == 0) kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
+                    if (hi1 == 0) kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
                     const bool any_override = __any(!keep);
                     if (lane == 0) tflag[blk] = any_override ? 1 : 0;
                 }
-                // [K|Q]: lane (pos, hi) registers 0-7 = K, 8-15 = Q channels {4hi+e, 8+4hi+e}
+                // [K|Q]: lane (pos, hi1) registers 0-7 = K, 8-15 = Q channels {4hi+e, 8+4hi+e}
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
                 for (int s_ = 0; s_ < P / 16; ++s_) {
                     u32x4 wh, wl;
-                    wop(r, s_, wh, wl);
+                    wop(r1, s_, wh, wl);
                     acc = mfma_h(wh, xs[0][s_], acc);
                     acc = mfma_h(wh, xs[1][s_], acc);
                     acc = mfma_h(wl, xs[0][s_], acc);
@@ -378,18 +383,18 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 u32x4 kh4, kl4, qh4, ql4;
                 split8_rn(acc, 0, kh4, kl4);
                 split8_rn(acc, 8, qh4, ql4);
-                const unsigned po = (unsigned)hi * L.plane + (unsigned)(blk * 32 + r) * 16u;
+                const unsigned po = (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
                 *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
                 *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
                 *reinterpret_cast<u32x4*>(lds + L.qh + po) = qh4;
                 *reinterpret_cast<u32x4*>(lds + L.ql + po) = ql4;
             }
             if (p1_kinds & 2) {
-                // [G]: A = G rows 32 + (r & 15) (lanes 16-31 repeat them): registers 0-7 = gate channels {4hi+e, 8+4hi+e}
-                // [V]: SWAPPED, B = V rows 48 + (r & 15): lane (n, hi) register j = V channel n & 15 of position drow32(j, hi)
+                // [G]: A = G rows 32 + (r1 & 15) (lanes 16-31 repeat them): registers 0-7 = gate channels {4hi+e, 8+4hi+e}
+                // [V]: SWAPPED, B = V rows 48 + (r1 & 15): lane (n, hi1) register j = V channel n & 15 of position drow32(j, hi1)
                 f32x16 ag, av;
                 {
-                    const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
                     ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
 #pragma unroll
                     for (int e = 8; e < 16; ++e) ag[e] = 0.f;
@@ -399,8 +404,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
 #pragma unroll
                 for (int s_ = 0; s_ < P / 16; ++s_) {
                     u32x4 gh, gl, vh, vl;
-                    wop(32 + (r & 15), s_, gh, gl);
-                    wop(48 + (r & 15), s_, vh, vl);
+                    wop(32 + (r1 & 15), s_, gh, gl);
+                    wop(48 + (r1 & 15), s_, vh, vl);
                     ag = mfma_h(gh, xs[0][s_], ag);
                     av = mfma_h(xs[0][s_], vh, av);
                     ag = mfma_h(gh, xs[1][s_], ag);
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                     ag = mfma_h(gl, xs[0][s_], ag);
                     av = mfma_h(xs[0][s_], vl, av);
                 }
-                float* gp = Gl + (size_t)((blk * 32 + r) * 2 + hi) * 8;
+                float* gp = Gl + (size_t)((blk * 32 + r1) * 2 + hi1) * 8;
                 *reinterpret_cast<float4*>(gp) = make_float4(gate_from_scaled(ag[0] * inv16), gate_from_scaled(ag[1] * inv16),
                                                              gate_from_scaled(ag[2] * inv16), gate_from_scaled(ag[3] * inv16));
                 *reinterpret_cast<float4*>(gp + 4) = make_float4(gate_from_scaled(ag[4] * inv16), gate_from_scaled(ag[5] * inv16),
@@ -416,11 +421,11 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 u32x4 vh0, vl0, vh1, vl1;               // V stays x 16
                 split8_rn(av, 0, vh0, vl0);
                 split8_rn(av, 8, vh1, vl1);
-                const bool lo_lane = r >= 16;
+                const bool lo_lane = r1 >= 16;
                 u32x4 s0, s1;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
-                const unsigned vo = L.v + (unsigned)(blk * 4 + hi) * 512u + (unsigned)r * 16u;
+                const unsigned vo = L.v + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
                 *reinterpret_cast<u32x4*>(lds + vo) = s0;
                 *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
             }

@@ -115,7 +115,8 @@ class TriAttnFn(torch.autograd.Function):
         return (dpair, None, None, None, None, *grads)
 
 
-TRI_ATTN_BWD_MAX_N = 352        # prd_tri_attn_bwd_core keeps q, k, v, gate, do of a row (padded to 32) and the head's weights in LDS
+TRI_ATTN_BWD_MAX_N = 384        # prd_tri_attn_bwd_core keeps q, k, v, gate, do of a row (padded to 32) and the head's weights in LDS:
+                                # 154 KB at N = 384 -- the largest complex BASELINE configs[3] draws (N in [100, 384])
 
 
 def tri_attn_update(ta, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
