@@ -4,6 +4,7 @@
 // as transposed MFMA GEMMs with the weights in LDS, so LayerNorm / gates / residuals stay in
 // registers and every pair row is read and written exactly once per operator.
 #include "prd_common.h"
+#include <cstdlib>
 #include "../../include/prd_hip.h"
 #include <mutex>
 
@@ -1425,6 +1426,211 @@ extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, cons
     return (int)hipGetLastError();
 }
 
+namespace {
+// OuterLinear with the K axis (single_dim) split over the eight waves of a workgroup (modules.py:283-287, split form
+// out[i,j,:] = W1 (x_i * x_j) + u_i - u_j + bias; symmetric half: the product term of (i, j) and (j, i) is the same).
+//
+// Why: the round-2 kernel (outer_linear_res_h2_kernel) gives one wave a whole (i, 32 j) tile and walks the 512 channels in 32
+// dependent K steps.  Its time is neither MFMA (4.4 us of work) nor VALU: every operand / pair-row access is "one row per lane"
+// (16 bytes from each of 32-64 cache lines per instruction), and the texture-address path of a CU serialises a wave instruction
+// by cache line: ~10k cycles of address processing per tile (tools/phase_timing.py), 33 us per launch.  Here
+//   * a TILE belongs to a workgroup; wave w takes channels [w S/8, (w+1) S/8); its slice of W1 lives in REGISTERS as MFMA A
+//     operands (fp16 hi | lo, 64 VGPRs at S = 512): no LDS image, no staging barrier;
+//   * a task = 8 rows i of one (i-block, j-block) pair: the x_j slice is fetched ONCE per task, COALESCED (16 lanes x 16 B = the
+//     256 contiguous bytes a row contributes to the wave's slice, 4 rows per instruction: 8 lines instead of 64), turned into
+//     the row-per-lane operand layout through a wave-private LDS tile (row pitch 272 B: conflict-free b128 reads) and kept in
+//     registers for the 8 rows -- the operand traffic per output drops 8-fold; x_i and the pair rows of row i+1 are requested
+//     while row i is reduced;
+//   * the eight partial accumulators meet in LDS; wave g then finishes ROWS 4g .. 4g+3 of the tile, 16 lanes per row, so that the
+//     pair rows are read and written as whole 256-byte rows (both the (i, j) rows and the mirrored (j, i) rows).
+template <int P, int KS>          // KS = K steps (16 channels each) per wave: S = 128 KS
+__global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const float* pair, const float* __restrict__ x,
+                                                              const float* __restrict__ u, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int b, int N, int residual) {
+    constexpr int NB = P / 32, NW = 8, S = 128 * KS, NG = NB * 4;      // NG = 4-register groups of the accumulator
+    constexpr int CW = 16 * KS;                                         // channels per wave
+    constexpr int XP = CW * 4 + 16;                                     // staging row pitch in bytes (+16: bank spread)
+    constexpr int LR = CW / 4;                                          // lanes per row of a coalesced slice load (16-byte pieces)
+    constexpr int RPI = 64 / LR;                                        // rows per load instruction
+    constexpr int NLD = 32 / RPI;                                       // load instructions per 32-row slice
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ks[];
+    float4* part = reinterpret_cast<float4*>(smem_ks);                  // [2 buffers][NW waves][NG groups][64 lanes]
+    float4* stage = part;                                               // [NW waves][32 rows][XP bytes]: task start only, aliased
+    constexpr int PSZ = NW * NG * 64;                                   // float4 per partial buffer
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PairPhaseTimer pt;
+    const int k0 = wave * CW;                                           // first channel of this wave's slice
+    float4* mystage = stage + (size_t)wave * 32 * (XP / 16);             // 16-byte units
+    // ---- this wave's slice of W1 as A operands: lane (row, hi) holds W1[32 nb + row][k0 + 16 s + 8 hi .. + 8], x 16 ----
+    u32x4 wh[NB][KS], wl[NB][KS];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            const float* wp = w + (size_t)(32 * nb + r) * (2 * S) + k0 + 16 * st + 8 * hi;
+            const float4 g0 = *reinterpret_cast<const float4*>(wp), g1 = *reinterpret_cast<const float4*>(wp + 4);
+            const float v[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned a_, b_;
+                split2h(H2_WSCALE * v[2 * q], H2_WSCALE * v[2 * q + 1], a_, b_);
+                wh[nb][st][q] = a_;
+                wl[nb][st][q] = b_;
+            }
+        }
+    const int nvb = (N + 31) / 32;
+    const int npairs = nvb * (nvb + 1) / 2;                 // block pairs (ib <= jb)
+    constexpr int RG = 8;                                   // rows i per task: the x_j slice is fetched once for RG rows
+    const int ntask = b * npairs * (32 / RG);
+    struct Task { int bb, i0, jb; };                        // wave-uniform
+    auto decode = [&](int t) {
+        Task T;
+        const int grp = t % (32 / RG), t2 = t / (32 / RG);
+        T.bb = t2 / npairs;
+        int pidx = t2 - T.bb * npairs, ib = 0;
+        while (pidx >= nvb - ib) { pidx -= nvb - ib; ++ib; }
+        T.jb = ib + pidx;
+        T.i0 = ib * 32 + grp * RG;
+        return T;
+    };
+    const int lrow = lane / LR, lpiece = lane % LR;
+    // epilogue: wave g owns rows 4g .. 4g+3 of the tile; lane = (row 4g + lane / 16, 16-byte piece lane % 16 of the P channels).
+    // For P = 32 (8 pieces per row) the upper half of every 16-lane group idles.
+    const int erow = 4 * wave + (lane >> 4), epiece = lane & 15;
+    const bool elive = epiece < P / 4;
+    const int ech = 4 * (elive ? epiece : 0);
+    // channel ech .. ech+3 sits in accumulator group (ech >> 5) * 4 + ((ech >> 3) & 3) of the lane of row erow with hi = (ech >> 2) & 1
+    const int egrp = (ech >> 5) * 4 + ((ech >> 3) & 3), esrc = erow + 32 * ((ech >> 2) & 1);
+    const float4 bs = *reinterpret_cast<const float4*>(bias + ech);
+    struct Epi { float4 ui, pu, pm; };
+    pt.mark(6);                                             // 6: prologue (W1 slice -> registers)
+    for (int t = blockIdx.x; t < ntask; t += gridDim.x) {
+        const Task T = decode(t);
+        // ---- x_j slice of the block, once per task: coalesced -> wave-private LDS tile -> row-per-lane operands ----
+        {
+            float4 xj[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int j = T.jb * 32 + RPI * q + lrow;
+                const int jc = j < N ? j : N - 1;
+                xj[q] = *reinterpret_cast<const float4*>(x + ((size_t)T.bb * N + jc) * S + k0 + 4 * lpiece);
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; ++q)      // (a whole-struct copy of the HIP float4 keeps the array in scratch)
+                mystage[(RPI * q + lrow) * (XP / 16) + lpiece] = make_float4(xj[q].x, xj[q].y, xj[q].z, xj[q].w);
+        }
+        wave_lds_fence();
+        float4 xb[KS][2];
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            xb[st][0] = mystage[r * (XP / 16) + 4 * st + 2 * hi];
+            xb[st][1] = mystage[r * (XP / 16) + 4 * st + 2 * hi + 1];
+        }
+        const int je = T.jb * 32 + erow;                    // this lane's row j in the epilogue
+        const bool jvalid = elive && je < N;
+        const int jj = jvalid ? je : 0;
+        const float4 uj = *reinterpret_cast<const float4*>(u + ((size_t)T.bb * N + jj) * P + ech);
+        auto row_ok = [&](int i) { return i < N; };
+        auto fetch_x = [&](int i, float4 (&xa)[KS][2]) {
+            const float* xi = x + ((size_t)T.bb * N + (row_ok(i) ? i : 0)) * S + k0 + 8 * hi;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                xa[st][0] = *reinterpret_cast<const float4*>(xi + 16 * st);
+                xa[st][1] = *reinterpret_cast<const float4*>(xi + 16 * st + 4);
+            }
+        };
+        auto fetch_epi = [&](int i, Epi& e) {
+            const bool ok = row_ok(i);
+            const int ic = ok ? i : 0;
+            const bool upper = ok && jvalid && je >= i, mirror = ok && jvalid && je > i;
+            e.ui = *reinterpret_cast<const float4*>(u + ((size_t)T.bb * N + ic) * P + ech);
+            e.pu = make_float4(0.f, 0.f, 0.f, 0.f);
+            e.pm = e.pu;
+            if (upper && residual) e.pu = *reinterpret_cast<const float4*>(pair + (((size_t)T.bb * N + ic) * N + jj) * P + ech);
+            if (mirror && residual) e.pm = *reinterpret_cast<const float4*>(pair + (((size_t)T.bb * N + jj) * N + ic) * P + ech);
+        };
+        float4 xa[KS][2];
+        Epi ecur, enext;
+        fetch_x(T.i0, xa);
+        __syncthreads();                                    // every wave has its x_j slice: the staging tiles become partial buffers
+        pt.mark(4);                                         // 4: task decode, x_j slice through LDS, first row's requests
+        // rows are software-pipelined: the MFMAs of row ii run while the partials of row ii-1 are reduced and stored; the
+        // partial buffers alternate, so one LDS barrier per row suffices
+        auto finish = [&](int i, const float4* pb, const Epi& e) {
+            if (!row_ok(i)) return;
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) {
+                const float4 v = pb[((size_t)w2 * NG + egrp) * 64 + esrc];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            const bool upper = jvalid && je >= i, mirror = jvalid && je > i;
+            const float4 ui = e.ui, pu = e.pu, pm = e.pm;
+            if (upper)
+                *reinterpret_cast<float4*>(out + (((size_t)T.bb * N + i) * N + je) * P + ech) =
+                    make_float4(pu.x + (((sum.x * H2_INV_WSCALE + ui.x) - uj.x) + bs.x), pu.y + (((sum.y * H2_INV_WSCALE + ui.y) - uj.y) + bs.y),
+                                pu.z + (((sum.z * H2_INV_WSCALE + ui.z) - uj.z) + bs.z), pu.w + (((sum.w * H2_INV_WSCALE + ui.w) - uj.w) + bs.w));
+            if (mirror)
+                *reinterpret_cast<float4*>(out + (((size_t)T.bb * N + je) * N + i) * P + ech) =
+                    make_float4(pm.x + (((sum.x * H2_INV_WSCALE + uj.x) - ui.x) + bs.x), pm.y + (((sum.y * H2_INV_WSCALE + uj.y) - ui.y) + bs.y),
+                                pm.z + (((sum.z * H2_INV_WSCALE + uj.z) - ui.z) + bs.z), pm.w + (((sum.w * H2_INV_WSCALE + uj.w) - ui.w) + bs.w));
+        };
+        for (int ii = 0; ii < RG; ++ii) {
+            const int i = T.i0 + ii;
+            fetch_epi(i, enext);                            // needed one iteration later
+            // ---- partial product over this wave's channels ----
+            f32x16 acc[NB];
+            zero_acc(acc);
+            if (row_ok(i)) {
+#pragma unroll
+                for (int st = 0; st < KS; ++st) {
+                    const float f[8] = {xa[st][0].x * xb[st][0].x, xa[st][0].y * xb[st][0].y, xa[st][0].z * xb[st][0].z, xa[st][0].w * xb[st][0].w,
+                                        xa[st][1].x * xb[st][1].x, xa[st][1].y * xb[st][1].y, xa[st][1].z * xb[st][1].z, xa[st][1].w * xb[st][1].w};
+                    u32x4 ph, pl;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned a_, b_;
+                        split2h(f[2 * q], f[2 * q + 1], a_, b_);
+                        ph[q] = a_;
+                        pl[q] = b_;
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh[nb][st]), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wh[nb][st]), __builtin_bit_cast(f16x8_t, pl), acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wl[nb][st]), __builtin_bit_cast(f16x8_t, ph), acc[nb], 0, 0, 0);
+                }
+            }
+            if (ii + 1 < RG) fetch_x(i + 1, xa);
+            pt.mark(0);                                     // 0: products, MFMA issue, next row's requests
+            if (ii > 0) finish(i - 1, part + (size_t)((ii - 1) & 1) * PSZ, ecur);      // while the MFMAs drain
+            ecur = enext;
+            pt.mark(3);                                     // 3: reduction + epilogue of the previous row
+            {
+                float4* pw = part + (size_t)(ii & 1) * PSZ + ((size_t)wave * NG) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    pw[(size_t)g * 64] = make_float4(acc[g >> 2][4 * (g & 3)], acc[g >> 2][4 * (g & 3) + 1], acc[g >> 2][4 * (g & 3) + 2],
+                                                     acc[g >> 2][4 * (g & 3) + 3]);
+            }
+            pt.mark(1);                                     // 1: partial stores
+            // LDS-only barrier: __syncthreads() would also drain the global loads just requested and the previous row's stores
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            pt.mark(2);                                     // 2: barrier
+        }
+        finish(T.i0 + RG - 1, part + (size_t)((RG - 1) & 1) * PSZ, ecur);
+        __syncthreads();                                    // partials consumed before the next task's staging overwrites them
+    }
+    pt.mark(7);
+    pt.flush();
+}
+}  // namespace
+
 extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
                                 const float* bias, int residual, int b, int N, int P, int S, int* queue, int arith, hipStream_t stream) {
     PRD_CHECK_ARITH(arith);
@@ -1433,6 +1639,24 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
     if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const size_t lds = ((size_t)P * (S + 4) + P) * sizeof(float);
+    static const bool ol_v1 = getenv("PRD_OL_VARIANT") && atoi(getenv("PRD_OL_VARIANT")) == 1;      // tuning: the round-2 kernel
+    if (arith == PRD_ARITH_SPLIT16 && !ol_v1 && (S == 128 || S == 256 || S == 512) && (long)b * N * N < (1L << 30)) {
+        // K split over the waves of a workgroup, W1 slices in registers (outer_linear_ks_kernel)
+        const int nvb = prd_ceil_div(N, 32);
+        const long ntile = (long)b * (nvb * (nvb + 1) / 2) * 4;       // (block pair, 8 rows i) tasks
+        const int grid = (int)(ntile < 256 ? ntile : 256);
+        const size_t ldsp = (size_t)2 * 8 * (P / 32 * 4) * 64 * 16, ldss = (size_t)8 * 32 * ((S / 8) * 4 + 16);
+        const size_t ldsk = ldsp > ldss ? ldsp : ldss;             // two partial buffers; the staging tiles alias them
+#define PRD_OLKS(PP, KK)                                                                                               \
+        do {                                                                                                           \
+            PRD_SET_LDS((outer_linear_ks_kernel<PP, KK>), ldsk);                                                       \
+            hipLaunchKernelGGL((outer_linear_ks_kernel<PP, KK>), dim3(grid), dim3(512), ldsk, stream, out, pair, x, u, w, bias, b, N, residual); \
+        } while (0)
+        if (P == 64) { if (S == 512) PRD_OLKS(64, 4); else if (S == 256) PRD_OLKS(64, 2); else PRD_OLKS(64, 1); }
+        else { if (S == 512) PRD_OLKS(32, 4); else if (S == 256) PRD_OLKS(32, 2); else PRD_OLKS(32, 1); }
+#undef PRD_OLKS
+        return (int)hipGetLastError();
+    }
     if (arith == PRD_ARITH_SPLIT16 && (S % 128) == 0 && (size_t)4 * P * S + 4 * P <= 160 * 1024) {   // fp16 x 2 split operands
         constexpr int NWL = 8;
         const int nvb = prd_ceil_div(N, 32);

@@ -189,13 +189,15 @@ def test_outer_linear(setup, gemm_mode):
     assert rel_l2(got.cpu(), O.outer_linear(s["params"], "Denoiser.folding_blocks.0.outer_linear", s["single"])) < OP_TOL
 
 
+@pytest.mark.parametrize("S", [128, 256, 512])
 @pytest.mark.parametrize("P", [32, 64])
-def test_outer_linear_full_width(P, gemm_mode):
-    """OuterLinear at the reference's single_dim = 512 (W1 resident in LDS; in gemm mode 1 the fp16 x 2 split kernel), ragged
-    N = 70: (i, j) / (j, i) symmetric-half tasks with a partial last 32-block."""
+def test_outer_linear_full_width(P, S, gemm_mode):
+    """OuterLinear at the reference's single_dim = 512 and at the narrower widths the K-split kernel is built for (in gemm
+    mode 1: W1 slices in registers, K split over the eight waves; S = 128 / 256 / 512 -> 1 / 2 / 4 K steps per wave), ragged
+    N = 70: (i, j) / (j, i) symmetric-half tasks with a partial last 32-block and row groups that run past N."""
     from protein_redesign_amd.trunk import OuterLinear
-    g = torch.Generator().manual_seed(40 + P)
-    S, N = 512, 70
+    g = torch.Generator().manual_seed(40 + P + S)
+    N = 70
     mod = OuterLinear(S, P)
     w, b = torch.randn(P, 2 * S, generator=g) / math.sqrt(2 * S), 0.1 * torch.randn(P, generator=g)
     mod.load_state_dict({"linear.weight": w, "linear.bias": b})

@@ -18,7 +18,9 @@ from protein_redesign_amd.weights import spec_tensors  # noqa: E402
 PHASES = {"tri_mul_contract": ["load issue + LDS reads + MFMA", "wait next chunk + split + LDS writes", "barrier", "first chunk (exposed)",
                                "output stores", "-", "tile decode"],
           "tri_mul_proj": ["fetch+prefetch issue", "wait for row", "layernorm", "mfma", "epilogue+stores", "exit", "prologue"],
-          "outer_linear": ["task decode", "K loop", "u / pair rows + store", "mirrored rows + store", "-", "-", "prologue", "exit"],
+          "outer_linear": ["wait x_i + products + MFMA issue + next row's requests", "partial stores (wait MFMAs)", "barrier", "reduction + epilogue of the previous row",
+                           "task decode + x_j slice through LDS", "-", "prologue (W1 slice -> registers)", "exit"],
+          "outer_linear_v1": ["task decode", "K loop", "u / pair rows + store", "mirrored rows + store", "-", "-", "prologue", "exit"],
           "pair_tail": ["decode + load issue", "wait rows + out-projection", "LayerNorm + split", "transition GEMMs", "epilogue + stores",
                         "next attention bias", "prologue", "exit"],
           "tri_mul_out": ["decode + load issue", "wait row + LN", "gate GEMM + sigmoid", "wait O + LN", "projection GEMM",
