@@ -199,7 +199,8 @@ int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float* pair, con
 /* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x). */
 int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream);
 /* Weight gradient of a linear applied at every pair position (autograd of nn.Linear over [b,N,N,*] activations, e.g.
- * modules.py:262-274, 321-326): dw[O][I] = sum over rows of dy[row][0..O) (x) x[row][0..I); row pitches lddy / ldx floats (even).
+ * modules.py:262-274, 321-326): dw[O][I] = sum over rows of dy[row][0..O) (x) x[row][0..I); row pitches lddy / ldx floats (for O > 16: even, and dy / x
+ * 8-byte aligned -- PRD_ERR_ALIGN otherwise).
  * I a multiple of 64, O a multiple of 64 or at most 16 (the attention-bias / coordinate-head linears), both at most 256.
  * db (optional, NULL = skip): the bias gradient db[O] = sum over rows of dy, from the same pass over dy.
  * ws: prd_linear_wgrad_workspace(rows, O, I) bytes of slab partials. */

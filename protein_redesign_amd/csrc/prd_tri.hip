@@ -2172,6 +2172,8 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     const long rtask = (long)b * N * (ldn / 32);
     const int rgrid = grid_for(rtask, 4, 256);
     const size_t ldsf = ((size_t)2 * P * P + (size_t)2 * 2 * P * P + 6 * P) * sizeof(float);
+    // a failed launch must not let the later stages run over a half-written workspace: checked after every stage
+#define PRD_CHAIN_STAGE_OK() do { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
     // 1. a | b of the outgoing module
     if (P == 64) {
         PRD_SET_LDS((tri_mul_proj_kernel<64, 12, true>), ldsp);
@@ -2182,9 +2184,11 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
         hipLaunchKernelGGL((tri_mul_proj_kernel<32, 12, true>), dim3(pgrid), dim3(12 * 64), ldsp, stream, (int*)nullptr, AB, pair, mask,
                            wa[0], wa[1], wa[2], wa[3], b, N, ldn, 0);
     }
+    PRD_CHAIN_STAGE_OK();
     // 2. its contraction, transposed: O^T[c][j][i]
-        if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
+    if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
+    PRD_CHAIN_STAGE_OK();
     // 3. output stage of the outgoing module + a | b of the incoming one
     if (P == 64) {
         PRD_SET_LDS((tri_mul_out_proj_kernel<64, 8>), ldsf);
@@ -2195,9 +2199,11 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
         hipLaunchKernelGGL((tri_mul_out_proj_kernel<32, 8>), dim3(rgrid), dim3(8 * 64), ldsf, stream, pair, O, mask, wa[4], wa[5], wa[6], wa[7],
                            wb[0], wb[1], wb[2], wb[3], AB, b, N, ldn);
     }
+    PRD_CHAIN_STAGE_OK();
     // 4. contraction of the incoming module
     if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    PRD_CHAIN_STAGE_OK();
     // 5. its output stage
     {
         const long ntask = (long)b * N * prd_ceil_div(N, 32);
@@ -2207,6 +2213,7 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
         else hipLaunchKernelGGL((tri_mul_out_kernel<32, 8, true>), dim3(grid), dim3(8 * 64), 0, stream, (int*)nullptr, pair, pair, O,
                                 wb[4], wb[5], wb[6], wb[7], b, N, ldn, 1);
     }
+#undef PRD_CHAIN_STAGE_OK
     return (int)hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ static int failures = 0;
     } while (0)
 
 int main(void) {
-    float buf[16];                      /* host memory standing in for device pointers: never dereferenced by the checks */
+    _Alignas(16) float buf[16];                      /* host memory standing in for device pointers: never dereferenced by the checks */
     int64_t ibuf[4];
     float* p = buf;
     hipStream_t s = 0;
@@ -102,6 +102,9 @@ int main(void) {
     EXPECT(prd_linear_wgrad(p, p, p, p, 100, 96, 64, 96, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);       /* O neither <= 16 nor a multiple of 64 */
     EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 65, 64, p, 1 << 20, s), PRD_ERR_ALIGN);            /* odd row pitch */
     EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_linear_wgrad(p, p, p + 1, p, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ALIGN);        /* dy 4-byte aligned only: the wide kernel loads 8 bytes */
+    EXPECT(prd_linear_wgrad(p, p, p, p + 1, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ALIGN);
+    EXPECT(prd_linear_wgrad(p, p, p + 1, p, 100, 4, 64, 4, 64, p, 16, s), PRD_ERR_WORKSPACE);            /* narrow form: scalar loads, no alignment demand */
     EXPECT(prd_embed_wgrad(0, (const long long*)ibuf, p, 100, 8, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
     EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 200, 64, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);   /* more than 128 table rows */
     EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 8, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
