@@ -37,6 +37,7 @@ def algorithmic(N, P, S, H=4, c=16):
         "tri_mul_out_kernel": (4 * N * N * P * P, 3 * U),
         "tri_mul_out_proj_kernel": (12 * N * N * P * P, 5 * U),
         "outer_linear_res_h2_kernel": (N * N * S * P + 4 * N * S * P, 2 * U),       # symmetric half of 2 N^2 S P
+        "outer_linear_ks_kernel": (N * N * S * P + 4 * N * S * P, 2 * U),
         "pair_init_h2_kernel": (2 * N * N * 256 * P, 2 * U),
         "opm_pair_h2_kernel": (2 * N * N * (S // 4) * P, 2 * U),
         "coord_head_kernel": (2 * N * N * P * P + 2 * N * N * P, 2 * U),
