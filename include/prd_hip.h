@@ -221,9 +221,19 @@ int prd_tri_attn(float* out, const float* pair, const float* mask, const float* 
                  int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream);
 /* which core kernel prd_tri_attn uses for rows of N positions under arithmetic `arith`: 0 = short rows (K, V, Q and gate
  * of a row resident in LDS: N <= 448 in fp32 mode, N <= 384 with split operands), 1 = long rows on the fp32 kernel (Q / gate
- * re-projected per query block), 2 = long rows on the split-operand kernel (gemm mode 1, N <= 832),
- * PRD_ERR_UNSUPPORTED = N too large (beyond ~1000). */
+ * re-projected per query block), 2 = long rows on the split-operand kernel (gemm mode 1, N <= 864),
+ * 3 = rows whose K / V no longer fit the LDS (N > 960): key-chunked, prd_tri_attn_core_chunked. */
 int prd_tri_attn_variant(int N, int P, int arith);
+/* Rows of any length (variant 3): the keys of a row are processed in chunks of <= 960 by consecutive launches of the fp32
+ * long-row kernel; every launch attends all queries of the row to its chunk and merges its (gated, normalised) output into og
+ * by the softmax statistics (reference m, sum l) kept per (position, head) in `stats` -- the softmax over the union of the
+ * chunks (modules.py:216-223), exact up to fp32 rounding.  stats: prd_tri_attn_stats_bytes() bytes = b N N H 2 floats (0 for
+ * variants 0-2).  prd_tri_attn takes the statistics from its ws (prd_workspace_bytes("tri_attn") includes them);
+ * prd_tri_attn_core returns PRD_ERR_UNSUPPORTED for such rows. */
+size_t prd_tri_attn_stats_bytes(int b, int N, int P, int H, int arith);
+int prd_tri_attn_core_chunked(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
+                              const float* wv, const float* wg, const float* bg, int ending,
+                              int b, int N, int P, int H, int c, float* stats, size_t stats_bytes, hipStream_t stream);
 /* the two launches of prd_tri_attn, exposed separately (og = gated per-head output [b,N,N,64]) */
 int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                       const float* wv, const float* wg, const float* bg, int ending,

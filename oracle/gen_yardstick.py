@@ -66,7 +66,24 @@ class _Injected32(G._Injected):
 
 
 @torch.inference_mode()
-def run(name, case, ref_model, dtype, threads, max_steps=None):
+def _pack(name, case, dtype, states, model, pos=None, logits=None):
+    out = {"case": np.array(json.dumps(dict(case, name=name, dtype=dtype))),
+           "seg_step": np.array([s[0] for s in states])}
+    if dtype == "f64":
+        assert states[0][1].dtype == torch.float64
+        out.update(seg_z_f64=torch.cat([s[1] for s in states]).numpy(),                       # float64
+                   seg_seq_t_f64=torch.cat([s[2] for s in states]).float().numpy())           # rounded to fp32 (size)
+        if pos is not None:
+            out.update(traj_pos_f64=pos.numpy(), traj_logits_f64=logits.numpy())
+    else:
+        out["state_dict_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in model.state_dict().items()}))
+        out.update(seg_z=torch.cat([s[1] for s in states]).numpy(), seg_seq_t=torch.cat([s[2] for s in states]).numpy())
+        if pos is not None:
+            out.update(traj_pos=pos.numpy(), traj_logits=logits.numpy())
+    return out
+
+
+def run(name, case, ref_model, dtype, threads, max_steps=None, partial_path=None):
     torch.set_default_dtype(torch.float32)
     model, args = G.build_reference(ref_model, case)          # fp32 weights, fp32 schedule tables
     if dtype == "f64":
@@ -87,6 +104,9 @@ def run(name, case, ref_model, dtype, threads, max_steps=None):
         if step % every == 0:
             states.append((step, z.clone(), seq_t.clone()))
             print(f"[{name} {dtype}] step {step} t={time.time() - t0:.0f}s |z|={float(z.norm()):.4f}", flush=True)
+            if partial_path and len(states) % 4 == 0:       # a long run survives being stopped: the prefix is a valid fixture
+                np.savez_compressed(partial_path + ".tmp.npz", **_pack(name, case, dtype, states, model))
+                os.replace(partial_path + ".tmp.npz", partial_path)
         if max_steps is not None and step >= max_steps:
             raise _Stop
         return inner(batch, z, seq_t, mask, t)
@@ -102,20 +122,7 @@ def run(name, case, ref_model, dtype, threads, max_steps=None):
         pass
     finally:
         torch.set_default_dtype(torch.float32)
-    out = {"case": np.array(json.dumps(dict(case, name=name, dtype=dtype))),
-           "seg_step": np.array([s[0] for s in states])}
-    if dtype == "f64":
-        assert states[0][1].dtype == torch.float64
-        out.update(seg_z_f64=torch.cat([s[1] for s in states]).numpy(),                       # float64
-                   seg_seq_t_f64=torch.cat([s[2] for s in states]).float().numpy())           # rounded to fp32 (size)
-        if pos is not None:
-            out.update(traj_pos_f64=pos.numpy(), traj_logits_f64=logits.numpy())
-    else:
-        out["state_dict_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in model.state_dict().items()}))
-        out.update(seg_z=torch.cat([s[1] for s in states]).numpy(), seg_seq_t=torch.cat([s[2] for s in states]).numpy())
-        if pos is not None:
-            out.update(traj_pos=pos.numpy(), traj_logits=logits.numpy())
-    return out
+    return _pack(name, case, dtype, states, model, pos, logits)
 
 
 def main():
@@ -129,11 +136,11 @@ def main():
     ref_model, _ = import_reference()
     for name in a.cases:
         torch.manual_seed(0)
-        res = run(name, CASES[name], ref_model, a.dtype, a.threads, a.max_steps)
         suffix = "_f64" if a.dtype == "f64" else ""
         if a.dtype == "f32" and name in G.CASES:
             raise SystemExit(f"{name}: the fp32 fixture belongs to gen_golden.py")
         path = os.path.join(ROOT, "tests", "golden", f"{name}{suffix}.npz")
+        res = run(name, CASES[name], ref_model, a.dtype, a.threads, a.max_steps, partial_path=path)
         np.savez_compressed(path, **res)
         print(name, a.dtype, "->", path, f"{os.path.getsize(path) / 1024:.1f} KiB", flush=True)
 

@@ -74,6 +74,8 @@ SIGNATURES = {
     "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 7 + [vp],
     "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 6 + [vp],
+    "prd_tri_attn_core_chunked": [vp] * 8 + [ci] * 6 + [vp, cz, vp],
+    "prd_tri_attn_stats_bytes": [ci] * 5,
     "prd_tri_attn_v2_supported": [ci, ci],
     "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, ci, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
@@ -86,7 +88,7 @@ DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (e
 _ARITH_BEFORE_STREAM = ("prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
                         "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail")
 # ... and the queries that take it as their last argument
-_ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported")
+_ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes")
 
 
 class _Library:
@@ -139,7 +141,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(cdll, name)
             fn.argtypes = argtypes
-            fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace") else ci
+            fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace", "prd_tri_attn_stats_bytes") else ci
         mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)
         if os.environ.get("PRD_BF16X3"):                               # older spelling of PRD_GEMM_MODE=bf16x3
             mode = "bf16x3"

@@ -881,7 +881,8 @@ PRD_DEV void ta_block(const float* __restrict__ Kl, const float* __restrict__ Vt
 // overflows to inf -- then, and only then, the wave redoes its tiles with the online update in every block.
 template <int NTQ, bool MASKED>
 PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ Vt, const float* __restrict__ kadd,
-                        const float4 (&qf)[NTQ], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ]) {
+                        const float4 (&qf)[NTQ], int npad, int ql, int g4, f32x4 (&o)[NTQ], float (&l_tot)[NTQ],
+                        float* m_out = nullptr) {
     float m_run[NTQ], l_run[NTQ];
     bool online_all = false;                     // second pass only: online update in every block
     while (true) {
@@ -904,6 +905,10 @@ PRD_DEV void ta_keyloop(const float* __restrict__ Kl, const float* __restrict__ 
         }
         if (online_all || !__any(bad)) break;    // the second pass is never needed for logit spreads below 2^127
         online_all = true;
+    }
+    if (m_out) {                                 // the reference the sums are relative to (log2 domain), per query: chunk merges
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) m_out[t] = m_run[t];
     }
 }
 
@@ -1969,6 +1974,138 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_long_kernel(
     }
 }
 
+// Rows of any length (N > 960: K / V of a whole row no longer fit the LDS): the long-row kernel over ONE contiguous chunk of
+// keys [key0, key0 + klen).  The chunks of a row are processed by consecutive launches; every launch attends all queries of
+// the row to its chunk and merges with what the earlier chunks left: og holds the gated, normalised output so far, stats
+// [b][N][N][H][2] the (reference m in the log2 domain, sum l relative to it) of the softmax so far.  With w_c = l_c 2^(m_c - M),
+// M = max m_c:  og = sum_c w_c og_c / sum_c w_c -- the softmax over the union of the chunks (modules.py:216-223), exact up to
+// fp32 rounding.  fp32 MFMA arithmetic in either mode.
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_core_chunk_kernel(
+    float* __restrict__ og, float* __restrict__ stats, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int key0, int klen, int first, int H, int ending) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int npad = (klen + 63) / 64 * 64;    // keys of this chunk, padded
+    float* Wl = smem;                          // [64][P+4]: rows 0-15 k_h, 16-31 v_h, 32-47 q_h, 48-63 g_h
+    float* Kl = Wl + 64 * (P + 4);             // [npad][KP]
+    float* Vt = Kl + npad * KP;                // [16][npad+4]
+    float* kadd = Vt + C * (npad + 4);         // [npad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int ql = lane & 15, g4 = lane >> 4;
+    const int nvb = npad / 32;
+    const int nqb = (N + 31) / 32;
+    const int h = blockIdx.x % H;
+    const int rstride = gridDim.x / H;
+    stage_weight_cll<P>(Wl, wk + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + C * (P + 4), wv + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + 2 * C * (P + 4), wq + (long)h * C * P, C, P, tid, NT);
+    stage_weight_cll<P>(Wl + 3 * C * (P + 4), wg + (long)h * C * P, C, P, tid, NT);
+    const float sc = 0.25f * LOG2E;
+    for (long bu = blockIdx.x / H; bu < (long)b * N; bu += rstride) {
+        const int bb = (int)(bu / N), u = (int)(bu - (long)bb * N);
+        __syncthreads();
+        const float mu = mask[bu];
+        for (int k = tid; k < npad; k += NT) {
+            const bool inside = k < klen;
+            const bool keep = inside && (mu * mask[(long)bb * N + (inside ? key0 + k : 0)] >= 0.5f);
+            kadd[k] = keep ? 0.f : (inside ? -32768.0f * LOG2E : -INFINITY);
+        }
+        for (int vb = wave; vb < nvb; vb += NW) {
+            const int kk = vb * 32 + r;                  // key index inside the chunk
+            const bool valid = kk < klen;
+            const int vv = valid ? key0 + kk : 0;
+            const long pos = ending ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
+            f32x16 kv[1];
+            zero_acc(kv);
+            if (vb * 32 < klen) {
+                float x[KH];
+                load_row_cll<P>(pair + pos * P, hi, valid, x);
+                ln_cll<KH>(x);
+                rowgemm<P, 1>(Wl, x, kv, r, hi);
+            }
+            *reinterpret_cast<float4*>(Kl + kk * KP + 4 * hi) = make_float4(kv[0][0], kv[0][1], kv[0][2], kv[0][3]);
+            *reinterpret_cast<float4*>(Kl + kk * KP + 8 + 4 * hi) = make_float4(kv[0][4], kv[0][5], kv[0][6], kv[0][7]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Vt[(4 * hi + e) * (npad + 4) + kk] = kv[0][8 + e];
+                Vt[(8 + 4 * hi + e) * (npad + 4) + kk] = kv[0][12 + e];
+            }
+        }
+        __syncthreads();
+        for (int qb = wave; qb < nqb; qb += NW) {
+            float qg[16];
+            {
+                const int v = qb * 32 + r;
+                const bool valid = v < N;
+                const int vv = valid ? v : 0;
+                const long pos = ending ? (((long)bb * N + vv) * N + u) : (bu * N + vv);
+                float x[KH];
+                load_row_cll<P>(pair + pos * P, hi, valid, x);
+                ln_cll<KH>(x);
+                f32x16 acc[1];
+                zero_acc(acc);
+                rowgemm<P, 1>(Wl + 2 * C * (P + 4), x, acc, r, hi);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qg[i] = acc[0][i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qg[8 + e] = acc[0][8 + e] + bg[h * C + 4 * hi + e];
+                    qg[12 + e] = acc[0][12 + e] + bg[h * C + 8 + 4 * hi + e];
+                }
+            }
+            float4 qf[2], gf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {              // same redistribution as tri_attn_core_long_kernel
+                const int src = 16 * t + ql + 32 * (g4 & 1);
+                float lo[4], up[4], glo[4], gup[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = __shfl(qg[e], src);
+                    up[e] = __shfl(qg[4 + e], src);
+                    glo[e] = __shfl(qg[8 + e], src);
+                    gup[e] = __shfl(qg[12 + e], src);
+                }
+                const bool hiq = (g4 >> 1) != 0;
+                qf[t] = make_float4(sc * (hiq ? up[0] : lo[0]), sc * (hiq ? up[1] : lo[1]), sc * (hiq ? up[2] : lo[2]), sc * (hiq ? up[3] : lo[3]));
+                gf[t] = make_float4(sigmoid_fast(hiq ? gup[0] : glo[0]), sigmoid_fast(hiq ? gup[1] : glo[1]),
+                                    sigmoid_fast(hiq ? gup[2] : glo[2]), sigmoid_fast(hiq ? gup[3] : glo[3]));
+            }
+            f32x4 o[2];
+            float l_tot[2], m_ref[2];
+            ta_keyloop<2, true>(Kl, Vt, kadd, qf, npad, ql, g4, o, l_tot, m_ref);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int v = qb * 32 + 16 * t + ql;
+                if (v < N) {
+                    const long pos = ending ? (((long)bb * N + v) * N + u) : (bu * N + v);
+                    float4* dst = reinterpret_cast<float4*>(og + pos * HC + h * C + 4 * g4);
+                    float* st = stats + (pos * H + h) * 2;
+                    const float il = 1.0f / l_tot[t];
+                    float4 mine = make_float4(gf[t].x * (o[t][0] * il), gf[t].y * (o[t][1] * il), gf[t].z * (o[t][2] * il), gf[t].w * (o[t][3] * il));
+                    float m_new = m_ref[t], l_new = l_tot[t];
+                    if (!first) {
+                        const float m0 = st[0], l0 = st[1];
+                        const float4 prev = *dst;
+                        const float M = fmaxf(m0, m_ref[t]);
+                        const float w0 = l0 * exp2f(m0 - M), w1 = l_tot[t] * exp2f(m_ref[t] - M);
+                        const float iw = 1.0f / (w0 + w1);
+                        const float a0 = w0 * iw, a1 = w1 * iw;
+                        mine = make_float4(a0 * prev.x + a1 * mine.x, a0 * prev.y + a1 * mine.y, a0 * prev.z + a1 * mine.z, a0 * prev.w + a1 * mine.w);
+                        m_new = M;
+                        l_new = w0 + w1;
+                    }
+                    *dst = mine;
+                    // the four lanes (g4) of a query read the statistics above before lane g4 = 0 replaces them: one wave, program order
+                    if (g4 == 0) { st[0] = m_new; st[1] = l_new; }
+                }
+            }
+        }
+    }
+}
+
 template <int P, int NW, bool B3>
 __global__ __launch_bounds__(NW * 64) void tri_attn_out_kernel(int* queue, float* out, const float* pair, const float* __restrict__ og,
                                                                const float* __restrict__ wo, const float* __restrict__ bo, long rows, int residual) {
@@ -2050,10 +2187,55 @@ extern "C" int prd_tri_attn_variant(int N, int P, int arith) {
     bool long_row;
     const bool b3 = arith == PRD_ARITH_SPLIT16;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
-    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024) return 3;            // key-chunked (prd_tri_attn_core_chunked)
     if (!long_row) return 0;
     const int npad = prd_round_up(N, 64);
     return (b3 && lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096) ? 2 : 1;
+}
+
+namespace {
+constexpr int TA_CHUNK_MAX = 960;              // keys per chunk: (64 (P+4) + 148 npad + 64) floats... <= 160 KB for P = 64
+int ta_chunks(int N) { return prd_ceil_div(N, TA_CHUNK_MAX); }
+}  // namespace
+
+extern "C" size_t prd_tri_attn_stats_bytes(int b, int N, int P, int H, int arith) {
+    if (b <= 0 || N <= 0 || H <= 0) return 0;
+    return prd_tri_attn_variant(N, P, arith) == 3 ? (size_t)b * N * N * H * 2 * sizeof(float) : 0;
+}
+
+extern "C" int prd_tri_attn_core_chunked(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
+                                         const float* wv, const float* wg, const float* bg, int ending,
+                                         int b, int N, int P, int H, int c, float* stats, size_t stats_bytes, hipStream_t stream) {
+    if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || !stats || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
+    if (stats_bytes < (size_t)b * N * N * H * 2 * sizeof(float)) return PRD_ERR_WORKSPACE;
+    const int nchunk = ta_chunks(N);
+    const int per = prd_round_up(prd_ceil_div(N, nchunk), 64);         // keys per chunk (the last one may be shorter)
+    const size_t lds = ((size_t)64 * (P + 4) + (size_t)per * KP + 16 * (per + 4) + per) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
+    const long rows_total = (long)b * N;
+    const long cap = 256 / H;
+    long per_head = cap < rows_total ? cap : rows_total;
+    const long rounds = (rows_total + per_head - 1) / per_head;
+    per_head = (rows_total + rounds - 1) / rounds;
+    const int grid = (int)(per_head * H);
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const int key0 = ck * per;
+        const int klen = key0 + per <= N ? per : N - key0;
+        if (klen <= 0) break;
+        if (P == 64) {
+            PRD_SET_LDS((tri_attn_core_chunk_kernel<64, 8>), lds);
+            hipLaunchKernelGGL((tri_attn_core_chunk_kernel<64, 8>), dim3(grid), dim3(512), lds, stream, og, stats, pair, mask, wq, wk, wv, wg, bg,
+                               b, N, key0, klen, ck == 0 ? 1 : 0, H, ending);
+        } else {
+            PRD_SET_LDS((tri_attn_core_chunk_kernel<32, 8>), lds);
+            hipLaunchKernelGGL((tri_attn_core_chunk_kernel<32, 8>), dim3(grid), dim3(512), lds, stream, og, stats, pair, mask, wq, wk, wv, wg, bg,
+                               b, N, key0, klen, ck == 0 ? 1 : 0, H, ending);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
 }
 
 extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P) {
@@ -2061,7 +2243,8 @@ extern "C" size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P
     if (!op || b <= 0 || N <= 0) return 0;
     const size_t ldn = (size_t)prd_round_up(N, 32);
     if (op[0] == 't' && op[4] == 'm') return (size_t)3 * b * P * N * ldn * sizeof(float);   // "tri_mul": operands a | b + output
-    if (op[0] == 't' && op[4] == 'a') return (size_t)b * N * N * 64 * sizeof(float);        // "tri_attn"
+    if (op[0] == 't' && op[4] == 'a')        // "tri_attn": og, and for key-chunked rows the softmax statistics (either arithmetic)
+        return (size_t)b * N * N * 64 * sizeof(float) + prd_tri_attn_stats_bytes(b, N, P, 4, PRD_ARITH_FP32);
     return 0;
 }
 
@@ -2341,7 +2524,13 @@ extern "C" int prd_tri_attn(float* out, const float* pair, const float* mask, co
     PRD_CHECK_ARITH(arith);
     if (!ws) return PRD_ERR_ARG;
     if (ws_bytes < prd_workspace_bytes("tri_attn", b, N, 0, P)) return PRD_ERR_WORKSPACE;
-    int e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, arith, stream);
+    int e;
+    if (prd_tri_attn_variant(N, P, arith) == 3) {
+        const size_t nog = (size_t)b * N * N * 64;
+        e = prd_tri_attn_core_chunked(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, ws + nog, ws_bytes - nog * sizeof(float), stream);
+    } else {
+        e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, arith, stream);
+    }
     if (e) return e;
     return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, queue, arith, stream);
 }

@@ -392,7 +392,8 @@ def tri_attn_uses_long_rows(N: int, P: int) -> bool:
 
 
 def tri_attn_variant(N: int, P: int) -> int:
-    """0 short rows, 1 long rows (fp32 kernel), 2 long rows (split-operand kernel) -- prd_hip.h: prd_tri_attn_variant."""
+    """0 short rows, 1 long rows (fp32 kernel), 2 long rows (split-operand kernel), 3 key-chunked rows (N > 960) --
+    prd_hip.h: prd_tri_attn_variant."""
     v = lib().prd_tri_attn_variant(N, P)
     if v < 0:
         check(v, "prd_tri_attn_variant")
@@ -470,11 +471,26 @@ def step_boundary_(z, seq_t, t, eps_raw, seq_pred, noise, mask, coef, num_steps:
                                   num_steps, static_single.shape[-1], P, TD, stream()), "prd_step_boundary")
 
 
-def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) -> torch.Tensor:
-    """First launch of tri_attn alone (bench / profiling): og[b,N,N,64]; wts = (q.w, k.w, v.w, gate.w, gate.b)."""
+def tri_attn_stats_floats(b: int, N: int, P: int, H: int = 4) -> int:
+    """floats of softmax statistics the key-chunked core needs (0 unless rows exceed the LDS: prd_tri_attn_stats_bytes)"""
+    return lib().prd_tri_attn_stats_bytes(b, N, P, H) // 4
+
+
+def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None, stats=None) -> torch.Tensor:
+    """First launch of tri_attn alone: og[b,N,N,64]; wts = (q.w, k.w, v.w, gate.w, gate.b).  Rows beyond the LDS (N > 960) run
+    key-chunked and need ``stats`` (tri_attn_stats_floats; allocated here if not given)."""
     b, N, _, P = pair.shape
     if og is None:
         og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
+    nst = tri_attn_stats_floats(b, N, P, H)
+    if nst:
+        if stats is None:
+            stats = torch.empty(nst, device=pair.device, dtype=F32)
+        if stats.numel() < nst:
+            raise ValueError("tri_attn_core: stats buffer too small")
+        check(lib().prd_tri_attn_core_chunked(dptr(og), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
+                                              b, N, P, H, c, dptr(stats), stats.numel() * 4, stream()), "prd_tri_attn_core_chunked")
+        return og
     check(lib().prd_tri_attn_core(dptr(og), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
                                   b, N, P, H, c, stream()), "prd_tri_attn_core")
     return og

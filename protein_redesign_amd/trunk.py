@@ -267,7 +267,7 @@ class FoldingBlock(nn.Module):
             # ending triangle attention: core kernel, then ONE fused row pass = its output projection + the pair
             # transition + (if there is a next block) that block's attention bias
             og = ops.tri_attn_core(pair, mask, ta.weights()[:5], ta.num_heads, ta.head_dim, ending=True,
-                                   og=ws[:nog].view(b, N, N, 64))
+                                   og=ws[:nog].view(b, N, N, 64), stats=ws[nog:] if ws.numel() > nog else None)
         pf = self.pair_fc
         nb_w = next_block.attn_bias[1].weight if next_block is not None else None
         nb_b = next_block.attn_bias[1].bias if next_block is not None else None

@@ -741,10 +741,13 @@ def test_full_size_step_vs_oracle(num_blocks, gemm_mode):
     assert rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
 
 
-def test_long_sequence_step_vs_oracle(gemm_mode):
+@pytest.mark.parametrize("na,nr", [(1, 768), (24, 1000)])
+def test_long_sequence_step_vs_oracle(na, nr, gemm_mode):
     """BASELINE configs[4]: 768 residues + 1 dummy atom (N = 769), one block: the whole step (long-row triangle attention
-    included) against the oracle, which evaluates triangle attention in row blocks (same arithmetic, bounded memory)."""
-    args, model, params, pb, z, seq_t, t = _full_size_case(1, 768, 1, seed=7)
+    included) against the oracle, which evaluates triangle attention in row blocks (same arithmetic, bounded memory).
+    N = 1024 (1000 residues + 24 atoms): rows beyond the LDS, key-chunked triangle attention, every other kernel at a
+    size where the 32-bit index arithmetic of a row kernel passes 2^28 elements."""
+    args, model, params, pb, z, seq_t, t = _full_size_case(na, nr, 1, seed=7)
     with torch.inference_mode():
         want = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
         dpb = batch_to(pb, DEV)
@@ -754,15 +757,19 @@ def test_long_sequence_step_vs_oracle(gemm_mode):
 
 
 @pytest.mark.parametrize("mode", ["starting", "ending"])
-@pytest.mark.parametrize("N,valid", [(449, 449), (640, 611), (769, 750)])
+@pytest.mark.parametrize("N,valid", [(449, 449), (640, 611), (769, 750), (961, 961), (1000, 975), (1961, 1930)])
 def test_triangle_attention_long_rows(setup, mode, N, valid, gemm_mode):
-    """tri_attn_core_long_kernel (rows whose K / V leave no LDS for the Q / gate tiles, N > ~440) against the oracle, for
-    P in {32, 64}, both modes, with a masked tail.  The oracle is evaluated on a subset of rows (first, last valid, masked and
+    """tri_attn_core_long_kernel (rows whose K / V leave no LDS for the Q / gate tiles, N > ~440) and, beyond N = 960, the
+    key-chunked form (two chunks at 961 / 1000, three at 1961; chunk partials merged by their softmax statistics) against the
+    oracle, for P in {32, 64}, both modes, with a masked tail.  The oracle is evaluated on a subset of rows (first, last valid, masked and
     scattered ones) so that it costs seconds: row i of the update only depends on row i of the (transposed) pair."""
     s = setup
     P = s["P"]
     H, c = s["args"]["num_heads"], s["args"]["head_dim"]
     assert ops.tri_attn_uses_long_rows(N, P)
+    if P == 64:                                      # (P = 32 leaves a little more LDS: its limit is 992)
+        assert (ops.tri_attn_variant(N, P) == 3) == (N > 960)
+    assert N < 1900 or ops.tri_attn_variant(N, P) == 3
     g = torch.Generator().manual_seed(N + (mode == "ending"))
     pair = torch.randn(1, N, N, P, generator=g)
     mask = torch.ones(1, N)
