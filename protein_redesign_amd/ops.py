@@ -353,6 +353,14 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
 WGRAD_MIN_ROWS = 8192
 
 
+def ln_rows_bwd(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dx of nn.LayerNorm(C, elementwise_affine=False) over the rows of x2 [rows, C] (prd_ln_rows_bwd)."""
+    rows, Cn = x2.shape
+    dx = torch.empty_like(x2)
+    check(lib().prd_ln_rows_bwd(dptr(dx), dptr(dy2), dptr(x2), rows, Cn, stream()), "prd_ln_rows_bwd")
+    return dx
+
+
 def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor, bias: bool = False):
     """dW [O, I] = dy2^T x2 for row-major 2-D views dy2 [rows, O] and x2 [rows, I] (row stride = their stride(0), unit column
     stride): the weight gradient of a linear applied at every pair position; with ``bias`` also db [O] = column sums of dy2 from the

@@ -30,6 +30,8 @@ from . import torch_ref as R
 # recomputing them: peak memory of a 2-complex step 1.9 -> 3.9 GB -- nothing against 288 GB -- and 56.8 -> 47.9 ms per step.
 # Off by default; PRD_TRAIN_CHECKPOINT=1 restores the reference's memory behaviour (same gradients either way).
 USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
+# 0: the pair transition's backward through the torch restatement (HipOp), as in round 2 -- A/B measurements only
+PAIR_TRANSITION_BWD = os.environ.get("PRD_PAIR_TRANSITION_BWD", "1") != "0"
 
 
 class HipOp(torch.autograd.Function):
@@ -57,6 +59,36 @@ class HipOp(torch.autograd.Function):
             grads = torch.autograd.grad([o for o, _ in pairs], wrt, [g.contiguous() for _, g in pairs], allow_unused=True)
         it = iter(grads)
         return (None, None) + tuple(next(it) if i.requires_grad else None for i in ins)
+
+
+class PairTransitionFn(torch.autograd.Function):
+    """pair_fc (modules.py:321-326): y = W2 relu(W1 LN(x) + b1) + b2 at every pair position.  Forward: the row kernel of the
+    inference path.  Backward entirely on the library's kernels (no torch restatement, no autograd graph over [b N N, 256]
+    activations): h = relu(W1 LN(x) + b1) recomputed by the LayerNorm-fused GEMM, g = (dy W2) * [h > 0], dLN = g W1,
+    dx = LN'(dLN; x) (prd_ln_rows_bwd), dW2 | db2 = dy^T h, dW1 | db1 = g^T LN(x) (prd_linear_wgrad slab reductions)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ctx.save_for_backward(x, w1, b1, w2, b2)
+        with torch.no_grad():
+            return ops.pair_transition(x.detach().contiguous(), w1, b1, w2, b2, residual=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        P, HID = x.shape[-1], w1.shape[0]
+        with torch.no_grad():
+            x2 = x.detach().contiguous().view(-1, P)
+            dy2 = dy.contiguous().view(-1, P)
+            h = ops.linear(x2, w1, b1, act=1, ln_a=True)                       # [rows, HID]
+            g = ops.linear(dy2, w2.t().contiguous())                           # dy W2
+            g.mul_(h > 0)
+            dxn = ops.linear(g, w1.t().contiguous())                           # [rows, P]
+            dx = ops.ln_rows_bwd(dxn, x2)
+            dw2, db2 = ops.linear_wgrad(dy2, h, bias=True)
+            xn = ops.layer_norm(x2)
+            dw1, db1 = ops.linear_wgrad(g, xn, bias=True)
+        return dx.view_as(x), dw1, db1, dw2, db2
 
 
 class TriMulFn(torch.autograd.Function):
@@ -115,8 +147,8 @@ class TriAttnFn(torch.autograd.Function):
         return (dpair, None, None, None, None, *grads)
 
 
-TRI_ATTN_BWD_MAX_N = 384        # prd_tri_attn_bwd_core keeps q, k, v, gate, do of a row (padded to 32) and the head's weights in LDS:
-                                # 154 KB at N = 384 -- the largest complex BASELINE configs[3] draws (N in [100, 384])
+TRI_ATTN_BWD_MAX_N = 352        # prd_tri_attn_bwd_core keeps q, k, v, gate, do of a row (padded to 32) and the head's weights in LDS:
+                                # exactly 160 KB at N = 352 (pitch 20 floats: 16-byte aligned rows); longer rows recompute through torch_ref
 
 
 def tri_attn_update(ta, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -187,8 +219,11 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
 
     pf = blk.pair_fc
     pfw = (pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias)
-    pair = pair + HipOp.apply(lambda x, *w: ops.pair_transition(x.contiguous(), *w, residual=False),
-                              R.transition, pair, *pfw)
+    if pair.is_cuda and pair.numel() // pair.shape[-1] >= ops.WGRAD_MIN_ROWS and PAIR_TRANSITION_BWD:
+        pair = pair + PairTransitionFn.apply(pair, *pfw)
+    else:
+        pair = pair + HipOp.apply(lambda x, *w: ops.pair_transition(x.contiguous(), *w, residual=False),
+                                  R.transition, pair, *pfw)
     return single, pair
 
 
