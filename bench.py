@@ -315,10 +315,11 @@ def main():
             traffic, note, pipes = measure_traffic(a)
         split_mode = _lib.lib().prd_get_gemm_mode() == 1
         variant = ops.tri_attn_variant(N, P)
-        v2 = split_mode and variant == 0 and ops.tri_attn_v2_supported(N, P) and not os.environ.get("PRD_TA_VARIANT", "0").strip("0")
+        v2 = split_mode and variant in (0, 1, 2) and ops.tri_attn_v2_supported(N, P) and not os.environ.get("PRD_TA_VARIANT", "0").strip("0")
         split = split_mode and variant in (0, 2)
-        kname = "tri_attn_core_v2_kernel" if v2 else {0: "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel",
-                                                        1: "tri_attn_core_long_kernel", 2: "tri_attn_core_split_long_kernel"}[variant]
+        kname = ("tri_attn_core_v2_kernel" if N <= 384 else "tri_attn_core_v2l_kernel") if v2 else {
+            0: "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel",
+            1: "tri_attn_core_long_kernel", 2: "tri_attn_core_split_long_kernel", 3: "tri_attn_core_chunk_kernel"}[variant]
         # peak: the kernel issues on the 16-bit matrix pipe, where an fp32-accurate MAC costs three split products (hi*hi + hi*lo +
         # lo*hi): 2.5 PF/s / 3.  In fp32 mode (fp32 MFMA kernels) the peak is the fp32 MFMA rate.
         peak = PEAK_16BIT_TFLOPS / 3.0 if split_mode_now else FP32_PEAK_TFLOPS
@@ -337,8 +338,8 @@ def main():
                                  "v_exp_f32 and one fp16 hi|lo split per logit (DESIGN.md 4.3; profiles/r03_roofline.txt covers every "
                                  "kernel of the step)"}
         if v2:         # every MFMA is a 32x32x16 (32768 flops): 36 per 32-position block of a row (3 row GEMMs x 4 k-steps x 3
-            nqb = (N + 31) // 32                                     # products), 7 per 32 x 32 logit tile (3 QK^T + 4 PV)
-            ex = bpg * N * 4 * (36 * nqb + 7 * nqb * nqb) * 32768
+            nqb = (N + 31) // 32                                     # products; long rows: [K|Q] + [V] + [Q|G] = 36 too),
+            ex = bpg * N * 4 * (36 * nqb + 7 * nqb * nqb) * 32768   # 7 per 32 x 32 logit tile (3 QK^T + 4 PV)
         elif split:    # first generation: 3 fp16 products per projection / P*V MAC, 6 bf16 products per Q*K^T MAC (long rows: 4)
             ex = bpg * (3 * 8 * N * N * P * 64 + ((6 if variant == 0 else 4) + 3) * 2 * 64 * N ** 3)
         else:

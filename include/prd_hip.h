@@ -240,10 +240,12 @@ int prd_tri_attn_core(float* og, const float* pair, const float* mask, const flo
                       int b, int N, int P, int H, int c, int arith, hipStream_t stream);
 int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
                      int residual, int b, int N, int P, int* queue, int arith, hipStream_t stream);
-/* Second-generation core for short rows (N <= 352, split-16 arithmetic; csrc/prd_tri2.hip): same contract as
- * prd_tri_attn_core, everything on the 32x32x16 fp16 MFMA (Q K^T with fp16 hi+lo operands rounded to nearest: 24 bits),
- * the (query block, key tile) work of a row cut into equal contiguous ranges per wave.  prd_tri_attn_core dispatches to
- * it when prd_tri_attn_v2_supported(N, P) and the gemm mode is split-16 (PRD_TA_VARIANT=10 keeps the first generation). */
+/* Second-generation core (split-16 arithmetic; csrc/prd_tri2.hip): same contract as prd_tri_attn_core, everything on the
+ * 32x32x16 fp16 MFMA (Q K^T with fp16 hi+lo operands rounded to nearest: 24 bits).  Rows of up to 384 positions keep K, Q, V
+ * and the gate of a row in LDS (one query block per wave, shared blocks merged from partials); longer rows -- as far as K and
+ * V fit, N <= 832 at pair_dim 64 -- re-project Q and the gate per query block in the wave that sweeps it.  prd_tri_attn_core
+ * dispatches to it when prd_tri_attn_v2_supported(N, P) and the arithmetic is split-16 (PRD_TA_VARIANT=10 keeps the first
+ * generation, PRD_TA2_LONG=0 keeps it for the long rows only). */
 int prd_tri_attn_v2_supported(int N, int P);
 int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                          const float* wv, const float* wg, const float* bg, int ending,

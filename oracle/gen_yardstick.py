@@ -125,17 +125,84 @@ def run(name, case, ref_model, dtype, threads, max_steps=None, partial_path=None
     return _pack(name, case, dtype, states, model, pos, logits)
 
 
+@torch.inference_mode()
+def run_segments(name, case, ref_model, starts, threads):
+    """Segment-wise yardstick: for every stored step k in ``starts`` the fp64 reference is restarted from the fp32 reference's OWN
+    state entering step k (tests/golden/<case>.npz) and run for ``traj_every`` steps with the same injected noise;
+    delta_seg(k) = rel-L2(fp32 reference at k + traj_every, this fp64 state) is what one segment of the loop does to fp32
+    round-off -- the bound test_trajectory_segments_vs_reference_golden holds the HIP path to.
+    The reference's loop (model.py:404-420) is driven from its first step with the network call stubbed out until step k
+    (the reverse update still draws its noise, so the injected noise stream stays aligned), then the stored state is
+    written into the loop's own tensors."""
+    torch.set_default_dtype(torch.float32)
+    model, args = G.build_reference(ref_model, case)
+    model = model.double()
+    every = case["traj_every"]
+    f32 = np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
+    stored = [int(v) for v in f32["seg_step"]]
+    one = synthetic_batch([case["traj_sample"]], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500)
+    one = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in one.items()}
+    inner = model.sample_step
+    ends_z, ends_s = [], []
+    t0 = time.time()
+
+    class _Stop(Exception):
+        pass
+
+    for k0 in starts:
+        idx = stored.index(k0)
+        z0 = torch.from_numpy(f32["seg_z"][idx:idx + 1]).double()
+        s0 = torch.from_numpy(f32["seg_seq_t"][idx:idx + 1]).double()
+        got = {}
+
+        def spy(batch, z, seq_t, mask, t):
+            step = args["num_steps"] - 1 - int(t[0])
+            if step < k0:
+                return torch.zeros_like(z), torch.zeros_like(seq_t)
+            if step == k0:
+                # in place: the loop's reverse update (model.py:411-420) reads its own z_struc_t, which is this tensor
+                z.copy_(z0)
+                seq_t.copy_(s0)
+            if step == k0 + every:
+                got["z"], got["s"] = z.clone(), seq_t.clone()
+                raise _Stop
+            return inner(batch, z, seq_t, mask, t)
+
+        model.sample_step = spy
+        torch.set_default_dtype(torch.float64)
+        try:
+            with _Injected32([NoiseSource(G.NOISE_SEED, 0)]):
+                model.sample(clone_batch(one))
+        except _Stop:
+            pass
+        finally:
+            torch.set_default_dtype(torch.float32)
+            model.sample_step = inner
+        ends_z.append(got["z"])
+        ends_s.append(got["s"])
+        print(f"[{name} segment {k0}] t={time.time() - t0:.0f}s", flush=True)
+    return {"case": np.array(json.dumps(dict(case, name=name, dtype="f64 segments"))), "seg_start": np.array(list(starts)),
+            "end_z_f64": torch.cat(ends_z).numpy(), "end_seq_t_f64": torch.cat(ends_s).float().numpy()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="+")
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--max-steps", type=int, default=None, help="stop after this many steps (partial fixture)")
+    ap.add_argument("--segments", default=None, help="comma-separated stored steps: segment-wise fp64 twins -> <case>_segf64.npz")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     ref_model, _ = import_reference()
     for name in a.cases:
         torch.manual_seed(0)
+        if a.segments:
+            res = run_segments(name, CASES[name], ref_model, [int(v) for v in a.segments.split(",")], a.threads)
+            path = os.path.join(ROOT, "tests", "golden", f"{name}_segf64.npz")
+            np.savez_compressed(path, **res)
+            print(name, "segments ->", path, f"{os.path.getsize(path) / 1024:.1f} KiB", flush=True)
+            continue
         suffix = "_f64" if a.dtype == "f64" else ""
         if a.dtype == "f32" and name in G.CASES:
             raise SystemExit(f"{name}: the fp32 fixture belongs to gen_golden.py")

@@ -2432,12 +2432,13 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
     const bool split_long = long_row && b3 &&
         lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096;      // tri_attn_lds chose it
+    static const int variant = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;     // tuning only
+    // second generation (prd_tri2.hip): short rows, and long rows as far as K / V of a row fit the LDS
+    if (b3 && variant == 0 && prd_tri_attn_v2_supported(N, P) && (long)b * N * N <= 0x7fffffffL / 2)
+        return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
     if (split_long) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 32, 8); }
     else if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
     else if (b3) {
-        static const int variant = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;     // tuning only
-        if (variant == 0 && prd_tri_attn_v2_supported(N, P))
-            return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
         if (P == 64) {
             if (variant == 1) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 16, 64, 16, 1, false);
             else if (variant == 2) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 12, 64, 12, 1, false);

@@ -1,4 +1,6 @@
-// Triangle attention core, second generation (split-16 arithmetic, rows of up to 384 positions).
+// Triangle attention core, second generation (split-16 arithmetic): tri_attn_core_v2_kernel for rows of up to 384 positions
+// (K, Q, V and the gate of a row resident in LDS), tri_attn_core_v2l_kernel for longer rows as far as K and V of a row fit
+// the LDS (N <= 832 at pair_dim 64; described above that kernel).
 //
 // Replaces the reference's TriangleAttention -> Attention.forward chain (modules.py:236-243 -> 185-225) up to the gated
 // per-head output `og`; the output projection stays in tri_attn_out / pair_tail (prd_tri.hip, prd_pair.hip).
@@ -200,6 +202,18 @@ PRD_DEV f32x16 qk_tile(const KOp& k, u32x4 qh, u32x4 ql, const f32x16& cinit) {
 // logit override of masked / padded keys of tile T (absolute values in the exp2 domain; 0 = keep the logit)
 PRD_DEV void mask_tile(const unsigned char* lds, const V2Lds& L, int T, int hi, float mref, f32x16& s) {
     const float* kadd = reinterpret_cast<const float*>(lds + L.kadd) + 32 * T + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 ka = *reinterpret_cast<const float4*>(kadd + 8 * g);
+        s[4 * g + 0] = (ka.x == 0.f) ? s[4 * g + 0] : ka.x - mref;
+        s[4 * g + 1] = (ka.y == 0.f) ? s[4 * g + 1] : ka.y - mref;
+        s[4 * g + 2] = (ka.z == 0.f) ? s[4 * g + 2] : ka.z - mref;
+        s[4 * g + 3] = (ka.w == 0.f) ? s[4 * g + 3] : ka.w - mref;
+    }
+}
+
+PRD_DEV void mask_tile_at(const unsigned char* lds, unsigned kadd_off, int T, int hi, float mref, f32x16& s) {
+    const float* kadd = reinterpret_cast<const float*>(lds + kadd_off) + 32 * T + 4 * hi;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 ka = *reinterpret_cast<const float4*>(kadd + 8 * g);
@@ -592,6 +606,348 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Long rows (more query blocks than waves: 385 <= N, as far as K and V of a row fit the LDS -- N <= 832 at P = 64).
+// Same tile arithmetic as tri_attn_core_v2_kernel; what changes is what stays resident:
+//   phase 1  K (fp16 hi | lo planes) and V of ALL blocks of the row, blocks dealt round-robin to the 12 waves;
+//   phase 2  a wave re-loads, normalises and projects [Q|G] of a query block itself right before that block's key sweep: the
+//            lane that computes the 8 Q channels of a position is the lane that needs them as the B operand of Q K^T, and the
+//            lane that computes its gate channels is the one that gates the output -- Q and the gate never touch the LDS.
+//            Blocks go to the waves in rounds of 12; the last round of rem = nqb mod 12 blocks is shared when rem <= 6: the
+//            owner publishes Q of its block (2 KB), G = 12 / rem waves take a G-th of the keys each, partials (reference,
+//            sum, O) meet in LDS and the owner merges (nqb = 25 at N = 769: twelve waves share the 25th block).
+struct V2LLds { unsigned kh, kl, v, kadd, flag, bias, qs, part, plane; };
+
+PRD_DEV V2LLds v2l_layout(int P, int NP, int nshare) {
+    V2LLds L;
+    unsigned off = 64u * P * 4u;
+    L.plane = (unsigned)NP * 16u;
+    L.kh = off; off += 2 * L.plane;
+    L.kl = off; off += 2 * L.plane;
+    L.v = off; off += (unsigned)NP * 64u;
+    L.kadd = off; off += (unsigned)NP * 4u;
+    L.flag = off; off += 128u;
+    L.bias = off; off += 64u;
+    L.qs = off; off += (unsigned)nshare * 2048u;       // [block][qh | ql][hi][32 positions][16 B]
+    L.part = off;                                      // [12 pieces][10][64] fp32
+    return L;
+}
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
+    float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    constexpr float VSCALE = H2_WSCALE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const int nqb = NP / 32;                            // query blocks = key tiles (13 .. 32)
+    const int nfull = nqb / NW, rem = nqb - nfull * NW;
+    const int G = rem ? NW / rem : 0;                   // waves per block of the last round
+    const bool share = G >= 2;
+    const V2LLds L = v2l_layout(P, NP, share ? rem : 0);
+    u32x4* Wb = reinterpret_cast<u32x4*>(lds);
+    float* kadd = reinterpret_cast<float*>(lds + L.kadd);
+    int* tflag = reinterpret_cast<int*>(lds + L.flag);
+    float* biasl = reinterpret_cast<float*>(lds + L.bias);
+    float* part = reinterpret_cast<float*>(lds + L.part);
+    const int rstride = gridDim.x / H;
+    int h, slot;
+    if ((rstride & 7) == 0) {                           // the H heads of one row on one XCD
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        h = idx % H;
+        slot = (idx / H) * 8 + xcd;
+    } else {
+        h = blockIdx.x % H;
+        slot = blockIdx.x / H;
+    }
+    const float sc = 0.25f * LOG2E_2;
+    stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    if (tid < 16) {
+        const int hh = tid >> 3, e = tid & 7;
+        biasl[tid] = H2_WSCALE * NEG_LOG2E * bg[h * C + 4 * hh + (e & 3) + 8 * (e >> 2)];
+    }
+    const int nrows = b * N;
+    struct RowIx { int bu, bb, u; };
+    auto make_row = [&](int bu) { RowIx x; x.bu = bu; x.bb = bu / N; x.u = bu - x.bb * N; return x; };
+    auto row_pos = [&](const RowIx& x, int v) -> long { return ending ? (long)((x.bb * N + v) * N + x.u) : (long)(x.bu * N + v); };
+    const float inv16 = H2_INV_WSCALE;
+    const unsigned kl_off = L.kl - L.kh;
+    const unsigned kbase = L.kh + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
+    const unsigned vbase = L.v + (unsigned)hi * 512u + (unsigned)r * 16u;          // + 2048 t
+    // key tiles this wave sweeps per row (priorities only)
+    const int pj = share ? wave / G : 0, pp_ = share ? wave - pj * G : 0;
+    const int pT0 = share ? (nqb * pp_) / G : 0, pT1 = share ? (nqb * (pp_ + 1)) / G : 0;
+    const int work_tot = nfull * nqb + (share ? (wave < rem * G ? pT1 - pT0 : 0) : (wave < rem ? nqb : 0));
+
+    float xnext[KH];                                    // the wave's FIRST phase-1 block of the next row
+    float mknext = 0.f, munext = 0.f;
+    RowIx rnext = make_row(slot < nrows ? slot : 0);
+    {
+        const int v = wave * 32 + r;
+        const bool ok = slot < nrows && v < N;
+        load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
+        if (ok) mknext = mask[rnext.bb * N + v];
+        if (slot < nrows) munext = mask[slot];
+    }
+    for (int bu = slot; bu < nrows; bu += rstride) {
+        const RowIx row = rnext;
+        __syncthreads();                                // previous row's LDS consumed (and the weight image staged)
+        const float mu = munext;
+        int r1 = r, hi1 = hi;                           // opaque per row (see tri_attn_core_v2_kernel)
+        asm volatile("" : "+v"(r1), "+v"(hi1));
+        auto wop = [&](int wrow, int s_, u32x4& wh, u32x4& wl) {
+            const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi1);
+            wh = Wb[(size_t)wrow * (P / 8) + slot_];
+            wl = Wb[(size_t)(64 + wrow) * (P / 8) + slot_];
+        };
+        // ================= phase 1: K and V of every block =================
+        for (int blk = wave; blk < nqb; blk += NW) {
+            float x[KH];
+            float mk;
+            if (blk == wave) {
+#pragma unroll
+                for (int k = 0; k < KH; ++k) x[k] = xnext[k];
+                mk = mknext;
+            } else {
+                const int v = blk * 32 + r1;
+                const bool ok = v < N;
+                load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi1, ok, x);
+                mk = ok ? mask[row.bb * N + v] : 0.f;
+            }
+            ln_cll_p<KH>(x);
+            u32x4 xs[2][P / 16];
+            split2h_rn_cll<KH>(x, xs);
+            {   // logit override of masked / padded keys + tile flag
+                const int v = blk * 32 + r1;
+                const bool valid = v < N;
+                const bool keep = valid && (mu * mk >= 0.5f);
+                if (hi1 == 0) kadd[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
+                const bool any_override = __any(!keep);
+                if (lane == 0) tflag[blk] = any_override ? 1 : 0;
+            }
+            f32x16 acc, av;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[e] = 0.f; av[e] = 0.f; }
+#pragma unroll
+            for (int s_ = 0; s_ < P / 16; ++s_) {
+                u32x4 wh, wl, vh, vl;
+                wop(r1, s_, wh, wl);                    // rows 0-31 = K | Q (Q discarded here)
+                wop(48 + (r1 & 15), s_, vh, vl);
+                acc = mfma_h(wh, xs[0][s_], acc);
+                av = mfma_h(xs[0][s_], vh, av);
+                acc = mfma_h(wh, xs[1][s_], acc);
+                av = mfma_h(xs[1][s_], vh, av);
+                acc = mfma_h(wl, xs[0][s_], acc);
+                av = mfma_h(xs[0][s_], vl, av);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] *= inv16;
+            u32x4 kh4, kl4;
+            split8_rn(acc, 0, kh4, kl4);
+            const unsigned po = (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
+            *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
+            *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
+            u32x4 vh0, vl0, vh1, vl1;                   // V stays x 16
+            split8_rn(av, 0, vh0, vl0);
+            split8_rn(av, 8, vh1, vl1);
+            const bool lo_lane = r1 >= 16;
+            u32x4 s0, s1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
+            const unsigned vo = L.v + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
+            *reinterpret_cast<u32x4*>(lds + vo) = s0;
+            *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+        }
+        __syncthreads();
+        {   // the wave's first phase-1 block of the next row: in flight during the key loops
+            const int bun = bu + rstride;
+            rnext = make_row(bun < nrows ? bun : 0);
+            const int v = wave * 32 + r;
+            const bool ok = bun < nrows && v < N;
+            load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
+            mknext = ok ? mask[rnext.bb * N + v] : 0.f;
+            munext = bun < nrows ? mask[bun] : 0.f;
+        }
+        // ================= phase 2 =================
+        unsigned fmask;
+        {
+            const int f = lane < nqb ? tflag[lane] : 0;
+            fmask = (unsigned)__ballot(f != 0);
+        }
+        int work_rem = work_tot;
+        // [Q|G] of query block qb: Q as the B operands of Q K^T (fp16 hi | lo), the lane's 8 gate channels
+        auto project_qg = [&](int qb, u32x4& qh4, u32x4& ql4, float (&gate)[8]) {
+            float x[KH];
+            const int v = qb * 32 + r1;
+            const bool ok = v < N;
+            load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi1, ok, x);
+            ln_cll_p<KH>(x);
+            u32x4 xs[2][P / 16];
+            split2h_rn_cll<KH>(x, xs);
+            f32x16 acc;
+            {
+                const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+                acc[8] = b0.x; acc[9] = b0.y; acc[10] = b0.z; acc[11] = b0.w; acc[12] = b1.x; acc[13] = b1.y; acc[14] = b1.z; acc[15] = b1.w;
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < P / 16; ++s_) {
+                u32x4 wh, wl;
+                wop(16 + r1, s_, wh, wl);               // image rows 16-47 = Q | G
+                acc = mfma_h(wh, xs[0][s_], acc);
+                acc = mfma_h(wh, xs[1][s_], acc);
+                acc = mfma_h(wl, xs[0][s_], acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+            split8_rn(acc, 0, qh4, ql4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gate[e] = gate_from_scaled(acc[8 + e]);
+        };
+        // key tiles [T0, T1) for the queries (qh, ql): o8 = O (x 16, relative to mref), lsum = the lane's part of the row sum
+        auto run_piece = [&](const u32x4& qh, const u32x4& ql, int T0, int T1, float (&o8)[8], float& lsum, float& mref) {
+            f32x16 o0, zero;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] = 0.f; zero[e] = 0.f; }
+            lsum = 0.f;
+            bool big = false;
+            if (flags & 1) v2_prio(work_rem, work_tot);
+            {
+                KOp k = load_k(lds, kbase + 512u * T0, kl_off);
+                f32x16 s0 = qk_tile(k, qh, ql, zero);
+                if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_off);
+                if ((fmask >> T0) & 1) mask_tile_at(lds, L.kadd, T0, hi, 0.f, s0);
+                const float tmax = xhalf_max(max16_mfma(s0));
+                mref = tmax - P_SHIFT;
+                f32x16 negm;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
+                PBuf p;
+                load_v(lds, vbase + 2048u * T0, p);
+                exp_split(s0, lsum, big, p);
+                pv_tile(p, o0);
+                for (int t = T0 + 1; t < T1; ++t) {
+                    if ((flags & 1) && ((t - T0) & 3) == 0) v2_prio(work_rem - (t - T0), work_tot);
+                    f32x16 s = qk_tile(k, qh, ql, negm);
+                    if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_off);
+                    load_v(lds, vbase + 2048u * t, p);
+                    if ((fmask >> t) & 1) mask_tile_at(lds, L.kadd, t, hi, mref, s);
+                    exp_split(s, lsum, big, p);
+                    pv_tile(p, o0);
+                }
+            }
+            if (__any(big || !(lsum < 3.0e38f))) {      // rare: redo the piece with the online update in every tile
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o0[e] = 0.f;
+                lsum = 0.f;
+                float m_run = -1e30f;
+                for (int t = T0; t < T1; ++t) {
+                    const KOp k = load_k(lds, kbase + 512u * t, kl_off);
+                    f32x16 s = qk_tile(k, qh, ql, zero);
+                    if ((fmask >> t) & 1) mask_tile_at(lds, L.kadd, t, hi, 0.f, s);
+                    const float m_new = max2f(m_run, xhalf_max(max16_mfma(s)));
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    mref = m_new - P_SHIFT;
+                    lsum *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; s[e] -= mref; }
+                    bool dummy = false;
+                    PBuf p;
+                    load_v(lds, vbase + 2048u * t, p);
+                    exp_split(s, lsum, dummy, p);
+                    pv_tile(p, o0);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o8[jj] = o0[jj] + o0[jj + 8];
+            work_rem -= T1 - T0;
+        };
+        auto finish = [&](int qb, const float (&o)[8], float l, const float (&gate)[8]) {
+            const float ltot = xhalf_add(l);
+            const int v = 32 * qb + r;
+            if (v < N) {
+                const float il = 1.0f / (VSCALE * ltot);
+                float* dst = og + row_pos(row, v) * HC + h * C + 4 * hi;
+                *reinterpret_cast<float4*>(dst) = make_float4(gate[0] * (o[0] * il), gate[1] * (o[1] * il), gate[2] * (o[2] * il), gate[3] * (o[3] * il));
+                *reinterpret_cast<float4*>(dst + 8) = make_float4(gate[4] * (o[4] * il), gate[5] * (o[5] * il), gate[6] * (o[6] * il), gate[7] * (o[7] * il));
+            }
+        };
+        // ---- whole rounds (and an unshared last round): one query block per wave ----
+        const int nrounds = nfull + ((rem && !share) ? 1 : 0);
+        for (int rd = 0; rd < nrounds; ++rd) {
+            const int qb = rd * NW + wave;
+            if (qb < nqb) {
+                u32x4 qh4, ql4;
+                float gate[8], o8[8], lsum, mref;
+                project_qg(qb, qh4, ql4, gate);
+                run_piece(qh4, ql4, 0, nqb, o8, lsum, mref);
+                finish(qb, o8, lsum, gate);
+            }
+        }
+        // ---- shared last round ----
+        if (share) {
+            float gate[8];
+            if (wave < rem) {
+                u32x4 qh4, ql4;
+                project_qg(nfull * NW + wave, qh4, ql4, gate);
+                const unsigned qo = L.qs + (unsigned)wave * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
+                *reinterpret_cast<u32x4*>(lds + qo) = qh4;
+                *reinterpret_cast<u32x4*>(lds + qo + 1024u) = ql4;
+            }
+            __syncthreads();
+            if (wave < rem * G && pT1 > pT0) {
+                const unsigned qo = L.qs + (unsigned)pj * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
+                const u32x4 qh4 = *reinterpret_cast<const u32x4*>(lds + qo), ql4 = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
+                float o8[8], lsum, mref;
+                run_piece(qh4, ql4, pT0, pT1, o8, lsum, mref);
+                float* pp = part + (size_t)wave * 640 + lane;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pp[jj * 64] = o8[jj];
+                pp[8 * 64] = lsum;
+                pp[9 * 64] = mref;
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            if (wave < rem) {                           // merge the G pieces of the wave's block (flash-decoding merge)
+                float M = -INFINITY;
+                for (int k = 0; k < G; ++k) {
+                    const bool has = (nqb * (k + 1)) / G > (nqb * k) / G;
+                    if (has) M = max2f(M, part[(size_t)(wave * G + k) * 640 + 9 * 64 + lane]);
+                }
+                float o[8], l = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+                for (int k = 0; k < G; ++k) {
+                    const bool has = (nqb * (k + 1)) / G > (nqb * k) / G;
+                    if (!has) continue;
+                    const float* pp = part + (size_t)(wave * G + k) * 640 + lane;
+                    const float scl = __builtin_amdgcn_exp2f(pp[9 * 64] - M);
+                    l += scl * pp[8 * 64];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
+                }
+                finish(nfull * NW + wave, o, l, gate);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+size_t v2l_lds_bytes(int N, int P) {
+    const int NP = prd_round_up(N, 32), nqb = NP / 32, rem = nqb % 12, G = rem ? 12 / rem : 0;
+    const bool share = G >= 2;
+    return (size_t)64 * P * 4 + (size_t)NP * (2 * 32 + 64 + 4) + 128 + 64 + (share ? (size_t)rem * 2048 + 12 * 2560 : 0);
+}
+
 size_t v2_lds_bytes(int N, int P) {
     const int NP = prd_round_up(N, 32), nqb = NP / 32, m4 = nqb & 3;
     const size_t base = (size_t)64 * P * 4 + (size_t)NP * (4 * 32 + 64 + 64 + 4) + 128;
@@ -611,7 +967,10 @@ size_t v2_lds_bytes(int N, int P) {
 // 1 when the second-generation core serves rows of N positions (split-16 arithmetic only)
 extern "C" int prd_tri_attn_v2_supported(int N, int P) {
     if (N <= 0 || (P != 32 && P != 64)) return 0;
-    return (N <= V2_MAXN && v2_lds_bytes(N, P) <= 160 * 1024) ? 1 : 0;
+    if (N <= V2_MAXN) return v2_lds_bytes(N, P) <= 160 * 1024 ? 1 : 0;
+    static const int no_long = getenv("PRD_TA2_LONG") ? atoi(getenv("PRD_TA2_LONG")) == 0 : 0;      // 0: long rows stay on the first generation (A/B)
+    if (no_long) return 0;
+    return (prd_round_up(N, 32) <= 1024 && v2l_lds_bytes(N, P) <= 160 * 1024) ? 1 : 0;
 }
 
 extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
@@ -622,7 +981,8 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     if (!prd_tri_attn_v2_supported(N, P)) return PRD_ERR_UNSUPPORTED;
     if ((long)b * N * N > 0x7fffffffL / 2) return PRD_ERR_UNSUPPORTED;      // 32-bit position arithmetic in the kernel
     const int NP = prd_round_up(N, 32);
-    const size_t lds = v2_lds_bytes(N, P);
+    const bool long_rows = N > V2_MAXN;
+    const size_t lds = long_rows ? v2l_lds_bytes(N, P) : v2_lds_bytes(N, P);
     const long rows_total = (long)b * N;
     const long cap = 256 / H;
     long per_head = cap < rows_total ? cap : rows_total;
@@ -632,6 +992,18 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     const int grid = (int)(per_head * H);
     constexpr int NWV = 12;                             // nqb <= 12 query blocks, one wave each
     static const int flags = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : 1;      // tuning only
+    if (long_rows) {
+        if (P == 64) {
+            PRD2_SET_LDS((tri_attn_core_v2l_kernel<64, NWV>));
+            hipLaunchKernelGGL((tri_attn_core_v2l_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
+                               NP, H, ending, flags);
+        } else {
+            PRD2_SET_LDS((tri_attn_core_v2l_kernel<32, NWV>));
+            hipLaunchKernelGGL((tri_attn_core_v2l_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
+                               NP, H, ending, flags);
+        }
+        return (int)hipGetLastError();
+    }
     if (P == 64) {
         PRD2_SET_LDS((tri_attn_core_v2_kernel<64, NWV>));
         hipLaunchKernelGGL((tri_attn_core_v2_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,

@@ -670,6 +670,19 @@ def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
     steps = [int(v) for v in z["seg_step"]]
     seg_z, seg_s = torch.from_numpy(z["seg_z"]), torch.from_numpy(z["seg_seq_t"])
     assert steps[0] == 0 and rel_l2(loop.z.cpu(), seg_z[0:1]) < 1e-6 and rel_l2(loop.seq_t.cpu(), seg_s[0:1]) < 1e-6
+    # Segment-wise yardstick (oracle/gen_yardstick.py --segments): where the fp64 reference, restarted from the fp32
+    # reference's own state, was run over the same segment, delta_seg = rel-L2(fp32 reference, fp64 reference) at the segment's
+    # end says what ONE segment does to fp32 round-off; the bound of such a segment is max(TRAJ_TOL, 3 delta_seg).  (N = 320 /
+    # T = 1000 with untrained weights: the positions blow up to 1e4 and the sequence softmax saturates -- a handful of segments
+    # amplify a 1e-6 perturbation beyond 1e-4 in the reference itself.)
+    seg_bound = {}
+    twin = os.path.join(os.path.dirname(__file__), "golden", name + "_segf64.npz")
+    if os.path.exists(twin):
+        y = np.load(twin)
+        for q, k0 in enumerate(int(v) for v in y["seg_start"]):
+            k = steps.index(k0)
+            if k + 1 < len(steps):
+                seg_bound[k0] = (3 * rel_l2(seg_z[k + 1:k + 2], y["end_z_f64"][q:q + 1]), 3 * rel_l2(seg_s[k + 1:k + 2], y["end_seq_t_f64"][q:q + 1]))
     worst = 0.0
     with torch.inference_mode():
         for k, start in enumerate(steps):
@@ -683,7 +696,8 @@ def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
                 pos, logits = loop.result()
                 ez, es = rel_l2(pos.cpu(), z["traj_pos"]), rel_l2(logits.cpu(), z["traj_logits"])
             worst = max(worst, ez, es)
-            assert ez < TRAJ_TOL and es < TRAJ_TOL, (start, end, ez, es)
+            bz, bs = seg_bound.get(start, (0.0, 0.0))
+            assert ez < max(TRAJ_TOL, bz) and es < max(TRAJ_TOL, bs), (start, end, ez, es, bz, bs)
         loop.restart(0, seg_z[0:1], seg_s[0:1])
         loop.run()
         pos, _ = loop.result()
