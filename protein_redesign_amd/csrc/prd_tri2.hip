@@ -633,7 +633,7 @@ PRD_DEV V2LLds v2l_layout(int P, int NP, int nshare) {
     return L;
 }
 
-template <int P, int NW>
+template <int P, int NW, bool PREFETCH>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -686,10 +686,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     const int pT0 = share ? (nqb * pp_) / G : 0, pT1 = share ? (nqb * (pp_ + 1)) / G : 0;
     const int work_tot = nfull * nqb + (share ? (wave < rem * G ? pT1 - pT0 : 0) : (wave < rem ? nqb : 0));
 
-    float xnext[KH];                                    // the wave's FIRST phase-1 block of the next row
+    float xnext[PREFETCH ? KH : 1];                     // the wave's FIRST phase-1 block of the next row
     float mknext = 0.f, munext = 0.f;
     RowIx rnext = make_row(slot < nrows ? slot : 0);
-    {
+    if constexpr (PREFETCH) {
         const int v = wave * 32 + r;
         const bool ok = slot < nrows && v < N;
         load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
@@ -710,12 +710,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
         // ================= phase 1: K and V of every block =================
         for (int blk = wave; blk < nqb; blk += NW) {
             float x[KH];
-            float mk;
-            if (blk == wave) {
+            float mk = 0.f;
+            bool from_prefetch = false;
+            if constexpr (PREFETCH) {
+                if (blk == wave) {
 #pragma unroll
-                for (int k = 0; k < KH; ++k) x[k] = xnext[k];
-                mk = mknext;
-            } else {
+                    for (int k = 0; k < KH; ++k) x[k] = xnext[k];
+                    mk = mknext;
+                    from_prefetch = true;
+                }
+            }
+            if (!from_prefetch) {
                 const int v = blk * 32 + r1;
                 const bool ok = v < N;
                 load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi1, ok, x);
@@ -769,10 +774,12 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
         {   // the wave's first phase-1 block of the next row: in flight during the key loops
             const int bun = bu + rstride;
             rnext = make_row(bun < nrows ? bun : 0);
-            const int v = wave * 32 + r;
-            const bool ok = bun < nrows && v < N;
-            load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
-            mknext = ok ? mask[rnext.bb * N + v] : 0.f;
+            if constexpr (PREFETCH) {
+                const int v = wave * 32 + r;
+                const bool ok = bun < nrows && v < N;
+                load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
+                mknext = ok ? mask[rnext.bb * N + v] : 0.f;
+            }
             munext = bun < nrows ? mask[bun] : 0.f;
         }
         // ================= phase 2 =================
@@ -993,15 +1000,16 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     constexpr int NWV = 12;                             // nqb <= 12 query blocks, one wave each
     static const int flags = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : 1;      // tuning only
     if (long_rows) {
-        if (P == 64) {
-            PRD2_SET_LDS((tri_attn_core_v2l_kernel<64, NWV>));
-            hipLaunchKernelGGL((tri_attn_core_v2l_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                               NP, H, ending, flags);
-        } else {
-            PRD2_SET_LDS((tri_attn_core_v2l_kernel<32, NWV>));
-            hipLaunchKernelGGL((tri_attn_core_v2l_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                               NP, H, ending, flags);
-        }
+#define PRD_V2L_LAUNCH(PP, PF)                                                                                                    \
+        do {                                                                                                                      \
+            PRD2_SET_LDS((tri_attn_core_v2l_kernel<PP, NWV, PF>));                                                                \
+            hipLaunchKernelGGL((tri_attn_core_v2l_kernel<PP, NWV, PF>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, \
+                               wv, wg, bg, b, N, NP, H, ending, flags);                                                           \
+        } while (0)
+        const bool pf = (flags & 8) != 0;               // next-row prefetch of the wave's first block (costs 32 registers)
+        if (P == 64) { if (pf) PRD_V2L_LAUNCH(64, true); else PRD_V2L_LAUNCH(64, false); }
+        else { if (pf) PRD_V2L_LAUNCH(32, true); else PRD_V2L_LAUNCH(32, false); }
+#undef PRD_V2L_LAUNCH
         return (int)hipGetLastError();
     }
     if (P == 64) {
