@@ -221,8 +221,9 @@ int prd_tri_attn(float* out, const float* pair, const float* mask, const float* 
                  int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream);
 /* which core kernel prd_tri_attn uses for rows of N positions under arithmetic `arith`: 0 = short rows (K, V, Q and gate
  * of a row resident in LDS: N <= 448 in fp32 mode, N <= 384 with split operands), 1 = long rows on the fp32 kernel (Q / gate
- * re-projected per query block), 2 = long rows on the split-operand kernel (gemm mode 1, N <= 864),
- * 3 = rows whose K / V no longer fit the LDS (N > 960): key-chunked, prd_tri_attn_core_chunked. */
+ * re-projected per query block), 2 = long rows on a split-operand kernel (PRD_ARITH_SPLIT16, N <= 1024),
+ * 3 = rows whose K / V no longer fit the LDS (N > 960 in fp32 arithmetic, N > 1024 with split operands): key-chunked,
+ * prd_tri_attn_core_chunked. */
 int prd_tri_attn_variant(int N, int P, int arith);
 /* Rows of any length (variant 3): the keys of a row are processed in chunks of <= 960 by consecutive launches of the fp32
  * long-row kernel; every launch attends all queries of the row to its chunk and merges its (gated, normalised) output into og
@@ -243,7 +244,7 @@ int prd_tri_attn_out(float* out, const float* pair, const float* og, const float
 /* Second-generation core (split-16 arithmetic; csrc/prd_tri2.hip): same contract as prd_tri_attn_core, everything on the
  * 32x32x16 fp16 MFMA (Q K^T with fp16 hi+lo operands rounded to nearest: 24 bits).  Rows of up to 384 positions keep K, Q, V
  * and the gate of a row in LDS (one query block per wave, shared blocks merged from partials); longer rows -- as far as K and
- * V fit, N <= 832 at pair_dim 64 -- re-project Q and the gate per query block in the wave that sweeps it.  prd_tri_attn_core
+ * V fit as fp16 planes, N <= 1024 -- re-project Q and the gate per query block in the wave that sweeps it.  prd_tri_attn_core
  * dispatches to it when prd_tri_attn_v2_supported(N, P) and the arithmetic is split-16 (PRD_TA_VARIANT=10 keeps the first
  * generation, PRD_TA2_LONG=0 keeps it for the long rows only). */
 int prd_tri_attn_v2_supported(int N, int P);

@@ -2180,6 +2180,13 @@ size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
 }
 }  // namespace
 
+namespace {
+int ta_variant_env() {                         // PRD_TA_VARIANT (tuning / A-B runs only): 0 = default dispatch
+    static const int v = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;
+    return v;
+}
+}  // namespace
+
 extern "C" int prd_tri_attn_variant(int N, int P, int arith) {
     PRD_CHECK_ARITH(arith);
     if (N <= 0) return PRD_ERR_ARG;
@@ -2187,7 +2194,8 @@ extern "C" int prd_tri_attn_variant(int N, int P, int arith) {
     bool long_row;
     const bool b3 = arith == PRD_ARITH_SPLIT16;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
-    if (lds > 160 * 1024) return 3;            // key-chunked (prd_tri_attn_core_chunked)
+    if (lds > 160 * 1024)                      // the round-3 core keeps K / V as fp16 planes: rows up to 1024; beyond: key-chunked
+        return (b3 && ta_variant_env() == 0 && prd_tri_attn_v2_supported(N, P)) ? 2 : 3;
     if (!long_row) return 0;
     const int npad = prd_round_up(N, 64);
     return (b3 && lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096) ? 2 : 1;
@@ -2409,6 +2417,10 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
     const bool b3 = arith == PRD_ARITH_SPLIT16;   // split 16-bit operands
+    const int variant = ta_variant_env();
+    // second generation (prd_tri2.hip): short rows, and long rows as far as K / V of a row fit the LDS as fp16 planes
+    if (b3 && variant == 0 && prd_tri_attn_v2_supported(N, P) && (long)b * N * N <= 0x7fffffffL / 2)
+        return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
     bool long_row;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
@@ -2432,10 +2444,6 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
     const bool split_long = long_row && b3 &&
         lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096;      // tri_attn_lds chose it
-    static const int variant = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;     // tuning only
-    // second generation (prd_tri2.hip): short rows, and long rows as far as K / V of a row fit the LDS
-    if (b3 && variant == 0 && prd_tri_attn_v2_supported(N, P) && (long)b * N * N <= 0x7fffffffL / 2)
-        return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
     if (split_long) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 32, 8); }
     else if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
     else if (b3) {

@@ -1,6 +1,6 @@
 // Triangle attention core, second generation (split-16 arithmetic): tri_attn_core_v2_kernel for rows of up to 384 positions
 // (K, Q, V and the gate of a row resident in LDS), tri_attn_core_v2l_kernel for longer rows as far as K and V of a row fit
-// the LDS (N <= 832 at pair_dim 64; described above that kernel).
+// the LDS as fp16 planes (N <= 1024; described above that kernel).
 //
 // Replaces the reference's TriangleAttention -> Attention.forward chain (modules.py:236-243 -> 185-225) up to the gated
 // per-head output `og`; the output projection stays in tri_attn_out / pair_tail (prd_tri.hip, prd_pair.hip).
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Long rows (more query blocks than waves: 385 <= N, as far as K and V of a row fit the LDS -- N <= 832 at P = 64).
+// Long rows (more query blocks than waves: 385 <= N <= 1024: K and V of a row as fp16 hi | lo planes, 128 B per position).
 // Same tile arithmetic as tri_attn_core_v2_kernel; what changes is what stays resident:
 //   phase 1  K (fp16 hi | lo planes) and V of ALL blocks of the row, blocks dealt round-robin to the 12 waves;
 //   phase 2  a wave re-loads, normalises and projects [Q|G] of a query block itself right before that block's key sweep: the
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     const int nqb = NP / 32;                            // query blocks = key tiles (13 .. 32)
     const int nfull = nqb / NW, rem = nqb - nfull * NW;
     const int G = rem ? NW / rem : 0;                   // waves per block of the last round
-    const bool share = G >= 2;
+    const bool share = G >= 2 && (flags & 16) == 0;     // (flag 16: the host found no room for the partials -- rows near 1024)
     const V2LLds L = v2l_layout(P, NP, share ? rem : 0);
     u32x4* Wb = reinterpret_cast<u32x4*>(lds);
     float* kadd = reinterpret_cast<float*>(lds + L.kadd);
@@ -694,8 +694,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
         const bool ok = slot < nrows && v < N;
         load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
         if (ok) mknext = mask[rnext.bb * N + v];
-        if (slot < nrows) munext = mask[slot];
     }
+    if (slot < nrows) munext = mask[slot];
     for (int bu = slot; bu < nrows; bu += rstride) {
         const RowIx row = rnext;
         __syncthreads();                                // previous row's LDS consumed (and the weight image staged)
@@ -949,10 +949,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     }
 }
 
-size_t v2l_lds_bytes(int N, int P) {
+size_t v2l_lds_bytes(int N, int P, bool* share_out = nullptr) {
     const int NP = prd_round_up(N, 32), nqb = NP / 32, rem = nqb % 12, G = rem ? 12 / rem : 0;
-    const bool share = G >= 2;
-    return (size_t)64 * P * 4 + (size_t)NP * (2 * 32 + 64 + 4) + 128 + 64 + (share ? (size_t)rem * 2048 + 12 * 2560 : 0);
+    const size_t base = (size_t)64 * P * 4 + (size_t)NP * (2 * 32 + 64 + 4) + 128 + 64;
+    const size_t extra = G >= 2 ? (size_t)rem * 2048 + 12 * 2560 : 0;
+    const bool share = G >= 2 && base + extra <= 160 * 1024;       // else the last round runs unshared (idle waves, same result)
+    if (share_out) *share_out = share;
+    return base + (share ? extra : 0);
 }
 
 size_t v2_lds_bytes(int N, int P) {
@@ -989,7 +992,8 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     if ((long)b * N * N > 0x7fffffffL / 2) return PRD_ERR_UNSUPPORTED;      // 32-bit position arithmetic in the kernel
     const int NP = prd_round_up(N, 32);
     const bool long_rows = N > V2_MAXN;
-    const size_t lds = long_rows ? v2l_lds_bytes(N, P) : v2_lds_bytes(N, P);
+    bool share = false;
+    const size_t lds = long_rows ? v2l_lds_bytes(N, P, &share) : v2_lds_bytes(N, P);
     const long rows_total = (long)b * N;
     const long cap = 256 / H;
     long per_head = cap < rows_total ? cap : rows_total;
@@ -998,7 +1002,9 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
     constexpr int NWV = 12;                             // nqb <= 12 query blocks, one wave each
-    static const int flags = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : 1;      // tuning only
+    static const int flags0 = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : 1;     // tuning only
+    const int nqb_ = NP / 32, rem_ = nqb_ % 12;
+    const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0);
     if (long_rows) {
 #define PRD_V2L_LAUNCH(PP, PF)                                                                                                    \
         do {                                                                                                                      \

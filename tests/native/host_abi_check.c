@@ -87,19 +87,26 @@ int main(void) {
     EXPECT(prd_tri_attn_core_fused_supported(320, 64, A1), 1);
     EXPECT(prd_tri_attn_core_fused_supported(769, 64, A1), 0);      /* long rows: no fused form */
     EXPECT(prd_tri_attn_v2_supported(320, 64), 1);
-    EXPECT(prd_tri_attn_v2_supported(400, 64), 0);                  /* more than 12 query blocks */
+    EXPECT(prd_tri_attn_v2_supported(400, 64), 1);                  /* long-row form */
+    EXPECT(prd_tri_attn_v2_supported(1024, 64), 1);
+    EXPECT(prd_tri_attn_v2_supported(1025, 64), 0);                 /* more than 32 key tiles */
     EXPECT(prd_tri_attn_variant(960, 64, A1), 1);                   /* last length whose K / V fit the LDS (fp32 long-row kernel) */
-    EXPECT(prd_tri_attn_variant(961, 64, A1), 3);                   /* key-chunked */
-    EXPECT(prd_tri_attn_variant(961, 64, 0), 3);
+    EXPECT(prd_tri_attn_variant(961, 64, A0), 3);                   /* fp32 arithmetic: key-chunked */
+    EXPECT(prd_tri_attn_variant(961, 64, A1), 2);                   /* split-16: K / V as fp16 planes fit up to N = 1024 */
+    EXPECT(prd_tri_attn_variant(1024, 64, A1), 2);
+    EXPECT(prd_tri_attn_variant(1025, 64, A1), 3);
     EXPECT((int)prd_tri_attn_stats_bytes(1, 960, 64, 4, A1), 0);
-    EXPECT((int)(prd_tri_attn_stats_bytes(1, 1000, 64, 4, A1) != (size_t)1000 * 1000 * 4 * 2 * 4), 0);
+    EXPECT((int)prd_tri_attn_stats_bytes(1, 1000, 64, 4, A1), 0);
+    EXPECT((int)(prd_tri_attn_stats_bytes(1, 1000, 64, 4, A0) != (size_t)1000 * 1000 * 4 * 2 * 4), 0);
+    EXPECT((int)(prd_tri_attn_stats_bytes(1, 1100, 64, 4, A1) != (size_t)1100 * 1100 * 4 * 2 * 4), 0);
     EXPECT((int)(prd_workspace_bytes("tri_attn", 1, 1000, 0, 64) != (size_t)1000 * 1000 * (64 + 8) * 4), 0);
-    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 1000, 64, 4, 16, A1, s), PRD_ERR_UNSUPPORTED);   /* needs the statistics buffer */
+    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 1000, 64, 4, 16, A0, s), PRD_ERR_UNSUPPORTED);   /* needs the statistics buffer */
+    EXPECT(prd_tri_attn_core(p, p, p, p, p, p, p, p, 0, 1, 1100, 64, 4, 16, A1, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_core_chunked(p, p, p, p, p, p, p, p, 0, 1, 1000, 64, 4, 16, 0, 0, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_core_chunked(p, p, p, p, p, p, p, p, 0, 1, 1000, 64, 4, 16, p, 64, s), PRD_ERR_WORKSPACE);
     EXPECT(prd_tri_attn_core_chunked(p, p, p, p, p, p, p, p, 0, 1, 1000, 48, 4, 16, p, (size_t)1 << 30, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_core_v2(0, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
-    EXPECT(prd_tri_attn_core_v2(p, p, p, p, p, p, p, p, 0, 1, 400, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn_core_v2(p, p, p, p, p, p, p, p, 0, 1, 1100, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_core_fused(p, p, p, p, p, p, p, p, p, p, p, p, 1, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);   /* pair_out aliases pair */
     EXPECT(prd_tri_mul_out_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, A1, s), PRD_ERR_ARG);
