@@ -317,7 +317,8 @@ def main():
         variant = ops.tri_attn_variant(N, P)
         v2 = split_mode and variant in (0, 1, 2) and ops.tri_attn_v2_supported(N, P) and not os.environ.get("PRD_TA_VARIANT", "0").strip("0")
         split = split_mode and variant in (0, 2)
-        kname = ("tri_attn_core_v2_kernel" if N <= 384 else "tri_attn_core_v2l_kernel") if v2 else {
+        kname = {1: "tri_attn_core_v2_kernel", 2: "tri_attn_core_v3_kernel", 3: "tri_attn_core_v2l_kernel"}[
+            _lib.lib().prd_tri_attn_v2_form(N, P)] if v2 else {
             0: "tri_attn_core_split_kernel" if split else "tri_attn_core_kernel",
             1: "tri_attn_core_long_kernel", 2: "tri_attn_core_split_long_kernel", 3: "tri_attn_core_chunk_kernel"}[variant]
         # peak: the kernel issues on the 16-bit matrix pipe, where an fp32-accurate MAC costs three split products (hi*hi + hi*lo +

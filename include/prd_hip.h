@@ -248,6 +248,10 @@ int prd_tri_attn_out(float* out, const float* pair, const float* og, const float
  * dispatches to it when prd_tri_attn_v2_supported(N, P) and the arithmetic is split-16 (PRD_TA_VARIANT=10 keeps the first
  * generation, PRD_TA2_LONG=0 keeps it for the long rows only). */
 int prd_tri_attn_v2_supported(int N, int P);
+/* which of its kernels serves rows of N positions: 0 none, 1 short rows with one barrier per phase (tri_attn_core_v2_kernel),
+ * 2 short rows with the phases of consecutive rows overlapped (tri_attn_core_v3_kernel; the default where its two K / V buffers
+ * fit the LDS), 3 long rows (tri_attn_core_v2l_kernel) */
+int prd_tri_attn_v2_form(int N, int P);
 int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                          const float* wv, const float* wg, const float* bg, int ending,
                          int b, int N, int P, int H, int c, hipStream_t stream);

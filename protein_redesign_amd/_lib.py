@@ -74,6 +74,7 @@ SIGNATURES = {
     "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 7 + [vp],
     "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 6 + [vp],
+    "prd_tri_attn_v2_form": [ci, ci],
     "prd_tri_attn_core_chunked": [vp] * 8 + [ci] * 6 + [vp, cz, vp],
     "prd_tri_attn_stats_bytes": [ci] * 5,
     "prd_tri_attn_v2_supported": [ci, ci],

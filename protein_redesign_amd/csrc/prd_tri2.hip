@@ -607,6 +607,356 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Third form for short rows (N <= 384): the phases of consecutive rows OVERLAP.  tri_attn_core_v2_kernel runs
+// barrier | phase 1 | barrier | phase 2 | barrier | merge per row, and 39 % of a row's cycles are not key loops: phase 1 is
+// latency (row load), LayerNorm / split VALU and a short MFMA burst, executed by all waves at the same time, then everybody
+// waits.  Here K / V of a row live in one of TWO LDS buffers and a wave runs, per iteration,
+//     barrier | merge of the previous row's shared blocks | phase 2 of row r (buffer r & 1) | phase 1 of row r + 1 (other buffer)
+// so that one wave's projection of the next row fills the SIMD while its neighbours are still in their key loops, and a row
+// costs ONE barrier.  What makes the second buffer fit: Q and the gate never go to LDS -- wave q projects block q and sweeps
+// block q, and the lane that computes the 8 Q channels (gate channels) of a position is the lane that needs them as the B
+// operand of Q K^T (that gates that position's output): they stay in 16 registers from phase 1 to phase 2.  Only the shared
+// ("group") blocks publish Q (2 KB each, for their helpers) and their gate (for the merge).
+// Buffer reuse is safe by construction: a buffer / Q-share slot / partial slot written in iteration i was last read in
+// iteration i - 1, one barrier earlier; the gate share is read at the top of iteration i + 2 and therefore rotates over three.
+struct V3Lds { unsigned buf0, bufsize, plane, bias, qs, gs, part; int nslot; };
+
+PRD_DEV V3Lds v3_layout(int P, int NP) {
+    V3Lds L;
+    const int nqb = NP / 32, m4 = nqb & 3, nhelp = m4 ? 4 - m4 : 0;
+    unsigned off = 64u * P * 4u;
+    L.plane = (unsigned)NP * 16u;
+    L.bufsize = 8u * L.plane + (unsigned)NP * 4u + 64u;      // kh (2 planes) | kl (2) | v (4) | kadd | tile flags
+    L.buf0 = off; off += 2u * L.bufsize;
+    L.bias = off; off += 64u;
+    L.qs = off; off += 2u * (unsigned)m4 * 2048u;            // [2][group block][qh | ql][hi][32][16 B]
+    L.gs = off; off += 3u * (unsigned)m4 * 2048u;            // [3][group block][position][hi][8] fp32
+    L.nslot = (nhelp + 1) * m4;
+    L.part = off;                                            // [2][slot][10][64] fp32
+    return L;
+}
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
+    float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    constexpr float VSCALE = H2_WSCALE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const V3Lds L = v3_layout(P, NP);
+    u32x4* Wb = reinterpret_cast<u32x4*>(lds);
+    float* biasl = reinterpret_cast<float*>(lds + L.bias);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const int nqb = NP / 32;                            // query blocks = key tiles (<= NW)
+    const int rstride = gridDim.x / H;
+    int h, slot;
+    if ((rstride & 7) == 0) {                           // the H heads of one row on one XCD
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        h = idx % H;
+        slot = (idx / H) * 8 + xcd;
+    } else {
+        h = blockIdx.x % H;
+        slot = blockIdx.x / H;
+    }
+    const float sc = 0.25f * LOG2E_2;
+    stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    if (tid < 16) {
+        const int hh = tid >> 3, e = tid & 7;
+        biasl[tid] = H2_WSCALE * NEG_LOG2E * bg[h * C + 4 * hh + (e & 3) + 8 * (e >> 2)];
+    }
+    __syncthreads();
+    const int nrows = b * N;
+    struct RowIx { int bu, bb, u; };
+    auto make_row = [&](int bu) { RowIx x; x.bu = bu; x.bb = bu / N; x.u = bu - x.bb * N; return x; };
+    auto row_pos = [&](const RowIx& x, int v) -> long { return ending ? (long)((x.bb * N + v) * N + x.u) : (long)(x.bu * N + v); };
+    // ---- static work split: as tri_attn_core_v2_kernel ----
+    const int m4 = nqb & 3, gbase = nqb - m4, nhelp = m4 ? 4 - m4 : 0;
+    const bool owner = wave < nqb, helper = wave >= nqb && wave < nqb + nhelp;
+    const int hj = wave - nqb;
+    const bool group_owner = owner && wave >= gbase;
+    const int gi = wave - gbase;
+    int p1_blk = -1, p1_kinds = 0;
+    if (owner) { p1_blk = wave; p1_kinds = (group_owner && gi < nhelp) ? 1 : 3; }
+    else if (helper && hj < m4) { p1_blk = gbase + hj; p1_kinds = 2; }
+    auto qtile = [&](int k) { return (nqb * k) >> 2; };
+    const int own_t1 = group_owner ? qtile(m4) : nqb;
+    const int work_tot = owner ? own_t1 : (helper ? m4 * (qtile(m4 + hj + 1) - qtile(m4 + hj)) : 0);
+    const float inv16 = H2_INV_WSCALE;
+    const unsigned kl_rel = 2u * L.plane, v_rel = 4u * L.plane, kadd_rel = 8u * L.plane, flag_rel = 8u * L.plane + (unsigned)NP * 4u;
+    const unsigned klane = (unsigned)hi * L.plane + (unsigned)r * 16u;              // + buffer + 512 t
+    const unsigned vlane = v_rel + (unsigned)hi * 512u + (unsigned)r * 16u;         // + buffer + 2048 t
+
+    u32x4 qh4 = {0u, 0u, 0u, 0u}, ql4 = {0u, 0u, 0u, 0u};     // Q of the wave's own block (B operands of Q K^T)
+    float gate[8];                                             // the lane's gate channels of its own block (non-group owners)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gate[e] = 0.f;
+
+    // ================= phase 1 of one row into buffer `par`, gate share `gpar` =================
+    auto phase1 = [&](const RowIx& row, int par, int gpar) {
+        if (p1_blk < 0) return;
+        const unsigned bufo = L.buf0 + (unsigned)par * L.bufsize;
+        const int blk = p1_blk;
+        int r1 = r, hi1 = hi;                           // opaque (see tri_attn_core_v2_kernel)
+        asm volatile("" : "+v"(r1), "+v"(hi1));
+        auto wop = [&](int wrow, int s_, u32x4& wh, u32x4& wl) {
+            const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi1);
+            wh = Wb[(size_t)wrow * (P / 8) + slot_];
+            wl = Wb[(size_t)(64 + wrow) * (P / 8) + slot_];
+        };
+        float x[KH];
+        const int v = blk * 32 + r1;
+        const bool valid = v < N;
+        load_row_cll<P>(pair + row_pos(row, valid ? v : 0) * P, hi1, valid, x);
+        const float mu = mask[row.bu];
+        const float mk = valid ? mask[row.bb * N + v] : 0.f;
+        ln_cll_p<KH>(x);
+        u32x4 xs[2][P / 16];
+        split2h_rn_cll<KH>(x, xs);
+        if (p1_kinds & 1) {
+            {   // logit override of masked / padded keys + tile flag
+                const bool keep = valid && (mu * mk >= 0.5f);
+                if (hi1 == 0) reinterpret_cast<float*>(lds + bufo + kadd_rel)[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
+                const bool any_override = __any(!keep);
+                if (lane == 0) reinterpret_cast<int*>(lds + bufo + flag_rel)[blk] = any_override ? 1 : 0;
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < P / 16; ++s_) {
+                u32x4 wh, wl;
+                wop(r1, s_, wh, wl);
+                acc = mfma_h(wh, xs[0][s_], acc);
+                acc = mfma_h(wh, xs[1][s_], acc);
+                acc = mfma_h(wl, xs[0][s_], acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+            u32x4 kh4, kl4;
+            split8_rn(acc, 0, kh4, kl4);
+            split8_rn(acc, 8, qh4, ql4);
+            const unsigned po = bufo + (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
+            *reinterpret_cast<u32x4*>(lds + po) = kh4;
+            *reinterpret_cast<u32x4*>(lds + po + kl_rel) = kl4;
+            if (group_owner) {                          // the helpers of this block read Q from here
+                const unsigned qo = L.qs + (unsigned)(par * m4 + gi) * 2048u + (unsigned)hi1 * 512u + (unsigned)r1 * 16u;
+                *reinterpret_cast<u32x4*>(lds + qo) = qh4;
+                *reinterpret_cast<u32x4*>(lds + qo + 1024u) = ql4;
+            }
+        }
+        if (p1_kinds & 2) {
+            f32x16 ag, av;
+            {
+                const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
+                ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
+#pragma unroll
+                for (int e = 8; e < 16; ++e) ag[e] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) av[e] = 0.f;
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < P / 16; ++s_) {
+                u32x4 gh, gl, vh, vl;
+                wop(32 + (r1 & 15), s_, gh, gl);
+                wop(48 + (r1 & 15), s_, vh, vl);
+                ag = mfma_h(gh, xs[0][s_], ag);
+                av = mfma_h(xs[0][s_], vh, av);
+                ag = mfma_h(gh, xs[1][s_], ag);
+                av = mfma_h(xs[1][s_], vh, av);
+                ag = mfma_h(gl, xs[0][s_], ag);
+                av = mfma_h(xs[0][s_], vl, av);
+            }
+            float gv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = gate_from_scaled(ag[e] * inv16);
+            if (blk >= gbase) {                         // a shared block: its owner gates at the merge
+                float* gp = reinterpret_cast<float*>(lds + L.gs + (unsigned)(gpar * m4 + (blk - gbase)) * 2048u) + (r1 * 2 + hi1) * 8;
+                *reinterpret_cast<float4*>(gp) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                *reinterpret_cast<float4*>(gp + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gate[e] = gv[e];
+            }
+            u32x4 vh0, vl0, vh1, vl1;                   // V stays x 16
+            split8_rn(av, 0, vh0, vl0);
+            split8_rn(av, 8, vh1, vl1);
+            const bool lo_lane = r1 >= 16;
+            u32x4 s0, s1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
+            const unsigned vo = bufo + v_rel + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
+            *reinterpret_cast<u32x4*>(lds + vo) = s0;
+            *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+        }
+    };
+
+    auto finish = [&](const RowIx& row, int qb, const float (&o)[8], float l, const float (&g)[8]) {
+        const float ltot = xhalf_add(l);
+        const int v = 32 * qb + r;
+        if (v < N) {
+            const float il = 1.0f / (VSCALE * ltot);
+            float* dst = og + row_pos(row, v) * HC + h * C + 4 * hi;
+            *reinterpret_cast<float4*>(dst) = make_float4(g[0] * (o[0] * il), g[1] * (o[1] * il), g[2] * (o[2] * il), g[3] * (o[3] * il));
+            *reinterpret_cast<float4*>(dst + 8) = make_float4(g[4] * (o[4] * il), g[5] * (o[5] * il), g[6] * (o[6] * il), g[7] * (o[7] * il));
+        }
+    };
+    // merge of the wave's shared block of `row` (partials in part[ppar], gate in gs[gpar])
+    auto merge = [&](const RowIx& row, int ppar, int gpar) {
+        const float* part = reinterpret_cast<const float*>(lds + L.part) + (size_t)ppar * L.nslot * 640;
+        const int s0 = (nhelp + 1) * gi;
+        float mm[5];
+        bool has[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            has[k] = k == 0 ? own_t1 > 0 : (k - 1 < nhelp && qtile(m4 + k) > qtile(m4 + k - 1));
+            const float v_ = part[(size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + 9 * 64 + lane];
+            mm[k] = has[k] ? v_ : -INFINITY;
+        }
+        float M = mm[0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) M = max2f(M, mm[k]);
+        float o[8], l = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float* pp = part + (size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + lane;
+            const float scl = has[k] ? __builtin_amdgcn_exp2f(mm[k] - M) : 0.f;
+            l += scl * pp[8 * 64];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
+        }
+        const float* gp = reinterpret_cast<const float*>(lds + L.gs + (unsigned)(gpar * m4 + gi) * 2048u) + (r * 2 + hi) * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        finish(row, wave, o, l, g);
+    };
+
+    RowIx rcur = make_row(slot < nrows ? slot : 0), rprev = rcur;
+    if (slot < nrows) phase1(rcur, 0, 0);
+    int it = 0, gpar = 0;                               // gpar = it % 3
+    for (int bu = slot; bu < nrows; bu += rstride, ++it) {
+        const int par = it & 1;
+        const unsigned bufo = L.buf0 + (unsigned)par * L.bufsize;
+        __syncthreads();
+        if (it > 0 && group_owner) merge(rprev, par ^ 1, gpar == 0 ? 2 : gpar - 1);
+        // ================= phase 2 of row rcur =================
+        unsigned fmask;
+        {
+            const int f = lane < nqb ? reinterpret_cast<const int*>(lds + bufo + flag_rel)[lane] : 0;
+            fmask = (unsigned)__ballot(f != 0);
+        }
+        const unsigned kbase = bufo + klane, vbase = bufo + vlane, kaddo = bufo + kadd_rel;
+        int work_rem = work_tot;
+        auto run_piece = [&](const u32x4& qh, const u32x4& ql, int T0, int T1, float (&o8)[8], float& lsum, float& mref) {
+            f32x16 o0, zero;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] = 0.f; zero[e] = 0.f; }
+            lsum = 0.f;
+            bool big = false;
+            if (flags & 1) v2_prio(work_rem, work_tot);
+            {
+                KOp k = load_k(lds, kbase + 512u * T0, kl_rel);
+                f32x16 s0 = qk_tile(k, qh, ql, zero);
+                if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_rel);
+                if ((fmask >> T0) & 1) mask_tile_at(lds, kaddo, T0, hi, 0.f, s0);
+                const float tmax = xhalf_max(max16_mfma(s0));
+                mref = tmax - P_SHIFT;
+                f32x16 negm;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
+                PBuf p;
+                load_v(lds, vbase + 2048u * T0, p);
+                exp_split(s0, lsum, big, p);
+                pv_tile(p, o0);
+                for (int t = T0 + 1; t < T1; ++t) {
+                    if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
+                    f32x16 s = qk_tile(k, qh, ql, negm);
+                    if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_rel);
+                    load_v(lds, vbase + 2048u * t, p);
+                    if ((fmask >> t) & 1) mask_tile_at(lds, kaddo, t, hi, mref, s);
+                    exp_split(s, lsum, big, p);
+                    pv_tile(p, o0);
+                }
+            }
+            if (__any(big || !(lsum < 3.0e38f))) {      // rare: redo the piece with the online update in every tile
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o0[e] = 0.f;
+                lsum = 0.f;
+                float m_run = -1e30f;
+                for (int t = T0; t < T1; ++t) {
+                    const KOp k = load_k(lds, kbase + 512u * t, kl_rel);
+                    f32x16 s = qk_tile(k, qh, ql, zero);
+                    if ((fmask >> t) & 1) mask_tile_at(lds, kaddo, t, hi, 0.f, s);
+                    const float m_new = max2f(m_run, xhalf_max(max16_mfma(s)));
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    mref = m_new - P_SHIFT;
+                    lsum *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; s[e] -= mref; }
+                    bool dummy = false;
+                    PBuf p;
+                    load_v(lds, vbase + 2048u * t, p);
+                    exp_split(s, lsum, dummy, p);
+                    pv_tile(p, o0);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o8[jj] = o0[jj] + o0[jj + 8];
+            work_rem -= T1 - T0;
+        };
+        auto put_partial = [&](int pslot, const float (&o8)[8], float lsum, float mref) {
+            float* pp = reinterpret_cast<float*>(lds + L.part) + ((size_t)par * L.nslot + pslot) * 640 + lane;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pp[jj * 64] = o8[jj];
+            pp[8 * 64] = lsum;
+            pp[9 * 64] = mref;
+        };
+        if (owner) {
+            float o8[8], lsum = 0.f, mref = 0.f;
+            if (own_t1 > 0) run_piece(qh4, ql4, 0, own_t1, o8, lsum, mref);
+            if (!group_owner) finish(rcur, wave, o8, lsum, gate);
+            else if (own_t1 > 0) put_partial((nhelp + 1) * gi, o8, lsum, mref);
+        } else if (helper) {
+            const int T0 = qtile(m4 + hj), T1 = qtile(m4 + hj + 1);
+            for (int i = 0; i < m4; ++i) {
+                if (T1 <= T0) break;
+                const unsigned qo = L.qs + (unsigned)(par * m4 + i) * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
+                const u32x4 qh = *reinterpret_cast<const u32x4*>(lds + qo), ql = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
+                float o8[8], lsum, mref;
+                run_piece(qh, ql, T0, T1, o8, lsum, mref);
+                put_partial((nhelp + 1) * i + 1 + hj, o8, lsum, mref);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ================= phase 1 of the next row =================
+        rprev = rcur;
+        const int bun = bu + rstride;
+        if (bun < nrows) {
+            rcur = make_row(bun);
+            phase1(rcur, par ^ 1, gpar == 2 ? 0 : gpar + 1);
+        }
+        gpar = gpar == 2 ? 0 : gpar + 1;
+    }
+    if (it > 0 && m4 > 0) {
+        __syncthreads();
+        if (group_owner) merge(rprev, (it - 1) & 1, gpar == 0 ? 2 : gpar - 1);
+    }
+}
+
+size_t v3_lds_bytes(int N, int P) {
+    const int NP = prd_round_up(N, 32), nqb = NP / 32, m4 = nqb & 3, nhelp = m4 ? 4 - m4 : 0;
+    return (size_t)64 * P * 4 + 2 * ((size_t)NP * 132 + 64) + 64 + (size_t)5 * m4 * 2048 + (size_t)2 * (nhelp + 1) * m4 * 2560;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Long rows (more query blocks than waves: 385 <= N <= 1024: K and V of a row as fp16 hi | lo planes, 128 B per position).
 // Same tile arithmetic as tri_attn_core_v2_kernel; what changes is what stays resident:
 //   phase 1  K (fp16 hi | lo planes) and V of ALL blocks of the row, blocks dealt round-robin to the 12 waves;
@@ -983,6 +1333,15 @@ extern "C" int prd_tri_attn_v2_supported(int N, int P) {
     return (prd_round_up(N, 32) <= 1024 && v2l_lds_bytes(N, P) <= 160 * 1024) ? 1 : 0;
 }
 
+// which kernel prd_tri_attn_core_v2 launches for rows of N positions: 0 = none (unsupported), 1 = tri_attn_core_v2_kernel,
+// 2 = tri_attn_core_v3_kernel (overlapped phases), 3 = tri_attn_core_v2l_kernel (long rows)
+extern "C" int prd_tri_attn_v2_form(int N, int P) {
+    if (!prd_tri_attn_v2_supported(N, P)) return 0;
+    if (N > V2_MAXN) return 3;
+    static const int use_v3 = getenv("PRD_TA2_V3") ? atoi(getenv("PRD_TA2_V3")) : 1;
+    return (use_v3 && v3_lds_bytes(N, P) <= 160 * 1024) ? 2 : 1;
+}
+
 extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                                     const float* wv, const float* wg, const float* bg, int ending,
                                     int b, int N, int P, int H, int c, hipStream_t stream) {
@@ -1002,7 +1361,12 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
     constexpr int NWV = 12;                             // nqb <= 12 query blocks, one wave each
-    static const int flags0 = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : 1;     // tuning only
+    static const int flags_env = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : -1; // tuning only
+    static const int use_v3 = getenv("PRD_TA2_V3") ? atoi(getenv("PRD_TA2_V3")) : 1;           // 0: the barrier-per-phase form (A/B)
+    const bool v3 = !long_rows && use_v3 && v3_lds_bytes(N, P) <= 160 * 1024;
+    // bit 0 = key-loop priorities by remaining work: needed where the waves of a SIMD must end together (v2, v2l); with
+    // overlapped phases (v3) an early finisher starts the next row's projection instead: 67.5 -> 65.9 us without them
+    const int flags0 = flags_env >= 0 ? flags_env : (v3 ? 0 : 1);
     const int nqb_ = NP / 32, rem_ = nqb_ % 12;
     const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0);
     if (long_rows) {
@@ -1016,6 +1380,19 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
         if (P == 64) { if (pf) PRD_V2L_LAUNCH(64, true); else PRD_V2L_LAUNCH(64, false); }
         else { if (pf) PRD_V2L_LAUNCH(32, true); else PRD_V2L_LAUNCH(32, false); }
 #undef PRD_V2L_LAUNCH
+        return (int)hipGetLastError();
+    }
+    if (v3) {
+        const size_t lds3 = v3_lds_bytes(N, P);
+        if (P == 64) {
+            PRD2_SET_LDS((tri_attn_core_v3_kernel<64, NWV>));
+            hipLaunchKernelGGL((tri_attn_core_v3_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
+                               NP, H, ending, flags);
+        } else {
+            PRD2_SET_LDS((tri_attn_core_v3_kernel<32, NWV>));
+            hipLaunchKernelGGL((tri_attn_core_v3_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
+                               NP, H, ending, flags);
+        }
         return (int)hipGetLastError();
     }
     if (P == 64) {

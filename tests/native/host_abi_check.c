@@ -90,6 +90,10 @@ int main(void) {
     EXPECT(prd_tri_attn_v2_supported(400, 64), 1);                  /* long-row form */
     EXPECT(prd_tri_attn_v2_supported(1024, 64), 1);
     EXPECT(prd_tri_attn_v2_supported(1025, 64), 0);                 /* more than 32 key tiles */
+    EXPECT(prd_tri_attn_v2_form(320, 64), 2);                       /* two K / V buffers fit: overlapped phases */
+    EXPECT(prd_tri_attn_v2_form(352, 64), 1);                       /* 11 blocks, three shared: the second buffer does not fit */
+    EXPECT(prd_tri_attn_v2_form(769, 64), 3);
+    EXPECT(prd_tri_attn_v2_form(1100, 64), 0);
     EXPECT(prd_tri_attn_variant(960, 64, A1), 1);                   /* last length whose K / V fit the LDS (fp32 long-row kernel) */
     EXPECT(prd_tri_attn_variant(961, 64, A0), 3);                   /* fp32 arithmetic: key-chunked */
     EXPECT(prd_tri_attn_variant(961, 64, A1), 2);                   /* split-16: K / V as fp16 planes fit up to N = 1024 */

@@ -27,11 +27,15 @@ cat $OUT/${TAG}_roofline.txt
   $B 2>/dev/null
   $B --samples-per-gpu 8 --steps 50 --warmup 3 2>/dev/null
   $B --residues 768 --atoms 1 --steps 30 --warmup 3 2>/dev/null
+  $B --residues 1000 --atoms 24 --steps 20 --warmup 2 2>/dev/null
   PRD_GEMM_MODE=fp32 $B 2>/dev/null
 } > $OUT/${TAG}_bench_lines.jsonl
 # the dominant kernel alone: both generations, counters
-bash tools/ta_pmc.sh r03_v2 > /dev/null 2>&1; cp gpurun_out/r03_v2_ta_pmc.txt $OUT/${TAG}_pmc_tri_attn_core.txt
+bash tools/ta_pmc.sh r03_v3 > /dev/null 2>&1; cp gpurun_out/r03_v3_ta_pmc.txt $OUT/${TAG}_pmc_tri_attn_core.txt
+PRD_TA2_V3=0 bash tools/ta_pmc.sh r03_v2 > /dev/null 2>&1; cat gpurun_out/r03_v2_ta_pmc.txt >> $OUT/${TAG}_pmc_tri_attn_core.txt
 PRD_TA_VARIANT=10 bash tools/ta_pmc.sh r03_v1 > /dev/null 2>&1; cat gpurun_out/r03_v1_ta_pmc.txt >> $OUT/${TAG}_pmc_tri_attn_core.txt
+{ echo "# round-3 long-row core"; python tools/ta_long_bench.py 449 640 769 832 960 1024 2>&1 | grep N=
+  echo "# first-generation long-row kernels (PRD_TA2_LONG=0)"; PRD_TA2_LONG=0 python tools/ta_long_bench.py 449 640 769 832 960 2>&1 | grep N=; } > $OUT/${TAG}_ta_long_bench.txt
 # micro-benchmarks behind the kernel design
 for ub in valu_rate_bench overlap_bench tile_step_bench; do
   if [ -x tools/ubench/$ub ]; then ./tools/ubench/$ub > $OUT/${TAG}_ubench_$ub.txt 2>&1; fi
@@ -41,9 +45,12 @@ python tools/train_bench.py > $OUT/${TAG}_train_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_train_trace -o t -- python3 tools/train_bench.py --steps 3 --warmup 2 > gpurun_out/${TAG}_train_trace.log 2>&1
 python tools/rocprof_summary.py $(db gpurun_out/${TAG}_train_trace) $OUT/${TAG}_train_kernel_stats.txt > /dev/null
 if [ -f protein_redesign_amd/libprd_hip_timing.so ]; then
-  PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/ta2_timing.py 320 > $OUT/${TAG}_tri_attn_phases.txt 2>&1
+  PRD_TA2_V3=0 PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/ta2_timing.py 320 > $OUT/${TAG}_tri_attn_phases.txt 2>&1
   { PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py tri_mul_out 320 1
-    PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py tri_mul_proj 320 1; } > $OUT/${TAG}_row_kernel_phases.txt 2>&1 || echo "phase_timing failed" >> $OUT/${TAG}_row_kernel_phases.txt
+    PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py tri_mul_proj 320 1
+    PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py outer_linear 320 1
+    PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py tri_mul_contract 320 1
+    PRD_LIB=$PWD/protein_redesign_amd/libprd_hip_timing.so python tools/phase_timing.py pair_tail 320 1; } > $OUT/${TAG}_row_kernel_phases.txt 2>&1 || echo "phase_timing failed" >> $OUT/${TAG}_row_kernel_phases.txt
 fi
 ls -la $OUT
 rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_pmc_* gpurun_out/${TAG}_train_trace

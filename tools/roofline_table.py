@@ -29,6 +29,7 @@ def algorithmic(N, P, S, H=4, c=16):
     return {
         "tri_attn_core_v2_kernel": (8 * N * N * P * Hc + 4 * Hc * N ** 3, 2 * U),
         "tri_attn_core_v2l_kernel": (8 * N * N * P * Hc + 4 * Hc * N ** 3, 2 * U),
+        "tri_attn_core_v3_kernel": (8 * N * N * P * Hc + 4 * Hc * N ** 3, 2 * U),
         "tri_attn_core_split_kernel": (8 * N * N * P * Hc + 4 * Hc * N ** 3, 2 * U),
         "tri_attn_core_split_long_kernel": (8 * N * N * P * Hc + 4 * Hc * N ** 3, 2 * U),
         "tri_attn_out_kernel": (2 * N * N * Hc * P, 3 * U),
