@@ -314,13 +314,16 @@ def test_triangle_attention(setup, mode, gemm_mode):
 
 
 @pytest.mark.parametrize("ending", [False, True])
-@pytest.mark.parametrize("b,N,valid", [(1, 320, 320), (2, 140, 131), (1, 33, 33), (1, 97, 64), (3, 200, 200), (1, 352, 340), (1, 31, 17)])
+@pytest.mark.parametrize("b,N,valid", [(1, 320, 320), (2, 140, 131), (1, 33, 33), (1, 97, 64), (3, 200, 200), (1, 352, 340), (1, 31, 17),
+                                       (1, 384, 384), (2, 288, 280), (2, 449, 440), (1, 640, 640), (1, 832, 800), (1, 1024, 1000)])
 def test_triangle_attention_core_v2(setup, b, N, valid, ending):
     """Second-generation core (prd_tri2.hip: 32x32x16 MFMA, fp16 hi+lo rounded to nearest, work cut into contiguous ranges per
     wave) called directly: the whole og tensor against the first-generation core in fp32-MFMA mode (a different kernel, exact
     fp32 arithmetic), and a subset of rows against the oracle's gated attention.  Shapes: the bench shape (10 x 10 iterations on
     8 waves: every query block is shared by two waves), ragged rows with masked tails, rows shorter than one tile, rows whose
-    padding reaches into the last tile, more waves than iterations (N = 31, 33), the longest row the kernel takes (352)."""
+    padding reaches into the last tile, more waves than iterations (N = 31, 33); N = 352 runs the barrier-per-phase kernel (its
+    two K / V buffers do not fit), the other short rows the overlapped form (several rows per workgroup: buffer / share-slot
+    rotation; 0, 1, 3 shared blocks); N >= 449 the long-row form (shared last round at 449 / 832, unshared at 640 / 1024)."""
     from protein_redesign_amd import _lib
     s = setup
     P = s["P"]
