@@ -843,8 +843,9 @@ extern "C" int prd_linear_wgrad(float* dw, float* db, const float* dy, const flo
     if (!dw || !dy || !x || !ws || rows <= 0 || O <= 0 || I <= 0) return PRD_ERR_ARG;
     const bool narrow = O <= 16;
     if ((!narrow && (O % 64)) || (I % 64) || O > 256 || I > 256) return PRD_ERR_UNSUPPORTED;
-    // the wide kernel reads dy / x with 8-byte loads: even leading dimensions AND 8-byte aligned base pointers
-    if (!narrow && ((lddy & 1) || (ldx & 1) || (reinterpret_cast<uintptr_t>(dy) & 7) || (reinterpret_cast<uintptr_t>(x) & 7))) return PRD_ERR_ALIGN;
+    // the wide kernel reads dy / x and writes its partials with 8-byte accesses: even leading dimensions AND 8-byte aligned pointers
+    if (!narrow && ((lddy & 1) || (ldx & 1) || ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 7)))
+        return PRD_ERR_ALIGN;
     if (lddy < O || ldx < I) return PRD_ERR_ARG;
     if (ws_bytes < prd_linear_wgrad_workspace(rows, O, I)) return PRD_ERR_WORKSPACE;
     const long slabs = wgrad_slabs(rows);

@@ -47,6 +47,35 @@ def test_triangle_multiplication_operand_scale(setup, mode, scale, gemm_mode):
     check(got, want32, want64, (mode, scale))
 
 
+def test_out_of_range_operands_fail_loudly(setup):
+    """include/prd_hip.h, OPERAND RANGE: an un-normalised operand beyond the fp16 range (ab_proj x 1e5: contraction operands of
+    magnitude 1e5 > 65504) is not silently saturated under PRD_ARITH_SPLIT16 -- the result is non-finite -- and the same call
+    under PRD_ARITH_FP32 is accurate."""
+    from protein_redesign_amd import _lib
+    s = setup
+    pfx = "Denoiser.folding_blocks.0.pair_mul_outgoing"
+    scale = 1e5
+    params = dict(s["params"])
+    params[pfx + ".ab_proj.weight"] = s["params"][pfx + ".ab_proj.weight"] * scale
+    params[pfx + ".ab_proj.bias"] = s["params"][pfx + ".ab_proj.bias"] * scale
+    m2 = s["mask"].unsqueeze(-1) * s["mask"].unsqueeze(-2)
+    with torch.inference_mode():
+        want32 = O.triangle_multiplication(params, pfx, s["pair"], m2, False)
+        want64 = O.triangle_multiplication(to64(params), pfx, s["pair"].double(), m2.double(), False)
+    w = [t.clone() for t in s["model"].Denoiser.folding_blocks[0].pair_mul_outgoing.weights()]
+    w[0], w[1] = w[0] * scale, w[1] * scale
+    prev = _lib.lib().prd_get_gemm_mode()
+    try:
+        assert _lib.lib().prd_set_gemm_mode(1) == 0
+        loud = ops.tri_mul(cu(s["pair"]), cu(s["mask"]), w, incoming=False, residual=False)
+        assert _lib.lib().prd_set_gemm_mode(0) == 0
+        exact = ops.tri_mul(cu(s["pair"]), cu(s["mask"]), w, incoming=False, residual=False)
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+    assert not torch.isfinite(loud).all()
+    check(exact, want32, want64, "fp32 arithmetic at x 1e5")
+
+
 @pytest.mark.parametrize("N", [200, 449, 769])
 @pytest.mark.parametrize("scale", [30.0, 400.0])
 def test_triangle_attention_large_logits(setup, N, scale, gemm_mode):
