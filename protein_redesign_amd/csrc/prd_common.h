@@ -406,70 +406,86 @@ PRD_DEV int h2_slot(int row, int j) {
     if (SL >= 16) return j ^ (row & 15);
     return j ^ ((row >> 1) & (SL - 1));           // SL = 8: rows 2a, 2a+1 differ in bit 3 of the bank-group index already
 }
-template <int K>
-PRD_DEV void stage_weight_h2(u32x4* Wh, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads, float scale) {
-    constexpr int S = K / 16;
-    for (int idx = tid; idx < nout * S * 2; idx += nthreads) {
-        const int o = idx / (2 * S), rem = idx - o * (2 * S), st = rem >> 1, h = rem & 1;
-        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 4 * h);        // CLL elements 8st .. 8st+3
-        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 8 + 4 * h);    // 8st+4 .. 8st+7
-        const float v[8] = {scale * g0.x, scale * g0.y, scale * g0.z, scale * g0.w, scale * g1.x, scale * g1.y, scale * g1.z, scale * g1.w};
-        u32x4 ph, pl;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a, b;
-            split2h(v[2 * q], v[2 * q + 1], a, b);
-            ph[q] = a;
-            pl[q] = b;
-        }
-        const int slot = h2_slot<K>(o, 2 * st + h);
-        Wh[(size_t)o * (K / 8) + slot] = ph;
-        Wh[(size_t)(nout + o) * (K / 8) + slot] = pl;
-    }
-}
-// same, for `nrows` rows of W placed at rows row0.. of an image of `nout` rows
+// G row pieces (2 x 16 bytes each) in flight per thread before the first split / LDS write, as in stage_weight_cll.  (Measured:
+// the prologue of a row kernel is NOT these round trips -- pair_tail 10.0k -> 8.8k cycles for 151 KB on 768 threads, while an
+// L2-warm copy of the same bytes takes 4.1k, 3.2k with global_load_lds: tools/ubench/lds_fill_bench.hip.  The image is L2-cold
+// at kernel start -- the previous kernel streamed 80-130 MB through the 4 MB L2s -- and 32 CUs of an XCD ask for the same lines.)
 template <int K>
 PRD_DEV void stage_weight_h2_rows(u32x4* Wh, int nout, int row0, const float* __restrict__ W, int nrows, int ldw, int tid, int nthreads,
                                   float scale) {
-    constexpr int S = K / 16;
-    for (int idx = tid; idx < nrows * S * 2; idx += nthreads) {
-        const int o = idx / (2 * S), rem = idx - o * (2 * S), st = rem >> 1, h = rem & 1;
-        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 4 * h);
-        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 8 + 4 * h);
-        const float v[8] = {scale * g0.x, scale * g0.y, scale * g0.z, scale * g0.w, scale * g1.x, scale * g1.y, scale * g1.z, scale * g1.w};
-        u32x4 ph, pl;
+    constexpr int S = K / 16, G = 4;
+    const int total = nrows * S * 2;
+    for (int base = tid; base < total; base += G * nthreads) {
+        float4 g0[G], g1[G];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a, b;
-            split2h(v[2 * q], v[2 * q + 1], a, b);
-            ph[q] = a;
-            pl[q] = b;
+        for (int u = 0; u < G; ++u) {
+            const int idx = base + u * nthreads;
+            const int ic = idx < total ? idx : tid;             // clamped: unconditional loads
+            const int o = ic / (2 * S), rem = ic - o * (2 * S), st = rem >> 1, h = rem & 1;
+            g0[u] = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 4 * h);        // CLL elements 8st .. 8st+3
+            g1[u] = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + 16 * st + 8 + 4 * h);    // 8st+4 .. 8st+7
         }
-        const int slot = h2_slot<K>(row0 + o, 2 * st + h);
-        Wh[(size_t)(row0 + o) * (K / 8) + slot] = ph;
-        Wh[(size_t)(nout + row0 + o) * (K / 8) + slot] = pl;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int idx = base + u * nthreads;
+            if (idx < total) {
+                const int o = idx / (2 * S), rem = idx - o * (2 * S), st = rem >> 1, h = rem & 1;
+                const float v[8] = {scale * g0[u].x, scale * g0[u].y, scale * g0[u].z, scale * g0[u].w,
+                                    scale * g1[u].x, scale * g1[u].y, scale * g1[u].z, scale * g1[u].w};
+                u32x4 ph, pl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned a, b;
+                    split2h(v[2 * q], v[2 * q + 1], a, b);
+                    ph[q] = a;
+                    pl[q] = b;
+                }
+                const int slot = h2_slot<K>(row0 + o, 2 * st + h);
+                Wh[(size_t)(row0 + o) * (K / 8) + slot] = ph;
+                Wh[(size_t)(nout + row0 + o) * (K / 8) + slot] = pl;
+            }
+        }
     }
+}
+template <int K>
+PRD_DEV void stage_weight_h2(u32x4* Wh, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads, float scale) {
+    stage_weight_h2_rows<K>(Wh, nout, 0, W, nout, ldw, tid, nthreads, scale);
 }
 // NATURAL K order (for operands generated per K step, not rows in CLL): slot j of row o holds W[o][k0 + 8 j .. + 7]; K must be a
 // multiple of 128 (16 | K/8), slot j is stored at j ^ (o & 15).  K step s of lane (r, hi) then covers k = 16 s + 8 hi .. + 7.
 PRD_DEV void stage_weight_h2_nat(u32x4* Wh, const float* __restrict__ W, int nout, int K, int ldw, int k0, int tid, int nthreads, float scale) {
     const int SL = K / 8;
-    for (int idx = tid; idx < nout * SL; idx += nthreads) {
-        const int o = idx / SL, j = idx - o * SL;
-        const float4 g0 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + k0 + 8 * j);
-        const float4 g1 = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + k0 + 8 * j + 4);
-        const float v[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        u32x4 ph, pl;
+    constexpr int G = 4;                                        // pieces in flight per thread (see stage_weight_h2_rows)
+    const int total = nout * SL;
+    for (int base = tid; base < total; base += G * nthreads) {
+        float4 g0[G], g1[G];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a, b;
-            split2h(scale * v[2 * q], scale * v[2 * q + 1], a, b);
-            ph[q] = a;
-            pl[q] = b;
+        for (int u = 0; u < G; ++u) {
+            const int idx = base + u * nthreads;
+            const int ic = idx < total ? idx : tid;
+            const int o = ic / SL, j = ic - o * SL;
+            g0[u] = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + k0 + 8 * j);
+            g1[u] = *reinterpret_cast<const float4*>(W + (size_t)o * ldw + k0 + 8 * j + 4);
         }
-        const int slot = j ^ (o & 15);
-        Wh[(size_t)o * SL + slot] = ph;
-        Wh[(size_t)(nout + o) * SL + slot] = pl;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int idx = base + u * nthreads;
+            if (idx < total) {
+                const int o = idx / SL, j = idx - o * SL;
+                const float v[8] = {g0[u].x, g0[u].y, g0[u].z, g0[u].w, g1[u].x, g1[u].y, g1[u].z, g1[u].w};
+                u32x4 ph, pl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned a_, b_;
+                    split2h(scale * v[2 * q], scale * v[2 * q + 1], a_, b_);
+                    ph[q] = a_;
+                    pl[q] = b_;
+                }
+                const int slot = j ^ (o & 15);
+                Wh[(size_t)o * SL + slot] = ph;
+                Wh[(size_t)(nout + o) * SL + slot] = pl;
+            }
+        }
     }
 }
 // one K step of the natural-order form: acc[nb] += W[32 nb + r][16 st + 8 hi ..] * f (f = the lane's 8 generated operand values)

@@ -37,7 +37,7 @@ PRD_TA_VARIANT=10 bash tools/ta_pmc.sh r03_v1 > /dev/null 2>&1; cat gpurun_out/r
 { echo "# round-3 long-row core"; python tools/ta_long_bench.py 449 640 769 832 960 1024 2>&1 | grep N=
   echo "# first-generation long-row kernels (PRD_TA2_LONG=0)"; PRD_TA2_LONG=0 python tools/ta_long_bench.py 449 640 769 832 960 2>&1 | grep N=; } > $OUT/${TAG}_ta_long_bench.txt
 # micro-benchmarks behind the kernel design
-for ub in valu_rate_bench overlap_bench tile_step_bench; do
+for ub in valu_rate_bench overlap_bench tile_step_bench lds_fill_bench; do
   if [ -x tools/ubench/$ub ]; then ./tools/ubench/$ub > $OUT/${TAG}_ubench_$ub.txt 2>&1; fi
 done
 python tools/op_bench.py > $OUT/${TAG}_op_bench.txt 2>&1
