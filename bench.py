@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--no-traffic", action="store_true", help="skip the child rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-shard-check", action="store_true", help="N > 1: skip the sample_sharded == single-rank check")
     ap.add_argument("--kernel-only", action="store_true", help="(internal) run only the dominant kernel, for the PMC passes")
+    ap.add_argument("--train", action="store_true",
+                    help="NOT the headline: print the optimisation-step line of tools/train_bench.py (BASELINE configs[3] per-GPU share: "
+                         "2 complexes of N = 320, training_step + backward + Adam + EMA) and exit")
     return ap.parse_args()
 
 
@@ -213,6 +216,11 @@ def cpu_baseline(a, N, margs, params):
 
 def main():
     a = parse_args()
+    if a.train:                                                  # a separate JSON line with its own metric, never the headline
+        sys.argv = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "train_bench.py")]
+        sys.path.insert(0, os.path.dirname(sys.argv[0]))
+        import train_bench
+        return train_bench.main()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.kernel_only:
         sys.exit(self_launch(a))                                 # before any GPU call in this process
 
