@@ -143,7 +143,7 @@ def run_segments(name, case, ref_model, starts, threads):
     one = synthetic_batch([case["traj_sample"]], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500)
     one = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in one.items()}
     inner = model.sample_step
-    ends_z, ends_s = [], []
+    ends_z, ends_s, kept, finals = [], [], [], {}
     t0 = time.time()
 
     class _Stop(Exception):
@@ -170,19 +170,27 @@ def run_segments(name, case, ref_model, starts, threads):
 
         model.sample_step = spy
         torch.set_default_dtype(torch.float64)
+        final = None
         try:
             with _Injected32([NoiseSource(G.NOISE_SEED, 0)]):
-                model.sample(clone_batch(one))
+                final = model.sample(clone_batch(one))       # only the LAST segment runs to the end of the loop
         except _Stop:
             pass
         finally:
             torch.set_default_dtype(torch.float32)
             model.sample_step = inner
-        ends_z.append(got["z"])
-        ends_s.append(got["s"])
+        if final is not None:                                 # the loop's results (positions in Angstrom, masked logits)
+            finals = {"final_start": np.array(k0), "final_pos_f64": final[0].numpy(), "final_logits_f64": final[1].numpy()}
+        else:
+            kept.append(k0)
+            ends_z.append(got["z"])
+            ends_s.append(got["s"])
         print(f"[{name} segment {k0}] t={time.time() - t0:.0f}s", flush=True)
-    return {"case": np.array(json.dumps(dict(case, name=name, dtype="f64 segments"))), "seg_start": np.array(list(starts)),
-            "end_z_f64": torch.cat(ends_z).numpy(), "end_seq_t_f64": torch.cat(ends_s).float().numpy()}
+    out = {"case": np.array(json.dumps(dict(case, name=name, dtype="f64 segments")))}
+    if kept:
+        out.update(seg_start=np.array(kept), end_z_f64=torch.cat(ends_z).numpy(), end_seq_t_f64=torch.cat(ends_s).float().numpy())
+    out.update(finals)
+    return out
 
 
 def main():
@@ -200,6 +208,13 @@ def main():
         if a.segments:
             res = run_segments(name, CASES[name], ref_model, [int(v) for v in a.segments.split(",")], a.threads)
             path = os.path.join(ROOT, "tests", "golden", f"{name}_segf64.npz")
+            if os.path.exists(path):                            # add to the twins already there
+                old = dict(np.load(path))
+                if "seg_start" in res and "seg_start" in old:
+                    res["seg_start"] = np.concatenate([old["seg_start"], res["seg_start"]])
+                    res["end_z_f64"] = np.concatenate([old["end_z_f64"], res["end_z_f64"]])
+                    res["end_seq_t_f64"] = np.concatenate([old["end_seq_t_f64"], res["end_seq_t_f64"]])
+                res = {**old, **res}
             np.savez_compressed(path, **res)
             print(name, "segments ->", path, f"{os.path.getsize(path) / 1024:.1f} KiB", flush=True)
             continue

@@ -686,6 +686,8 @@ def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
             k = steps.index(k0)
             if k + 1 < len(steps):
                 seg_bound[k0] = (3 * rel_l2(seg_z[k + 1:k + 2], y["end_z_f64"][q:q + 1]), 3 * rel_l2(seg_s[k + 1:k + 2], y["end_seq_t_f64"][q:q + 1]))
+        if "final_pos_f64" in y:                         # the last segment ends in the loop's results (positions, masked logits)
+            seg_bound[int(y["final_start"])] = (3 * rel_l2(z["traj_pos"], y["final_pos_f64"]), 3 * rel_l2(z["traj_logits"], y["final_logits_f64"]))
     worst = 0.0
     with torch.inference_mode():
         for k, start in enumerate(steps):
