@@ -30,8 +30,9 @@ from . import torch_ref as R
 # recomputing them: peak memory of a 2-complex step 1.9 -> 3.9 GB -- nothing against 288 GB -- and 56.8 -> 47.9 ms per step.
 # Off by default; PRD_TRAIN_CHECKPOINT=1 restores the reference's memory behaviour (same gradients either way).
 USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
-# 0: the pair transition's backward through the torch restatement (HipOp), as in round 2 -- A/B measurements only
-PAIR_TRANSITION_BWD = os.environ.get("PRD_PAIR_TRANSITION_BWD", "1") != "0"
+# 0: the backward of the pair transition, the attention bias and the outer-linear through the torch restatement (HipOp), as in
+# round 2 -- A/B measurements only
+LIBRARY_BWD = os.environ.get("PRD_LIBRARY_BWD", "1") != "0"
 
 
 class HipOp(torch.autograd.Function):
@@ -89,6 +90,62 @@ class PairTransitionFn(torch.autograd.Function):
             xn = ops.layer_norm(x2)
             dw1, db1 = ops.linear_wgrad(g, xn, bias=True)
         return dx.view_as(x), dw1, db1, dw2, db2
+
+
+class PairBiasFn(torch.autograd.Function):
+    """attn_bias of a folding block (modules.py:300-304): bias[b,h,i,j] = (W LN(pair[b,i,j]) + c)[h].  Backward on the library's
+    kernels: dLN = dbias W (a K = H GEMM), dpair = LN'(dLN; pair), dW | dc = dbias^T LN(pair) from the narrow slab reduction."""
+
+    @staticmethod
+    def forward(ctx, pair, w, c):
+        ctx.save_for_backward(pair, w)
+        with torch.no_grad():
+            return ops.pair_bias(pair.detach().contiguous(), w, c)
+
+    @staticmethod
+    def backward(ctx, dbias):
+        pair, w = ctx.saved_tensors
+        P, H = pair.shape[-1], w.shape[0]
+        with torch.no_grad():
+            x2 = pair.detach().contiguous().view(-1, P)
+            d2 = dbias.permute(0, 2, 3, 1).contiguous().view(-1, H)           # [rows, H]
+            dxn = d2 @ w                                                      # [rows, P]: K = H = 4, not a matrix-pipe shape
+            dx = ops.ln_rows_bwd(dxn, x2)
+            dw, dc = ops.linear_wgrad(d2, ops.layer_norm(x2), bias=True)
+        return dx.view_as(pair), dw, dc
+
+
+class OuterLinearFn(torch.autograd.Function):
+    """OuterLinear (modules.py:283-287) in the split form out[i,j] = W1 (x_i * x_j) + u_i - u_j + c, x = LN(single), u = W2 x.
+    Forward: the HIP kernels of the inference path.  Backward without re-running the forward and without a [b,N,N,S] tensor:
+    T[b,i,p,s] = sum_j (dy[b,i,j,p] + dy[b,j,i,p]) x[b,j,s] (one batched GEMM), dx = sum_p W1[p,s] T + du W2,
+    dW1 = 1/2 sum_{b,i} x T, du = sum_j dy[i,j] - sum_j dy[j,i], dW2 = du^T x, dc = sum dy, dsingle = LN'(dx; single)."""
+
+    @staticmethod
+    def forward(ctx, single, w, c, fwd):
+        ctx.save_for_backward(single, w)
+        with torch.no_grad():
+            return fwd(single.detach(), w, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        single, w = ctx.saved_tensors
+        b, N, S = single.shape
+        P = w.shape[0]
+        with torch.no_grad():
+            s2 = single.detach().contiguous()
+            x = ops.layer_norm(s2)
+            w1, w2 = w[:, :S], w[:, S:]
+            dyt = dy.transpose(1, 2)
+            dsym = (dy + dyt).permute(0, 1, 3, 2).reshape(b, N * P, N)
+            T = torch.bmm(dsym, x).view(b, N, P, S)
+            du = dy.sum(2) - dy.sum(1)                                          # [b, N, P]
+            dx = (T * w1).sum(dim=2) + du @ w2
+            dw1 = 0.5 * (T * x.unsqueeze(2)).sum(dim=(0, 1))
+            dw2 = du.reshape(-1, P).t() @ x.reshape(-1, S)
+            dc = dy.sum(dim=(0, 1, 2))
+            dsingle = ops.ln_rows_bwd(dx.reshape(-1, S).contiguous(), s2.view(-1, S)).view_as(single)
+        return dsingle, torch.cat([dw1, dw2], dim=1), dc, None
 
 
 class TriMulFn(torch.autograd.Function):
@@ -182,7 +239,11 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
     sa, H, c = blk.single_attn, blk.single_attn.num_heads, blk.single_attn.head_dim
     wb, bb = blk.attn_bias[1].weight, blk.attn_bias[1].bias
 
-    bias = HipOp.apply(lambda p, w, b: ops.pair_bias(p.contiguous(), w, b), R.pair_bias, pair, wb, bb)
+    big = pair.is_cuda and pair.numel() // pair.shape[-1] >= ops.WGRAD_MIN_ROWS and LIBRARY_BWD
+    if big:
+        bias = PairBiasFn.apply(pair, wb, bb)
+    else:
+        bias = HipOp.apply(lambda p, w, b: ops.pair_bias(p.contiguous(), w, b), R.pair_bias, pair, wb, bb)
 
     def sa_ref(x, bias_, *w):
         return R.gated_attention(x, mask, *w, H, c, bias=bias_)
@@ -209,7 +270,10 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
         ops.gemm(xn, w, u, bsz * n, ol.pair_dim, S, S, 2 * S, ol.pair_dim, b_off=S)
         return ops.outer_linear_pair(out, xn, u, w, b, residual=False, out=out)
 
-    pair = pair + HipOp.apply(ol_hip, R.outer_linear, single, ol.linear.weight, ol.linear.bias)
+    if big:
+        pair = pair + OuterLinearFn.apply(single, ol.linear.weight, ol.linear.bias, ol_hip)
+    else:
+        pair = pair + HipOp.apply(ol_hip, R.outer_linear, single, ol.linear.weight, ol.linear.bias)
 
     for tm in (blk.pair_mul_outgoing, blk.pair_mul_incoming):
         pair = pair + tri_mul_update(tm, pair, mask)
@@ -219,7 +283,7 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
 
     pf = blk.pair_fc
     pfw = (pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias)
-    if pair.is_cuda and pair.numel() // pair.shape[-1] >= ops.WGRAD_MIN_ROWS and PAIR_TRANSITION_BWD:
+    if big:
         pair = pair + PairTransitionFn.apply(pair, *pfw)
     else:
         pair = pair + HipOp.apply(lambda x, *w: ops.pair_transition(x.contiguous(), *w, residual=False),
