@@ -158,6 +158,30 @@ class _OuterProduct(torch.autograd.Function):
         return dx, dw1
 
 
+class _OuterProductAB(torch.autograd.Function):
+    """prod[b,i,j,p] = sum_s a[b,i,s] bb[b,j,s] wo[p,s] (the outer-product update's a_i (x) b_j -> Linear, AF2_modules.py:532-545)
+    without the [b,N,N,S] intermediate: forward and backward as batched GEMMs over the N P rows of a batch element.
+    T1[b,i,p,s] = sum_j dy[b,i,j,p] bb[b,j,s]: da = sum_p wo T1, dwo = sum_{b,i} a T1;  T2[b,j,p,s] = sum_i dy[b,i,j,p] a[b,i,s]:
+    dbb = sum_p wo T2."""
+
+    @staticmethod
+    def forward(ctx, a, bb, wo):
+        ctx.save_for_backward(a, bb, wo)
+        b, N, S = a.shape
+        P = wo.shape[0]
+        aw = (a.unsqueeze(2) * wo).view(b, N * P, S)                    # [b, (i,p), s]
+        return torch.bmm(aw, bb.transpose(1, 2)).view(b, N, P, N).permute(0, 1, 3, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, bb, wo = ctx.saved_tensors
+        b, N, S = a.shape
+        P = wo.shape[0]
+        T1 = torch.bmm(dy.permute(0, 1, 3, 2).reshape(b, N * P, N), bb).view(b, N, P, S)
+        T2 = torch.bmm(dy.permute(0, 2, 3, 1).reshape(b, N * P, N), a).view(b, N, P, S)
+        return (T1 * wo).sum(dim=2), (T2 * wo).sum(dim=2), (T1 * a.unsqueeze(2)).sum(dim=(0, 1))
+
+
 def outer_linear(single, w, b):
     """modules.py:283-287 in the split form W1 (x_i * x_j) + W2 x_i - W2 x_j + b (no [N,N,2S] concat)."""
     x = ln(single)
@@ -178,7 +202,7 @@ def outer_product_update(single, mask, g, bta, w1, b1, w2, b2, wo, bo):
     x = ln(single, g, bta)
     m = mask.unsqueeze(-1)
     a, b = F.linear(x, w1, b1) * m, F.linear(x, w2, b2) * m
-    outer = linear(a.unsqueeze(2) * b.unsqueeze(1), wo, bo)
+    outer = _OuterProductAB.apply(a, b, wo) + bo
     m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
     return m2 * (outer / (m2 + 1e-3))
 
