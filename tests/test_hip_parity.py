@@ -315,7 +315,8 @@ def test_triangle_attention(setup, mode, gemm_mode):
 
 @pytest.mark.parametrize("ending", [False, True])
 @pytest.mark.parametrize("b,N,valid", [(1, 320, 320), (2, 140, 131), (1, 33, 33), (1, 97, 64), (3, 200, 200), (1, 352, 340), (1, 31, 17),
-                                       (1, 384, 384), (2, 288, 280), (2, 449, 440), (1, 640, 640), (1, 832, 800), (1, 1024, 1000)])
+                                       (1, 384, 384), (2, 288, 280), (1, 416, 390), (2, 449, 440), (1, 640, 640), (1, 768, 768), (1, 832, 800),
+                                       (1, 1024, 1000)])
 def test_triangle_attention_core_v2(setup, b, N, valid, ending):
     """Second-generation core (prd_tri2.hip: 32x32x16 MFMA, fp16 hi+lo rounded to nearest, work cut into contiguous ranges per
     wave) called directly: the whole og tensor against the first-generation core in fp32-MFMA mode (a different kernel, exact
