@@ -2380,10 +2380,12 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     PRD_CHAIN_STAGE_OK();
-    // 3. output stage of the outgoing module + a | b of the incoming one
+    // 3. output stage of the outgoing module + a | b of the incoming one.  P = 64: 12 waves (168 VGPRs, three per SIMD) cover the
+    // task's latency chain better than 8 (36.6 -> 31.7 us at N = 320; the plain output stage below needs 192 VGPRs and stays at 8:
+    // 12 waves spill, 19.9 -> 28.7 us)
     if (P == 64) {
-        PRD_SET_LDS((tri_mul_out_proj_kernel<64, 8>), ldsf);
-        hipLaunchKernelGGL((tri_mul_out_proj_kernel<64, 8>), dim3(rgrid), dim3(8 * 64), ldsf, stream, pair, O, mask, wa[4], wa[5], wa[6], wa[7],
+        PRD_SET_LDS((tri_mul_out_proj_kernel<64, 12>), ldsf);
+        hipLaunchKernelGGL((tri_mul_out_proj_kernel<64, 12>), dim3(rgrid), dim3(12 * 64), ldsf, stream, pair, O, mask, wa[4], wa[5], wa[6], wa[7],
                            wb[0], wb[1], wb[2], wb[3], AB, b, N, ldn);
     } else {
         PRD_SET_LDS((tri_mul_out_proj_kernel<32, 8>), ldsf);
