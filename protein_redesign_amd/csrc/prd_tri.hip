@@ -434,9 +434,9 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
 // sixteen lanes of a ds_read_b128 group (rows distinct mod 16, same logical slot) hit sixteen different 4-bank groups.
 constexpr int TMS_T = 160, TMS_PLANE = TMS_T * 64, TMS_OPER = 2 * TMS_PLANE;       // bytes
 // waves per workgroup of the split contraction: 8 by default; 16 (PRD_TMS_NW=16) makes the kernel itself 1 us faster (18.8 vs
-// 19.8 us) but the whole step 15 us slower in the same run (1.932 vs 1.918 ms, twice) -- kept as a tuning knob only
+// 19.8 us) but the whole step 15 us slower in the same run (1.932 vs 1.918 ms, twice); 12 waves: 22.5 vs 22.7 us -- tuning knobs only
 static int tms_nw() {
-    static const int v = [] { const char* e = getenv("PRD_TMS_NW"); return (e && atoi(e) == 16) ? 16 : 8; }();
+    static const int v = [] { const char* e = getenv("PRD_TMS_NW"); const int n = e ? atoi(e) : 8; return (n == 16 || n == 12) ? n : 8; }();
     return v;
 }
 template <int NWV>                                  // 8 or 16 waves: 25 sub-tiles dealt round-robin, 4 or 2 accumulators per wave
@@ -2297,6 +2297,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
             const int vb3 = b * P * tl * tl;
             const size_t lds3 = (size_t)4 * TMS_OPER;
                         if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
         }
         else
@@ -2329,6 +2330,7 @@ extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int
         const int vb3 = b * P * tl * tl;
         const size_t lds3 = (size_t)4 * TMS_OPER;
                 if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     } else {
         const int tiles = prd_ceil_div(N, 64);
@@ -2378,6 +2380,7 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     PRD_CHAIN_STAGE_OK();
     // 2. its contraction, transposed: O^T[c][j][i]
     if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
+    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     PRD_CHAIN_STAGE_OK();
     // 3. output stage of the outgoing module + a | b of the incoming one.  P = 64: 12 waves (168 VGPRs, three per SIMD) cover the
@@ -2395,6 +2398,7 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     PRD_CHAIN_STAGE_OK();
     // 4. contraction of the incoming module
     if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     PRD_CHAIN_STAGE_OK();
     // 5. its output stage
