@@ -1,3 +1,8 @@
+#!/usr/bin/env python
+"""Per-segment deviations of the N = 320 / T = 1000 loop (tests/golden/cfg2_t1000.npz): every 25-step segment restarted from the
+reference's own state, in both arithmetics, against the fp32 reference's next stored state, and the two arithmetics against each
+other.  GPU box:  python tools/segment_probe.py   (the bound of tests/test_hip_parity.py::test_trajectory_segments_vs_reference_golden
+comes from oracle/gen_yardstick.py --segments: the fp64 reference over the same segments)."""
 import sys, os, json, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from protein_redesign_amd import _lib
