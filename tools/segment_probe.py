@@ -4,7 +4,8 @@ reference's own state, in both arithmetics, against the fp32 reference's next st
 other.  GPU box:  python tools/segment_probe.py   (the bound of tests/test_hip_parity.py::test_trajectory_segments_vs_reference_golden
 comes from oracle/gen_yardstick.py --segments: the fp64 reference over the same segments)."""
 import sys, os, json, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); os.chdir(ROOT)
 from protein_redesign_amd import _lib
 from protein_redesign_amd.constants import make_args
 from protein_redesign_amd.diffusion_model import ProteinReDiffModel, ReverseDiffusion
