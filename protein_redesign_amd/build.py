@@ -93,5 +93,5 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--asan" in sys.argv:
         exe = build_asan()
-        sys.exit(subprocess.call([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")))
+        sys.exit(subprocess.call([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")))
     build(force="--force" in sys.argv)

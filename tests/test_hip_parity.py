@@ -776,6 +776,23 @@ def test_long_sequence_step_vs_oracle(na, nr, gemm_mode):
     assert rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
 
 
+_CFG4_ORACLE = {}
+
+
+def test_long_sequence_four_blocks_vs_oracle(gemm_mode):
+    """BASELINE configs[4] at its own depth: N = 769 and all FOUR folding blocks (the graph `bench.py --residues 768 --atoms 1`
+    replays) against the oracle; the oracle's step is evaluated once and shared by the two arithmetic modes."""
+    args, model, params, pb, z, seq_t, t = _full_size_case(1, 768, 4, seed=11)
+    with torch.inference_mode():
+        if "want" not in _CFG4_ORACLE:
+            _CFG4_ORACLE["want"] = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
+        want = _CFG4_ORACLE["want"]
+        dpb = batch_to(pb, DEV)
+        got = model.sample_step(dpb, cu(z), cu(seq_t), dpb["residue_and_atom_mask"], cu(t))
+    assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2
+    assert rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
+
+
 @pytest.mark.parametrize("mode", ["starting", "ending"])
 @pytest.mark.parametrize("N,valid", [(449, 449), (640, 611), (769, 750), (961, 961), (1000, 975), (1961, 1930)])
 def test_triangle_attention_long_rows(setup, mode, N, valid, gemm_mode):

@@ -198,6 +198,6 @@ def test_c_abi_argument_checks_under_asan():
         pytest.skip("hipcc not available")
     from protein_redesign_amd.build import build_asan
     exe = build_asan(verbose=False)
-    out = subprocess.run([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = subprocess.run([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = out.stdout.decode(errors="replace")
     assert out.returncode == 0 and "host ABI check: OK" in text and "AddressSanitizer" not in text, text[-2000:]
