@@ -193,49 +193,97 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
         zero_acc(adx);
         u32x4 xs[2][P / 16];
         if (B3) split2h_cll<KH>(x, xs);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {            // h = 0: the a operand (output channels 0 .. P-1), h = 1: the b operand
-            f32x16 ap[NB], ag[NB];
-            zero_acc(ap);
-            zero_acc(ag);
-            if (B3) {
-                rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wpl), OUT, h * P, xs, ap, r, hi);
-                rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wgl), OUT, h * P, xs, ag, r, hi);
-            } else {
-                rowgemm<P, NB>(Wpl + h * P * (P + 4), x, ap, r, hi);
-                rowgemm<P, NB>(Wgl + h * P * (P + 4), x, ag, r, hi);
+        if constexpr (B3) {
+            // dAB through a buffer descriptor: the lane part of the address once, the channel stride as a scalar offset (64
+            // scattered 64-bit address computations per task otherwise)
+            const prd_rsrc rdab = make_rsrc(dAB + (((long)bb * OUT) * N + u) * ldn + vb * 32);
+            const unsigned cbytes = (unsigned)N * (unsigned)ldn * 4u;
+            const unsigned lo_dab = valid ? (unsigned)r * 4u + (unsigned)(4 * hi) * cbytes : BUF_OOB;
+            // Split form: one 32-channel block (16 CLL elements per lane) of one operand at a time.  The whole-operand form below
+            // keeps ap, ag, dpp, dpg and both split copies of 32 elements alive next to x, its split and adx: > 256 VGPRs, 592 bytes
+            // of scratch per lane at P = 64.
+#define PRD_PB_PART(H_, NB_)                                                                                            \
+            {                                                                                                           \
+                __builtin_amdgcn_sched_barrier(0);      /* no loads / LDS reads of this part hoisted into the previous one */ \
+                f32x16 ap1[1], ag1[1];                                                                                  \
+                zero_acc(ap1);                                                                                          \
+                zero_acc(ag1);                                                                                          \
+                rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wpl), OUT, (H_) * P + (NB_) * 32, xs, ap1, r, hi);      \
+                rowgemm_h2<P, 1>(reinterpret_cast<const u32x4*>(Wgl), OUT, (H_) * P + (NB_) * 32, xs, ag1, r, hi);      \
+                float dpp[16], dpg[16];                                                                                 \
+                _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                        \
+                    const int s_ = 16 * (NB_) + q;                                                                      \
+                    const float dab = buf_load(rdab, lo_dab, (unsigned)((H_) * P + 8 * (s_ >> 2) + (s_ & 3)) * cbytes); \
+                    const float pp = ap1[0][q] * ASC + bpl[hi * P + (H_) * KH + s_];                                    \
+                    const float sg = sigmoidf_(ag1[0][q] * ASC + bgl[hi * P + (H_) * KH + s_]);                         \
+                    dpp[q] = dab * m2 * sg;                                                                             \
+                    dpg[q] = dab * m2 * pp * sg * (1.0f - sg);                                                          \
+                }                                                                                                       \
+                if (valid) {        /* CLL elements 16 nb .. +15 = four 16-byte groups of the row: channels 32 nb + 8 g + 4 hi */ \
+                    float* d0 = dpp_out + prow * OUT + (H_) * P + 32 * (NB_) + 4 * hi;                                  \
+                    float* d1 = dpg_out + prow * OUT + (H_) * P + 32 * (NB_) + 4 * hi;                                  \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                     \
+                        *reinterpret_cast<float4*>(d0 + 8 * g) = make_float4(dpp[4 * g], dpp[4 * g + 1], dpp[4 * g + 2], dpp[4 * g + 3]); \
+                        *reinterpret_cast<float4*>(d1 + 8 * g) = make_float4(dpg[4 * g], dpg[4 * g + 1], dpg[4 * g + 2], dpg[4 * g + 3]); \
+                    }                                                                                                   \
+                }                                                                                                       \
+                u32x4 ps[2][2], gs[2][2];                                                                               \
+                split2h_cll<16>(dpp, ps);                                                                               \
+                split2h_cll<16>(dpg, gs);                                                                               \
+                constexpr int S0_ = (H_) * (KH / 8) + 2 * (NB_);      /* K steps of 16 on the 2P-wide K axis of W^T */   \
+                rowgemm_h2_part<OUT, NB, S0_, S0_ + 2>(reinterpret_cast<const u32x4*>(WpTl), P, 0, ps, adx, r, hi);     \
+                rowgemm_h2_part<OUT, NB, S0_, S0_ + 2>(reinterpret_cast<const u32x4*>(WgTl), P, 0, gs, adx, r, hi);     \
             }
-            float dpp[KH], dpg[KH];
+            PRD_PB_PART(0, 0)
+            if constexpr (NB == 2) PRD_PB_PART(0, 1)
+            PRD_PB_PART(1, 0)
+            if constexpr (NB == 2) PRD_PB_PART(1, 1)
+#undef PRD_PB_PART
+        } else {
 #pragma unroll
-            for (int s = 0; s < KH; ++s) {
-                const int ch = h * P + cll_ch(s, hi);
-                const float dab = valid ? dAB[(((long)bb * OUT + ch) * N + u) * ldn + vv] : 0.f;
-                const float pp = ap[s >> 4][s & 15] * ASC + bpl[hi * P + h * KH + s];
-                const float sg = sigmoidf_(ag[s >> 4][s & 15] * ASC + bgl[hi * P + h * KH + s]);
-                dpp[s] = dab * m2 * sg;
-                dpg[s] = dab * m2 * pp * sg * (1.0f - sg);
-            }
-            // kept for the weight-gradient GEMMs: row layout [pair position][2P], this half at columns h P ..
-            store_row_cll<P>(dpp_out + prow * OUT + h * P, hi, valid, dpp);
-            store_row_cll<P>(dpg_out + prow * OUT + h * P, hi, valid, dpg);
-            // dx += Wp[h]^T dpp + Wg[h]^T dpg: the half is CLL elements [32 h, 32 h + 32) of the 2P-wide K axis = groups [8h, 8h+8)
-            if (B3) {                            // K steps of 16 (8 per lane): the half is steps [KH/8 h, KH/8 (h + 1)) of the 2P-wide K axis
-                u32x4 ps[2][KH / 8], gs[2][KH / 8];
-                split2h_cll<KH>(dpp, ps);
-                split2h_cll<KH>(dpg, gs);
-                if (h == 0) {
-                    rowgemm_h2_part<OUT, NB, 0, KH / 8>(reinterpret_cast<const u32x4*>(WpTl), P, 0, ps, adx, r, hi);
-                    rowgemm_h2_part<OUT, NB, 0, KH / 8>(reinterpret_cast<const u32x4*>(WgTl), P, 0, gs, adx, r, hi);
+            for (int h = 0; h < 2; ++h) {            // h = 0: the a operand (output channels 0 .. P-1), h = 1: the b operand
+                f32x16 ap[NB], ag[NB];
+                zero_acc(ap);
+                zero_acc(ag);
+                if (B3) {
+                    rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wpl), OUT, h * P, xs, ap, r, hi);
+                    rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(Wgl), OUT, h * P, xs, ag, r, hi);
                 } else {
-                    rowgemm_h2_part<OUT, NB, KH / 8, KH / 4>(reinterpret_cast<const u32x4*>(WpTl), P, 0, ps, adx, r, hi);
-                    rowgemm_h2_part<OUT, NB, KH / 8, KH / 4>(reinterpret_cast<const u32x4*>(WgTl), P, 0, gs, adx, r, hi);
+                    rowgemm<P, NB>(Wpl + h * P * (P + 4), x, ap, r, hi);
+                    rowgemm<P, NB>(Wgl + h * P * (P + 4), x, ag, r, hi);
                 }
-            } else if (h == 0) {
-                rowgemm_part<OUT, NB, 0, KH / 4>(WpTl, dpp, adx, r, hi);
-                rowgemm_part<OUT, NB, 0, KH / 4>(WgTl, dpg, adx, r, hi);
-            } else {
-                rowgemm_part<OUT, NB, KH / 4, KH / 2>(WpTl, dpp, adx, r, hi);
-                rowgemm_part<OUT, NB, KH / 4, KH / 2>(WgTl, dpg, adx, r, hi);
+                float dpp[KH], dpg[KH];
+    #pragma unroll
+                for (int s = 0; s < KH; ++s) {
+                    const int ch = h * P + cll_ch(s, hi);
+                    const float dab = valid ? dAB[(((long)bb * OUT + ch) * N + u) * ldn + vv] : 0.f;
+                    const float pp = ap[s >> 4][s & 15] * ASC + bpl[hi * P + h * KH + s];
+                    const float sg = sigmoidf_(ag[s >> 4][s & 15] * ASC + bgl[hi * P + h * KH + s]);
+                    dpp[s] = dab * m2 * sg;
+                    dpg[s] = dab * m2 * pp * sg * (1.0f - sg);
+                }
+                // kept for the weight-gradient GEMMs: row layout [pair position][2P], this half at columns h P ..
+                store_row_cll<P>(dpp_out + prow * OUT + h * P, hi, valid, dpp);
+                store_row_cll<P>(dpg_out + prow * OUT + h * P, hi, valid, dpg);
+                // dx += Wp[h]^T dpp + Wg[h]^T dpg: the half is CLL elements [32 h, 32 h + 32) of the 2P-wide K axis = groups [8h, 8h+8)
+                if (B3) {                            // K steps of 16 (8 per lane): the half is steps [KH/8 h, KH/8 (h + 1)) of the 2P-wide K axis
+                    u32x4 ps[2][KH / 8], gs[2][KH / 8];
+                    split2h_cll<KH>(dpp, ps);
+                    split2h_cll<KH>(dpg, gs);
+                    if (h == 0) {
+                        rowgemm_h2_part<OUT, NB, 0, KH / 8>(reinterpret_cast<const u32x4*>(WpTl), P, 0, ps, adx, r, hi);
+                        rowgemm_h2_part<OUT, NB, 0, KH / 8>(reinterpret_cast<const u32x4*>(WgTl), P, 0, gs, adx, r, hi);
+                    } else {
+                        rowgemm_h2_part<OUT, NB, KH / 8, KH / 4>(reinterpret_cast<const u32x4*>(WpTl), P, 0, ps, adx, r, hi);
+                        rowgemm_h2_part<OUT, NB, KH / 8, KH / 4>(reinterpret_cast<const u32x4*>(WgTl), P, 0, gs, adx, r, hi);
+                    }
+                } else if (h == 0) {
+                    rowgemm_part<OUT, NB, 0, KH / 4>(WpTl, dpp, adx, r, hi);
+                    rowgemm_part<OUT, NB, 0, KH / 4>(WgTl, dpg, adx, r, hi);
+                } else {
+                    rowgemm_part<OUT, NB, KH / 4, KH / 2>(WpTl, dpp, adx, r, hi);
+                    rowgemm_part<OUT, NB, KH / 4, KH / 2>(WgTl, dpg, adx, r, hi);
+                }
             }
         }
         float dx[KH];
