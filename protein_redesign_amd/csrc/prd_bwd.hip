@@ -96,9 +96,16 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
 #pragma unroll
             for (int s = 0; s < KH; ++s) g[s] = sigmoidf_(ag[s >> 4][s & 15] + bgl[hi * KH + s]);
         }
+        // O / dO through buffer descriptors: the lane part of the address once, the channel stride as a scalar offset (as the
+        // forward's tri_mul_out_kernel; 64 scattered 64-bit address computations per task otherwise)
+        const unsigned cbytes = (unsigned)N * (unsigned)ldn * 4u;
+        const unsigned lane_o = valid ? (unsigned)r * 4u + (unsigned)(4 * hi) * cbytes : BUF_OOB;
         float lo[KH];
+        {
+            const prd_rsrc ro = make_rsrc(O + (((long)bb * P) * N + i) * ldn + vb * 32);
 #pragma unroll
-        for (int s = 0; s < KH; ++s) lo[s] = valid ? O[(((long)bb * P + cll_ch(s, hi)) * N + i) * ldn + jj] : 0.f;
+            for (int s = 0; s < KH; ++s) lo[s] = buf_load(ro, lane_o, (unsigned)(8 * (s >> 2) + (s & 3)) * cbytes);
+        }
         const float rstd_o = ln_cll_rstd<KH>(lo);
         float dz[KH], dgp[KH];
         {
@@ -124,9 +131,10 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
 #pragma unroll
             for (int s = 0; s < KH; ++s) dlo[s] = a[s >> 4][s & 15];
             ln_cll_bwd<KH>(dlo, lo, rstd_o);
-            if (valid) {
+            {
+                const prd_rsrc rdo = make_rsrc(dO + (((long)bb * P) * N + i) * ldn + vb * 32);
 #pragma unroll
-                for (int s = 0; s < KH; ++s) dO[(((long)bb * P + cll_ch(s, hi)) * N + i) * ldn + jj] = dlo[s];
+                for (int s = 0; s < KH; ++s) buf_store(dlo[s], rdo, lane_o, (unsigned)(8 * (s >> 2) + (s & 3)) * cbytes);
             }
         }
         {   // gate path of dx
