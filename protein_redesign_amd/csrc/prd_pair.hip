@@ -963,7 +963,14 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
         pt.mark(4);                                     // 4: epilogue + store issue
         if (bias_out) {
             ln_cll<KH>(raw);
-            const long bb = pos / nn, rem = pos - bb * nn;
+            // batch element / position inside it: the 64-bit division once per TASK on the scalar unit (the task id is wave-uniform),
+            // a compare per lane -- not a 64-bit VALU division per lane
+            const long pos0 = task * 32;
+            const long bb0 = pos0 / nn;
+            long rem = pos0 - bb0 * nn + r;
+            long bbl = bb0;
+            if (rem >= nn) { rem -= nn; ++bbl; }
+            float* bo_ = bias_out + (bbl * H) * nn + rem;
             for (int h = 0; h < H; ++h) {
                 const float4* wv = reinterpret_cast<const float4*>(wbl + h * P + hi * KH);      // 16-byte LDS reads, two addresses per wave
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
                 }
                 float a = xhalf_sum((a0 + a1) + (a2 + a3));
                 if (bb_) a += bb_[h];
-                if (valid && hi == 0) bias_out[(bb * H + h) * nn + rem] = a;
+                if (valid && hi == 0) bo_[(long)h * nn] = a;
             }
         }
         pt.mark(5);                                     // 5: next block's attention bias
