@@ -347,7 +347,8 @@ __global__ __launch_bounds__(WG) void pair_bias_kernel(float* __restrict__ out, 
         float xn[KH];
         load_row_cll<P>(pair + pos * P, hi, valid, xn);
         ln_cll<KH>(xn);
-        const long bb = pos / nn, rem = pos - bb * nn;
+        long bb = (task * 32) / nn, rem = task * 32 - bb * nn + r;       // the division on the scalar unit (wave-uniform task), not per lane
+        if (rem >= nn) { rem -= nn; ++bb; }
 #pragma unroll
         for (int set = 0; set < 2; ++set) {
             if (set == 1 && !out2) break;
