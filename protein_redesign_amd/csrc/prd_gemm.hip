@@ -709,9 +709,8 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
         }
         return (int)hipGetLastError();
     }
-    // gemm mode 1, latency-bound node-row linears (fewer 64x64 tiles than that): 32x32 tiles with a deep operand ring; also the
-    // batched [N, K] x [N, K]^T products without LayerNorm (SPAttention's per-head logits: 16.0 -> 13.0 us)
-    if (g.arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 && (batches == 1 || (!g.a_ln && !g.ln_out))) {
+    // gemm mode 1, latency-bound node-row linears (fewer 64x64 tiles than that): 32x32 tiles with a deep operand ring
+    if (g.arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 && batches == 1) {
         const int nch = g.K / 64;
         dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
         const bool many = (long)grid.x * grid.y > 1024;         // throughput regime: one group per workgroup, more workgroups per CU
