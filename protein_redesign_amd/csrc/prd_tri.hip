@@ -2194,9 +2194,11 @@ extern "C" int prd_tri_attn_variant(int N, int P, int arith) {
     bool long_row;
     const bool b3 = arith == PRD_ARITH_SPLIT16;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
+    const bool v2 = b3 && ta_variant_env() == 0 && prd_tri_attn_v2_supported(N, P);      // what prd_tri_attn_core dispatches to first
     if (lds > 160 * 1024)                      // the round-3 core keeps K / V as fp16 planes: rows up to 1024; beyond: key-chunked
-        return (b3 && ta_variant_env() == 0 && prd_tri_attn_v2_supported(N, P)) ? 2 : 3;
+        return v2 ? 2 : 3;
     if (!long_row) return 0;
+    if (v2) return 2;                          // long rows on the round-3 core (also where the fp32 long-row kernel would fit)
     const int npad = prd_round_up(N, 64);
     return (b3 && lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096) ? 2 : 1;
 }

@@ -54,7 +54,7 @@ int main(void) {
     EXPECT(prd_tri_attn_variant(320, 64, A1), 0);
     EXPECT(prd_tri_attn_variant(769, 64, A1), 2);       /* split-16: the split-operand long-row kernel */
     EXPECT(prd_tri_attn_variant(769, 64, A0), 1);
-    EXPECT(prd_tri_attn_variant(900, 64, A1), 1);
+    EXPECT(prd_tri_attn_variant(900, 64, A1), 2);                   /* split-16: the round-3 long-row core (K / V as fp16 planes) */
     EXPECT(prd_tri_attn_variant(100000, 64, A1), 3);                 /* any row length: key-chunked */
     EXPECT(prd_tri_attn_variant(320, 48, A1), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_variant(320, 64, 2), PRD_ERR_ARG);
@@ -94,7 +94,8 @@ int main(void) {
     EXPECT(prd_tri_attn_v2_form(352, 64), 1);                       /* 11 blocks, three shared: the second buffer does not fit */
     EXPECT(prd_tri_attn_v2_form(769, 64), 3);
     EXPECT(prd_tri_attn_v2_form(1100, 64), 0);
-    EXPECT(prd_tri_attn_variant(960, 64, A1), 1);                   /* last length whose K / V fit the LDS (fp32 long-row kernel) */
+    EXPECT(prd_tri_attn_variant(960, 64, A1), 2);
+    EXPECT(prd_tri_attn_variant(960, 64, A0), 1);                   /* last length whose K / V fit the LDS in fp32 (fp32 long-row kernel) */
     EXPECT(prd_tri_attn_variant(961, 64, A0), 3);                   /* fp32 arithmetic: key-chunked */
     EXPECT(prd_tri_attn_variant(961, 64, A1), 2);                   /* split-16: K / V as fp16 planes fit up to N = 1024 */
     EXPECT(prd_tri_attn_variant(1024, 64, A1), 2);

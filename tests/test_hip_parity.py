@@ -776,6 +776,36 @@ def test_long_sequence_step_vs_oracle(na, nr, gemm_mode):
     assert rel_l2(got[1].cpu(), want[1]) < BLOCK_TOL * 2
 
 
+@pytest.mark.parametrize("ending", [False, True])
+def test_chunked_and_resident_long_row_cores_agree(setup, ending):
+    """b = 2 ragged complexes of N = 1000: the key-chunked fp32 kernel (two chunks of 512 / 488 keys merged by their softmax
+    statistics) against the split-16 long-row core that keeps K / V of the whole row resident -- two different kernels and
+    arithmetics, the WHOLE og tensor (every row of both batch elements, masked tail in the second)."""
+    from protein_redesign_amd import _lib
+    s = setup
+    P = s["P"]
+    H, c = s["args"]["num_heads"], s["args"]["head_dim"]
+    b, N = 2, 1000
+    g = torch.Generator().manual_seed(4242 + int(ending))
+    pair = torch.randn(b, N, N, P, generator=g)
+    mask = torch.ones(b, N)
+    mask[1, 930:] = 0
+    mod = s["model"].Denoiser.folding_blocks[0].pair_attn_ending if ending else s["model"].Denoiser.folding_blocks[0].pair_attn_starting
+    wts = [t.clone() for t in mod.attn.weights()][:5]
+    prev = _lib.lib().prd_get_gemm_mode()
+    try:
+        assert _lib.lib().prd_set_gemm_mode(0) == 0
+        assert ops.tri_attn_variant(N, P) == 3 or P == 32          # (P = 32: the fp32 long-row kernel still holds 1000 keys)
+        chunked = ops.tri_attn_core(cu(pair), cu(mask), wts, H, c, ending=ending)
+        assert _lib.lib().prd_set_gemm_mode(1) == 0
+        assert ops.tri_attn_variant(N, P) == 2
+        resident = ops.tri_attn_core(cu(pair), cu(mask), wts, H, c, ending=ending)
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+    assert torch.isfinite(chunked).all() and torch.isfinite(resident).all()
+    assert rel_l2(resident.cpu(), chunked.cpu()) < OP_TOL
+
+
 _CFG4_ORACLE = {}
 
 
