@@ -33,6 +33,9 @@ USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
 # 0: the backward of the pair transition, the attention bias and the outer-linear through the torch restatement (HipOp), as in
 # round 2 -- A/B measurements only
 LIBRARY_BWD = os.environ.get("PRD_LIBRARY_BWD", "1") != "0"
+# 1: the residual adds of a folding block's pair updates ride in the kernels' own residual paths (pair + update written by the
+# operator, dy added to its input gradient) instead of eight torch adds over the pair tensor per block; 0: A/B measurements
+FUSED_RESIDUAL = os.environ.get("PRD_TRAIN_FUSED_RESIDUAL", "1") != "0"
 
 
 class HipOp(torch.autograd.Function):
@@ -69,10 +72,11 @@ class PairTransitionFn(torch.autograd.Function):
     dx = LN'(dLN; x) (prd_ln_rows_bwd), dW2 | db2 = dy^T h, dW1 | db1 = g^T LN(x) (prd_linear_wgrad slab reductions)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, residual=False):
         ctx.save_for_backward(x, w1, b1, w2, b2)
+        ctx.residual = residual
         with torch.no_grad():
-            return ops.pair_transition(x.detach().contiguous(), w1, b1, w2, b2, residual=False)
+            return ops.pair_transition(x.detach().contiguous(), w1, b1, w2, b2, residual=residual)
 
     @staticmethod
     def backward(ctx, dy):
@@ -89,7 +93,10 @@ class PairTransitionFn(torch.autograd.Function):
             dw2, db2 = ops.linear_wgrad(dy2, h, bias=True)
             xn = ops.layer_norm(x2)
             dw1, db1 = ops.linear_wgrad(g, xn, bias=True)
-        return dx.view_as(x), dw1, db1, dw2, db2
+            dx = dx.view_as(x)
+            if ctx.residual:
+                dx = dx.add_(dy)
+        return dx, dw1, db1, dw2, db2, None
 
 
 class PairBiasFn(torch.autograd.Function):
@@ -122,10 +129,11 @@ class OuterLinearFn(torch.autograd.Function):
     dW1 = 1/2 sum_{b,i} x T, du = sum_j dy[i,j] - sum_j dy[j,i], dW2 = du^T x, dc = sum dy, dsingle = LN'(dx; single)."""
 
     @staticmethod
-    def forward(ctx, single, w, c, fwd):
+    def forward(ctx, single, w, c, fwd, pair=None):
         ctx.save_for_backward(single, w)
+        ctx.residual = pair is not None            # with ``pair``: returns pair + update (the kernel's residual path)
         with torch.no_grad():
-            return fwd(single.detach(), w, c)
+            return fwd(single.detach(), w, c) if pair is None else fwd(single.detach(), w, c, pair.detach().contiguous())
 
     @staticmethod
     def backward(ctx, dy):
@@ -145,7 +153,7 @@ class OuterLinearFn(torch.autograd.Function):
             dw2 = du.reshape(-1, P).t() @ x.reshape(-1, S)
             dc = dy.sum(dim=(0, 1, 2))
             dsingle = ops.ln_rows_bwd(dx.reshape(-1, S).contiguous(), s2.view(-1, S)).view_as(single)
-        return dsingle, torch.cat([dw1, dw2], dim=1), dc, None
+        return dsingle, torch.cat([dw1, dw2], dim=1), dc, None, (dy if ctx.residual else None)
 
 
 class TriMulFn(torch.autograd.Function):
@@ -154,14 +162,15 @@ class TriMulFn(torch.autograd.Function):
     reductions (tall-skinny GEMMs over all N^2 rows) go through the BLAS library.  Nothing is recomputed in torch ops."""
 
     @staticmethod
-    def forward(ctx, pair, mask, incoming: bool, *wts):
+    def forward(ctx, pair, mask, incoming: bool, residual: bool, *wts):
         ctx.incoming = incoming
+        ctx.residual = residual                    # True: returns pair + update from the kernel's own residual path (no torch add)
         ctx.keep_ws = not USE_CHECKPOINT           # the operands a | b and the contraction output (3 pair-sized tensors) stay for the backward
         with torch.no_grad():
             p = pair.detach().contiguous()
             b, N, _, P = p.shape
             ws = torch.empty(ops.workspace_bytes("tri_mul", b, N, 0, P) // 4, device=p.device, dtype=torch.float32) if ctx.keep_ws else None
-            out = ops.tri_mul(p, mask, [w.detach() for w in wts], incoming=incoming, residual=False, ws=ws)
+            out = ops.tri_mul(p, mask, [w.detach() for w in wts], incoming=incoming, residual=residual, ws=ws)
         ctx.save_for_backward(pair, mask, *wts, *([ws] if ctx.keep_ws else []))
         return out
 
@@ -172,7 +181,9 @@ class TriMulFn(torch.autograd.Function):
         pair, mask, *wts = saved
         with torch.no_grad():
             dpair, grads = ops.tri_mul_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], incoming=ctx.incoming, ws=ws)
-        return (dpair, None, None, *grads)
+            if ctx.residual:
+                dpair = dpair.add_(dy)
+        return (dpair, None, None, None, *grads)
 
 
 class TriAttnFn(torch.autograd.Function):
@@ -181,12 +192,13 @@ class TriAttnFn(torch.autograd.Function):
     Rows longer than the backward core's LDS layout (N > ~400) fall back to the recompute-in-torch node (HipOp)."""
 
     @staticmethod
-    def forward(ctx, pair, mask, ending: bool, H: int, c: int, *wts):
+    def forward(ctx, pair, mask, ending: bool, H: int, c: int, residual: bool, *wts):
         ctx.cfg = (ending, H, c)
+        ctx.residual = residual
         with torch.no_grad():
             p, w = pair.detach().contiguous(), [x.detach() for x in wts]
             og = ops.tri_attn_core(p, mask, w[:5], H, c, ending=ending)
-            out = ops.tri_attn_out(p, og, w[5], w[6], residual=False)
+            out = ops.tri_attn_out(p, og, w[5], w[6], residual=residual)
         # without per-block checkpointing the gated head outputs (64 floats per pair position) are kept for the backward
         # instead of being recomputed by a second core launch
         ctx.keep_og = not USE_CHECKPOINT
@@ -201,18 +213,21 @@ class TriAttnFn(torch.autograd.Function):
         ending, H, c = ctx.cfg
         with torch.no_grad():
             dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, og=og)
-        return (dpair, None, None, None, None, *grads)
+            if ctx.residual:
+                dpair = dpair.add_(dy)
+        return (dpair, None, None, None, None, None, *grads)
 
 
 TRI_ATTN_BWD_MAX_N = 352        # prd_tri_attn_bwd_core keeps q, k, v, gate, do of a row (padded to 32) and the head's weights in LDS:
                                 # exactly 160 KB at N = 352 (pitch 20 floats: 16-byte aligned rows); longer rows recompute through torch_ref
 
 
-def tri_attn_update(ta, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+def tri_attn_update(ta, pair: torch.Tensor, mask: torch.Tensor, residual: bool = False) -> torch.Tensor:
+    """The update, or with ``residual`` pair + update."""
     a = ta.attn
     H, c, end = a.num_heads, a.head_dim, ta.mode == "ending"
     if pair.shape[1] <= TRI_ATTN_BWD_MAX_N:
-        return TriAttnFn.apply(pair, mask, end, H, c, *a.weights())
+        return TriAttnFn.apply(pair, mask, end, H, c, residual, *a.weights())
 
     def ref(p, *w):
         return R.triangle_attention(p, mask, *w, H, c, ending=end)
@@ -220,11 +235,12 @@ def tri_attn_update(ta, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     def hip(p, *w):
         return ops.tri_attn(p.contiguous(), mask, w, H, c, ending=end, residual=False)
 
-    return HipOp.apply(hip, ref, pair, *a.weights())
+    upd = HipOp.apply(hip, ref, pair, *a.weights())
+    return pair + upd if residual else upd
 
 
-def tri_mul_update(tm, pair: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
-    return TriMulFn.apply(pair, mask, tm.mode == "incoming", *tm.weights())
+def tri_mul_update(tm, pair: torch.Tensor, mask: torch.Tensor, residual: bool = False) -> torch.Tensor:
+    return TriMulFn.apply(pair, mask, tm.mode == "incoming", residual, *tm.weights())
 
 
 def _lin(m) -> Tuple[torch.Tensor, ...]:
@@ -261,29 +277,36 @@ def folding_block(blk, single: torch.Tensor, pair: torch.Tensor, mask: torch.Ten
 
     ol = blk.outer_linear
 
-    def ol_hip(x, w, b):
+    def ol_hip(x, w, b, pair_in=None):
         bsz, n, _ = x.shape
         out = torch.empty(bsz, n, n, ol.pair_dim, device=x.device, dtype=torch.float32)
         xn = ops.layer_norm(x.contiguous())
         u = torch.empty(bsz, n, ol.pair_dim, device=x.device, dtype=torch.float32)
         S = x.shape[-1]
         ops.gemm(xn, w, u, bsz * n, ol.pair_dim, S, S, 2 * S, ol.pair_dim, b_off=S)
+        if pair_in is not None:
+            return ops.outer_linear_pair(pair_in, xn, u, w, b, residual=True, out=out)
         return ops.outer_linear_pair(out, xn, u, w, b, residual=False, out=out)
 
-    if big:
+    fuse = big and FUSED_RESIDUAL
+    if fuse:
+        pair = OuterLinearFn.apply(single, ol.linear.weight, ol.linear.bias, ol_hip, pair)
+    elif big:
         pair = pair + OuterLinearFn.apply(single, ol.linear.weight, ol.linear.bias, ol_hip)
     else:
         pair = pair + HipOp.apply(ol_hip, R.outer_linear, single, ol.linear.weight, ol.linear.bias)
 
     for tm in (blk.pair_mul_outgoing, blk.pair_mul_incoming):
-        pair = pair + tri_mul_update(tm, pair, mask)
+        pair = tri_mul_update(tm, pair, mask, residual=True) if fuse else pair + tri_mul_update(tm, pair, mask)
 
     for ta in (blk.pair_attn_starting, blk.pair_attn_ending):
-        pair = pair + tri_attn_update(ta, pair, mask)
+        pair = tri_attn_update(ta, pair, mask, residual=True) if fuse else pair + tri_attn_update(ta, pair, mask)
 
     pf = blk.pair_fc
     pfw = (pf[1].weight, pf[1].bias, pf[3].weight, pf[3].bias)
-    if big:
+    if fuse:
+        pair = PairTransitionFn.apply(pair, *pfw, True)
+    elif big:
         pair = pair + PairTransitionFn.apply(pair, *pfw)
     else:
         pair = pair + HipOp.apply(lambda x, *w: ops.pair_transition(x.contiguous(), *w, residual=False),
