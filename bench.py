@@ -272,16 +272,23 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     advance(a.steps)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                             # this rank's own loop, before it waits for anybody
     pos_all, logits_all = gather_samples(*loop.result(), world * bpg)   # the sampling job's one collective (RCCL all_gather)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rank_ms = [dt_own / a.steps * 1e3]
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        own = torch.tensor([dt_own / a.steps * 1e3], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(every, own)
+        rank_ms = [float(v.item()) for v in every]
     finite = bool(torch.isfinite(pos_all).all() and torch.isfinite(logits_all).all())
 
     # ---- N > 1: the product's sharded sampler end to end, against single-rank runs (bit-identical by construction) ----
@@ -305,7 +312,7 @@ def main():
         pos_1, log_1 = model.sample(clone(one), sources=[NoiseSource(0, k)])
         alone = max(float((pos_s[k] - pos_1[0]).norm() / pos_1[0].norm()), float((log_s[k] - log_1[0]).norm() / log_1[0].norm()))
         dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        shard_check = {"num_samples": world * bpg, "num_steps": 24, "identical_to_single_rank": bool(same.item()),
+        shard_check = {"num_samples": world * bpg, "num_steps": 24, "identical_to_same_batch_size_recompute": bool(same.item()),
                        "batch_size": bpg, "rel_l2_vs_sample_drawn_alone": float(f"{alone:.3g}"), "seconds": round(secs, 3)}
         if not same.item() or not alone < 2e-5:
             raise SystemExit("bench.py: sample_sharded over RCCL differs from the single-rank samples")
@@ -399,7 +406,11 @@ def main():
                        "samples_per_gpu": bpg, "hip_graph": not a.no_graph, "outputs_finite": finite,
                        "row_gemm": _lib.row_gemm_description(b3),
                        ("fp32_mode_ms_per_step" if b3 else "split16_mode_ms_per_step"): other_ms,
-                       "backend": "nccl (RCCL)" if dist is not None else "single process", "sharded_sample_check": shard_check},
+                       "backend": "nccl (RCCL)" if dist is not None else "single process", "sharded_sample_check": shard_check,
+                       # each rank's OWN loop time per step, before the closing all_gather / barrier: imbalance shows here, the
+                       # headline value is priced by the slowest rank (max over ranks of the whole timed region)
+                       "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
+                                            "all": [round(v, 4) for v in rank_ms]}},
             "step_gflop": round(flops / 1e9, 1),
             "step_tflops": round(flops * bpg / (dt / a.steps) / 1e12, 2),
             "roofline": roofline, "cpu_baseline": cpu,

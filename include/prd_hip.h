@@ -10,9 +10,11 @@
  *   - extern "C", plain pointers / ints / floats only.  All pointers are DEVICE pointers to
  *     contiguous fp32 (or int64 where stated) buffers owned by the caller (PyTorch's allocator).
  *   - The library never allocates or frees device memory; scratch is passed in as `ws` with its
- *     size in bytes (query with prd_workspace_bytes).  Its ONLY process-wide state is the row-GEMM
- *     arithmetic mode below (one relaxed atomic int, read once per call) -- everything else is
- *     re-entrant across threads and streams because outputs and workspace are caller-provided.
+ *     size in bytes (query with prd_workspace_bytes).  It keeps NO process-wide state and reads no
+ *     environment variable: the arithmetic and every kernel-selection switch are arguments (`arith`
+ *     below), outputs and workspace are caller-provided, so all entry points are re-entrant across
+ *     threads and streams (tests/native/host_abi_check.c calls one entry with both arithmetics
+ *     from two threads).
  *   - Every call only enqueues kernels on `stream` (the caller's current HIP stream), never
  *     synchronises, and is therefore capturable into a hipGraph.
  *   - Return value: 0 on success, a positive hipError_t from the launch, or a negative PRD_ERR_*.
@@ -44,15 +46,17 @@ int prd_version(void);
 
 /* Arithmetic of the GEMMs inside the operators.  The library keeps NO state: every entry point whose kernels depend on the
  * arithmetic takes it as its `arith` argument (the last one before `stream`; PrdGemm carries it as a field), so calls with
- * different arithmetics may run concurrently on different streams / threads.  (The Python host side keeps the process default:
- * protein_redesign_amd._lib.set_gemm_mode, env PRD_GEMM_MODE.)
+ * different arithmetics may run concurrently on different streams / threads.  (The Python host side keeps the process default
+ * and injects it per call: protein_redesign_amd._lib: `lib().prd_set_gemm_mode`, env PRD_GEMM_MODE.)
+ * The low byte of `arith` is the arithmetic; the bits above it are PRD_TUNE_* kernel-selection switches for A/B measurements
+ * (0 = default dispatch; defined after PRD_ARITH_* below).
  *   PRD_ARITH_FP32 (0)     fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): plain fp32 FMA chains;
  *   PRD_ARITH_SPLIT16 (1)  fp32 operands are split into fp16 hi + lo -- hi = RN_fp16(x), lo = RN_fp16(x - hi): 24 bits while lo is
  *      a normal fp16 number -- and multiplied on the fp16 matrix pipe with fp32 accumulation: hi*hi + hi*lo + lo*hi, 16/3 of
  *      the fp32 rate.  Used by the row GEMMs (tri_mul projection / output, attention projections and output projection, pair
  *      transition / block tail, outer-linear, pair_init, OPM), the triangle-multiplication contraction, Q*K^T and P*V of the
  *      triangle attention and the node-row linears of the single track (prd_gemm with one batch, K a multiple of 64 or 32).
- *      Weight images stay the size of the fp32 ones.  The first-generation short-row attention core (PRD_TA_VARIANT=10) uses
+ *      Weight images stay the size of the fp32 ones.  The first-generation short-row attention core (PRD_TUNE_TA_VARIANT 10) uses
  *      bf16 x 3 by truncation (24 bits, 6 products) for Q*K^T.  The single-track attention core, SPAttention's batched
  *      logits / P*V GEMMs, pair_bias and the coordinate head run fp32 MFMA in either mode.
  *      OPERAND RANGE: fp16 holds magnitudes up to 65504 (a larger operand becomes +-inf, the result NaN -- loudly wrong, never
@@ -65,6 +69,20 @@ int prd_version(void);
  * Both arithmetics meet every parity tolerance of tests/ (the GPU suite runs its operator / step / trajectory / gradient tests in both). */
 #define PRD_ARITH_FP32 0
 #define PRD_ARITH_SPLIT16 1
+/* Kernel-selection switches (A/B measurements; never needed for correctness -- every selectable kernel meets the same
+ * tolerances): arith = PRD_ARITH_* | PRD_TUNE(switches).  Entry points without an `arith` argument that dispatch between
+ * kernel generations take the switch word itself as `tune`.  The Python binding fills them from the environment variables named
+ * here (protein_redesign_amd/_lib.py), the library itself never reads the environment. */
+#define PRD_TUNE(switches) ((switches) << 8)
+#define PRD_TUNE_TA_VARIANT_MASK 15     /* bits 0-3 (PRD_TA_VARIANT): 10 = first-generation short-row attention core, 1/2/3 = its
+                                          16- / 12- / single-buffered 8-wave forms; 0 = default dispatch (second generation) */
+#define PRD_TUNE_TA2_NO_V3 (1 << 4)     /* PRD_TA2_V3=0: short rows on tri_attn_core_v2 (one barrier per phase) */
+#define PRD_TUNE_TA2_NO_LONG (1 << 5)   /* PRD_TA2_LONG=0: rows of 385..1024 positions stay on the first-generation long-row kernels */
+#define PRD_TUNE_TA2_FLAGS_SET (1 << 6) /* PRD_TA2_FLAGS=f: bits 7-11 = f replace the per-kernel default flags of the second-generation */
+#define PRD_TUNE_TA2_FLAGS(f) (PRD_TUNE_TA2_FLAGS_SET | (((f) & 31) << 7))    /* core (bit 0 key-loop priorities, bit 3 next-row prefetch) */
+#define PRD_TUNE_OL_GEN2 (1 << 12)      /* PRD_OL_VARIANT=1: round-2 outer-linear kernel instead of the K-split one */
+#define PRD_TUNE_TMS_NW12 (1 << 13)     /* PRD_TMS_NW=12 / 16: waves per workgroup of the split contraction (default 8) */
+#define PRD_TUNE_TMS_NW16 (2 << 13)
 
 /* ---- generic batched GEMM:  C[g] = epilogue(A[g] * B[g]^T)  (b_kn = 1: A[g] * B[g]) -------------
  * Replaces aten::linear / bmm / matmul on the single track (modules.py:185-225, 306-311;
@@ -175,7 +193,7 @@ int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, int ari
  * b_out, w_ogate, b_ogate).  Workspace as for prd_tri_mul.  Results equal two prd_tri_mul calls up to fp32 rounding. */
 int prd_tri_mul_chain_supported(int N, int P, int arith);
 int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outgoing, const float* const* w_incoming,
-                      int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream);
+                      int b, int N, int P, float* ws, size_t ws_bytes, int arith, hipStream_t stream);
 /* Output stage backward.  dy = gradient of the update [b,N,N,P]; O = contraction output (channel-major, as left in prd_tri_mul's
  * workspace); w_*_t = the transposed weights [in][out].  Writes dz = dy * gate and dgp = d(pre-activation of the output gate)
  * (row layout [b,N,N,P]; dW_out = dz^T LN(O), dW_ogate = dgp^T LN(pair) are left to the caller's BLAS), dO (channel-major) and
@@ -245,16 +263,16 @@ int prd_tri_attn_out(float* out, const float* pair, const float* og, const float
  * 32x32x16 fp16 MFMA (Q K^T with fp16 hi+lo operands rounded to nearest: 24 bits).  Rows of up to 384 positions keep K, Q, V
  * and the gate of a row in LDS (one query block per wave, shared blocks merged from partials); longer rows -- as far as K and
  * V fit as fp16 planes, N <= 1024 -- re-project Q and the gate per query block in the wave that sweeps it.  prd_tri_attn_core
- * dispatches to it when prd_tri_attn_v2_supported(N, P) and the arithmetic is split-16 (PRD_TA_VARIANT=10 keeps the first
- * generation, PRD_TA2_LONG=0 keeps it for the long rows only). */
-int prd_tri_attn_v2_supported(int N, int P);
+ * dispatches to it when prd_tri_attn_v2_supported(N, P, tune) and the arithmetic is split-16 (tune: the PRD_TUNE_* switch word;
+ * PRD_TUNE_TA_VARIANT 10 keeps the first generation, PRD_TUNE_TA2_NO_LONG keeps it for the long rows only). */
+int prd_tri_attn_v2_supported(int N, int P, int tune);
 /* which of its kernels serves rows of N positions: 0 none, 1 short rows with one barrier per phase (tri_attn_core_v2_kernel),
  * 2 short rows with the phases of consecutive rows overlapped (tri_attn_core_v3_kernel; the default where its two K / V buffers
  * fit the LDS), 3 long rows (tri_attn_core_v2l_kernel) */
-int prd_tri_attn_v2_form(int N, int P);
+int prd_tri_attn_v2_form(int N, int P, int tune);
 int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                          const float* wv, const float* wg, const float* bg, int ending,
-                         int b, int N, int P, int H, int c, hipStream_t stream);
+                         int b, int N, int P, int H, int c, int tune, hipStream_t stream);
 /* Triangle attention core whose input row is `pair + og_in W_o^T + b_o`: the residual update of the PREVIOUS triangle attention
  * (its output projection, modules.py:339-340) is applied while the row is loaded, and written to `pair_out` -- which must not
  * alias `pair` -- by the workgroups of head 0, instead of a separate prd_tri_attn_out launch.  gemm mode 1, short rows only

@@ -97,7 +97,7 @@ class _Injected:
 def build_reference(ref_model, case):
     args = make_args(**case["args"])
     model = ref_model.ProteinReDiffModel(args).eval()
-    sd = deterministic_state_dict(model.state_dict(), seed=case["weight_seed"], style=case.get("weight_style", "random"))
+    sd = deterministic_state_dict(model.state_dict(), seed=case["weight_seed"], style=case.get("weight_style", "random"), scales=case.get("weight_scales"))
     model.load_state_dict(sd)
     model.run_setup_schedule()
     model.setup_schedule = True

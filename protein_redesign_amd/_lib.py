@@ -55,7 +55,7 @@ SIGNATURES = {
     "prd_tri_mul_chain_supported": [ci, ci, ci],
     "prd_tri_attn_core_fused_supported": [ci, ci, ci],
     "prd_tri_attn_core_fused": [vp] * 12 + [ci] * 6 + [vp],
-    "prd_tri_mul_chain": [vp, vp, vp, vp, ci, ci, ci, vp, cz, vp],
+    "prd_tri_mul_chain": [vp, vp, vp, vp, ci, ci, ci, vp, cz, ci, vp],
     "prd_tri_mul_out_bwd": [vp] * 13 + [ci] * 3 + [vp],
     "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 5 + [vp],
     "prd_tri_attn_bwd_core": [vp] * 9 + [ci] * 6 + [vp],
@@ -73,11 +73,11 @@ SIGNATURES = {
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
     "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 7 + [vp],
-    "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 6 + [vp],
-    "prd_tri_attn_v2_form": [ci, ci],
+    "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 7 + [vp],
+    "prd_tri_attn_v2_form": [ci, ci, ci],
     "prd_tri_attn_core_chunked": [vp] * 8 + [ci] * 6 + [vp, cz, vp],
     "prd_tri_attn_stats_bytes": [ci] * 5,
-    "prd_tri_attn_v2_supported": [ci, ci],
+    "prd_tri_attn_v2_supported": [ci, ci, ci],
     "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, ci, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
 }
@@ -87,9 +87,36 @@ DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (e
 
 # entry points that take the arithmetic as their last argument before the stream ...
 _ARITH_BEFORE_STREAM = ("prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
-                        "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail")
+                        "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain")
 # ... and the queries that take it as their last argument
 _ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes")
+# entry points without an arithmetic that still dispatch between kernel generations: the PRD_TUNE_* switch word alone
+_TUNE_BEFORE_STREAM = ("prd_tri_attn_core_v2",)
+_TUNE_LAST = ("prd_tri_attn_v2_supported", "prd_tri_attn_v2_form")
+
+
+def tune_from_env(env=None) -> int:
+    """The PRD_TUNE_* switch word (prd_hip.h) from the A/B environment variables -- read HERE, on the host side: the library
+    itself never looks at the environment."""
+    env = os.environ if env is None else env
+
+    def geti(name, default):
+        v = env.get(name)
+        return default if v is None or v == "" else int(v)
+
+    t = geti("PRD_TA_VARIANT", 0) & 15
+    if geti("PRD_TA2_V3", 1) == 0:
+        t |= 1 << 4
+    if geti("PRD_TA2_LONG", 1) == 0:
+        t |= 1 << 5
+    f = geti("PRD_TA2_FLAGS", -1)
+    if f >= 0:
+        t |= (1 << 6) | ((f & 31) << 7)
+    if geti("PRD_OL_VARIANT", 0) == 1:
+        t |= 1 << 12
+    nw = geti("PRD_TMS_NW", 8)
+    t |= (1 << 13) if nw == 12 else (2 << 13) if nw == 16 else 0
+    return t
 
 
 class _Library:
@@ -97,10 +124,20 @@ class _Library:
     Python operators pass to every call.  The C ABI itself is stateless; ``prd_set_gemm_mode`` / ``prd_get_gemm_mode`` live
     here, in the host language, with the names round 2 used so that callers and tests read the same."""
 
-    def __init__(self, cdll, mode: int):
+    def __init__(self, cdll, mode: int, tune: int = 0):
         self._cdll = cdll
         self._mode = mode
+        self._tune = tune               # PRD_TUNE_* switches (A/B measurements), injected with the arithmetic
         self._wrapped = {}
+
+    def prd_set_tune(self, tune: int) -> int:
+        if tune < 0 or tune >= (1 << 15):
+            return -1
+        self._tune = int(tune)
+        return 0
+
+    def prd_get_tune(self) -> int:
+        return self._tune
 
     def prd_set_gemm_mode(self, mode: int) -> int:
         if mode not in (0, 1):
@@ -117,10 +154,16 @@ class _Library:
             raw = getattr(self._cdll, name)
             if name in _ARITH_BEFORE_STREAM:
                 def fn(*args, _raw=raw):
-                    return _raw(*args[:-1], self._mode, args[-1])
+                    return _raw(*args[:-1], self._mode | (self._tune << 8), args[-1])
             elif name in _ARITH_LAST:
                 def fn(*args, _raw=raw):
-                    return _raw(*args, self._mode)
+                    return _raw(*args, self._mode | (self._tune << 8))
+            elif name in _TUNE_BEFORE_STREAM:
+                def fn(*args, _raw=raw):
+                    return _raw(*args[:-1], self._tune, args[-1])
+            elif name in _TUNE_LAST:
+                def fn(*args, _raw=raw):
+                    return _raw(*args, self._tune)
             else:
                 fn = raw
             self._wrapped[name] = fn
@@ -148,7 +191,7 @@ def lib():
             mode = "bf16x3"
         if mode not in GEMM_MODES:
             raise RuntimeError(f"PRD_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got {mode!r}")
-        _lib = _Library(cdll, GEMM_MODES[mode])
+        _lib = _Library(cdll, GEMM_MODES[mode], tune_from_env())
     return _lib
 
 

@@ -834,7 +834,7 @@ extern "C" int prd_tri_mul_out_bwd(float* dz, float* dgp, float* dO, float* dx1,
 extern "C" int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const float* dAB, const float* dx1, const float* pair,
                                     const float* mask, const float* w_proj, const float* b_proj, const float* w_gate, const float* b_gate,
                                     const float* w_proj_t, const float* w_gate_t, int incoming, int b, int N, int P, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!dpair || !dpp || !dpg || !dAB || !dx1 || !pair || !mask || !w_proj || !b_proj || !w_gate || !b_gate || !w_proj_t || !w_gate_t ||
         b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;

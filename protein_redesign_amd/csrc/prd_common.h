@@ -625,8 +625,21 @@ struct WaveTasks {
     }
 };
 
-// every entry point whose kernels depend on the arithmetic takes it as an argument (prd_hip.h: PRD_ARITH_*); the library keeps no state
-#define PRD_CHECK_ARITH(a) do { if ((a) != 0 && (a) != 1) return -1; } while (0)
+// every entry point whose kernels depend on the arithmetic takes it as an argument (prd_hip.h: PRD_ARITH_* in the low byte,
+// PRD_TUNE_* kernel-selection switches above it); the library keeps no state and reads no environment variable.
+// PRD_SPLIT_ARITH(arith): validates the word, leaves the arithmetic in `arith`, the switches in `tune`, the whole word in `arith_full`
+#define PRD_SPLIT_ARITH(a)                                                                       \
+    const int arith_full = (a);                                                                  \
+    const int tune = (a) >> 8;                                                                   \
+    (void)tune; (void)arith_full;                                                                \
+    if ((a) < 0 || ((a) & 0xff) > 1) return -1;                                                  \
+    (a) &= 0xff
+#define PRD_TGET_TA_VARIANT(t) ((t) & 15)                   /* first-generation attention core: 0 = default dispatch */
+#define PRD_TGET_TA2_NO_V3(t) (((t) >> 4) & 1)
+#define PRD_TGET_TA2_NO_LONG(t) (((t) >> 5) & 1)
+#define PRD_TGET_TA2_FLAGS(t) ((((t) >> 6) & 1) ? (((t) >> 7) & 31) : -1)
+#define PRD_TGET_OL_GEN2(t) (((t) >> 12) & 1)
+#define PRD_TGET_TMS_NW(t) ((((t) >> 13) & 3) == 1 ? 12 : (((t) >> 13) & 3) == 2 ? 16 : 8)
 
 static inline int prd_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int prd_round_up(int a, int b) { return prd_ceil_div(a, b) * b; }

@@ -687,14 +687,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     const PrdGemm& g = *args;
     if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.G1 <= 0 || g.G2 <= 0) return PRD_ERR_ARG;
-    PRD_CHECK_ARITH(g.arith);
+    if (g.arith < 0 || (g.arith & 0xff) > 1) return PRD_ERR_ARG;
+    const int arith = g.arith & 0xff;                  // upper bits: PRD_TUNE_* switches (none applies to the GEMMs)
     if ((g.lda & 3) || (g.ldb & 3)) return PRD_ERR_ALIGN;
     const int batches = g.G1 * g.G2;
     if (g.ln_out && (!g.a_ln || batches != 1 || (g.ldlo & 3) || g.ldlo < g.K)) return PRD_ERR_ARG;
     const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
     // gemm mode 1: THROUGHPUT-bound linears (>= 512 tiles of 64x64: SPAttention's 512 -> 4 x 2048 projection, the transition at
     // b = 8) go to the 64x64-tile fp16 x 2 kernel (41 -> 26 us); the latency-bound ones (20-160 tiles) to gemm_ring_kernel below.
-    if (g.arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 32) == 0 && tiles64 >= 512 && g.G1 * g.G2 == 1 &&
+    if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 32) == 0 && tiles64 >= 512 && g.G1 * g.G2 == 1 &&
         (!g.a_ln || (g.K % 16) == 0) && !g.ln_out) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
         static std::once_flag once1, once4;
@@ -710,7 +711,7 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
         return (int)hipGetLastError();
     }
     // gemm mode 1, latency-bound node-row linears (fewer 64x64 tiles than that): 32x32 tiles with a deep operand ring
-    if (g.arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 && batches == 1) {
+    if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 && batches == 1) {
         const int nch = g.K / 64;
         dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
         const bool many = (long)grid.x * grid.y > 1024;         // throughput regime: one group per workgroup, more workgroups per CU

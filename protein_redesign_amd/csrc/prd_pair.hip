@@ -1347,7 +1347,7 @@ extern "C" int prd_time_embed(float* ebeta, const int64_t* t, const float* freqs
 extern "C" int prd_pair_init(float* pair, const float* static_pair, const float* z, const float* mask,
                              const float* centers, const float* w_dist, const float* ebeta,
                              int b, int N, int P, int dist_dim, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!pair || !static_pair || !z || !mask || !centers || !w_dist || !ebeta || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (dist_dim <= 0 || (dist_dim & 7)) return PRD_ERR_UNSUPPORTED;
@@ -1405,7 +1405,7 @@ extern "C" int prd_pair_bias2(float* bias_a, const float* pair, const float* gam
 
 extern "C" int prd_opm_pair(float* out, const float* pair, const float* ab, const float* mask, const float* w_out,
                             const float* b_out, int flags, int b, int N, int P, int C, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!out || !pair || !ab || !mask || !w_out || !b_out || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (C <= 0 || (C & 7)) return PRD_ERR_UNSUPPORTED;
@@ -1641,13 +1641,13 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
 
 extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
                                 const float* bias, int residual, int b, int N, int P, int S, int* queue, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!out || !pair || !x || !u || !w || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
     const size_t lds = ((size_t)P * (S + 4) + P) * sizeof(float);
-    static const bool ol_v1 = getenv("PRD_OL_VARIANT") && atoi(getenv("PRD_OL_VARIANT")) == 1;      // tuning: the round-2 kernel
+    const bool ol_v1 = PRD_TGET_OL_GEN2(tune);          // A/B switch: the round-2 kernel
     if (arith == PRD_ARITH_SPLIT16 && !ol_v1 && (S == 128 || S == 256 || S == 512) && (long)b * N * N < (1L << 30)) {
         // K split over the waves of a workgroup, W1 slices in registers (outer_linear_ks_kernel)
         const int nvb = prd_ceil_div(N, 32);
@@ -1720,7 +1720,7 @@ int launch_pair_tail_h2(float* out, const float* pair, const float* og, const fl
 
 extern "C" int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,
                                    const float* b2, int residual, int b, int N, int P, int* queue, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!out || !pair || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     if (arith == PRD_ARITH_SPLIT16) {             // split 16-bit operands (fp16 x 2), see pair_tail_h2_kernel
@@ -1745,7 +1745,7 @@ extern "C" int prd_pair_transition(float* out, const float* pair, const float* w
 extern "C" int prd_block_tail(float* pair, const float* og, const float* wo, const float* bo, const float* w1, const float* b1,
                               const float* w2, const float* b2, const float* bias_w, const float* bias_b, float* bias_out,
                               int b, int N, int P, int H, int* queue, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!pair || !og || !wo || !bo || !w1 || !b1 || !w2 || !b2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (bias_out && (!bias_w || H <= 0 || H > 8)) return PRD_ERR_ARG;
     PRD_CHECK_P(P);

@@ -434,11 +434,8 @@ __global__ __launch_bounds__(256) void tri_mul_contract_kernel(float* __restrict
 // sixteen lanes of a ds_read_b128 group (rows distinct mod 16, same logical slot) hit sixteen different 4-bank groups.
 constexpr int TMS_T = 160, TMS_PLANE = TMS_T * 64, TMS_OPER = 2 * TMS_PLANE;       // bytes
 // waves per workgroup of the split contraction: 8 by default; 16 (PRD_TMS_NW=16) makes the kernel itself 1 us faster (18.8 vs
-// 19.8 us) but the whole step 15 us slower in the same run (1.932 vs 1.918 ms, twice); 12 waves: 22.5 vs 22.7 us -- tuning knobs only
-static int tms_nw() {
-    static const int v = [] { const char* e = getenv("PRD_TMS_NW"); const int n = e ? atoi(e) : 8; return (n == 16 || n == 12) ? n : 8; }();
-    return v;
-}
+// 19.8 us) but the whole step 15 us slower in the same run (1.932 vs 1.918 ms, twice); 12 waves: 22.5 vs 22.7 us -- A/B switch
+// PRD_TUNE_TMS_NW in the upper bits of `arith`
 template <int NWV>                                  // 8 or 16 waves: 25 sub-tiles dealt round-robin, 4 or 2 accumulators per wave
 __global__ __launch_bounds__(NWV * 64) void tri_mul_contract_split_kernel(float* __restrict__ O, const float* __restrict__ AB,
                                                                           int N, int ldn, int P, int nbatch, int tiles, int swap) {
@@ -2180,21 +2177,14 @@ size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
 }
 }  // namespace
 
-namespace {
-int ta_variant_env() {                         // PRD_TA_VARIANT (tuning / A-B runs only): 0 = default dispatch
-    static const int v = getenv("PRD_TA_VARIANT") ? atoi(getenv("PRD_TA_VARIANT")) : 0;
-    return v;
-}
-}  // namespace
-
 extern "C" int prd_tri_attn_variant(int N, int P, int arith) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     bool long_row;
     const bool b3 = arith == PRD_ARITH_SPLIT16;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
-    const bool v2 = b3 && ta_variant_env() == 0 && prd_tri_attn_v2_supported(N, P);      // what prd_tri_attn_core dispatches to first
+    const bool v2 = b3 && PRD_TGET_TA_VARIANT(tune) == 0 && prd_tri_attn_v2_supported(N, P, tune);      // what prd_tri_attn_core dispatches to first
     if (lds > 160 * 1024)                      // the round-3 core keeps K / V as fp16 planes: rows up to 1024; beyond: key-chunked
         return v2 ? 2 : 3;
     if (!long_row) return 0;
@@ -2262,7 +2252,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
                            const float* w_gate, const float* b_gate, const float* w_out, const float* b_out,
                            const float* w_ogate, const float* b_ogate, int incoming, int residual,
                            int b, int N, int P, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!out || !pair || !mask || !w_proj || !b_proj || !w_gate || !b_gate || !w_out || !b_out || !w_ogate || !b_ogate || !ws ||
         b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
@@ -2298,8 +2288,8 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
             const int tl = prd_ceil_div(N, TMS_T);
             const int vb3 = b * P * tl * tl;
             const size_t lds3 = (size_t)4 * TMS_OPER;
-                        if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+                        if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
         }
         else
@@ -2323,7 +2313,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
 }
 
 extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!O || !AB || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     const int ldn = prd_round_up(N, 32);
@@ -2331,8 +2321,8 @@ extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int
         const int tl = prd_ceil_div(N, TMS_T);
         const int vb3 = b * P * tl * tl;
         const size_t lds3 = (size_t)4 * TMS_OPER;
-                if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+                if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     } else {
         const int tiles = prd_ceil_div(N, 64);
@@ -2343,15 +2333,16 @@ extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int
 }
 
 extern "C" int prd_tri_mul_chain_supported(int N, int P, int arith) {
-    return (N > 0 && (P == 32 || P == 64) && arith == PRD_ARITH_SPLIT16) ? 1 : 0;
+    return (N > 0 && (P == 32 || P == 64) && arith >= 0 && (arith & 0xff) == PRD_ARITH_SPLIT16) ? 1 : 0;
 }
 
 extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outgoing, const float* const* w_incoming,
-                                 int b, int N, int P, float* ws, size_t ws_bytes, hipStream_t stream) {
+                                 int b, int N, int P, float* ws, size_t ws_bytes, int arith, hipStream_t stream) {
+    PRD_SPLIT_ARITH(arith);
     if (!pair || !mask || !w_outgoing || !w_incoming || !ws || b <= 0 || N <= 0) return PRD_ERR_ARG;
     for (int k = 0; k < 8; ++k)
         if (!w_outgoing[k] || !w_incoming[k]) return PRD_ERR_ARG;
-    if (!prd_tri_mul_chain_supported(N, P, PRD_ARITH_SPLIT16)) return PRD_ERR_UNSUPPORTED;
+    if (!prd_tri_mul_chain_supported(N, P, arith)) return PRD_ERR_UNSUPPORTED;
     if (ws_bytes < prd_workspace_bytes("tri_mul", b, N, 0, P)) return PRD_ERR_WORKSPACE;
     const int ldn = prd_round_up(N, 32);
     float* AB = ws;                                   // [b][2P][N][ldn]
@@ -2381,8 +2372,8 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     }
     PRD_CHAIN_STAGE_OK();
     // 2. its contraction, transposed: O^T[c][j][i]
-    if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
-    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
+    if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
+    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
     PRD_CHAIN_STAGE_OK();
     // 3. output stage of the outgoing module + a | b of the incoming one.  P = 64: 12 waves (168 VGPRs, three per SIMD) cover the
@@ -2399,8 +2390,8 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     }
     PRD_CHAIN_STAGE_OK();
     // 4. contraction of the incoming module
-    if (tms_nw() == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else if (tms_nw() == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
     PRD_CHAIN_STAGE_OK();
     // 5. its output stage
@@ -2419,16 +2410,16 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
 extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                                  const float* wv, const float* wg, const float* bg, int ending,
                                  int b, int N, int P, int H, int c, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
     const bool b3 = arith == PRD_ARITH_SPLIT16;   // split 16-bit operands
-    const int variant = ta_variant_env();
+    const int variant = PRD_TGET_TA_VARIANT(tune);    // A/B switch: first-generation kernels
     // second generation (prd_tri2.hip): short rows, and long rows as far as K / V of a row fit the LDS as fp16 planes
-    if (b3 && variant == 0 && prd_tri_attn_v2_supported(N, P) && (long)b * N * N <= 0x7fffffffL / 2)
-        return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, stream);
+    if (b3 && variant == 0 && prd_tri_attn_v2_supported(N, P, tune) && (long)b * N * N <= 0x7fffffffL / 2)
+        return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, tune, stream);
     bool long_row;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
@@ -2486,7 +2477,7 @@ static size_t tri_attn_fused_lds(int N, int P) {
 }
 
 extern "C" int prd_tri_attn_core_fused_supported(int N, int P, int arith) {
-    return (N > 0 && (P == 32 || P == 64) && arith == PRD_ARITH_SPLIT16 &&
+    return (N > 0 && (P == 32 || P == 64) && arith >= 0 && (arith & 0xff) == PRD_ARITH_SPLIT16 &&
             tri_attn_fused_lds(N, P) <= 160 * 1024) ? 1 : 0;
 }
 
@@ -2521,7 +2512,7 @@ extern "C" int prd_tri_attn_core_fused(float* og, float* pair_out, const float* 
 
 extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,
                                 int residual, int b, int N, int P, int* queue, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!out || !pair || !og || !wo || !bo || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     constexpr int NWA = 12;
@@ -2538,16 +2529,16 @@ extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, 
 extern "C" int prd_tri_attn(float* out, const float* pair, const float* mask, const float* wq, const float* wk, const float* wv,
                             const float* wg, const float* bg, const float* wo, const float* bo, int ending, int residual,
                             int b, int N, int P, int H, int c, float* ws, size_t ws_bytes, int* queue, int arith, hipStream_t stream) {
-    PRD_CHECK_ARITH(arith);
+    PRD_SPLIT_ARITH(arith);
     if (!ws) return PRD_ERR_ARG;
     if (ws_bytes < prd_workspace_bytes("tri_attn", b, N, 0, P)) return PRD_ERR_WORKSPACE;
     int e;
-    if (prd_tri_attn_variant(N, P, arith) == 3) {
+    if (prd_tri_attn_variant(N, P, arith_full) == 3) {
         const size_t nog = (size_t)b * N * N * 64;
         e = prd_tri_attn_core_chunked(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, ws + nog, ws_bytes - nog * sizeof(float), stream);
     } else {
-        e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, arith, stream);
+        e = prd_tri_attn_core(ws, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, arith_full, stream);
     }
     if (e) return e;
-    return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, queue, arith, stream);
+    return prd_tri_attn_out(out, pair, ws, wo, bo, residual, b, N, P, queue, arith_full, stream);
 }

@@ -1325,29 +1325,27 @@ size_t v2_lds_bytes(int N, int P) {
     } while (0)
 
 // 1 when the second-generation core serves rows of N positions (split-16 arithmetic only)
-extern "C" int prd_tri_attn_v2_supported(int N, int P) {
+extern "C" int prd_tri_attn_v2_supported(int N, int P, int tune) {
     if (N <= 0 || (P != 32 && P != 64)) return 0;
     if (N <= V2_MAXN) return v2_lds_bytes(N, P) <= 160 * 1024 ? 1 : 0;
-    static const int no_long = getenv("PRD_TA2_LONG") ? atoi(getenv("PRD_TA2_LONG")) == 0 : 0;      // 0: long rows stay on the first generation (A/B)
-    if (no_long) return 0;
+    if (PRD_TGET_TA2_NO_LONG(tune)) return 0;           // A/B switch: long rows stay on the first generation
     return (prd_round_up(N, 32) <= 1024 && v2l_lds_bytes(N, P) <= 160 * 1024) ? 1 : 0;
 }
 
 // which kernel prd_tri_attn_core_v2 launches for rows of N positions: 0 = none (unsupported), 1 = tri_attn_core_v2_kernel,
 // 2 = tri_attn_core_v3_kernel (overlapped phases), 3 = tri_attn_core_v2l_kernel (long rows)
-extern "C" int prd_tri_attn_v2_form(int N, int P) {
-    if (!prd_tri_attn_v2_supported(N, P)) return 0;
+extern "C" int prd_tri_attn_v2_form(int N, int P, int tune) {
+    if (!prd_tri_attn_v2_supported(N, P, tune)) return 0;
     if (N > V2_MAXN) return 3;
-    static const int use_v3 = getenv("PRD_TA2_V3") ? atoi(getenv("PRD_TA2_V3")) : 1;
-    return (use_v3 && v3_lds_bytes(N, P) <= 160 * 1024) ? 2 : 1;
+    return (!PRD_TGET_TA2_NO_V3(tune) && v3_lds_bytes(N, P) <= 160 * 1024) ? 2 : 1;
 }
 
 extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                                     const float* wv, const float* wg, const float* bg, int ending,
-                                    int b, int N, int P, int H, int c, hipStream_t stream) {
-    if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
+                                    int b, int N, int P, int H, int c, int tune, hipStream_t stream) {
+    if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0 || tune < 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
-    if (!prd_tri_attn_v2_supported(N, P)) return PRD_ERR_UNSUPPORTED;
+    if (!prd_tri_attn_v2_supported(N, P, tune)) return PRD_ERR_UNSUPPORTED;
     if ((long)b * N * N > 0x7fffffffL / 2) return PRD_ERR_UNSUPPORTED;      // 32-bit position arithmetic in the kernel
     const int NP = prd_round_up(N, 32);
     const bool long_rows = N > V2_MAXN;
@@ -1361,8 +1359,8 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
     constexpr int NWV = 12;                             // nqb <= 12 query blocks, one wave each
-    static const int flags_env = getenv("PRD_TA2_FLAGS") ? atoi(getenv("PRD_TA2_FLAGS")) : -1; // tuning only
-    static const int use_v3 = getenv("PRD_TA2_V3") ? atoi(getenv("PRD_TA2_V3")) : 1;           // 0: the barrier-per-phase form (A/B)
+    const int flags_env = PRD_TGET_TA2_FLAGS(tune);     // A/B switch: kernel flags given by the caller (-1: per-kernel default)
+    const int use_v3 = !PRD_TGET_TA2_NO_V3(tune);       // A/B switch: 0 = the barrier-per-phase form
     const bool v3 = !long_rows && use_v3 && v3_lds_bytes(N, P) <= 160 * 1024;
     // bit 0 = key-loop priorities by remaining work: needed where the waves of a SIMD must end together (v2, v2l); with
     // overlapped phases (v3) an early finisher starts the next row's projection instead: 67.5 -> 65.9 us without them

@@ -89,7 +89,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.colscale, g.tile_hint = dptr(colscale), tile_hint
     g.a_ln = 1 if a_ln else 0
     g.ln_out, g.ldlo = dptr(ln_out), (ln_out.shape[-1] if ln_out is not None else 0)
-    g.arith = lib().prd_get_gemm_mode()
+    g.arith = lib().prd_get_gemm_mode() | (lib().prd_get_tune() << 8)
     import ctypes
     check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
     return Cout

@@ -12,6 +12,7 @@ Nothing here is on the arithmetic path; the model call goes to the HIP path thro
 from __future__ import annotations
 
 import dataclasses
+import os
 from pathlib import Path
 from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple, Union
 
@@ -149,8 +150,10 @@ class BucketBatchSampler(torch.utils.data.Sampler):
             if self.shuffle:
                 members = [members[j] for j in torch.randperm(len(members), generator=g).tolist()]
             batches = [members[k:k + self.batch_size] for k in range(0, len(members), self.batch_size)]
-            while len(batches) % self.world_size:                 # complete the last step with batches of the same bucket
-                batches.append(batches[len(batches) % max(1, len(batches) - 1)] if len(batches) > 1 else batches[0])
+            n0, k = len(batches), 0
+            while len(batches) % self.world_size:                 # complete the last step by wrapping around inside the bucket:
+                batches.append(batches[k % n0])                   # distinct batches as long as the bucket has them
+                k += 1
             steps.extend(batches[k:k + self.world_size] for k in range(0, len(batches), self.world_size))
         if self.shuffle:
             steps = [steps[j] for j in torch.randperm(len(steps), generator=g).tolist()]
@@ -203,10 +206,46 @@ class PDBDataModule:
     def train_dataloader(self):
         ds = PDBDataset(self.cache_dir, self.train_pdb_ids)
         if self.bucket_width <= 0:
+            if self.world_size > 1:         # what Lightning injects under DDP (train.py:38): a disjoint shard per rank, reshuffled per epoch
+                self.train_sampler = torch.utils.data.distributed.DistributedSampler(
+                    ds, num_replicas=self.world_size, rank=self.rank, shuffle=True, seed=self.seed)
+                return torch.utils.data.DataLoader(ds, batch_size=self.batch_size, sampler=self.train_sampler,
+                                                   num_workers=self.num_workers, collate_fn=collate_fn)
             return torch.utils.data.DataLoader(ds, batch_size=self.batch_size, shuffle=True, num_workers=self.num_workers, collate_fn=collate_fn)
-        sizes = [int(d["num_atoms"]) + int(d["num_residues"]) for d in (ds[i] for i in range(len(ds)))]
-        self.train_sampler = BucketBatchSampler(sizes, self.batch_size, self.world_size, self.rank, self.bucket_width, self.seed)
+        self.train_sampler = BucketBatchSampler(self._train_sizes(ds), self.batch_size, self.world_size, self.rank, self.bucket_width, self.seed)
         return torch.utils.data.DataLoader(ds, batch_sampler=self.train_sampler, num_workers=self.num_workers, collate_fn=collate_fn)
+
+    def set_epoch(self, epoch: int) -> None:
+        """Reshuffle for a new epoch (both samplers are deterministic in (seed, epoch), identical on every rank)."""
+        if self.train_sampler is not None:
+            self.train_sampler.set_epoch(epoch)
+
+    def _train_sizes(self, ds) -> List[int]:
+        """num_atoms + num_residues of every training complex.  Read from ``<cache>/sizes_index.json`` when it covers the id
+        list; otherwise one pass over the cache, persisted there for the next start-up (best effort: a read-only cache is
+        scanned every time)."""
+        import json
+        index_path = self.cache_dir / "sizes_index.json"
+        index: Dict[str, int] = {}
+        if index_path.exists():
+            try:
+                with open(index_path, "r") as f:
+                    index = {str(k): int(v) for k, v in json.load(f).items()}
+            except (OSError, ValueError):
+                index = {}
+        missing = [i for i, pid in enumerate(ds.pdb_ids) if pid not in index]
+        for i in missing:
+            d = ds[i]
+            index[ds.pdb_ids[i]] = int(d["num_atoms"]) + int(d["num_residues"])
+        if missing:
+            try:
+                tmp = index_path.with_suffix(".json.tmp%d" % os.getpid())
+                with open(tmp, "w") as f:
+                    json.dump(index, f)
+                os.replace(tmp, index_path)
+            except OSError:
+                pass
+        return [index[pid] for pid in ds.pdb_ids]
 
     def val_dataloader(self):
         return torch.utils.data.DataLoader(PDBDataset(self.cache_dir, self.val_pdb_ids), batch_size=self.batch_size,

@@ -120,7 +120,8 @@ _FINAL_INIT = ("out_proj.weight", "out_proj.bias", "single_fc.3.", "pair_fc.3.",
 _GATING_INIT = ("gate_proj.", "ab_gate.", "out_gate.", "linear_g.")
 
 
-def deterministic_state_dict(spec: Mapping[str, torch.Tensor], seed: int = 1, style: str = "random") -> Dict[str, torch.Tensor]:
+def deterministic_state_dict(spec: Mapping[str, torch.Tensor], seed: int = 1, style: str = "random",
+                             scales: Mapping[str, float] | None = None) -> Dict[str, torch.Tensor]:
     """Seeded weights for every key of ``spec`` (a state_dict used for names/shapes).
 
     ``style="random"``: matrices ~ N(0, 1/fan_in), biases ~ N(0, 0.1^2), LayerNorm scales 1 + N(0, 0.1^2), embedding
@@ -130,8 +131,16 @@ def deterministic_state_dict(spec: Mapping[str, torch.Tensor], seed: int = 1, st
 
     ``style="near_init"``: the same, except that the layers the reference initialises to zero ("final") or to pass-through
     gates ("gating") sit an N(0, 0.02^2) perturbation away from that initialisation -- a network early in training, the
-    recipe of SURVEY.md §8d.  Every branch is still live, residual updates are small, and the reverse-diffusion loop is
-    well conditioned: this is the style of the long-trajectory fixtures.
+    recipe of SURVEY.md §8d.  Every branch is still live and residual updates are small.  Whether the reverse-diffusion LOOP
+    built on such a network stays in the network's working range is a separate question, decided by the coordinate head: it is
+    well conditioned at N = 140 (|z| contracts) and diverges at N = 320 (the head's update grows with the number of pairs) --
+    see ``scales``.
+
+    ``scales``: ``{key suffix: factor}`` applied to the generated tensors whose name ends with the suffix (after everything
+    else; the random stream is unchanged).  The long-trajectory fixtures of the headline shape use it to put the coordinate
+    head (``weight_radial.3.weight``) where the loop keeps the pair distances inside the support of the distance embedding
+    (tools/conditioning_scan.py chooses the factor with the HIP path; oracle/gen_yardstick.py generates the fixtures with the
+    imported reference).
 
     The two frozen buffers-as-parameters keep the values the reference constructs (modules.py:77-79, 91-93)."""
     if style not in ("random", "near_init"):
@@ -158,6 +167,9 @@ def deterministic_state_dict(spec: Mapping[str, torch.Tensor], seed: int = 1, st
                 w = 0.02 * torch.randn(shape, generator=g)
             elif any(t in name for t in _GATING_INIT):
                 w = 0.02 * torch.randn(shape, generator=g) + (1.0 if name.endswith("bias") else 0.0)
+        for suffix, factor in (scales or {}).items():
+            if name.endswith(suffix):
+                w = w * float(factor)
         out[name] = w.float()
     return out
 

@@ -424,7 +424,9 @@ def all_reduce_gradients(params: Sequence[torch.nn.Parameter], group: Optional[d
     if missing:
         raise RuntimeError(f"all_reduce_gradients: {len(missing)} trainable parameter(s) have no gradient (first index "
                            f"{missing[0]}); like DDP with find_unused_parameters=False this is an error")
-    grads = [p.grad.reshape(-1) for p in params]
+    # view(-1), not reshape: a gradient in a non-viewable layout must raise here -- reshape would hand back a COPY and the
+    # averaged values would land in a temporary while p.grad stayed un-averaged
+    grads = [p.grad.view(-1) for p in params]
     n = sum(g.numel() for g in grads)
     key = (grads[0].device, n)
     flat = _FLAT_GRAD_BUFFERS.get(key)

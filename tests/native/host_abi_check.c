@@ -2,6 +2,7 @@
  * WITHOUT a GPU: every call below must be rejected by the argument checks (negative PRD_ERR_* code) before any HIP API is
  * touched, with no out-of-bounds access, leak or use of uninitialised memory on the host side of libprd_hip.
  * Build + run: python -m protein_redesign_amd.build --asan   (tests/test_host_cpu.py::test_c_abi_argument_checks_under_asan) */
+#include <pthread.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -13,6 +14,19 @@ static int failures = 0;
         const int got_ = (call);                                                           \
         if (got_ != (code)) { printf("FAIL %s -> %d (want %d)\n", #call, got_, (code)); ++failures; } \
     } while (0)
+
+/* Two threads call the same entry points with DIFFERENT arithmetics and switches at the same time; each must get the answer
+ * that belongs to ITS arguments every time (the library has no mode to race on). */
+struct thread_arg { int arith; int want_variant; int want_chain; int want_stats; int bad; };
+static void* hammer(void* v) {
+    struct thread_arg* a = (struct thread_arg*)v;
+    for (int it = 0; it < 20000; ++it) {
+        if (prd_tri_attn_variant(1000, 64, a->arith) != a->want_variant) ++a->bad;
+        if (prd_tri_mul_chain_supported(320, 64, a->arith) != a->want_chain) ++a->bad;
+        if ((prd_tri_attn_stats_bytes(1, 1000, 64, 4, a->arith) != 0) != a->want_stats) ++a->bad;
+    }
+    return 0;
+}
 
 int main(void) {
     _Alignas(16) float buf[16];                      /* host memory standing in for device pointers: never dereferenced by the checks */
@@ -80,20 +94,29 @@ int main(void) {
         EXPECT(prd_tri_mul_chain_supported(320, 64, A1), 1);
         EXPECT(prd_tri_mul_chain_supported(320, 48, A1), 0);
         EXPECT(prd_tri_mul_chain_supported(320, 64, A0), 0);        /* fp32 arithmetic has no fused chain */
-        EXPECT(prd_tri_mul_chain(0, p, w8, w8, 1, 8, 64, p, 1 << 20, s), PRD_ERR_ARG);
-        EXPECT(prd_tri_mul_chain(p, p, w8, w7, 1, 8, 64, p, 1 << 20, s), PRD_ERR_ARG);          /* a missing weight pointer */
-        EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 16, s), PRD_ERR_WORKSPACE);
+        EXPECT(prd_tri_mul_chain(0, p, w8, w8, 1, 8, 64, p, 1 << 20, A1, s), PRD_ERR_ARG);
+        EXPECT(prd_tri_mul_chain(p, p, w8, w7, 1, 8, 64, p, 1 << 20, A1, s), PRD_ERR_ARG);          /* a missing weight pointer */
+        EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 16, A1, s), PRD_ERR_WORKSPACE);
+        EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 1 << 20, A0, s), PRD_ERR_UNSUPPORTED);     /* fp32 arithmetic has no fused chain */
+        EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 16, A1 | PRD_TUNE(PRD_TUNE_TMS_NW16), s), PRD_ERR_WORKSPACE);  /* switches ride above the arithmetic */
     }
     EXPECT(prd_tri_attn_core_fused_supported(320, 64, A1), 1);
     EXPECT(prd_tri_attn_core_fused_supported(769, 64, A1), 0);      /* long rows: no fused form */
-    EXPECT(prd_tri_attn_v2_supported(320, 64), 1);
-    EXPECT(prd_tri_attn_v2_supported(400, 64), 1);                  /* long-row form */
-    EXPECT(prd_tri_attn_v2_supported(1024, 64), 1);
-    EXPECT(prd_tri_attn_v2_supported(1025, 64), 0);                 /* more than 32 key tiles */
-    EXPECT(prd_tri_attn_v2_form(320, 64), 2);                       /* two K / V buffers fit: overlapped phases */
-    EXPECT(prd_tri_attn_v2_form(352, 64), 1);                       /* 11 blocks, three shared: the second buffer does not fit */
-    EXPECT(prd_tri_attn_v2_form(769, 64), 3);
-    EXPECT(prd_tri_attn_v2_form(1100, 64), 0);
+    EXPECT(prd_tri_attn_v2_supported(320, 64, 0), 1);
+    EXPECT(prd_tri_attn_v2_supported(400, 64, 0), 1);                  /* long-row form */
+    EXPECT(prd_tri_attn_v2_supported(1024, 64, 0), 1);
+    EXPECT(prd_tri_attn_v2_supported(1025, 64, 0), 0);                 /* more than 32 key tiles */
+    EXPECT(prd_tri_attn_v2_form(320, 64, 0), 2);                       /* two K / V buffers fit: overlapped phases */
+    EXPECT(prd_tri_attn_v2_form(352, 64, 0), 1);                       /* 11 blocks, three shared: the second buffer does not fit */
+    EXPECT(prd_tri_attn_v2_form(769, 64, 0), 3);
+    EXPECT(prd_tri_attn_v2_form(1100, 64, 0), 0);
+    /* kernel-selection switches are ARGUMENTS (the library reads no environment variable and keeps no state) */
+    EXPECT(prd_tri_attn_v2_form(320, 64, PRD_TUNE_TA2_NO_V3), 1);
+    EXPECT(prd_tri_attn_v2_supported(769, 64, PRD_TUNE_TA2_NO_LONG), 0);
+    EXPECT(prd_tri_attn_variant(1000, 64, A1 | PRD_TUNE(PRD_TUNE_TA2_NO_LONG)), 3);   /* first generation: K / V of 1000 positions do not fit -> key-chunked */
+    EXPECT(prd_tri_attn_variant(1000, 64, A1 | PRD_TUNE(10)), 3);                     /* PRD_TUNE_TA_VARIANT 10: first generation */
+    EXPECT(prd_tri_attn_variant(1000, 64, A1), 2);                                    /* ... and the default is unchanged by those calls */
+    EXPECT(prd_tri_attn_variant(320, 64, -1), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_variant(960, 64, A1), 2);
     EXPECT(prd_tri_attn_variant(960, 64, A0), 1);                   /* last length whose K / V fit the LDS in fp32 (fp32 long-row kernel) */
     EXPECT(prd_tri_attn_variant(961, 64, A0), 3);                   /* fp32 arithmetic: key-chunked */
@@ -110,8 +133,8 @@ int main(void) {
     EXPECT(prd_tri_attn_core_chunked(p, p, p, p, p, p, p, p, 0, 1, 1000, 64, 4, 16, 0, 0, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_core_chunked(p, p, p, p, p, p, p, p, 0, 1, 1000, 64, 4, 16, p, 64, s), PRD_ERR_WORKSPACE);
     EXPECT(prd_tri_attn_core_chunked(p, p, p, p, p, p, p, p, 0, 1, 1000, 48, 4, 16, p, (size_t)1 << 30, s), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_tri_attn_core_v2(0, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
-    EXPECT(prd_tri_attn_core_v2(p, p, p, p, p, p, p, p, 0, 1, 1100, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_tri_attn_core_v2(0, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, 0, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_attn_core_v2(p, p, p, p, p, p, p, p, 0, 1, 1100, 64, 4, 16, 0, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_core_fused(p, p, p, p, p, p, p, p, p, p, p, p, 1, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);   /* pair_out aliases pair */
     EXPECT(prd_tri_mul_out_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, A1, s), PRD_ERR_ARG);
@@ -135,6 +158,16 @@ int main(void) {
     EXPECT((int)(prd_workspace_bytes("tri_mul", 1, 320, 512, 64) != (size_t)3 * 64 * 320 * 320 * 4), 0);
     EXPECT((int)prd_workspace_bytes("nonsense", 1, 320, 512, 64), 0);
     EXPECT((int)prd_workspace_bytes(0, 1, 320, 512, 64), 0);
+    {
+        struct thread_arg t0 = {PRD_ARITH_FP32, 3, 0, 1, 0}, t1 = {PRD_ARITH_SPLIT16, 2, 1, 0, 0},
+                          t2 = {PRD_ARITH_SPLIT16 | PRD_TUNE(PRD_TUNE_TA2_NO_LONG), 3, 1, 1, 0};
+        pthread_t th[3];
+        pthread_create(&th[0], 0, hammer, &t0);
+        pthread_create(&th[1], 0, hammer, &t1);
+        pthread_create(&th[2], 0, hammer, &t2);
+        for (int k = 0; k < 3; ++k) pthread_join(th[k], 0);
+        EXPECT(t0.bad + t1.bad + t2.bad, 0);
+    }
     printf(failures ? "host ABI check: %d failure(s)\n" : "host ABI check: OK\n", failures);
     return failures ? 1 : 0;
 }

@@ -30,8 +30,8 @@ CFG = {
 }
 
 
-def build(args, seed, style="random"):
-    params = deterministic_state_dict(spec_tensors(args), seed=seed, style=style)
+def build(args, seed, style="random", scales=None):
+    params = deterministic_state_dict(spec_tensors(args), seed=seed, style=style, scales=scales)
     model = ProteinReDiffModel(args)
     model.load_state_dict(params)
     return model.to(DEV).eval(), params
@@ -584,7 +584,7 @@ def test_input_embedding_and_heads(setup, gemm_mode):
 def golden_case(golden, name):
     case, z = golden(name)
     args = make_args(**case["args"])
-    model, params = build(args, case["weight_seed"], case.get("weight_style", "random"))
+    model, params = build(args, case["weight_seed"], case.get("weight_style", "random"), case.get("weight_scales"))
     return case, z, args, model, params
 
 

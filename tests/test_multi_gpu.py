@@ -61,7 +61,7 @@ def test_bench_under_one_rank_rccl_launcher():
                                "--no-cpu-baseline", "--no-traffic"], 29621)
     assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl (RCCL)"
     chk = line["config"]["sharded_sample_check"]
-    assert chk["identical_to_single_rank"] is True and chk["batch_size"] == 2 and chk["rel_l2_vs_sample_drawn_alone"] < 2e-5
+    assert chk["identical_to_same_batch_size_recompute"] is True and chk["batch_size"] == 2 and chk["rel_l2_vs_sample_drawn_alone"] < 2e-5
     assert line["config"]["outputs_finite"] is True and line["value"] > 0
 
 

@@ -130,6 +130,22 @@ def test_bucket_batch_sampler_covers_every_complex_and_shards_by_size():
         BucketBatchSampler(sizes, bs, world, world)
 
 
+def test_bucket_batch_sampler_pads_a_step_with_distinct_batches():
+    """The incomplete last step of a bucket is completed by wrapping around INSIDE the bucket: the ranks of a padded step get
+    distinct batches as long as the bucket has that many (9 complexes on 8 ranks used to give 7 ranks the same complex)."""
+    from protein_redesign_amd.pipeline import BucketBatchSampler
+    world = 8
+    for n_members, bs in ((9, 1), (5, 1), (11, 2), (3, 1)):
+        sizes = [200] * n_members
+        steps = list(zip(*[list(BucketBatchSampler(sizes, bs, world, r, bucket_width=32, seed=1)) for r in range(world)]))
+        n_batches = -(-n_members // bs)
+        for step in steps:
+            distinct = len({tuple(bt) for bt in step})
+            assert distinct == min(world, n_batches), (n_members, bs, step)
+        drawn = [i for step in steps for bt in step for i in bt]
+        assert set(drawn) == set(range(n_members))
+
+
 def test_pdb_datamodule_round_trip(tmp_path):
     """data.py:206-259: id lists + preprocessed cache -> collated batches; the training loader is size-bucketed."""
     from protein_redesign_amd.pipeline import PDBDataModule
@@ -151,3 +167,19 @@ def test_pdb_datamodule_round_trip(tmp_path):
         n = bt["atom_mask"].shape[1]
         assert bt["residue_mask"].shape[1] == n and bt["bond_mask"].shape[1:] == (n, n)
     assert len(list(dm.val_dataloader())) == 1 and len(list(dm.test_dataloader())) == 1
+    # the sizes found by the first scan are persisted next to the cache and re-used
+    import json
+    index = json.loads((cache / "sizes_index.json").read_text())
+    assert sorted(index) == sorted(ids[:6]) and all(v > 0 for v in index.values())
+    dm2 = PDBDataModule(tmp_path, batch_size=2, num_workers=0, bucket_width=8)
+    dm2.setup()
+    assert dm2._train_sizes(type("D", (), {"pdb_ids": ids[:6], "__getitem__": lambda self, i: 1 / 0})()) == [index[p] for p in ids[:6]]
+    # free shuffling under data parallelism: disjoint shards per rank (what Lightning's DistributedSampler gives the reference)
+    seen = []
+    for r in range(2):
+        dmr = PDBDataModule(tmp_path, batch_size=1, num_workers=0, bucket_width=0, world_size=2, rank=r, seed=3)
+        dmr.setup()
+        loader = dmr.train_dataloader()
+        dmr.set_epoch(1)
+        seen.append(sorted(pid for bt in loader for pid in bt["pdb_id"]))
+    assert len(seen[0]) == len(seen[1]) == 3 and sorted(seen[0] + seen[1]) == sorted(ids[:6])

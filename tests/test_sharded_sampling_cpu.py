@@ -65,3 +65,49 @@ def test_two_ranks_match_one_rank(tmp_path, num_samples, batch_size):
         assert torch.allclose(logits, want_logits, rtol=0, atol=1e-5)
     # samples are distinct (keyed noise), not the duplicates of the reference's identically seeded ranks
     assert not torch.allclose(want_pos[0], want_pos[1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: 64 samples over 8 ranks, as one batch of 8 or two batches of 4 per rank
+# ---------------------------------------------------------------------------------------------------
+
+def _stub_sampler(calls):
+    """A sampler that costs nothing and is keyed on the NoiseSource alone: sample k is the first draws of NoiseSource(seed, k),
+    whatever rank, shard or batch it is drawn in.  Records the batch sizes it was called with."""
+    def sampler(batch, sources):
+        b, N = batch["atom_mask"].shape
+        assert b == len(sources)
+        calls.append(b)
+        return torch.stack([s.randn(N, 3) for s in sources]), torch.stack([s.randn(N, 21) for s in sources])
+    return sampler
+
+
+def _worker_stub(rank, world, port, num_samples, batch_size, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = synthetic_batch([(3, 8)], esm_dim=16, seed=4)
+    calls = []
+    pos, logits = sample_sharded(_stub_sampler(calls), batch, num_samples, seed=5, batch_size=batch_size)
+    torch.save((pos, logits, calls), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,num_samples,batch_size", [(8, 64, 8), (8, 64, 4), (2, 64, 8), (8, 61, 8)])
+def test_configs2_split_over_ranks(tmp_path, world, num_samples, batch_size):
+    """The product's sample_sharded + gather_samples under a real multi-rank process group (gloo): 64 samples on 8 ranks as
+    1 x 8 or 2 x 4 per rank (BASELINE configs[2]), on 2 ranks, and an uneven 61: every rank ends with all samples in global
+    index order, equal to what one process draws, and each rank ran exactly its contiguous block in batches of batch_size."""
+    from protein_redesign_amd.synthetic import NoiseSource
+    batch = synthetic_batch([(3, 8)], esm_dim=16, seed=4)
+    want_pos = torch.stack([NoiseSource(5, k).randn(11, 3) for k in range(num_samples)])
+    port = 29700 + (os.getpid() % 200) + world + batch_size
+    mp.spawn(_worker_stub, args=(world, port, num_samples, batch_size, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        pos, logits, calls = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert pos.shape == (num_samples, 11, 3) and logits.shape == (num_samples, 11, 21)
+        assert torch.equal(pos, want_pos)
+        mine = len(shard_range(num_samples, world, r))
+        full, rest = divmod(mine, batch_size)
+        assert calls == [batch_size] * full + ([rest] if rest else [])
+    del batch

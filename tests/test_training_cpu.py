@@ -51,7 +51,7 @@ def oracle_training_loss(params, args, pb, t, nz, ns):
 def case_inputs(golden, name):
     case, z = golden(name)
     args = make_args(**case["args"])
-    params = deterministic_state_dict(spec_tensors(args), seed=case["weight_seed"], style=case.get("weight_style", "random"))
+    params = deterministic_state_dict(spec_tensors(args), seed=case["weight_seed"], style=case.get("weight_style", "random"), scales=case.get("weight_scales"))
     sizes = [tuple(s) for s in case["sizes"]]
     batch = synthetic_batch(sizes, esm_dim=args["esm_dim"], seed=case["batch_seed"], n_total=case["n_total"])
     perms = [NoiseSource(NOISE_SEED, 100 + k).randperm(n) for k, (_, n) in enumerate(sizes)]

@@ -15,7 +15,7 @@ z = np.load('tests/golden/cfg2_t1000.npz'); case = json.loads(str(z['case']))
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64); return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 args = make_args(**case['args'])
-params = deterministic_state_dict(spec_tensors(args), seed=case['weight_seed'], style=case.get('weight_style', 'random'))
+params = deterministic_state_dict(spec_tensors(args), seed=case['weight_seed'], style=case.get('weight_style', 'random'), scales=case.get('weight_scales'))
 model = ProteinReDiffModel(args); model.load_state_dict(params); model = model.to('cuda').eval()
 one = batch_to(synthetic_batch([tuple(case['traj_sample'])], esm_dim=args['esm_dim'], seed=case['batch_seed'] + 500), 'cuda')
 steps = [int(v) for v in z['seg_step']]

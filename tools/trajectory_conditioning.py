@@ -43,7 +43,7 @@ def free_run(case, mode):
     assert lib.prd_set_gemm_mode(1 if mode == "split16" else 0) == 0
     try:
         args = make_args(**case["args"])
-        params = deterministic_state_dict(spec_tensors(args), seed=case["weight_seed"], style=case.get("weight_style", "random"))
+        params = deterministic_state_dict(spec_tensors(args), seed=case["weight_seed"], style=case.get("weight_style", "random"), scales=case.get("weight_scales"))
         model = ProteinReDiffModel(args)
         model.load_state_dict(params)
         model = model.to("cuda").eval()
