@@ -83,6 +83,7 @@ int prd_version(void);
 #define PRD_TUNE_OL_GEN2 (1 << 12)      /* PRD_OL_VARIANT=1: round-2 outer-linear kernel instead of the K-split one */
 #define PRD_TUNE_TMS_NW12 (1 << 13)     /* PRD_TMS_NW=12 / 16: waves per workgroup of the split contraction (default 8) */
 #define PRD_TUNE_TMS_NW16 (2 << 13)
+#define PRD_TUNE_GEMM_NO_KG (1 << 15)   /* PRD_GEMM_KG=0: node-row GEMMs with few tiles keep one wave group per workgroup (round-3 dispatch) */
 
 /* ---- generic batched GEMM:  C[g] = epilogue(A[g] * B[g]^T)  (b_kn = 1: A[g] * B[g]) -------------
  * Replaces aten::linear / bmm / matmul on the single track (modules.py:185-225, 306-311;
@@ -172,8 +173,10 @@ int prd_pair_bias2(float* bias_a, const float* pair, const float* gamma_a, const
 int prd_opm_pair(float* out, const float* pair, const float* ab, const float* mask, const float* w_out,
                  const float* b_out, int flags, int b, int N, int P, int C, int arith, hipStream_t stream);
 /* OuterLinear (modules.py:283-287): out[i,j,:] = (residual ? pair : 0) + W1 (x_i * x_j) + u_i - u_j + bias,
- * x = LN(single), u = x W2^T [b,N,P] (computed by prd_gemm), w = [W1 | W2] of shape [P, 2S]. */
-int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
+ * x = LN(single), u = x W2^T [b,N,P] with row pitch ldu floats (computed by prd_gemm; ldu > P when u is a column block of a wider
+ * GEMM output: the block's single track projects u and the NEXT block's attention q|k|v|gate from the same LN(single) in one
+ * launch), w = [W1 | W2] of shape [P, 2S]. */
+int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, int ldu, const float* w,
                      const float* bias, int residual, int b, int N, int P, int S, int* queue, int arith, hipStream_t stream);
 /* TriangleMultiplication (modules.py:262-274): out = (residual ? pair : 0) + update(pair).
  * ws: 3 * b * P * N * round_up(N,32) floats (query prd_workspace_bytes). */
@@ -284,8 +287,9 @@ int prd_tri_attn_core_fused(float* og, float* pair_out, const float* pair, const
                             const float* wg, const float* bg, int ending, int b, int N, int P, int H, int c,
                             hipStream_t stream);
 /* single-track gated attention core for heads of width 16 (modules.py:216-223): qkvg = [q/sqrt(c) | k | v | sigmoid(gate)]
- * of shape [b,N,4*H*c] (one packed prd_gemm), bias [b,H,N,N], mask [b,N] or NULL -> o[b,N,H*c] = gate * softmax(qk + bias) v */
-int prd_single_attn_core(float* o, const float* qkvg, const float* bias, const float* mask,
+ * of shape [b,N,4*H*c] with row pitch ldq floats (one packed prd_gemm; ldq > 4 H c when it is a column block of a wider GEMM
+ * output), bias [b,H,N,N], mask [b,N] or NULL -> o[b,N,H*c] = gate * softmax(qk + bias) v */
+int prd_single_attn_core(float* o, const float* qkvg, int ldq, const float* bias, const float* mask,
                          int b, int N, int H, int c, hipStream_t stream);
 /* pair transition (modules.py:321-326): out = (residual ? pair : 0) + W2 relu(W1 LN(pair) + b1) + b2, hidden = 4P */
 int prd_pair_transition(float* out, const float* pair, const float* w1, const float* b1, const float* w2,

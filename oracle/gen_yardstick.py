@@ -38,11 +38,16 @@ from ref_import import import_reference  # noqa: E402
 from protein_redesign_amd.synthetic import NoiseSource, clone_batch, synthetic_batch  # noqa: E402
 
 CASES = {k: v for k, v in G.CASES.items() if v.get("traj_only")}
-# BASELINE.json configs[1]: 256 residues + 64 ligand atoms, 512 / 64, 4 blocks, T = 1000, one sample
+# BASELINE.json configs[1]: 256 residues + 64 ligand atoms, 512 / 64, 4 blocks, T = 1000, one sample.
+# Weight seed 2 (round 4): chosen with tools/conditioning_scan.py (profiles/r04_conditioning_scan.txt) so that the loop STAYS IN THE
+# NETWORK'S WORKING RANGE -- with seed 1 (round 3) the coordinate head's mean pair weight has the expanding sign at N = 320: the
+# positions blow up to 1e4, the distance embedding (support [0, 2], modules.py:73-82) is identically 0 from step ~50 on and the
+# free-running comparison is vacuous.  With seed 2 every pair distance stays inside [0, 2] from step 50 to the end (median
+# 0.2 - 0.6) and two fp32-accurate runs drift apart smoothly (1e-6 at step 100 -> 2.5e-5 at step 900).
 CASES["cfg2_t1000"] = dict(
     args=dict(single_dim=512, pair_dim=64, head_dim=16, num_heads=4, num_blocks=4, esm_dim=1280,
               num_steps=1000, mask_prob=0.3),
-    sizes=[(64, 256)], n_total=None, batch_seed=0, weight_seed=1, leaves=False, traj_sample=(64, 256), traj_only=True,
+    sizes=[(64, 256)], n_total=None, batch_seed=0, weight_seed=2, leaves=False, traj_sample=(64, 256), traj_only=True,
     weight_style="near_init", traj_every=25)
 
 

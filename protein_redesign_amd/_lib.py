@@ -49,7 +49,7 @@ SIGNATURES = {
     "prd_pair_bias": [vp] * 6 + [ci] * 4 + [vp],
     "prd_pair_bias2": [vp] * 6 + [ci] + [vp] * 5 + [ci] * 4 + [vp],
     "prd_opm_pair": [vp] * 6 + [ci] * 6 + [vp],
-    "prd_outer_linear": [vp] * 6 + [ci] * 5 + [vp, ci, vp],
+    "prd_outer_linear": [vp] * 4 + [ci] + [vp] * 2 + [ci] * 5 + [vp, ci, vp],
     "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, ci, vp],
     "prd_tri_mul_contract": [vp, vp, ci, ci, ci, ci, vp],
     "prd_tri_mul_chain_supported": [ci, ci, ci],
@@ -67,7 +67,7 @@ SIGNATURES = {
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, ci, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, ci, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, ci, vp],
-    "prd_single_attn_core": [vp] * 4 + [ci] * 4 + [vp],
+    "prd_single_attn_core": [vp, vp, ci, vp, vp] + [ci] * 4 + [vp],
     "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
@@ -116,6 +116,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 12
     nw = geti("PRD_TMS_NW", 8)
     t |= (1 << 13) if nw == 12 else (2 << 13) if nw == 16 else 0
+    if geti("PRD_GEMM_KG", 1) == 0:
+        t |= 1 << 15
     return t
 
 
@@ -131,7 +133,7 @@ class _Library:
         self._wrapped = {}
 
     def prd_set_tune(self, tune: int) -> int:
-        if tune < 0 or tune >= (1 << 15):
+        if tune < 0 or tune >= (1 << 20):
             return -1
         self._tune = int(tune)
         return 0

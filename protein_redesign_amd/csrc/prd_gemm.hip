@@ -715,6 +715,13 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
         const int nch = g.K / 64;
         dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
         const bool many = (long)grid.x * grid.y > 1024;         // throughput regime: one group per workgroup, more workgroups per CU
+        // few tiles (the 512 -> 256 / 64 projections: 80 / 20 tiles on 256 CUs): the chunk loop is a serial chain of
+        // stage -> barrier -> MFMA steps per workgroup, so split it over two or four wave groups (PRD_TUNE_GEMM_NO_KG: A/B switch)
+        const long ntile = (long)grid.x * grid.y;
+        const bool kgsplit = !((g.arith >> 8) & (1 << 15));
+        if (kgsplit && nch == 8 && ntile <= 64) return launch_ring<2, 4>(g, grid, stream);
+        if (kgsplit && nch == 8 && ntile <= 192) return launch_ring<4, 2>(g, grid, stream);
+        if (kgsplit && nch == 4 && ntile <= 128) return launch_ring<2, 2>(g, grid, stream);
         if (nch <= 1) return launch_ring<1, 1>(g, grid, stream);
         if (nch <= 2) return launch_ring<2, 1>(g, grid, stream);
         if (nch <= 4) return launch_ring<4, 1>(g, grid, stream);

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(WG) void opm_pair_kernel(float* out, const float* p
 template <int P>
 __global__ __launch_bounds__(WG) void outer_linear_kernel(float* out, const float* pair, const float* __restrict__ x,
                                                           const float* __restrict__ u, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, int b, int N, int S, int residual) {
+                                                          const float* __restrict__ bias, int b, int N, int S, int residual, int ldu) {
     constexpr int NB = P / 32, KH = P / 2, KCH = 128;
     __shared__ __attribute__((aligned(16))) float Wl[P * (KCH + 4)];
     __shared__ __attribute__((aligned(16))) float bl[P];
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(WG) void outer_linear_kernel(float* out, const floa
             }
         }
         float ui[KH], uj[KH], pr[KH];
-        load_row_cll<P>(u + bi * P, hi, true, ui);
-        load_row_cll<P>(u + ((long)bb * N + jj) * P, hi, true, uj);
+        load_row_cll<P>(u + bi * ldu, hi, true, ui);
+        load_row_cll<P>(u + ((long)bb * N + jj) * ldu, hi, true, uj);
         const long off = (bi * N + jj) * P;
         load_row_cll<P>(pair + off, hi, valid && residual, pr);
 #pragma unroll
@@ -501,7 +501,7 @@ template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, float* out, const float* pair,
                                                                    const float* __restrict__ x, const float* __restrict__ u,
                                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                                   int b, int N, int S, int residual) {
+                                                                   int b, int N, int S, int residual, int ldu) {
     constexpr int NB = P / 32, KH = P / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                      // [P][S+4]
@@ -572,8 +572,8 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_kernel(int* queue, f
         // epilogue: (i,j) for j >= i ... and the mirrored (j,i) for j > i; positions j < i of the diagonal block belong
         // to the task of row j (which has i in ITS block, i > j)
         float ui[KH], uj[KH], pr[KH];
-        load_row_cll<P>(u + bi * P, hi, true, ui);
-        load_row_cll<P>(u + ((long)bb * N + jj) * P, hi, true, uj);
+        load_row_cll<P>(u + bi * ldu, hi, true, ui);
+        load_row_cll<P>(u + ((long)bb * N + jj) * ldu, hi, true, uj);
         const bool upper = valid && j >= i, mirror = valid && j > i;
         const long off = (bi * N + jj) * P;
         load_row_cll<P>(pair + off, hi, upper && residual, pr);
@@ -595,7 +595,7 @@ template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out, const float* pair,
                                                                       const float* __restrict__ x, const float* __restrict__ u,
                                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                                      int b, int N, int S, int residual) {
+                                                                      int b, int N, int S, int residual, int ldu) {
     constexpr int NB = P / 32, KH = P / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ol[];
     u32x4* Wh = reinterpret_cast<u32x4*>(smem_ol);          // [2 planes][P rows][S/8 slots]
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(NW * 64) void outer_linear_res_h2_kernel(float* out
         pt.mark(1);                                         // 1: K loop (x_i x_j products, splits, MFMAs)
         // epilogue: (i,j) for j >= i and the mirrored (j,i) for j > i (see outer_linear_res_kernel)
         float ui[KH], uj[KH], pr[KH];
-        load_row_cll<P>(u + bi * P, hi, true, ui);
-        load_row_cll<P>(u + ((long)bb * N + jj) * P, hi, true, uj);
+        load_row_cll<P>(u + bi * ldu, hi, true, ui);
+        load_row_cll<P>(u + ((long)bb * N + jj) * ldu, hi, true, uj);
         const bool upper = valid && j >= i, mirror = valid && j > i;
         const long off = (bi * N + jj) * P;
         load_row_cll<P>(pair + off, hi, upper && residual, pr);
@@ -1454,7 +1454,7 @@ namespace {
 template <int P, int KS>          // KS = K steps (16 channels each) per wave: S = 128 KS
 __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const float* pair, const float* __restrict__ x,
                                                               const float* __restrict__ u, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, int b, int N, int residual) {
+                                                              const float* __restrict__ bias, int b, int N, int residual, int ldu) {
     constexpr int NB = P / 32, NW = 8, S = 128 * KS, NG = NB * 4;      // NG = 4-register groups of the accumulator
     constexpr int CW = 16 * KS;                                         // channels per wave
     constexpr int XP = CW * 4 + 16;                                     // staging row pitch in bytes (+16: bank spread)
@@ -1510,6 +1510,11 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
     const int ech = 4 * (elive ? epiece : 0);
     // channel ech .. ech+3 sits in accumulator group (ech >> 5) * 4 + ((ech >> 3) & 3) of the lane of row erow with hi = (ech >> 2) & 1
     const int egrp = (ech >> 5) * 4 + ((ech >> 3) & 3), esrc = erow + 32 * ((ech >> 2) & 1);
+    // The partial tile of (wave, group g) is stored lane-linear EXCEPT that the low four lane bits are XORed with (2 g + hi): the
+    // sixteen lanes of a ds_read_b128 group of the reduction (two tile rows x 8 channel pieces: same low lane bits, all eight
+    // (group, hi) combinations) then read sixteen different 16-byte bank slots.  Unswizzled they hit two slots, 8-way: 67 % of the
+    // kernel's LDS cycles were bank conflicts (profiles/r03_roofline.txt).
+    const int eoff = egrp * 64 + ((esrc & 48) | ((esrc & 15) ^ ((2 * egrp + (esrc >> 5)) & 15)));
     const float4 bs = *reinterpret_cast<const float4*>(bias + ech);
     struct Epi { float4 ui, pu, pm; };
     pt.mark(6);                                             // 6: prologue (W1 slice -> registers)
@@ -1538,7 +1543,7 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
         const int je = T.jb * 32 + erow;                    // this lane's row j in the epilogue
         const bool jvalid = elive && je < N;
         const int jj = jvalid ? je : 0;
-        const float4 uj = *reinterpret_cast<const float4*>(u + ((size_t)T.bb * N + jj) * P + ech);
+        const float4 uj = *reinterpret_cast<const float4*>(u + ((size_t)T.bb * N + jj) * ldu + ech);
         auto row_ok = [&](int i) { return i < N; };
         auto fetch_x = [&](int i, float4 (&xa)[KS][2]) {
             const float* xi = x + ((size_t)T.bb * N + (row_ok(i) ? i : 0)) * S + k0 + 8 * hi;
@@ -1552,7 +1557,7 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
             const bool ok = row_ok(i);
             const int ic = ok ? i : 0;
             const bool upper = ok && jvalid && je >= i, mirror = ok && jvalid && je > i;
-            e.ui = *reinterpret_cast<const float4*>(u + ((size_t)T.bb * N + ic) * P + ech);
+            e.ui = *reinterpret_cast<const float4*>(u + ((size_t)T.bb * N + ic) * ldu + ech);
             e.pu = make_float4(0.f, 0.f, 0.f, 0.f);
             e.pm = e.pu;
             if (upper && residual) e.pu = *reinterpret_cast<const float4*>(pair + (((size_t)T.bb * N + ic) * N + jj) * P + ech);
@@ -1570,7 +1575,7 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int w2 = 0; w2 < NW; ++w2) {
-                const float4 v = pb[((size_t)w2 * NG + egrp) * 64 + esrc];
+                const float4 v = pb[(size_t)w2 * NG * 64 + eoff];
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
             const bool upper = jvalid && je >= i, mirror = jvalid && je > i;
@@ -1620,10 +1625,10 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
             ecur = enext;
             pt.mark(3);                                     // 3: reduction + epilogue of the previous row
             {
-                float4* pw = part + (size_t)(ii & 1) * PSZ + ((size_t)wave * NG) * 64 + lane;
+                float4* pw = part + (size_t)(ii & 1) * PSZ + ((size_t)wave * NG) * 64;
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
-                    pw[(size_t)g * 64] = make_float4(acc[g >> 2][4 * (g & 3)], acc[g >> 2][4 * (g & 3) + 1], acc[g >> 2][4 * (g & 3) + 2],
+                    pw[g * 64 + ((lane & 48) | ((lane & 15) ^ ((2 * g + hi) & 15)))] = make_float4(acc[g >> 2][4 * (g & 3)], acc[g >> 2][4 * (g & 3) + 1], acc[g >> 2][4 * (g & 3) + 2],
                                                      acc[g >> 2][4 * (g & 3) + 3]);
             }
             pt.mark(1);                                     // 1: partial stores
@@ -1639,10 +1644,11 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
 }
 }  // namespace
 
-extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, const float* w,
+extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, const float* u, int ldu, const float* w,
                                 const float* bias, int residual, int b, int N, int P, int S, int* queue, int arith, hipStream_t stream) {
     PRD_SPLIT_ARITH(arith);
     if (!out || !pair || !x || !u || !w || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (ldu < P || (ldu & 3)) return PRD_ERR_ALIGN;           // u rows are read in 16-byte pieces
     PRD_CHECK_P(P);
     if (S <= 0 || (S & 7)) return PRD_ERR_UNSUPPORTED;
     const long ntask = (long)b * N * prd_ceil_div(N, 32);
@@ -1658,7 +1664,7 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
 #define PRD_OLKS(PP, KK)                                                                                               \
         do {                                                                                                           \
             PRD_SET_LDS((outer_linear_ks_kernel<PP, KK>), ldsk);                                                       \
-            hipLaunchKernelGGL((outer_linear_ks_kernel<PP, KK>), dim3(grid), dim3(512), ldsk, stream, out, pair, x, u, w, bias, b, N, residual); \
+            hipLaunchKernelGGL((outer_linear_ks_kernel<PP, KK>), dim3(grid), dim3(512), ldsk, stream, out, pair, x, u, w, bias, b, N, residual, ldu); \
         } while (0)
         if (P == 64) { if (S == 512) PRD_OLKS(64, 4); else if (S == 256) PRD_OLKS(64, 2); else PRD_OLKS(64, 1); }
         else { if (S == 512) PRD_OLKS(32, 4); else if (S == 256) PRD_OLKS(32, 2); else PRD_OLKS(32, 1); }
@@ -1673,10 +1679,10 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
         const size_t lds2 = (size_t)4 * P * S + 4 * P;
         if (P == 64) {
             PRD_SET_LDS((outer_linear_res_h2_kernel<64, NWL>), lds2);
-            hipLaunchKernelGGL((outer_linear_res_h2_kernel<64, NWL>), dim3(grid), dim3(NWL * 64), lds2, stream, out, pair, x, u, w, bias, b, N, S, residual);
+            hipLaunchKernelGGL((outer_linear_res_h2_kernel<64, NWL>), dim3(grid), dim3(NWL * 64), lds2, stream, out, pair, x, u, w, bias, b, N, S, residual, ldu);
         } else {
             PRD_SET_LDS((outer_linear_res_h2_kernel<32, NWL>), lds2);
-            hipLaunchKernelGGL((outer_linear_res_h2_kernel<32, NWL>), dim3(grid), dim3(NWL * 64), lds2, stream, out, pair, x, u, w, bias, b, N, S, residual);
+            hipLaunchKernelGGL((outer_linear_res_h2_kernel<32, NWL>), dim3(grid), dim3(NWL * 64), lds2, stream, out, pair, x, u, w, bias, b, N, S, residual, ldu);
         }
         return (int)hipGetLastError();
     }
@@ -1689,16 +1695,16 @@ extern "C" int prd_outer_linear(float* out, const float* pair, const float* x, c
         int* oq = (nsym > (long)grid * NWL) ? queue : nullptr;
         if (P == 64) {
             PRD_SET_LDS((outer_linear_res_kernel<64, NWL>), lds);
-            hipLaunchKernelGGL((outer_linear_res_kernel<64, NWL>), dim3(grid), dim3(NWL * 64), lds, stream, oq, out, pair, x, u, w, bias, b, N, S, residual);
+            hipLaunchKernelGGL((outer_linear_res_kernel<64, NWL>), dim3(grid), dim3(NWL * 64), lds, stream, oq, out, pair, x, u, w, bias, b, N, S, residual, ldu);
         } else {
             PRD_SET_LDS((outer_linear_res_kernel<32, NWL>), lds);
-            hipLaunchKernelGGL((outer_linear_res_kernel<32, NWL>), dim3(grid), dim3(NWL * 64), lds, stream, oq, out, pair, x, u, w, bias, b, N, S, residual);
+            hipLaunchKernelGGL((outer_linear_res_kernel<32, NWL>), dim3(grid), dim3(NWL * 64), lds, stream, oq, out, pair, x, u, w, bias, b, N, S, residual, ldu);
         }
         return (int)hipGetLastError();
     }
     const int grid = grid_for(ntask, 4, 1024);       // very wide single track: stream W1 through LDS in K chunks
-    if (P == 64) hipLaunchKernelGGL(outer_linear_kernel<64>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual);
-    else hipLaunchKernelGGL(outer_linear_kernel<32>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual);
+    if (P == 64) hipLaunchKernelGGL(outer_linear_kernel<64>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual, ldu);
+    else hipLaunchKernelGGL(outer_linear_kernel<32>, dim3(grid), dim3(WG), 0, stream, out, pair, x, u, w, bias, b, N, S, residual, ldu);
     return (int)hipGetLastError();
 }
 

@@ -924,8 +924,8 @@ struct SaBlock {                      // one 32-key block in the lane layout (la
 };
 
 PRD_DEV void sa_load(SaBlock& s, const float* __restrict__ base, const float* __restrict__ brow, const float* __restrict__ mrow,
-                     int N, int key0, int h, int ql, int g4) {
-    constexpr int C = 16, HC = 64, L = 4 * HC;
+                     int N, int key0, int h, int ql, int g4, int L) {
+    constexpr int C = 16, HC = 64;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int kr = key0 + 16 * j + ql;
@@ -942,8 +942,8 @@ PRD_DEV void sa_load(SaBlock& s, const float* __restrict__ base, const float* __
 
 __global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict__ o_out, const float* __restrict__ qkvg,
                                                                const float* __restrict__ bias, const float* __restrict__ mask,
-                                                               int b, int N, int H) {
-    constexpr int C = 16, HC = 64, L = 4 * HC, RD = 3;
+                                                               int b, int N, int H, int L) {
+    constexpr int C = 16, HC = 64, RD = 3;                 // L: row pitch of qkvg in floats (>= 4 HC: the projection may sit inside a wider GEMM output)
     __shared__ float part[4][6][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 15, g4 = lane >> 4;
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict
     SaBlock ring[RD];
     if (nb > 0) {
 #pragma unroll
-        for (int d = 0; d < RD; ++d) sa_load(ring[d], base, brow, mrow, N, (blk0 + (d < nb ? d : nb - 1)) * 32, h, ql, g4);
+        for (int d = 0; d < RD; ++d) sa_load(ring[d], base, brow, mrow, N, (blk0 + (d < nb ? d : nb - 1)) * 32, h, ql, g4, L);
     }
     const float4 qf = *reinterpret_cast<const float4*>(base + (size_t)qq * L + h * C + 4 * g4);   // already scaled by 1/sqrt(c)
     float m_run = -1e30f, l_run = 0.f;
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256) void single_attn_core_kernel(float* __restrict
                     o = mfma16(key0 + 16 * j + 4 * g4 + 3 < N ? blk.v[j][3] : 0.f, s[j][3], o);
                 }
                 const int nx = i + RD;                              // refill the slot (clamped: the tail re-reads the last block)
-                sa_load(ring[d], base, brow, mrow, N, (blk0 + (nx < nb ? nx : nb - 1)) * 32, h, ql, g4);
+                sa_load(ring[d], base, brow, mrow, N, (blk0 + (nx < nb ? nx : nb - 1)) * 32, h, ql, g4, L);
             }
         }
     }
@@ -2460,11 +2460,12 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     return (int)hipGetLastError();
 }
 
-extern "C" int prd_single_attn_core(float* o, const float* qkvg, const float* bias, const float* mask,
+extern "C" int prd_single_attn_core(float* o, const float* qkvg, int ldq, const float* bias, const float* mask,
                                     int b, int N, int H, int c, hipStream_t stream) {
     if (!o || !qkvg || !bias || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(single_attn_core_kernel, dim3(b * H * prd_ceil_div(N, 16)), dim3(256), 0, stream, o, qkvg, bias, mask, b, N, H);
+    if (ldq < 4 * H * c || (ldq & 3)) return PRD_ERR_ALIGN;
+    hipLaunchKernelGGL(single_attn_core_kernel, dim3(b * H * prd_ceil_div(N, 16)), dim3(256), 0, stream, o, qkvg, bias, mask, b, N, H, ldq);
     return (int)hipGetLastError();
 }
 

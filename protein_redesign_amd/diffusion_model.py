@@ -450,10 +450,12 @@ class ProteinReDiffModel(_Base):
         with side.fork():
             pre = self.Denoiser.project_single(single, mask)
         pair = ops.pair_init(static["pair"], z, mask, self.embed_dist[0].center, self.embed_dist[1].weight, eb)
-        single, pair = self.Denoiser.run_(single, pair, mask, pre=pre, join=side.join)
         sm = self.seq_mlp
+        # the sequence head's first layer is linear in LN(single_out), like the last block's outer-linear term: one launch for both
+        single, pair, h = self.Denoiser.run_(single, pair, mask, pre=pre, join=side.join, tail=(sm[1].weight, sm[1].bias))
         with side.fork():
-            h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)    # LayerNorm (no affine) fused into the linear
+            if h is None:
+                h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)    # LayerNorm (no affine) fused into the linear
             seq_pred = ops.linear(h, sm[3].weight)
         wr = self.weight_radial
         eps_raw = ops.coord_head(pair, z, mask, wr[1].weight, wr[1].bias, wr[3].weight)

@@ -59,8 +59,9 @@ class SideStream:
             torch.cuda.current_stream().wait_stream(self.stream)
 
 
-def _off(t: torch.Tensor, elem_offset: int = 0) -> int:
-    return dptr(t) + 4 * elem_offset
+def _off(t, elem_offset: int = 0) -> int:
+    """device address of element ``elem_offset`` of a contiguous tensor (or of a raw device address, for column blocks)"""
+    return (t if isinstance(t, int) else dptr(t)) + 4 * elem_offset
 
 
 def round_up(a: int, b: int) -> int:
@@ -107,7 +108,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         x, ln_a = layer_norm(x.contiguous()), False
     if out is None:
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
-    gemm(x, w, out, M, N, K, K, w.stride(0), N, alpha=alpha, bias=bias, act=act,
+    a, lda = x, K
+    if not x.is_contiguous():          # a column block of a wider GEMM output
+        a, lda = row_block(x)
+    gemm(a, w, out, M, N, K, lda, w.stride(0), N, alpha=alpha, bias=bias, act=act,
          rowmask=rowmask, resid=resid, ldr=N, a_ln=ln_a)
     return out
 
@@ -221,11 +225,24 @@ def opm_pair(pair, ab, mask, w_out, b_out, *, residual: bool, apply_mask: bool, 
     return out
 
 
+def row_block(t: torch.Tensor):
+    """(device pointer, row pitch in floats) of ``t`` [b, N, C]: a contiguous tensor or a COLUMN BLOCK of one (``big[..., c0:c1]``:
+    unit column stride, rows ``pitch`` floats apart, batches N rows apart) -- how the kernels take an operand that sits inside a
+    wider GEMM output."""
+    if t.dim() != 3 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1) or not t.is_cuda or t.dtype != F32:
+        raise RuntimeError("expected a CUDA fp32 [b, N, C] tensor or a column block of one")
+    if (t.storage_offset() | t.stride(1)) & 3:
+        raise RuntimeError("column block must start on a 16-byte boundary and have a row pitch that is a multiple of 4 floats")
+    return t.data_ptr(), t.stride(1)
+
+
 def outer_linear_pair(pair, x, u, w, bias, *, residual: bool, out=None) -> torch.Tensor:
+    """``u`` [b,N,P]: contiguous, or a column block of a wider GEMM output (row_block)."""
     b, N, _, P = pair.shape
     if out is None:
         out = torch.empty_like(pair)
-    check(lib().prd_outer_linear(dptr(out), dptr(pair), dptr(x), dptr(u), dptr(w), dptr(bias), int(residual),
+    up, ldu = row_block(u)
+    check(lib().prd_outer_linear(dptr(out), dptr(pair), dptr(x), up, ldu, dptr(w), dptr(bias), int(residual),
                                  b, N, P, x.shape[-1], task_queue(pair.device), stream()), "prd_outer_linear")
     return out
 
@@ -601,7 +618,8 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     o = torch.empty(b, N, HC, device=x_normed.device, dtype=F32)
     if c == 16 and HC == 64:
         # heads of width 16 (FoldingBlock.single_attn): fused logits + bias + mask + softmax + PV + gate
-        check(lib().prd_single_attn_core(dptr(o), dptr(qkvg), dptr(bias), dptr(mask) if key_mask else None,
+        qp, ldq = row_block(qkvg)
+        check(lib().prd_single_attn_core(dptr(o), qp, ldq, dptr(bias), dptr(mask) if key_mask else None,
                                          b, N, H, c, stream()), "prd_single_attn_core")
         return linear(o, wo, bo, resid=resid)
     ldp = round_up(N, 4)
@@ -613,6 +631,23 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
          sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L)
     return linear(o, wo, bo, resid=resid)
+
+
+def project_many(single, packed, P_first: int, *, act: int, act_from: int):
+    """ONE GEMM over LN(single) (LayerNorm without affine, fused) for several consumers of the same normalised rows:
+    ``packed`` = (W [Ncat, S], bias [Ncat] or None, colscale [Ncat] or None).  Returns (x = LN(single) [b,N,S], C [b,N,Ncat]);
+    the consumers take column blocks of C (row_block)."""
+    b, N, S = single.shape
+    w, pbias, colscale = packed
+    Ncat = w.shape[0]
+    out = torch.empty(b, N, Ncat, device=single.device, dtype=F32)
+    if ln_fusable(S):
+        x = torch.empty_like(single)
+        gemm(single, w, out, b * N, Ncat, S, S, S, Ncat, bias=pbias, colscale=colscale, act=act, act_from=act_from, a_ln=True, ln_out=x)
+    else:
+        x = layer_norm(single)
+        gemm(x, w, out, b * N, Ncat, S, S, S, Ncat, bias=pbias, colscale=colscale, act=act, act_from=act_from)
+    return x, out
 
 
 def transition_single(single, w1, b1, w2, b2, *, residual: bool) -> torch.Tensor:

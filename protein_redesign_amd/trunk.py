@@ -95,10 +95,12 @@ class Attention(nn.Module):
         ws = self.weights()[:5]
         return ops.cached_pack(self, "qkvg", ws, lambda: ops.pack_attention(*ws, self.scale))
 
-    def run_single(self, x, mask, attn_bias, resid, ln_a=False):
-        """``x`` is the LayerNorm-ed input, or with ``ln_a`` the raw one (the norm is then fused into the projection)."""
+    def run_single(self, x, mask, attn_bias, resid, ln_a=False, qkvg=None):
+        """``x`` is the LayerNorm-ed input, or with ``ln_a`` the raw one (the norm is then fused into the projection).
+        ``qkvg``: the q|k|v|gate projection if the caller already has it (the previous block's single track computes it together
+        with its outer-linear term: both are linear in the same LN(single))."""
         return ops.gated_attention_single(x, mask, attn_bias, self.packed(), self.out_proj.weight, self.out_proj.bias,
-                                          self.num_heads, self.head_dim, key_mask=True, resid=resid, ln_a=ln_a)
+                                          self.num_heads, self.head_dim, key_mask=True, resid=resid, ln_a=ln_a, qkvg=qkvg)
 
     def forward(self, x: torch.Tensor, mask: torch.Tensor, attn_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         if x.dim() != 3:
@@ -159,6 +161,7 @@ _TRI_MUL_CHAIN = os.environ.get("PRD_TRI_MUL_CHAIN", "1") != "0"      # 0: two p
 # SLOWER (1.973 vs 1.931 ms per step, A/B in one run): each of the four head-workgroups of a row re-reads the previous og row
 # (4 x 26 MB instead of one pass) and repeats the projection.  Off by default; kept as a tested opt-in.
 _TRI_ATTN_FUSE = os.environ.get("PRD_TRI_ATTN_FUSE", "0") == "1"
+_MERGE_PROJ = os.environ.get("PRD_MERGE_PROJ", "1") != "0"            # 0: u and the next q|k|v|gate as two launches (A/B measurements)
 
 
 class OuterLinear(nn.Module):
@@ -224,11 +227,40 @@ class FoldingBlock(nn.Module):
             Linear(pair_dim * transition_factor, pair_dim, init="final"),
         )
 
-    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, bias=None, next_block=None, spare_holder=None):
+    def _after_transition_pack(self, next_block, tail):
+        """Weights of the ONE projection that follows the transition: [OuterLinear's W2 | next consumer of LN(single)] -- the next
+        block's q|k|v|gate (pack_attention layout) or ``tail`` = (weight, bias) of a ReLU layer (the sequence head's first)."""
+        S, P = self.outer_linear.single_dim, self.outer_linear.pair_dim
+        w_ol = self.outer_linear.linear.weight
+        if next_block is not None:
+            sa = next_block.single_attn
+            ws = (w_ol, *sa.weights()[:5])
+
+            def build():
+                w, pb, cs = sa.packed()
+                dev = w.device
+                return (torch.cat([w_ol[:, S:], w]).contiguous(), torch.cat([torch.zeros(P, device=dev), pb]).contiguous(),
+                        torch.cat([torch.ones(P, device=dev), cs]).contiguous())
+            return ops.cached_pack(self, "after_transition_next", ws, build), 2, P + 3 * sa.num_heads * sa.head_dim
+        if tail is not None:
+            tw, tb = tail
+            ws = (w_ol, tw, tb)
+
+            def build():
+                dev = tw.device
+                return (torch.cat([w_ol[:, S:], tw]).contiguous(), torch.cat([torch.zeros(P, device=dev), tb]).contiguous(), None)
+            return ops.cached_pack(self, "after_transition_tail", ws, build), 1, P
+        return None, 0, 0
+
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, bias=None, next_block=None, spare_holder=None,
+             qkvg=None, tail=None, extra=None):
         """In place on ``pair`` or -- fused attention form, gemm mode 1 -- ending in another buffer: use the RETURNED pair tensor.
         ``bias``: this block's attention bias if the previous block's fused tail
         already produced it; ``next_block``: the following FoldingBlock, whose attention bias is then computed
-        by this block's fused tail.  Returns (single, pair, next_bias or None)."""
+        by this block's fused tail.  ``qkvg``: this block's attention projection if the previous block already produced it.
+        ``tail`` = (weight, bias): a ReLU layer applied to LN(single_out) in the same launch as the outer-linear term (last block:
+        the sequence head's first layer).  Returns (single, pair, next_bias or None); with ``extra`` (a dict) the by-products go
+        there: "qkvg" = the next block's projection, "tail" = the tail layer's output."""
         sa = self.single_attn
         b, N = mask.shape
         if ws is None:
@@ -237,10 +269,20 @@ class FoldingBlock(nn.Module):
                              device=pair.device, dtype=torch.float32)
         if bias is None:
             bias = ops.pair_bias(pair, self.attn_bias[1].weight, self.attn_bias[1].bias)
-        single = sa.run_single(single, mask, bias, single, ln_a=True)
+        single = sa.run_single(single, mask, bias, single, ln_a=True, qkvg=qkvg)
         fc = self.single_fc
         single = ops.transition_single(single, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=True)
-        self.outer_linear.run(single, pair, residual=True, out=pair)
+        packed, act, act_from = self._after_transition_pack(next_block if extra is not None else None, tail if extra is not None else None)
+        if packed is not None and _MERGE_PROJ:
+            # everything that is linear in LN(single) goes through ONE launch: u of the outer-linear, and the next block's
+            # q|k|v|gate or the tail layer (-1 launch of ~8 us per block; these launches are latency-, not work-bound)
+            P = self.outer_linear.pair_dim
+            x, cat = ops.project_many(single, packed, P, act=act, act_from=act_from)
+            ol = self.outer_linear.linear
+            ops.outer_linear_pair(pair, x, cat[..., :P], ol.weight, ol.bias, residual=True, out=pair)
+            extra["qkvg" if next_block is not None else "tail"] = cat[..., P:]
+        else:
+            self.outer_linear.run(single, pair, residual=True, out=pair)
         if _TRI_MUL_CHAIN and ops.tri_mul_chain_supported(N, pair.shape[-1]):      # gemm mode 1: out-stage of the first + projection of the second fused
             ops.tri_mul_chain_(pair, mask, self.pair_mul_outgoing.weights(), self.pair_mul_incoming.weights(), ws=ws)
         else:
@@ -309,11 +351,12 @@ class Denoiser(nn.Module):
         mn, qkvg = self.SPAAttnBlock.project(single)
         return ab, mn, qkvg
 
-    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, pre=None, join=None):
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, pre=None, join=None, tail=None):
         """OPM, SPA and the folding blocks, in place on ``pair``, WITHOUT the final symmetrisation
         (the fused coordinate head symmetrises on the fly, so the hot path never writes it back).
         ``pre`` = ``project_single(single, mask)`` if the caller already enqueued it; ``join()`` is then called before its
-        results are consumed."""
+        results are consumed.  ``tail`` = (weight, bias) of a ReLU layer over LN(single_out) that the last block computes
+        together with its outer-linear term; its output is then returned as a third value."""
         b, N = mask.shape
         if ws is None:
             ws = torch.empty(self.ws_floats(b, N), device=pair.device, dtype=torch.float32)
@@ -333,9 +376,15 @@ class Denoiser(nn.Module):
             spa_bias, bias = spa.bias_from_pair(pair), None
         single = spa.attend(mn, qkvg, spa_bias)
         holder = [None]             # spare pair buffer of the fused attention form (the residual stream alternates between two)
+        qkvg, extra = None, {}
         for i, block in enumerate(blocks):
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-            single, pair, bias = block.run_(single, pair, mask, ws=ws, bias=bias, next_block=nxt, spare_holder=holder)
+            extra = {}
+            single, pair, bias = block.run_(single, pair, mask, ws=ws, bias=bias, next_block=nxt, spare_holder=holder, qkvg=qkvg,
+                                            tail=tail if nxt is None else None, extra=extra)
+            qkvg = extra.get("qkvg")
+        if tail is not None:
+            return single, pair, extra.get("tail")
         return single, pair
 
     def forward(self, batch, z, t, single, pair, cache):

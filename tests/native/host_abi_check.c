@@ -58,7 +58,8 @@ int main(void) {
     EXPECT(prd_pair_bias2(p, p, 0, 0, p, p, 4, 0, 0, 0, p, p, 4, 1, 8, 64, s), PRD_ERR_ARG);     /* second output missing */
     EXPECT(prd_pair_bias2(p, p, p, 0, p, p, 4, p, 0, 0, p, p, 4, 1, 8, 64, s), PRD_ERR_ARG);     /* gamma without beta */
     EXPECT(prd_opm_pair(p, p, p, p, p, p, 3, 1, 8, 64, 12, A1, s), PRD_ERR_UNSUPPORTED);
-    EXPECT(prd_outer_linear(p, p, p, p, p, p, 1, 1, 8, 64, 36, 0, A1, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_outer_linear(p, p, p, p, 64, p, p, 1, 1, 8, 64, 36, 0, A1, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_outer_linear(p, p, p, p, 48, p, p, 1, 1, 8, 64, 512, 0, A1, s), PRD_ERR_ALIGN);            /* u row pitch below P */
     EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, p, 16, 0, A1, s), PRD_ERR_WORKSPACE);
     EXPECT(prd_tri_mul(p, p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 40, p, 1 << 20, 0, A0, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn(p, p, p, p, p, p, p, p, p, p, 0, 1, 1, 8, 64, 4, 16, 0, 0, 0, A1, s), PRD_ERR_ARG);   /* no workspace */
@@ -72,7 +73,8 @@ int main(void) {
     EXPECT(prd_tri_attn_variant(100000, 64, A1), 3);                 /* any row length: key-chunked */
     EXPECT(prd_tri_attn_variant(320, 48, A1), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_variant(320, 64, 2), PRD_ERR_ARG);
-    EXPECT(prd_single_attn_core(p, p, p, p, 1, 8, 2, 32, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_single_attn_core(p, p, 256, p, p, 1, 8, 2, 32, s), PRD_ERR_UNSUPPORTED);
+    EXPECT(prd_single_attn_core(p, p, 200, p, p, 1, 8, 4, 16, s), PRD_ERR_ALIGN);                    /* qkvg row pitch below 4 H c */
     EXPECT(prd_block_tail(p, p, p, p, p, p, p, p, 0, 0, p, 1, 8, 64, 4, 0, A1, s), PRD_ERR_ARG);   /* bias_out without bias weights */
     EXPECT(prd_coord_head(p, p, p, p, p, p, 0, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_remove_mean(p, p, p, 1, 8, 65, s), PRD_ERR_ARG);
