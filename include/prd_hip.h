@@ -83,6 +83,7 @@ int prd_version(void);
 #define PRD_TUNE_OL_GEN2 (1 << 12)      /* PRD_OL_VARIANT=1: round-2 outer-linear kernel instead of the K-split one */
 #define PRD_TUNE_TMS_NW12 (1 << 13)     /* PRD_TMS_NW=12 / 16: waves per workgroup of the split contraction (default 8) */
 #define PRD_TUNE_TMS_NW16 (2 << 13)
+#define PRD_TUNE_GEMM_NO_SLAB (1 << 16) /* PRD_GEMM_SLAB=0: never split K across workgroups (round-3 kernels for the transition layers) */
 #define PRD_TUNE_GEMM_NO_KG (1 << 15)   /* PRD_GEMM_KG=0: node-row GEMMs with few tiles keep one wave group per workgroup (round-3 dispatch) */
 
 /* ---- generic batched GEMM:  C[g] = epilogue(A[g] * B[g]^T)  (b_kn = 1: A[g] * B[g]) -------------
@@ -90,8 +91,8 @@ int prd_version(void);
  * models/AF2_modules.py:251-293, 613-628) and the triangle-multiplication einsum (modules.py:272).
  * Batch index g = g1 * G2 + g2.  Epilogue, in this order:
  *   v = acc*alpha*colscale[n] + bias[n];  v += addmat[g][m][n];  if colmask[g1][n] < 0.5: v = fill;
- *   act (0 none, 1 relu, 2 sigmoid) applied to columns n >= act_from;  v *= rowmask[g1][m];
- *   v *= mulmat[g][m][n];  v += resid[g][m][n];  C[g][m][n] = v.
+ *   act (0 none, 1 relu, 2 sigmoid) applied to columns n >= act_from;  v *= rowmask[g1][m] (columns n < rowmask_cols if that is set);
+ *   v *= mulmat[g][m][n];  v += resid[g][m][n] (* rscale[n]);  C[g][m][n] = v  (or C2[m][n - n_split] for n >= n_split).
  * lda/ldb must be multiples of 4 floats (rows 16-byte aligned). */
 typedef struct PrdGemm {
     const float* A; const float* B; float* C;
@@ -119,7 +120,26 @@ typedef struct PrdGemm {
                                        ldlo floats) by the workgroups of the first column tile -- OuterLinear needs LN(single)
                                        itself next to the W2 projection of it (modules.py:283-287) */
     int arith;                      /* PRD_ARITH_FP32 / PRD_ARITH_SPLIT16 */
+    /* Several consumers of the same (LayerNorm-ed) rows in ONE launch -- the head of the trunk projects OuterProductUpdate's a | b
+     * and SPAttention's q | k | v | gate from the same normalised single representation (models/AF2_modules.py:421-545, affine
+     * LayerNorm parameters folded into the weights: LN_affine(x) W^T + b = LN(x) (W diag(gamma))^T + (b + W beta)): */
+    float* C2; int ldc2; int n_split;   /* optional: columns n >= n_split are stored to C2[m][n - n_split] (row pitch ldc2) instead of C */
+    int rowmask_cols;               /* > 0: rowmask multiplies only columns n < rowmask_cols */
+    const float* rscale;            /* optional per-column factor of resid: v += resid[m][n] * rscale[n] -- an AFFINE LayerNorm-ed
+                                       residual (SPAttention adds its update to LN_affine(m): models/AF2_modules.py:465-472)
+                                       given as the plain normalised rows x gamma (beta goes into bias) */
+    /* K split ACROSS workgroups for large weights on few rows (the single-track transition 512 -> 2048 -> 512 at M = b N = a few
+     * hundred: csrc/prd_gemm.hip gemm_slab_kernel).  Taken when `ws` is given and the shape qualifies (split-16 arithmetic, one
+     * batch, K % 128 == 0, N % 4 == 0, M >= 96, the epilogue uses none of addmat / colmask / mulmat / C2 / ln_out): fp32 partial
+     * tiles [K slabs][M][N] go to `ws`, a second launch sums them in slab order and applies the epilogue. */
+    float* ws; size_t ws_bytes;     /* optional workspace; prd_gemm_slab_workspace(M, N, K) bytes suffice */
+    const float* wsum;              /* with a_ln on this path: wsum[n] = sum_k B[n][k]; the GEMM runs on the RAW rows and the
+                                       LayerNorm is applied by linearity, LN(x) W^T = rstd (x W^T - mean wsum) */
+    float* out_ln; int ldol;        /* optional (this path only, N <= 512): nn.LayerNorm(N, elementwise_affine=False) of the OUTPUT rows
+                                       is written here as well -- the next linear of the single track starts with it */
 } PrdGemm;
+size_t prd_gemm_slab_workspace(int M, int N, int K);
+int prd_gemm_slab_ok(int M, int N, int K, int arith);   /* 1 when a PrdGemm of this shape with `ws` set takes the K-slab path */
 int prd_gemm(const PrdGemm* args, hipStream_t stream);
 
 /* nn.LayerNorm over the last axis, eps 1e-5; gamma/beta may be NULL (elementwise_affine=False). */

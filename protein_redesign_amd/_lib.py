@@ -31,6 +31,12 @@ class PrdGemm(C.Structure):
         ("a_ln", ci),
         ("ln_out", vp), ("ldlo", ci),
         ("arith", ci),
+        ("C2", vp), ("ldc2", ci), ("n_split", ci),
+        ("rowmask_cols", ci),
+        ("rscale", vp),
+        ("ws", vp), ("ws_bytes", cz),
+        ("wsum", vp),
+        ("out_ln", vp), ("ldol", ci),
     ]
 
 
@@ -39,6 +45,8 @@ SIGNATURES = {
     "prd_version": [],
     "prd_tri_attn_variant": [ci, ci, ci],
     "prd_gemm": [C.POINTER(PrdGemm), vp],
+    "prd_gemm_slab_workspace": [ci, ci, ci],
+    "prd_gemm_slab_ok": [ci, ci, ci, ci],
     "prd_ln_rows": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
     "prd_softmax_rows": [vp, ci, ci, ci, vp],
     "prd_static_pair": [vp] * 13 + [ci] * 5 + [vp],
@@ -89,7 +97,8 @@ DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (e
 _ARITH_BEFORE_STREAM = ("prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
                         "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain")
 # ... and the queries that take it as their last argument
-_ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes")
+_ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes",
+               "prd_gemm_slab_ok")
 # entry points without an arithmetic that still dispatch between kernel generations: the PRD_TUNE_* switch word alone
 _TUNE_BEFORE_STREAM = ("prd_tri_attn_core_v2",)
 _TUNE_LAST = ("prd_tri_attn_v2_supported", "prd_tri_attn_v2_form")
@@ -118,6 +127,8 @@ def tune_from_env(env=None) -> int:
     t |= (1 << 13) if nw == 12 else (2 << 13) if nw == 16 else 0
     if geti("PRD_GEMM_KG", 1) == 0:
         t |= 1 << 15
+    if geti("PRD_GEMM_SLAB", 1) == 0:
+        t |= 1 << 16
     return t
 
 
@@ -187,7 +198,8 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(cdll, name)
             fn.argtypes = argtypes
-            fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace", "prd_tri_attn_stats_bytes") else ci
+            fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace", "prd_tri_attn_stats_bytes",
+                                        "prd_gemm_slab_workspace") else ci
         mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)
         if os.environ.get("PRD_BF16X3"):                               # older spelling of PRD_GEMM_MODE=bf16x3
             mode = "bf16x3"

@@ -99,11 +99,19 @@ class SPAttention(nn.Module):
     def bias_from_pair(self, z: torch.Tensor) -> torch.Tensor:
         return ops.pair_bias(z.contiguous(), self.linear_z[1].weight, None, self.linear_z[0].weight, self.linear_z[0].bias)
 
-    def attend(self, mn: torch.Tensor, qkvg: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    def attend(self, mn: torch.Tensor, qkvg: torch.Tensor, bias: torch.Tensor, normed_only: bool = False) -> torch.Tensor:
+        """``normed_only``: ``mn`` is the PLAIN normalised input (no affine; Denoiser.project_single's merged projection); the
+        residual LN_affine(m) = mn * gamma + beta is then formed in the output projection's epilogue (gamma as the residual's
+        column factor, beta added to the bias)."""
         a = self.mha
+        ln = self.layer_norm_m
+        bo, rscale = a.linear_o.bias, None
+        if normed_only:
+            bo = ops.cached_pack(self, "bo_beta", (a.linear_o.bias, ln.bias), lambda: (a.linear_o.bias + ln.bias).contiguous())
+            rscale = ln.weight
         # no mask: the reference builds a mask bias and drops it (AF2_modules.py:447 vs 461-463)
-        return ops.gated_attention_single(mn, mn, bias, self._packed(), a.linear_o.weight, a.linear_o.bias,
-                                          self.no_heads, self.c_hidden, key_mask=False, resid=mn, qkvg=qkvg)
+        return ops.gated_attention_single(mn, mn, bias, self._packed(), a.linear_o.weight, bo,
+                                          self.no_heads, self.c_hidden, key_mask=False, resid=mn, qkvg=qkvg, rscale=rscale)
 
     def forward(self, m: torch.Tensor, z: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, N, _ = m.shape

@@ -23,10 +23,14 @@ PRD_DEV void epilogue_store(const PrdGemm& g, int g1, int g2, int m, int n, floa
     const int act = (n >= g.act_from) ? g.act : 0;
     if (act == 1) v = fmaxf(v, 0.f);
     else if (act == 2) v = sigmoidf_(v);
-    if (g.rowmask) v *= g.rowmask[g1 * g.srm1 + m];
+    if (g.rowmask && (g.rowmask_cols <= 0 || n < g.rowmask_cols)) v *= g.rowmask[g1 * g.srm1 + m];
     if (g.mulmat) v *= g.mulmat[g1 * g.smu1 + g2 * g.smu2 + (size_t)m * g.ldmul + n];
-    if (g.resid) v += g.resid[g1 * g.sr1 + g2 * g.sr2 + (size_t)m * g.ldr + n];
-    C[(size_t)m * g.ldc + n] = v;
+    if (g.resid) {
+        const float rv = g.resid[g1 * g.sr1 + g2 * g.sr2 + (size_t)m * g.ldr + n];
+        v += g.rscale ? rv * g.rscale[n] : rv;
+    }
+    if (g.C2 && n >= g.n_split) g.C2[(size_t)m * g.ldc2 + (n - g.n_split)] = v;
+    else C[(size_t)m * g.ldc + n] = v;
 }
 
 template <int WM, int WN>       // wave tile (multiples of 32); workgroup = 2 x 2 waves
@@ -368,19 +372,30 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
         if (tid < 256) {
             const int row = tid >> 2, part = tid & 3, m = m0 + row;
             const float* ar = A + (size_t)(m < g.M ? m : 0) * g.lda;
+            // eight 16-byte loads in flight per thread and pass (unconditional: groups past K re-read the row's start and are
+            // masked) -- a one-load-at-a-time loop is a chain of K / 16 L2 round trips per pass, 8 us at K = 512
+            constexpr int UB = 8;
             float s1 = 0.f;
-            for (int k = 4 * part; k < g.K; k += 16) {
-                const float4 v = *reinterpret_cast<const float4*>(ar + k);
-                s1 += (v.x + v.y) + (v.z + v.w);
+            for (int k0 = 4 * part; k0 < g.K; k0 += 16 * UB) {
+                float4 v[UB];
+#pragma unroll
+                for (int j = 0; j < UB; ++j) v[j] = *reinterpret_cast<const float4*>(ar + (k0 + 16 * j < g.K ? k0 + 16 * j : 0));
+#pragma unroll
+                for (int j = 0; j < UB; ++j) s1 += (k0 + 16 * j < g.K) ? (v[j].x + v[j].y) + (v[j].z + v[j].w) : 0.f;
             }
             s1 += __shfl_xor(s1, 1);
             s1 += __shfl_xor(s1, 2);
             const float mu = s1 / (float)g.K;
             float s2 = 0.f;
-            for (int k = 4 * part; k < g.K; k += 16) {
-                const float4 v = *reinterpret_cast<const float4*>(ar + k);
-                const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
-                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            for (int k0 = 4 * part; k0 < g.K; k0 += 16 * UB) {
+                float4 v[UB];
+#pragma unroll
+                for (int j = 0; j < UB; ++j) v[j] = *reinterpret_cast<const float4*>(ar + (k0 + 16 * j < g.K ? k0 + 16 * j : 0));
+#pragma unroll
+                for (int j = 0; j < UB; ++j) {
+                    const float d0 = v[j].x - mu, d1 = v[j].y - mu, d2 = v[j].z - mu, d3 = v[j].w - mu;
+                    s2 += (k0 + 16 * j < g.K) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+                }
             }
             s2 += __shfl_xor(s2, 1);
             s2 += __shfl_xor(s2, 2);
@@ -392,11 +407,13 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
     const prd_rsrc ra = make_rsrc(A + (size_t)m0 * g.lda), rb = make_rsrc(B + (size_t)n0 * g.ldb);
     unsigned off[4], dst[4];
     float amu[2], ars[2];
+    float* lo_[2] = {nullptr, nullptr};                 // PrdGemm.ln_out: the normalised A pieces this thread stages (first column tile only)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = (t8 + 256 * i) & 511, row = p >> 3, f = p & 7;
         const bool isb = i >= 2;
         const bool ok = isb ? (n0 + row < g.N) : (m0 + row < g.M);
+        if (!isb && ok && g.a_ln && g.ln_out && tile_n == 0) lo_[i] = g.ln_out + (size_t)(m0 + row) * g.ldlo + 4 * f;
         off[i] = ok ? ((unsigned)row * (isb ? g.ldb : g.lda) + 4 * f) * 4u : BUF_OOB;
         dst[i] = (isb ? 2 * PLANE : 0) + row * 64 + (((f >> 1) ^ ((row >> 2) & 3)) << 4) + (f & 1) * 8;
         if (!isb) { amu[i] = g.a_ln ? mean_l[row] : 0.f; ars[i] = g.a_ln ? (ok ? rstd_l[row] : 0.f) : 1.f; }
@@ -417,10 +434,11 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
         R[2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[2], c_ * 128, 0));           \
         R[3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off[3], c_ * 128, 0));           \
     }
-#define PRD_GH_STAGE(R, BUFI)                                                                                       \
+#define PRD_GH_STAGE(R, BUFI, SC_)                                                                                    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
         float x0 = __uint_as_float(R[i][0]), x1 = __uint_as_float(R[i][1]), x2 = __uint_as_float(R[i][2]), x3 = __uint_as_float(R[i][3]); \
-        if (i < 2) { x0 = (x0 - amu[i]) * ars[i]; x1 = (x1 - amu[i]) * ars[i]; x2 = (x2 - amu[i]) * ars[i]; x3 = (x3 - amu[i]) * ars[i]; } \
+        if (i < 2) { x0 = (x0 - amu[i]) * ars[i]; x1 = (x1 - amu[i]) * ars[i]; x2 = (x2 - amu[i]) * ars[i]; x3 = (x3 - amu[i]) * ars[i];   \
+                     if (lo_[i]) *reinterpret_cast<float4*>(lo_[i] + (size_t)(SC_) * 32) = make_float4(x0, x1, x2, x3); }               \
         else { x0 *= H2_WSCALE; x1 *= H2_WSCALE; x2 *= H2_WSCALE; x3 *= H2_WSCALE; }                                \
         unsigned h0, l0, h1, l1;                                                                                    \
         split2h(x0, x1, h0, l0);                                                                                    \
@@ -445,12 +463,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0); \
             }                                                                                                       \
         }                                                                                                           \
-        if ((CI) + 1 < myn) { PRD_GH_STAGE(R, (CUR) ^ 1) }                                                          \
+        if ((CI) + 1 < myn) { PRD_GH_STAGE(R, (CUR) ^ 1, kg + KG * ((CI) + 1)) }                                                        \
         __syncthreads();                                                                                            \
     }
     const int maxn = (nchunk + KG - 1) / KG;            // trip count of the longest K-group: barriers are workgroup-wide
     PRD_GH_LOAD(u, 0)
-    if (myn > 0) { PRD_GH_STAGE(u, 0) }
+    if (myn > 0) { PRD_GH_STAGE(u, 0, kg) }
     PRD_GH_LOAD(u, 1)
     __syncthreads();
     for (int ci = 0; ci < maxn; ci += 2) {
@@ -643,6 +661,185 @@ static int launch_ring(const PrdGemm& g, dim3 grid, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// ---- node-row linears with LARGE weights (the single-track transition 512 -> 2048 -> 512): K split ACROSS workgroups ----------
+// What bounds these GEMMs at M = b N = a few hundred rows is the operand stream per CU (~50 GB/s per CU whatever is in flight:
+// tools/ubench/nodegemm_bench.hip; the MI355X guide's M = 256 projection GEMM finds the same 21 B/clk), so the lever is BYTES PER
+// CU: 32 x 32 tiles move (1/32 + 1/32) x 4 K M N bytes in total (82 MB for 320 x 512 x 2048: 320 KB per CU, and the 2048 -> 512
+// layer has only 160 tiles of 512 KB each).  Here a workgroup owns a 160 x 64 tile of ONE 128-wide K slab: 112 KB of operands,
+// all requested up front, 256 workgroups = one per CU for both layers of the transition (64 tiles x 4 slabs / 16 tiles x 16
+// slabs), 29 MB in total.  Operands are split into fp16 hi | lo while they are staged into LDS (rows of 256 B per plane, 16-byte
+// slots XOR-swizzled by row: conflict-free fragment reads), ten waves take one 32 x 32 sub-tile each (24 MFMAs), and the fp32
+// partial tiles go to a workspace [slab][M][N]; gemm_slab_reduce_kernel sums the slabs in a fixed order and applies the epilogue.
+// (A reduction inside the launch -- last-arriver per tile -- costs a release + acquire fence pair and serialises 120 KB of reads
+// on one CU: the guide's `splitk-seam` row prices it above the kernel boundary it would save.)
+constexpr int SL_BM = 160, SL_BN = 64, SL_KS = 128, SL_NW = 10;
+constexpr int SL_LDS = (SL_BM + SL_BN) * SL_KS * 4;                  // hi | lo planes of A and W: 112 KB
+__global__ __launch_bounds__(SL_NW * 64) void gemm_slab_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                               float* __restrict__ ws, int M, int N, int K, int lda, int ldb,
+                                                               int tiles_m, int tiles_n, int nslab, int spw, int xmap, float wscale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sl[];      // A hi [160][256 B] | A lo | W hi [64][256 B] | W lo
+    constexpr int APL = SL_BM * 256, WOFF = 2 * APL, WPL = SL_BN * 256;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave >> 1, ct = wave & 1;
+    // Block -> (tile, slab group): every operand slab is shared -- the A slab (row block, slabs) by all column tiles, the W slab
+    // (column tile, slabs) by all row blocks -- so the workgroups of ONE slab group go to ONE XCD (block b is observed on XCD
+    // b % 8; speed only, any placement is correct): each slab then crosses the fabric once and is served from that XCD's L2.
+    // With fewer than 8 slab groups the column tiles of a group are cut into 8 / SK parts instead.
+    const int SK = (nslab + spw - 1) / spw;
+    int tile_m, tile_n, sg;
+    if (xmap == 1) {                    // SK % 8 == 0
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, tiles = tiles_m * tiles_n;
+        sg = xcd + 8 * (j / tiles);
+        const int t_ = j % tiles;
+        tile_m = t_ % tiles_m; tile_n = t_ / tiles_m;
+    } else if (xmap == 2) {             // 8 % SK == 0 and tiles_n % (8 / SK) == 0
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, tn_per = tiles_n / (8 / SK);
+        sg = xcd % SK;
+        tile_m = j % tiles_m; tile_n = (xcd / SK) * tn_per + j / tiles_m;
+    } else {
+        const int ncombo = tiles_m * SK, combo = blockIdx.x % ncombo;
+        tile_n = blockIdx.x / ncombo; tile_m = combo % tiles_m; sg = combo / tiles_m;
+    }
+    const int m0 = tile_m * SL_BM, n0 = tile_n * SL_BN;
+    const int prow = tid >> 5, piece = tid & 31;                            // 32 threads per row: 512 contiguous bytes
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int s_end = (sg + 1) * spw < nslab ? (sg + 1) * spw : nslab;
+    for (int sl_i = sg * spw; sl_i < s_end; ++sl_i) {
+        const prd_rsrc ra = make_rsrc(A + (size_t)m0 * lda + (size_t)sl_i * SL_KS), rb = make_rsrc(W + (size_t)n0 * ldb + (size_t)sl_i * SL_KS);
+        u32x4 va[8], vb[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = prow + 20 * i;
+            va[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (m0 + row < M) ? ((unsigned)row * lda + 4 * piece) * 4u : BUF_OOB, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = prow + 20 * i;
+            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (row < SL_BN && n0 + row < N) ? ((unsigned)row * ldb + 4 * piece) * 4u : BUF_OOB, 0, 0));
+        }
+        if (sl_i > sg * spw) __syncthreads();                               // the previous slab's fragments have been read
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = prow + 20 * i;
+            unsigned h0, l0, h1, l1;
+            split2h(__uint_as_float(va[i][0]), __uint_as_float(va[i][1]), h0, l0);
+            split2h(__uint_as_float(va[i][2]), __uint_as_float(va[i][3]), h1, l1);
+            unsigned char* d_ = sl + row * 256 + (((piece >> 1) ^ (row & 15)) << 4) + (piece & 1) * 8;
+            *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d_ + APL) = u32x2{l0, l1};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = prow + 20 * i;
+            if (row < SL_BN) {
+                unsigned h0, l0, h1, l1;
+                split2h(wscale * __uint_as_float(vb[i][0]), wscale * __uint_as_float(vb[i][1]), h0, l0);
+                split2h(wscale * __uint_as_float(vb[i][2]), wscale * __uint_as_float(vb[i][3]), h1, l1);
+                unsigned char* d_ = sl + WOFF + row * 256 + (((piece >> 1) ^ (row & 15)) << 4) + (piece & 1) * 8;
+                *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(d_ + WPL) = u32x2{l0, l1};
+            }
+        }
+        __syncthreads();
+        const unsigned char* ab = sl + (rt * 32 + r) * 256;
+        const unsigned char* bb = sl + WOFF + (ct * 32 + r) * 256;
+#pragma unroll
+        for (int st = 0; st < SL_KS / 16; ++st) {
+            const unsigned so = (unsigned)((2 * st + hi) ^ (r & 15)) << 4;   // (rt * 32 + r) & 15 == r & 15
+            const u32x4 ah = *reinterpret_cast<const u32x4*>(ab + so), al = *reinterpret_cast<const u32x4*>(ab + APL + so);
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(bb + so), bl = *reinterpret_cast<const u32x4*>(bb + WPL + so);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bl), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0);
+        }
+    }
+    // partial tile: lane holds column n of 16 rows; 32 lanes = 128 contiguous bytes of a workspace row per store
+    const int n = n0 + ct * 32 + r;
+    if (n < N) {
+        float* wp = ws + (size_t)sg * M * N + n;
+        const float inv = 1.0f / wscale;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + rt * 32 + drow32(q, hi);
+            if (m < M) wp[(size_t)m * N] = acc[q] * inv;
+        }
+    }
+}
+
+// Sum of the K slabs + epilogue of gemm_slab_kernel: one workgroup of 128 threads per (row, 512-column chunk), 16 bytes per
+// thread and slab, all slab loads in flight together, summed in slab order.  With a_ln the GEMM ran on the RAW rows and the
+// LayerNorm is applied here by linearity: LN(x) W^T = rstd (x W^T - mean colsum(W)) -- the workgroup computes the statistics
+// of its row of A itself (two passes over 4 K bytes) and `wsum` = row sums of W comes from the caller.  With out_ln (N <= 512:
+// the workgroup holds the whole output row) the LayerNorm of the OUTPUT row is written as well, for the next linear.
+__global__ __launch_bounds__(128) void gemm_slab_reduce_kernel(PrdGemm g, const float* __restrict__ ws, int SK) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunks = (g.N + 511) / 512;
+    const int m = blockIdx.x / chunks, n = (blockIdx.x - m * chunks) * 512 + 4 * tid;
+    const bool live = n < g.N;                                              // N is a multiple of 4 on this path
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* wp = ws + (size_t)m * g.N + (live ? n : 0);
+    const size_t sstride = (size_t)g.M * g.N;
+    for (int s0 = 0; s0 < SK; s0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(wp + (size_t)(s0 + j < SK ? s0 + j : 0) * sstride);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (s0 + j < SK) { sum.x += v[j].x; sum.y += v[j].y; sum.z += v[j].z; sum.w += v[j].w; }
+    }
+    auto block_sum = [&](float x) {                                         // over the 128 threads, same value in every thread
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        return red[0] + red[1];
+    };
+    float vv[4] = {sum.x, sum.y, sum.z, sum.w};
+    if (g.a_ln) {                                                           // LayerNorm of the A row by linearity
+        const float* ar = g.A + (size_t)m * g.lda;
+        float s1 = 0.f;
+        for (int k = 4 * tid; k < g.K; k += 512) { const float4 a = *reinterpret_cast<const float4*>(ar + k); s1 += (a.x + a.y) + (a.z + a.w); }
+        const float mu = block_sum(s1) / (float)g.K;
+        float s2 = 0.f;
+        for (int k = 4 * tid; k < g.K; k += 512) {
+            const float4 a = *reinterpret_cast<const float4*>(ar + k);
+            const float d0 = a.x - mu, d1 = a.y - mu, d2 = a.z - mu, d3 = a.w - mu;
+            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        const float rz = 1.0f / sqrtf(block_sum(s2) / (float)g.K + 1e-5f);
+        if (live) {
+            const float4 cs = *reinterpret_cast<const float4*>(g.wsum + n);
+            vv[0] = (vv[0] - mu * cs.x) * rz; vv[1] = (vv[1] - mu * cs.y) * rz; vv[2] = (vv[2] - mu * cs.z) * rz; vv[3] = (vv[3] - mu * cs.w) * rz;
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = vv[e] * g.alpha;
+            if (g.colscale) v *= g.colscale[n + e];
+            if (g.bias) v += g.bias[n + e];
+            const int act = (n + e >= g.act_from) ? g.act : 0;
+            if (act == 1) v = fmaxf(v, 0.f);
+            else if (act == 2) v = sigmoidf_(v);
+            if (g.rowmask && (g.rowmask_cols <= 0 || n + e < g.rowmask_cols)) v *= g.rowmask[m];
+            if (g.resid) { const float rv = g.resid[(size_t)m * g.ldr + n + e]; v += g.rscale ? rv * g.rscale[n + e] : rv; }
+            vv[e] = v;
+        }
+        *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    if (g.out_ln) {                                                         // N <= 512: this workgroup holds the whole output row
+        const float mu = block_sum(live ? (vv[0] + vv[1]) + (vv[2] + vv[3]) : 0.f) / (float)g.N;
+        const float d0 = vv[0] - mu, d1 = vv[1] - mu, d2 = vv[2] - mu, d3 = vv[3] - mu;
+        const float rz = 1.0f / sqrtf(block_sum(live ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f) / (float)g.N + 1e-5f);
+        if (live) *reinterpret_cast<float4*>(g.out_ln + (size_t)m * g.ldol + n) = make_float4(d0 * rz, d1 * rz, d2 * rz, d3 * rz);
+    }
+}
+
 // ---- LayerNorm rows: one wave per row ------------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -682,7 +879,26 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
     for (int c = lane; c < ld; c += 64) xr[c] = (c < n) ? expf(xr[c] - m) / s : 0.f;
 }
 
+// does the K-slab path serve this shape, and with which split?  (one predicate for prd_gemm and prd_gemm_slab_ok)
+bool slab_plan(int M, int N, int K, int arith_full, int* tiles_m, int* tiles_n, int* nslab, int* spw) {
+    if (arith_full < 0 || (arith_full & 0xff) != PRD_ARITH_SPLIT16 || ((arith_full >> 8) & (1 << 16))) return false;
+    if (M < 96 || N <= 0 || K <= 0 || (K % SL_KS) || (N % 4)) return false;
+    *tiles_m = prd_ceil_div(M, SL_BM);
+    *tiles_n = prd_ceil_div(N, SL_BN);
+    *nslab = K / SL_KS;
+    const long tiles = (long)*tiles_m * *tiles_n;
+    if (tiles * *nslab < 128 || tiles > 2048) return false;        // too little work for 256 CUs / too many tiles: other kernels
+    int s = 1;                                                     // slabs per workgroup: at most ~2 workgroups per CU
+    while (tiles * prd_ceil_div(*nslab, s) > 512 && s < *nslab) ++s;
+    *spw = s;
+    return true;
+}
 }  // namespace
+
+extern "C" int prd_gemm_slab_ok(int M, int N, int K, int arith) {
+    int a, b, c, d;
+    return slab_plan(M, N, K, arith, &a, &b, &c, &d) ? 1 : 0;
+}
 
 extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     const PrdGemm& g = *args;
@@ -692,11 +908,29 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     if ((g.lda & 3) || (g.ldb & 3)) return PRD_ERR_ALIGN;
     const int batches = g.G1 * g.G2;
     if (g.ln_out && (!g.a_ln || batches != 1 || (g.ldlo & 3) || g.ldlo < g.K)) return PRD_ERR_ARG;
+    if (g.C2 && (batches != 1 || g.n_split <= 0 || g.n_split >= g.N || g.ldc2 < g.N - g.n_split)) return PRD_ERR_ARG;
     const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
+    // gemm mode 1, large weights on few rows (the transition layers): K split across workgroups + reduce / epilogue launch
+    if (g.ws && g.tile_hint == 0 && !g.b_kn && batches == 1 && !g.addmat && !g.colmask && !g.mulmat && !g.C2 && !g.ln_out &&
+        (!g.a_ln || g.wsum) && (!g.out_ln || (g.N <= 512 && (g.ldol & 3) == 0)) && (g.ldc & 3) == 0 && (!g.resid || (g.ldr & 3) == 0)) {
+        int tiles_m, tiles_n, nslab, spw;
+        if (slab_plan(g.M, g.N, g.K, g.arith, &tiles_m, &tiles_n, &nslab, &spw)) {
+            const int SK = prd_ceil_div(nslab, spw);
+            if ((size_t)SK * g.M * g.N * sizeof(float) > g.ws_bytes) return PRD_ERR_WORKSPACE;
+            static std::once_flag once;
+            std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)gemm_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+            const int xmap = (SK % 8 == 0) ? 1 : ((SK < 8 && 8 % SK == 0 && tiles_n % (8 / SK) == 0) ? 2 : 0);
+            hipLaunchKernelGGL(gemm_slab_kernel, dim3((unsigned)(tiles_m * tiles_n * SK)), dim3(SL_NW * 64), SL_LDS, stream, g.A, g.B, g.ws, g.M, g.N,
+                               g.K, g.lda, g.ldb, tiles_m, tiles_n, nslab, spw, xmap, H2_WSCALE);
+            hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)(g.M * prd_ceil_div(g.N, 512))), dim3(128), 0, stream, g, g.ws, SK);
+            return (int)hipGetLastError();
+        }
+    }
+    if (g.out_ln) return PRD_ERR_UNSUPPORTED;           // the LayerNorm of the output rows exists on the slab path only (prd_gemm_slab_ok)
     // gemm mode 1: THROUGHPUT-bound linears (>= 512 tiles of 64x64: SPAttention's 512 -> 4 x 2048 projection, the transition at
     // b = 8) go to the 64x64-tile fp16 x 2 kernel (41 -> 26 us); the latency-bound ones (20-160 tiles) to gemm_ring_kernel below.
     if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 32) == 0 && tiles64 >= 512 && g.G1 * g.G2 == 1 &&
-        (!g.a_ln || (g.K % 16) == 0) && !g.ln_out) {
+        (!g.a_ln || (g.K % 16) == 0)) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
         static std::once_flag once1, once4;
         if (g.K >= 1024) {
@@ -767,4 +1001,9 @@ extern "C" int prd_softmax_rows(float* x, int rows, int n, int ld, hipStream_t s
     if (!x || rows <= 0 || n <= 0 || ld < n) return PRD_ERR_ARG;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(prd_ceil_div(rows, 4)), dim3(256), 0, stream, x, rows, n, ld);
     return (int)hipGetLastError();
+}
+
+extern "C" size_t prd_gemm_slab_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % SL_KS)) return 0;
+    return (size_t)(K / SL_KS) * M * N * sizeof(float);
 }

@@ -72,7 +72,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), b_kn=False, alpha=1.0, bias=None, act=0, act_from=0,
          addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
          mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0,
-         colscale=None, tile_hint=0, a_ln=False, ln_out=None):
+         colscale=None, tile_hint=0, a_ln=False, ln_out=None, c2=None, n_split=0, rowmask_cols=0, rscale=None,
+         slab=False, wsum=None, out_ln=None):
     """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h)."""
     g = PrdGemm()
     g.A, g.B, g.C = _off(A, a_off), _off(B, b_off), _off(Cout, c_off)
@@ -90,15 +91,44 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.colscale, g.tile_hint = dptr(colscale), tile_hint
     g.a_ln = 1 if a_ln else 0
     g.ln_out, g.ldlo = dptr(ln_out), (ln_out.shape[-1] if ln_out is not None else 0)
+    g.C2, g.ldc2, g.n_split = dptr(c2), (c2.shape[-1] if c2 is not None else 0), n_split
+    g.rowmask_cols, g.rscale = rowmask_cols, dptr(rscale)
+    if slab:                        # K split across workgroups (prd_hip.h: PrdGemm.ws); the library falls back by itself if the shape does not qualify
+        wsb = gemm_workspace(Cout.device, int(lib().prd_gemm_slab_workspace(M, N, K)))
+        g.ws, g.ws_bytes = dptr(wsb), wsb.numel() * 4
+    g.wsum = dptr(wsum)
+    g.out_ln, g.ldol = dptr(out_ln), (out_ln.shape[-1] if out_ln is not None else 0)
     g.arith = lib().prd_get_gemm_mode() | (lib().prd_get_tune() << 8)
     import ctypes
     check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
     return Cout
 
 
+_GEMM_WS = {}
+
+
+def gemm_workspace(device, nbytes: int) -> torch.Tensor:
+    """Persistent per-device scratch of the K-slab GEMM path (partial tiles; at most a few tens of MB).  One buffer per device
+    is enough: the launches that use it are ordered on one stream, and a captured graph keeps the address."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    buf = _GEMM_WS.get(key)
+    n = max(1, (nbytes + 3) // 4)
+    if buf is None or buf.numel() < n:
+        if buf is not None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gemm workspace would have to grow during graph capture; run one eager step first")
+        buf = _GEMM_WS[key] = torch.empty(n, device=f"cuda:{key}", dtype=F32)
+    return buf
+
+
+def slab_ok(M: int, N: int, K: int) -> bool:
+    """True when a linear of this shape takes the K-slab path (prd_hip.h: prd_gemm_slab_ok) in the current arithmetic."""
+    return lib().prd_gemm_slab_ok(M, N, K) == 1
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = 0,
            alpha: float = 1.0, resid: Optional[torch.Tensor] = None, rowmask: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, ln_a: bool = False) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, ln_a: bool = False, rscale: Optional[torch.Tensor] = None,
+           slab: bool = False, wsum: Optional[torch.Tensor] = None, out_ln: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(alpha * x W^T + bias) [* rowmask] [+ resid] for x [..., K], W [N, K]; ``ln_a``: x is LayerNorm-ed
     (no affine) inside the GEMM instead of by a separate launch."""
     K = x.shape[-1]
@@ -112,7 +142,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if not x.is_contiguous():          # a column block of a wider GEMM output
         a, lda = row_block(x)
     gemm(a, w, out, M, N, K, lda, w.stride(0), N, alpha=alpha, bias=bias, act=act,
-         rowmask=rowmask, resid=resid, ldr=N, a_ln=ln_a)
+         rowmask=rowmask, resid=resid, ldr=N, a_ln=ln_a, rscale=rscale, slab=slab, wsum=wsum, out_ln=out_ln)
     return out
 
 
@@ -599,14 +629,16 @@ def project_qkvg(x_normed, packed, HC: int, ln_a: bool = False) -> torch.Tensor:
 
 def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int, *,
                            key_mask: bool, resid: Optional[torch.Tensor], ln_a: bool = False,
-                           qkvg: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           qkvg: Optional[torch.Tensor] = None, rscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Multi-head gated attention over the node axis with an additive [b,H,N,N] bias.
 
     Covers reference modules.py:185-225 (c = head_dim, key mask filled with -2**15, q pre-scaled by
     1/sqrt(c)) and models/AF2_modules.py:251-293,613-628 (c = single_dim, no mask).  ``packed`` comes
     from ``pack_attention``.  Returns ``resid + out_proj(...)`` (or the bare update when ``resid`` is None).
     ``ln_a``: ``x_normed`` is the raw input and its (affine-free) LayerNorm is fused into the q|k|v|g projection.
-    ``qkvg``: the projection, if the caller already computed it (``project_qkvg``, e.g. on a side stream)."""
+    ``qkvg``: the projection, if the caller already computed it (``project_qkvg``, e.g. on a side stream).
+    ``rscale``: per-column factor of ``resid`` (an affine-LayerNorm-ed residual given as the plain normalised rows x gamma, with
+    beta folded into ``bo`` by the caller)."""
     b, N, S = x_normed.shape
     HC = H * c
     w, pbias, colscale = packed
@@ -621,7 +653,7 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
         qp, ldq = row_block(qkvg)
         check(lib().prd_single_attn_core(dptr(o), qp, ldq, dptr(bias), dptr(mask) if key_mask else None,
                                          b, N, H, c, stream()), "prd_single_attn_core")
-        return linear(o, wo, bo, resid=resid)
+        return linear(o, wo, bo, resid=resid, rscale=rscale)
     ldp = round_up(N, 4)
     logits = torch.empty(b, H, N, ldp, device=x_normed.device, dtype=F32)
     gemm(qkvg, qkvg, logits, N, N, c, L, L, ldp, b_off=HC, G1=b, G2=H, sa=(N * L, c), sb=(N * L, c),
@@ -630,17 +662,20 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     softmax_rows_(logits, N)
     gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
          sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L)
-    return linear(o, wo, bo, resid=resid)
+    return linear(o, wo, bo, resid=resid, rscale=rscale)
 
 
-def project_many(single, packed, P_first: int, *, act: int, act_from: int):
+def project_many(single, packed, P_first: int, *, act: int, act_from: int, xhat=None):
     """ONE GEMM over LN(single) (LayerNorm without affine, fused) for several consumers of the same normalised rows:
     ``packed`` = (W [Ncat, S], bias [Ncat] or None, colscale [Ncat] or None).  Returns (x = LN(single) [b,N,S], C [b,N,Ncat]);
-    the consumers take column blocks of C (row_block)."""
+    the consumers take column blocks of C (row_block).  ``xhat``: LN(single) if the producer of ``single`` already wrote it."""
     b, N, S = single.shape
     w, pbias, colscale = packed
     Ncat = w.shape[0]
     out = torch.empty(b, N, Ncat, device=single.device, dtype=F32)
+    if xhat is not None:
+        gemm(xhat, w, out, b * N, Ncat, S, S, S, Ncat, bias=pbias, colscale=colscale, act=act, act_from=act_from)
+        return xhat, out
     if ln_fusable(S):
         x = torch.empty_like(single)
         gemm(single, w, out, b * N, Ncat, S, S, S, Ncat, bias=pbias, colscale=colscale, act=act, act_from=act_from, a_ln=True, ln_out=x)
@@ -650,6 +685,16 @@ def project_many(single, packed, P_first: int, *, act: int, act_from: int):
     return x, out
 
 
-def transition_single(single, w1, b1, w2, b2, *, residual: bool) -> torch.Tensor:
-    h = linear(single, w1, b1, act=1, ln_a=True)        # LayerNorm (no affine) fused into the first linear
-    return linear(h, w2, b2, resid=single if residual else None)
+def transition_single(single, w1, b1, w2, b2, *, residual: bool, wsum1=None, want_ln: bool = False):
+    """single + W2 relu(W1 LN(single) + b1) + b2 (modules.py:306-311).  ``wsum1`` = row sums of W1: lets the first linear take
+    the K-slab path, where the LayerNorm is applied by linearity (PrdGemm.wsum).  ``want_ln``: also return
+    LN(result) -- the next linears of the block start with it -- when the second linear runs on the K-slab path, whose
+    reduce launch holds whole output rows; returns (result, LN(result) or None) then."""
+    b, N, S = single.shape
+    Hd = w1.shape[0]
+    slab1 = wsum1 is not None and slab_ok(b * N, Hd, S)
+    slab2 = slab_ok(b * N, S, Hd)
+    h = linear(single, w1, b1, act=1, ln_a=True, slab=slab1, wsum=wsum1 if slab1 else None)   # LayerNorm (no affine) fused into the first linear
+    xhat = torch.empty_like(single) if (want_ln and slab2 and S <= 512) else None
+    out = linear(h, w2, b2, resid=single if residual else None, slab=slab2, out_ln=xhat)
+    return (out, xhat) if want_ln else out

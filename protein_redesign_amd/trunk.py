@@ -161,6 +161,7 @@ _TRI_MUL_CHAIN = os.environ.get("PRD_TRI_MUL_CHAIN", "1") != "0"      # 0: two p
 # SLOWER (1.973 vs 1.931 ms per step, A/B in one run): each of the four head-workgroups of a row re-reads the previous og row
 # (4 x 26 MB instead of one pass) and repeats the projection.  Off by default; kept as a tested opt-in.
 _TRI_ATTN_FUSE = os.environ.get("PRD_TRI_ATTN_FUSE", "0") == "1"
+_MERGE_HEAD = os.environ.get("PRD_MERGE_HEAD", "1") != "0"            # 0: OPM / SPA LayerNorms and projections as four launches
 _MERGE_PROJ = os.environ.get("PRD_MERGE_PROJ", "1") != "0"            # 0: u and the next q|k|v|gate as two launches (A/B measurements)
 
 
@@ -271,13 +272,15 @@ class FoldingBlock(nn.Module):
             bias = ops.pair_bias(pair, self.attn_bias[1].weight, self.attn_bias[1].bias)
         single = sa.run_single(single, mask, bias, single, ln_a=True, qkvg=qkvg)
         fc = self.single_fc
-        single = ops.transition_single(single, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=True)
+        wsum1 = ops.cached_pack(self, "fc1_rowsum", (fc[1].weight,), lambda: fc[1].weight.double().sum(1).float().contiguous())
+        single, xhat = ops.transition_single(single, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, residual=True, wsum1=wsum1,
+                                             want_ln=True)
         packed, act, act_from = self._after_transition_pack(next_block if extra is not None else None, tail if extra is not None else None)
         if packed is not None and _MERGE_PROJ:
             # everything that is linear in LN(single) goes through ONE launch: u of the outer-linear, and the next block's
             # q|k|v|gate or the tail layer (-1 launch of ~8 us per block; these launches are latency-, not work-bound)
             P = self.outer_linear.pair_dim
-            x, cat = ops.project_many(single, packed, P, act=act, act_from=act_from)
+            x, cat = ops.project_many(single, packed, P, act=act, act_from=act_from, xhat=xhat)
             ol = self.outer_linear.linear
             ops.outer_linear_pair(pair, x, cat[..., :P], ol.weight, ol.bias, residual=True, out=pair)
             extra["qkvg" if next_block is not None else "tail"] = cat[..., P:]
@@ -347,9 +350,37 @@ class Denoiser(nn.Module):
     def project_single(self, single: torch.Tensor, mask: torch.Tensor):
         """Everything at the head of the trunk that depends on the single representation only (OPM's a | b projection, SPA's
         LayerNorm + q|k|v|g projection): independent of the pair input stage, so the caller may run it on a side stream."""
-        ab = self.opm.project(single, mask)
-        mn, qkvg = self.SPAAttnBlock.project(single)
-        return ab, mn, qkvg
+        if not _MERGE_HEAD or not ops.ln_fusable(single.shape[-1]):
+            ab = self.opm.project(single, mask)
+            mn, qkvg = self.SPAAttnBlock.project(single)
+            return ab, mn, qkvg, False
+        # Both projections are linear in the SAME normalised rows: the two affine LayerNorms differ only in (gamma, beta), which
+        # fold into the weights -- LN_affine(x) W^T + b = LN(x) (W diag(gamma))^T + (b + W beta).  One launch (LayerNorm fused,
+        # the plain normalised rows written on the side) instead of two LayerNorm + two GEMM launches.
+        opm, spa = self.opm, self.SPAAttnBlock
+        a = spa.mha
+        params = (opm.layer_norm.weight, opm.layer_norm.bias, opm.linear_1.weight, opm.linear_1.bias, opm.linear_2.weight,
+                  opm.linear_2.bias, spa.layer_norm_m.weight, spa.layer_norm_m.bias, a.linear_q.weight, a.linear_k.weight,
+                  a.linear_v.weight, a.linear_g.weight, a.linear_g.bias)
+
+        def build():
+            go, bo, w1, b1, w2, b2, gs, bs, wq, wk, wv, wg, bg = [p.detach().double() for p in params]
+            scale = 1.0 / math.sqrt(spa.c_hidden)
+            w = torch.cat([w1 * go, w2 * go, wq * gs, wk * gs, wv * gs, wg * gs])
+            bias = torch.cat([b1 + w1 @ bo, b2 + w2 @ bo, (wq @ bs) * scale, wk @ bs, wv @ bs, bg + wg @ bs])
+            cs = torch.cat([torch.ones(2 * opm.c_hidden, dtype=torch.float64, device=w.device),
+                            torch.full((wq.shape[0],), scale, dtype=torch.float64, device=w.device),
+                            torch.ones(3 * wq.shape[0], dtype=torch.float64, device=w.device)])
+            return w.float().contiguous(), bias.float().contiguous(), cs.float().contiguous()
+        w, bias, cs = ops.cached_pack(self, "head_proj", params, build)
+        b, N, S = single.shape
+        Ch2, HS = 2 * opm.c_hidden, a.linear_q.weight.shape[0]
+        ab = torch.empty(b, N, Ch2, device=single.device, dtype=torch.float32)
+        qkvg = torch.empty(b, N, 4 * HS, device=single.device, dtype=torch.float32)
+        xhat = torch.empty_like(single)
+        ops.gemm(single, w, ab, b * N, Ch2 + 4 * HS, S, S, S, Ch2, bias=bias, colscale=cs, act=2, act_from=Ch2 + 3 * HS,
+                 rowmask=mask, rowmask_cols=Ch2, a_ln=True, ln_out=xhat, c2=qkvg, n_split=Ch2)
+        return ab, xhat, qkvg, True
 
     def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, pre=None, join=None, tail=None):
         """OPM, SPA and the folding blocks, in place on ``pair``, WITHOUT the final symmetrisation
@@ -362,7 +393,7 @@ class Denoiser(nn.Module):
             ws = torch.empty(self.ws_floats(b, N), device=pair.device, dtype=torch.float32)
         if pre is None:
             pre = self.project_single(single, mask)
-        ab, mn, qkvg = pre
+        ab, mn, qkvg, normed_only = pre
         if join is not None:
             join()
         self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair, ab=ab)
@@ -374,7 +405,7 @@ class Denoiser(nn.Module):
                                             (ab0.weight, ab0.bias, None, None))
         else:
             spa_bias, bias = spa.bias_from_pair(pair), None
-        single = spa.attend(mn, qkvg, spa_bias)
+        single = spa.attend(mn, qkvg, spa_bias, normed_only=normed_only)
         holder = [None]             # spare pair buffer of the fused attention form (the residual stream alternates between two)
         qkvg, extra = None, {}
         for i, block in enumerate(blocks):

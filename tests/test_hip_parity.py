@@ -155,6 +155,39 @@ def test_operand_ring_gemm_edges(M, N, K, gemm_mode):
         assert rel_l2(out.cpu(), O.ln(x).double() @ w.double().t() + b.double()) < 5e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(320, 2048, 512), (320, 512, 2048), (173, 516, 1024), (2560, 512, 2048), (96, 2048, 512), (100, 960, 1152)])
+def test_k_slab_gemm(M, N, K):
+    """The K-slab path of the node-row linears (gemm_slab_kernel + gemm_slab_reduce_kernel: 160 x 64 tiles of one 128-wide K slab
+    per workgroup, partial tiles summed by a second launch) against fp64: the transition's two layers at the bench shape, ragged
+    M / N tiles, several slabs per workgroup (M = 2560), and the reduce launch's epilogues -- bias + ReLU with the LayerNorm of
+    the A rows applied BY LINEARITY (rows with |mean| of the order of the spread), and residual + LayerNorm of the output rows."""
+    from protein_redesign_amd import _lib
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(1) == 0
+    try:
+        assert ops.slab_ok(M, N, K)
+        g = torch.Generator().manual_seed(M + 3 * N + K)
+        x = torch.randn(M, K, generator=g) * 1.5 + 0.7
+        w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g)
+        xd, wd = x.double(), w.double()
+        # (1) plain: bias + ReLU + residual, and the LayerNorm of the output rows on the side
+        want = torch.relu(xd @ wd.t() + b.double()) + res.double()
+        xn = torch.empty(M, N, device=DEV) if N <= 512 else None
+        got = ops.linear(cu(x), cu(w), cu(b), act=1, resid=cu(res), slab=True, out_ln=xn)
+        assert rel_l2(got.cpu(), want) < 2e-6
+        if xn is not None:
+            assert rel_l2(xn.cpu(), O.ln(want.float())) < 3e-6
+        # (2) LayerNorm of the A rows by linearity (PrdGemm.wsum)
+        if K <= 512:
+            wsum = cu(wd.sum(1).float())
+            want2 = torch.relu(O.ln(x).double() @ wd.t() + b.double())
+            got2 = ops.linear(cu(x), cu(w), cu(b), act=1, ln_a=True, slab=True, wsum=wsum)
+            assert rel_l2(got2.cpu(), want2) < 5e-6
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+
+
 # ---------------------------------------------------------------------------------------------------
 # operators vs the oracle (module-level API of the mirror classes)
 # ---------------------------------------------------------------------------------------------------
