@@ -192,6 +192,15 @@ int prd_pair_bias2(float* bias_a, const float* pair, const float* gamma_a, const
  * ab = [a | b] of shape [b,N,2C].  `out` may alias `pair` (in-place residual update), here and below. */
 int prd_opm_pair(float* out, const float* pair, const float* ab, const float* mask, const float* w_out,
                  const float* b_out, int flags, int b, int N, int P, int C, int arith, hipStream_t stream);
+/* Head of the pair track in one row pass (split-16 arithmetic): prd_pair_init, then prd_opm_pair with flags = 1 | (apply_mask ? 2 : 0)
+ * in place, then prd_pair_bias2 on the result -- pair is written once instead of written, read + written and read again
+ * (model.py:339-361; models/AF2_modules.py:532-545, 454-459; modules.py:300-304, 395-397).  Arguments as in those three. */
+int prd_pair_head_supported(int P, int dist_dim, int C, int arith);
+int prd_pair_head(float* pair, const float* static_pair, const float* z, const float* mask, const float* centers,
+                  const float* w_dist, const float* ebeta, int dist_dim, const float* ab, const float* w_out,
+                  const float* b_out, int C, int apply_mask, float* bias_a, const float* gamma_a, const float* beta_a,
+                  const float* w_a, const float* bvec_a, int Ha, float* bias_b, const float* gamma_b, const float* beta_b,
+                  const float* w_b, const float* bvec_b, int Hb, int b, int N, int P, int arith, hipStream_t stream);
 /* OuterLinear (modules.py:283-287): out[i,j,:] = (residual ? pair : 0) + W1 (x_i * x_j) + u_i - u_j + bias,
  * x = LN(single), u = x W2^T [b,N,P] with row pitch ldu floats (computed by prd_gemm; ldu > P when u is a column block of a wider
  * GEMM output: the block's single track projects u and the NEXT block's attention q|k|v|gate from the same LN(single) in one

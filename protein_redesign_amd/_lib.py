@@ -57,6 +57,8 @@ SIGNATURES = {
     "prd_pair_bias": [vp] * 6 + [ci] * 4 + [vp],
     "prd_pair_bias2": [vp] * 6 + [ci] + [vp] * 5 + [ci] * 4 + [vp],
     "prd_opm_pair": [vp] * 6 + [ci] * 6 + [vp],
+    "prd_pair_head_supported": [ci, ci, ci, ci],
+    "prd_pair_head": [vp] * 7 + [ci] + [vp] * 3 + [ci, ci] + [vp] * 5 + [ci] + [vp] * 5 + [ci] * 5 + [vp],
     "prd_outer_linear": [vp] * 4 + [ci] + [vp] * 2 + [ci] * 5 + [vp, ci, vp],
     "prd_tri_mul": [vp] * 11 + [ci] * 5 + [vp, cz, vp, ci, vp],
     "prd_tri_mul_contract": [vp, vp, ci, ci, ci, ci, vp],
@@ -94,11 +96,11 @@ GEMM_MODES = {"fp32": 0, "split16": 1, "bf16x3": 1}      # "bf16x3": earlier nam
 DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (env PRD_GEMM_MODE overrides)
 
 # entry points that take the arithmetic as their last argument before the stream ...
-_ARITH_BEFORE_STREAM = ("prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
+_ARITH_BEFORE_STREAM = ("prd_pair_head", "prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
                         "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain")
 # ... and the queries that take it as their last argument
 _ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes",
-               "prd_gemm_slab_ok")
+               "prd_gemm_slab_ok", "prd_pair_head_supported")
 # entry points without an arithmetic that still dispatch between kernel generations: the PRD_TUNE_* switch word alone
 _TUNE_BEFORE_STREAM = ("prd_tri_attn_core_v2",)
 _TUNE_LAST = ("prd_tri_attn_v2_supported", "prd_tri_attn_v2_form")

@@ -372,6 +372,127 @@ __global__ __launch_bounds__(WG) void pair_bias_kernel(float* __restrict__ out, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Head of the pair track in ONE row pass (gemm mode 1): pair_init -> OuterProductUpdate tail -> the two attention-bias heads
+// (model.py:339-361 + models/AF2_modules.py:532-545 + modules.py:395-397 + AF2_modules.py:454-459 + modules.py:300-304).
+// All three are row-local in (i, j): as separate launches the pair tensor is written, read + written, and read again (4 U =
+// 105 MB at N = 320) and three prologues / tails are paid; here the row stays in registers from the radial-basis GEMM to the
+// bias heads and is written once (1 U + the two [H,N,N] outputs).  The arithmetic of each stage is that of its own kernel
+// (pair_init_h2_kernel, opm_pair_h2_kernel, pair_bias_kernel), in the same order.  A task = (batch row bi = bb N + i, 32 columns j).
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void pair_head_h2_kernel(
+    float* __restrict__ pair, const float* __restrict__ stat, const float* __restrict__ z, const float* __restrict__ mask,
+    const float* __restrict__ centers, const float* __restrict__ wd, const float* __restrict__ ebeta, int DK,
+    const float* __restrict__ ab, const float* __restrict__ wo, const float* __restrict__ bo, int C, int apply_mask,
+    float* __restrict__ out_a, const float* __restrict__ gamma_a, const float* __restrict__ beta_a, const float* __restrict__ w_a,
+    const float* __restrict__ bvec_a, int Ha,
+    float* __restrict__ out_b, const float* __restrict__ gamma_b, const float* __restrict__ beta_b, const float* __restrict__ w_b,
+    const float* __restrict__ bvec_b, int Hb, int b, int N) {
+    constexpr int NB = P / 32, KH = P / 2, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ph[];
+    u32x4* Wd = reinterpret_cast<u32x4*>(smem_ph);                      // [2][P][DK/8]
+    const int SLd = DK / 8, SLo = C / 8;
+    u32x4* Wo = Wd + 2 * P * SLd;                                        // [2][P][C/8]
+    float* cl = reinterpret_cast<float*>(Wo + 2 * P * SLo);              // [DK]
+    float* bl = cl + DK;                                                 // [P] CLL
+    float* wl = bl + P;                                                  // [2][8 P] CLL rows of the bias heads
+    float* gl = wl + 16 * P;                                             // [2][P]
+    float* sl_ = gl + 2 * P;                                             // [2][P]
+    stage_weight_h2_nat(Wd, wd, P, DK, DK, 0, threadIdx.x, NT, H2_WSCALE);
+    stage_weight_h2_nat(Wo, wo, P, C, C, 0, threadIdx.x, NT, H2_WSCALE);
+    for (int k = threadIdx.x; k < DK; k += NT) cl[k] = centers[k];
+    stage_vec_cll(bl, bo, P, threadIdx.x, NT);
+    for (int h = 0; h < Ha; ++h) stage_vec_cll(wl + h * P, w_a + h * P, P, threadIdx.x, NT);
+    for (int h = 0; h < Hb; ++h) stage_vec_cll(wl + 8 * P + h * P, w_b + h * P, P, threadIdx.x, NT);
+    if (gamma_a) { stage_vec_cll(gl, gamma_a, P, threadIdx.x, NT); stage_vec_cll(sl_, beta_a, P, threadIdx.x, NT); }
+    if (gamma_b) { stage_vec_cll(gl + P, gamma_b, P, threadIdx.x, NT); stage_vec_cll(sl_ + P, beta_b, P, threadIdx.x, NT); }
+    __syncthreads();
+    const float scale = (float)((DK - 1) / 2.0);
+    const float c2 = -scale * 1.4426950408889634f;
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int nvb = (N + 31) / 32;
+    const long ntask = (long)b * N * nvb, nn = (long)N * N;
+    for (long task = (long)blockIdx.x * NW + (threadIdx.x >> 6); task < ntask; task += (long)gridDim.x * NW) {
+        const int vb = (int)(task % nvb);
+        const long bi = task / nvb;            // bb*N + i
+        const int bb = (int)(bi / N), i = (int)(bi - (long)bb * N);
+        const int j = vb * 32 + r;
+        const bool valid = j < N;
+        const int jj = valid ? j : 0;
+        const long off = (bi * N + jj) * P;
+        const float m2 = mask[bi] * mask[(long)bb * N + jj];
+        float x[KH];
+        {   // ---- pair_init: static part + m2 (W_d rbf(|z_i - z_j|) + ebeta) ----
+            const float* zi = z + bi * 3;
+            const float* zj = z + ((long)bb * N + jj) * 3;
+            const float dx = zi[0] - zj[0], dy = zi[1] - zj[1], dz = zi[2] - zj[2];
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            f32x16 acc[NB];
+            zero_acc(acc);
+            for (int st = 0; st < DK / 16; ++st) {
+                const float4 c0 = *reinterpret_cast<const float4*>(cl + 16 * st + 8 * hi);
+                const float4 c1 = *reinterpret_cast<const float4*>(cl + 16 * st + 8 * hi + 4);
+                const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = d - cc[e];
+                    f[e] = __builtin_amdgcn_exp2f(c2 * (t * t));
+                }
+                h2_nat_step<NB>(Wd, P, SLd, st, f, acc, r, hi);
+            }
+            float st_[KH], eb[KH];                                       // (requested after the GEMM: 64 registers the loop needs; the
+            load_row_cll<P>(stat + off, hi, valid, st_);                 // other waves of the SIMD cover the latency)
+            load_row_cll<P>(ebeta + bb * P, hi, true, eb);
+#pragma unroll
+            for (int s_ = 0; s_ < KH; ++s_) x[s_] = st_[s_] + m2 * (acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + eb[s_]);
+        }
+        {   // ---- OuterProductUpdate tail: x += [m2] (W_o (a_i * b_j) + b_o) / (m2 + 1e-3) ----
+            const float* ai = ab + bi * 2 * C + 8 * hi;
+            const float* bj = ab + ((long)bb * N + jj) * 2 * C + C + 8 * hi;
+            f32x16 acc[NB];
+            zero_acc(acc);
+            float4 a0 = *reinterpret_cast<const float4*>(ai), a1 = *reinterpret_cast<const float4*>(ai + 4);
+            float4 b0 = *reinterpret_cast<const float4*>(bj), b1 = *reinterpret_cast<const float4*>(bj + 4);
+            const int nst = C / 16;
+            for (int st = 0; st < nst; ++st) {
+                const int sn = st + 1 < nst ? st + 1 : st;
+                const float4 na0 = *reinterpret_cast<const float4*>(ai + 16 * sn), na1 = *reinterpret_cast<const float4*>(ai + 16 * sn + 4);
+                const float4 nb0 = *reinterpret_cast<const float4*>(bj + 16 * sn), nb1 = *reinterpret_cast<const float4*>(bj + 16 * sn + 4);
+                const float f[8] = {a0.x * b0.x, a0.y * b0.y, a0.z * b0.z, a0.w * b0.w, a1.x * b1.x, a1.y * b1.y, a1.z * b1.z, a1.w * b1.w};
+                h2_nat_step<NB>(Wo, P, SLo, st, f, acc, r, hi);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            }
+            const float norm = m2 + 1e-3f;
+            const float mm = apply_mask ? m2 : 1.f;
+#pragma unroll
+            for (int s_ = 0; s_ < KH; ++s_) x[s_] = x[s_] + mm * ((acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bl[hi * KH + s_]) / norm);
+        }
+        store_row_cll<P>(pair + off, hi, valid, x);
+        // ---- the two bias heads on LN(x) ----
+        ln_cll<KH>(x);
+        const long rem = (long)i * N + jj;
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+            const float* ga = set ? gamma_b : gamma_a;
+            const float* bv = set ? bvec_b : bvec_a;
+            float* o = set ? out_b : out_a;
+            const int nh = set ? Hb : Ha;
+            float y[KH];
+#pragma unroll
+            for (int s = 0; s < KH; ++s) y[s] = ga ? x[s] * gl[set * P + hi * KH + s] + sl_[set * P + hi * KH + s] : x[s];
+            for (int h = 0; h < nh; ++h) {
+                float acc = 0.f;
+#pragma unroll
+                for (int s = 0; s < KH; ++s) acc += y[s] * wl[set * 8 * P + h * P + hi * KH + s];
+                acc = xhalf_sum(acc);
+                if (bv) acc += bv[h];
+                if (valid && hi == 0) o[((long)bb * nh + h) * nn + rem] = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // OPM tail: pair[i,j,:] += m2 * (W_o (a_i*b_j) + b_o) / (m2 + 1e-3)
 // ------------------------------------------------------------------------------------------------
 template <int P>
@@ -1400,6 +1521,42 @@ extern "C" int prd_pair_bias2(float* bias_a, const float* pair, const float* gam
                                     bias_b, gamma_b, beta_b, w_b, bvec_b, Hb, b, N, Ha);
     else hipLaunchKernelGGL(pair_bias_kernel<32>, dim3(grid), dim3(WG), 0, stream, bias_a, pair, gamma_a, beta_a, w_a, bvec_a,
                             bias_b, gamma_b, beta_b, w_b, bvec_b, Hb, b, N, Ha);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_pair_head_supported(int P, int dist_dim, int C, int arith) {
+    if (arith < 0 || (arith & 0xff) != PRD_ARITH_SPLIT16 || (P != 32 && P != 64)) return 0;
+    if (dist_dim <= 0 || (dist_dim % 128) || C <= 0 || (C % 128)) return 0;
+    const size_t lds = (size_t)4 * P * dist_dim + (size_t)4 * P * C + ((size_t)dist_dim + P + 16 * P + 4 * P) * 4;
+    return lds <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int prd_pair_head(float* pair, const float* static_pair, const float* z, const float* mask, const float* centers,
+                             const float* w_dist, const float* ebeta, int dist_dim, const float* ab, const float* w_out,
+                             const float* b_out, int C, int apply_mask, float* bias_a, const float* gamma_a, const float* beta_a,
+                             const float* w_a, const float* bvec_a, int Ha, float* bias_b, const float* gamma_b, const float* beta_b,
+                             const float* w_b, const float* bvec_b, int Hb, int b, int N, int P, int arith, hipStream_t stream) {
+    PRD_SPLIT_ARITH(arith);
+    if (!pair || !static_pair || !z || !mask || !centers || !w_dist || !ebeta || !ab || !w_out || !b_out || !bias_a || !bias_b ||
+        !w_a || !w_b || b <= 0 || N <= 0 || Ha <= 0 || Ha > 8 || Hb <= 0 || Hb > 8 || (gamma_a && !beta_a) || (gamma_b && !beta_b))
+        return PRD_ERR_ARG;
+    PRD_CHECK_P(P);
+    if (!prd_pair_head_supported(P, dist_dim, C, arith)) return PRD_ERR_UNSUPPORTED;
+    constexpr int NWH = 8;
+    const size_t lds = (size_t)4 * P * dist_dim + (size_t)4 * P * C + ((size_t)dist_dim + P + 16 * P + 4 * P) * 4;
+    const long ntask = (long)b * N * prd_ceil_div(N, 32);
+    const int grid = grid_for(ntask, NWH, 256);
+    if (P == 64) {
+        PRD_SET_LDS((pair_head_h2_kernel<64, NWH>), lds);
+        hipLaunchKernelGGL((pair_head_h2_kernel<64, NWH>), dim3(grid), dim3(NWH * 64), lds, stream, pair, static_pair, z, mask, centers, w_dist,
+                           ebeta, dist_dim, ab, w_out, b_out, C, apply_mask, bias_a, gamma_a, beta_a, w_a, bvec_a, Ha, bias_b, gamma_b, beta_b,
+                           w_b, bvec_b, Hb, b, N);
+    } else {
+        PRD_SET_LDS((pair_head_h2_kernel<32, NWH>), lds);
+        hipLaunchKernelGGL((pair_head_h2_kernel<32, NWH>), dim3(grid), dim3(NWH * 64), lds, stream, pair, static_pair, z, mask, centers, w_dist,
+                           ebeta, dist_dim, ab, w_out, b_out, C, apply_mask, bias_a, gamma_a, beta_a, w_a, bvec_a, Ha, bias_b, gamma_b, beta_b,
+                           w_b, bvec_b, Hb, b, N);
+    }
     return (int)hipGetLastError();
 }
 

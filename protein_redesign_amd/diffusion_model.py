@@ -449,10 +449,11 @@ class ProteinReDiffModel(_Base):
         # (opt-in, measured slower: ops.SideStream) the single-only chain beside the pair input stage, joined at the OPM
         with side.fork():
             pre = self.Denoiser.project_single(single, mask)
-        pair = ops.pair_init(static["pair"], z, mask, self.embed_dist[0].center, self.embed_dist[1].weight, eb)
         sm = self.seq_mlp
-        # the sequence head's first layer is linear in LN(single_out), like the last block's outer-linear term: one launch for both
-        single, pair, h = self.Denoiser.run_(single, pair, mask, pre=pre, join=side.join, tail=(sm[1].weight, sm[1].bias))
+        # the pair input stage runs inside Denoiser.run_ (fused with the outer-product update and the first bias heads); the
+        # sequence head's first layer is linear in LN(single_out), like the last block's outer-linear term: one launch for both
+        single, pair, h = self.Denoiser.run_(single, None, mask, pre=pre, join=side.join, tail=(sm[1].weight, sm[1].bias),
+                                             pair_init=(static["pair"], z, self.embed_dist[0].center, self.embed_dist[1].weight, eb))
         with side.fork():
             if h is None:
                 h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)    # LayerNorm (no affine) fused into the linear

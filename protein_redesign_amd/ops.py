@@ -266,6 +266,28 @@ def row_block(t: torch.Tensor):
     return t.data_ptr(), t.stride(1)
 
 
+def pair_head_supported(P: int, dist_dim: int, C: int) -> bool:
+    """True when the fused head of the pair track (prd_pair_head) exists for these widths in the current arithmetic."""
+    return lib().prd_pair_head_supported(P, dist_dim, C) == 1
+
+
+def pair_head(static_pair_t, z, mask, centers, w_dist, ebeta, ab, w_out, b_out, *, apply_mask: bool, set_a, set_b, out=None):
+    """pair_init -> OuterProductUpdate tail (residual) -> two attention-bias heads, one row pass (prd_pair_head).
+    set = (w, bvec, gamma, beta) as in pair_bias2.  Returns (pair, bias_a [b,Ha,N,N], bias_b [b,Hb,N,N])."""
+    b, N, _, P = static_pair_t.shape
+    (wa, ba, ga, bea), (wb, bb_, gb, beb) = set_a, set_b
+    Ha, Hb = wa.shape[0], wb.shape[0]
+    if out is None:
+        out = torch.empty_like(static_pair_t)
+    oa = torch.empty(b, Ha, N, N, device=out.device, dtype=F32)
+    ob = torch.empty(b, Hb, N, N, device=out.device, dtype=F32)
+    check(lib().prd_pair_head(dptr(out), dptr(static_pair_t), dptr(z), dptr(mask), dptr(centers), dptr(w_dist), dptr(ebeta),
+                              w_dist.shape[1], dptr(ab), dptr(w_out), dptr(b_out), ab.shape[-1] // 2, int(apply_mask),
+                              dptr(oa), dptr(ga), dptr(bea), dptr(wa), dptr(ba), Ha, dptr(ob), dptr(gb), dptr(beb), dptr(wb), dptr(bb_), Hb,
+                              b, N, P, stream()), "prd_pair_head")
+    return out, oa, ob
+
+
 def outer_linear_pair(pair, x, u, w, bias, *, residual: bool, out=None) -> torch.Tensor:
     """``u`` [b,N,P]: contiguous, or a column block of a wider GEMM output (row_block)."""
     b, N, _, P = pair.shape

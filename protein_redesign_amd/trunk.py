@@ -161,6 +161,7 @@ _TRI_MUL_CHAIN = os.environ.get("PRD_TRI_MUL_CHAIN", "1") != "0"      # 0: two p
 # SLOWER (1.973 vs 1.931 ms per step, A/B in one run): each of the four head-workgroups of a row re-reads the previous og row
 # (4 x 26 MB instead of one pass) and repeats the projection.  Off by default; kept as a tested opt-in.
 _TRI_ATTN_FUSE = os.environ.get("PRD_TRI_ATTN_FUSE", "0") == "1"
+_PAIR_HEAD = os.environ.get("PRD_PAIR_HEAD", "1") != "0"              # 0: pair_init, OPM tail and the first bias heads as three launches
 _MERGE_HEAD = os.environ.get("PRD_MERGE_HEAD", "1") != "0"            # 0: OPM / SPA LayerNorms and projections as four launches
 _MERGE_PROJ = os.environ.get("PRD_MERGE_PROJ", "1") != "0"            # 0: u and the next q|k|v|gate as two launches (A/B measurements)
 
@@ -382,29 +383,45 @@ class Denoiser(nn.Module):
                  rowmask=mask, rowmask_cols=Ch2, a_ln=True, ln_out=xhat, c2=qkvg, n_split=Ch2)
         return ab, xhat, qkvg, True
 
-    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, pre=None, join=None, tail=None):
+    def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, pre=None, join=None, tail=None, pair_init=None):
         """OPM, SPA and the folding blocks, in place on ``pair``, WITHOUT the final symmetrisation
         (the fused coordinate head symmetrises on the fly, so the hot path never writes it back).
         ``pre`` = ``project_single(single, mask)`` if the caller already enqueued it; ``join()`` is then called before its
         results are consumed.  ``tail`` = (weight, bias) of a ReLU layer over LN(single_out) that the last block computes
-        together with its outer-linear term; its output is then returned as a third value."""
+        together with its outer-linear term; its output is then returned as a third value.  ``pair`` may be None when
+        ``pair_init`` = (static_pair, z, centers, w_dist, ebeta) is given: the pair input stage then runs here, fused with the
+        outer-product update and the first attention-bias heads where the library has that form (ops.pair_head)."""
         b, N = mask.shape
         if ws is None:
-            ws = torch.empty(self.ws_floats(b, N), device=pair.device, dtype=torch.float32)
+            ws = torch.empty(self.ws_floats(b, N), device=mask.device, dtype=torch.float32)
         if pre is None:
             pre = self.project_single(single, mask)
         ab, mn, qkvg, normed_only = pre
         if join is not None:
             join()
-        self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair, ab=ab)
         spa = self.SPAAttnBlock
         blocks = list(self.folding_blocks)
-        if blocks:      # SPAttention's pair bias and the first block's attention bias: one pass over the pair tensor
-            ab0 = blocks[0].attn_bias[1]
-            spa_bias, bias = ops.pair_bias2(pair, (spa.linear_z[1].weight, None, spa.linear_z[0].weight, spa.linear_z[0].bias),
-                                            (ab0.weight, ab0.bias, None, None))
-        else:
-            spa_bias, bias = spa.bias_from_pair(pair), None
+        fused_head = False
+        if pair is None:
+            sp, z, centers, w_dist, eb = pair_init
+            opm = self.opm
+            if (_PAIR_HEAD and blocks and ops.pair_head_supported(self.pair_dim, w_dist.shape[1], opm.c_hidden)):
+                ab0 = blocks[0].attn_bias[1]
+                pair, spa_bias, bias = ops.pair_head(sp, z, mask, centers, w_dist, eb, ab, opm.linear_out.weight, opm.linear_out.bias,
+                                                     apply_mask=True,
+                                                     set_a=(spa.linear_z[1].weight, None, spa.linear_z[0].weight, spa.linear_z[0].bias),
+                                                     set_b=(ab0.weight, ab0.bias, None, None))
+                fused_head = True
+            else:
+                pair = ops.pair_init(sp, z, mask, centers, w_dist, eb)
+        if not fused_head:
+            self.opm.run(single, pair, mask, residual=True, apply_mask=True, out=pair, ab=ab)
+            if blocks:      # SPAttention's pair bias and the first block's attention bias: one pass over the pair tensor
+                ab0 = blocks[0].attn_bias[1]
+                spa_bias, bias = ops.pair_bias2(pair, (spa.linear_z[1].weight, None, spa.linear_z[0].weight, spa.linear_z[0].bias),
+                                                (ab0.weight, ab0.bias, None, None))
+            else:
+                spa_bias, bias = spa.bias_from_pair(pair), None
         single = spa.attend(mn, qkvg, spa_bias, normed_only=normed_only)
         holder = [None]             # spare pair buffer of the fused attention form (the residual stream alternates between two)
         qkvg, extra = None, {}
