@@ -83,6 +83,7 @@ int prd_version(void);
 #define PRD_TUNE_OL_GEN2 (1 << 12)      /* PRD_OL_VARIANT=1: round-2 outer-linear kernel instead of the K-split one */
 #define PRD_TUNE_TMS_NW12 (1 << 13)     /* PRD_TMS_NW=12 / 16: waves per workgroup of the split contraction (default 8) */
 #define PRD_TUNE_TMS_NW16 (2 << 13)
+#define PRD_TUNE_GEMM_NO_BATCHED_RING (1 << 17) /* PRD_GEMM_BRING=0: batched / [K][N]-operand GEMMs stay on the fp32 K-split kernel */
 #define PRD_TUNE_GEMM_NO_SLAB (1 << 16) /* PRD_GEMM_SLAB=0: never split K across workgroups (round-3 kernels for the transition layers) */
 #define PRD_TUNE_GEMM_NO_KG (1 << 15)   /* PRD_GEMM_KG=0: node-row GEMMs with few tiles keep one wave group per workgroup (round-3 dispatch) */
 
@@ -137,6 +138,10 @@ typedef struct PrdGemm {
                                        LayerNorm is applied by linearity, LN(x) W^T = rstd (x W^T - mean wsum) */
     float* out_ln; int ldol;        /* optional (this path only, N <= 512): nn.LayerNorm(N, elementwise_affine=False) of the OUTPUT rows
                                        is written here as well -- the next linear of the single track starts with it */
+    float a_scale;                  /* 0 or an exact power of two: the A operand is multiplied by it while it is split into fp16 hi | lo
+                                       (operand-ring kernel, split-16 arithmetic) and the accumulator divided by it -- for A operands
+                                       far below 1 (softmax probabilities: P V of SPAttention), whose lo part would otherwise fall
+                                       into the fp16 subnormal range (see OPERAND RANGE above).  Ignored by the fp32 kernels. */
 } PrdGemm;
 size_t prd_gemm_slab_workspace(int M, int N, int K);
 int prd_gemm_slab_ok(int M, int N, int K, int arith);   /* 1 when a PrdGemm of this shape with `ws` set takes the K-slab path */

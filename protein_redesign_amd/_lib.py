@@ -37,6 +37,7 @@ class PrdGemm(C.Structure):
         ("ws", vp), ("ws_bytes", cz),
         ("wsum", vp),
         ("out_ln", vp), ("ldol", ci),
+        ("a_scale", cf),
     ]
 
 
@@ -131,6 +132,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 15
     if geti("PRD_GEMM_SLAB", 1) == 0:
         t |= 1 << 16
+    if geti("PRD_GEMM_BRING", 1) == 0:
+        t |= 1 << 17
     return t
 
 

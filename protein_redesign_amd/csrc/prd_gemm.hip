@@ -372,34 +372,31 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
         if (tid < 256) {
             const int row = tid >> 2, part = tid & 3, m = m0 + row;
             const float* ar = A + (size_t)(m < g.M ? m : 0) * g.lda;
-            // eight 16-byte loads in flight per thread and pass (unconditional: groups past K re-read the row's start and are
-            // masked) -- a one-load-at-a-time loop is a chain of K / 16 L2 round trips per pass, 8 us at K = 512
-            constexpr int UB = 8;
-            float s1 = 0.f;
-            for (int k0 = 4 * part; k0 < g.K; k0 += 16 * UB) {
-                float4 v[UB];
-#pragma unroll
-                for (int j = 0; j < UB; ++j) v[j] = *reinterpret_cast<const float4*>(ar + (k0 + 16 * j < g.K ? k0 + 16 * j : 0));
-#pragma unroll
-                for (int j = 0; j < UB; ++j) s1 += (k0 + 16 * j < g.K) ? (v[j].x + v[j].y) + (v[j].z + v[j].w) : 0.f;
-            }
-            s1 += __shfl_xor(s1, 1);
-            s1 += __shfl_xor(s1, 2);
-            const float mu = s1 / (float)g.K;
-            float s2 = 0.f;
+            // ONE pass, sixteen 16-byte loads in flight per thread: sums of (x - p) and (x - p)^2 about a pivot p = the row's first
+            // element (a sample of the row: |mean - p| is of the order of the spread, so the shifted form loses nothing even for
+            // rows with |mean| >> spread).  A load-at-a-time two-pass loop is a chain of 2 K / 16 L2 round trips: 8 us at K = 512.
+            constexpr int UB = 16;
+            const float pv = ar[0];
+            float s1 = 0.f, s2 = 0.f;
             for (int k0 = 4 * part; k0 < g.K; k0 += 16 * UB) {
                 float4 v[UB];
 #pragma unroll
                 for (int j = 0; j < UB; ++j) v[j] = *reinterpret_cast<const float4*>(ar + (k0 + 16 * j < g.K ? k0 + 16 * j : 0));
 #pragma unroll
                 for (int j = 0; j < UB; ++j) {
-                    const float d0 = v[j].x - mu, d1 = v[j].y - mu, d2 = v[j].z - mu, d3 = v[j].w - mu;
-                    s2 += (k0 + 16 * j < g.K) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+                    const float d0 = v[j].x - pv, d1 = v[j].y - pv, d2 = v[j].z - pv, d3 = v[j].w - pv;
+                    const bool in = k0 + 16 * j < g.K;
+                    s1 += in ? (d0 + d1) + (d2 + d3) : 0.f;
+                    s2 += in ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
                 }
             }
+            s1 += __shfl_xor(s1, 1);
+            s1 += __shfl_xor(s1, 2);
+            const float dm = s1 / (float)g.K;                   // mean - p
+            const float mu = pv + dm;
             s2 += __shfl_xor(s2, 1);
             s2 += __shfl_xor(s2, 2);
-            if (part == 0) { mean_l[row] = mu; rstd_l[row] = 1.0f / sqrtf(s2 / (float)g.K + 1e-5f); }
+            if (part == 0) { mean_l[row] = mu; rstd_l[row] = 1.0f / sqrtf(fmaxf(s2 / (float)g.K - dm * dm, 0.f) + 1e-5f); }
         }
         __syncthreads();
     }
@@ -517,7 +514,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
 // columns XOR-swizzled by row), and -- for long K -- KG groups take every KG-th chunk with their own LDS stages.  The four
 // waves of a group each take one 16-wide k-step of a chunk; partial tiles are merged in LDS in a fixed order.  LayerNorm
 // statistics come from the ring itself (the whole row is in flight: K <= 64 D KG), so the first load is the only exposed one.
-template <int D, int KG, bool LN>
+template <int D, int KG, bool LN, bool BKN = false>      // BKN: B is given as [K][N] (row pitch ldb) -- staged transposed, 2 bytes at a time
 __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
     constexpr int KCH = 64, NJ = KCH / 32, PL = 32 * KCH * 2, STAGE = 4 * PL;      // plane = 32 rows x 64 fp16; A hi | A lo | B hi | B lo
     extern __shared__ __attribute__((aligned(16))) unsigned char gr[];             // [KG][2][STAGE] (the partial tiles alias it) + LN sums
@@ -530,16 +527,24 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
     const int row = t8 >> 3, seg = t8 & 7;
     // rows past the edge read row 0 (their outputs are never stored)
     const float* ap = g.A + g1 * g.sa1 + g2 * g.sa2 + (size_t)(m0 + row < g.M ? m0 + row : 0) * g.lda + 4 * seg;
-    const float* bp = g.B + g1 * g.sb1 + g2 * g.sb2 + (size_t)(n0 + row < g.N ? n0 + row : 0) * g.ldb + 4 * seg;
+    // BKN: thread (row, seg) takes k = row and row + 32 of a chunk, columns n0 + 4 seg .. + 3 (clamped inside the matrix: the
+    // columns past N are never stored)
+    const int bn4 = n0 + 4 * seg + 3 < g.N ? n0 + 4 * seg : (g.N >= 4 ? g.N - 4 : 0);
+    const float* bp = BKN ? g.B + g1 * g.sb1 + g2 * g.sb2 + (size_t)row * g.ldb + bn4
+                          : g.B + g1 * g.sb1 + g2 * g.sb2 + (size_t)(n0 + row < g.N ? n0 + row : 0) * g.ldb + 4 * seg;
     const int nch = g.K / KCH;
     const int myn = (nch - kg + KG - 1) / KG;           // chunks kg, kg + KG, ... of this group (>= 1: the host picks KG <= nch)
     unsigned char* mysm = gr + kg * 2 * STAGE;
+    // PrdGemm.a_scale: an exact power of two on the A operand while it is split (small operands -- probabilities -- would lose
+    // their lo part to the fp16 subnormal range), taken back out of the accumulator
+    const float asc = (g.a_scale > 0.f && !LN) ? g.a_scale : 1.0f, inv_asc = 1.0f / asc;
     float4 ra[D][NJ], rb[D][NJ];
 #define PRD_GR_LOAD(SLOT, CI)                                                                            \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
         const int c_ = kg + KG * ((CI) < myn ? (CI) : myn - 1);                                          \
         ra[SLOT][j] = *reinterpret_cast<const float4*>(ap + c_ * KCH + 32 * j);                          \
-        rb[SLOT][j] = *reinterpret_cast<const float4*>(bp + c_ * KCH + 32 * j);                          \
+        rb[SLOT][j] = BKN ? *reinterpret_cast<const float4*>(bp + (size_t)(c_ * KCH + 32 * j) * g.ldb)   \
+                          : *reinterpret_cast<const float4*>(bp + c_ * KCH + 32 * j);                    \
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) { PRD_GR_LOAD(d, d) }
@@ -582,6 +587,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
         float4 a = ra[SLOT][j];                                                                          \
         const float4 b = rb[SLOT][j];                                                                    \
+        if (!LN) { a.x *= asc; a.y *= asc; a.z *= asc; a.w *= asc; }                                     \
         if (LN) {                                                                                        \
             a.x = (a.x - mean) * rz; a.y = (a.y - mean) * rz; a.z = (a.z - mean) * rz; a.w = (a.w - mean) * rz; \
             if (lo) *reinterpret_cast<float4*>(lo + (kg + KG * (CI)) * KCH + 32 * j) = a;               \
@@ -592,8 +598,21 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
         *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};                                                   \
         *reinterpret_cast<u32x2*>(d_ + PL) = u32x2{l0, l1};                                              \
         split2h(H2_WSCALE * b.x, H2_WSCALE * b.y, h0, l0); split2h(H2_WSCALE * b.z, H2_WSCALE * b.w, h1, l1); \
-        *reinterpret_cast<u32x2*>(d_ + 2 * PL) = u32x2{h0, h1};                                          \
-        *reinterpret_cast<u32x2*>(d_ + 3 * PL) = u32x2{l0, l1};                                          \
+        if (!BKN) {                                                                                      \
+            *reinterpret_cast<u32x2*>(d_ + 2 * PL) = u32x2{h0, h1};                                      \
+            *reinterpret_cast<u32x2*>(d_ + 3 * PL) = u32x2{l0, l1};                                      \
+        } else {          /* element e of the piece belongs to B row (column of the matrix) bn4 - n0 + e, k = row + 32 j */ \
+            const unsigned hh[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16}, ll[4] = {l0 & 0xffffu, l0 >> 16, l1 & 0xffffu, l1 >> 16}; \
+            const int kl = row + 32 * j;                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
+                const int nl = bn4 - n0 + e;                                                             \
+                if (nl >= 0 && nl < 32) {                                                                \
+                    unsigned char* t_ = mysm + (ST) * STAGE + 2 * PL + nl * (KCH * 2) + ((((kl >> 3)) ^ (nl & 7)) << 4) + (kl & 7) * 2; \
+                    *reinterpret_cast<unsigned short*>(t_) = (unsigned short)hh[e];                      \
+                    *reinterpret_cast<unsigned short*>(t_ + PL) = (unsigned short)ll[e];                 \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
     }
     // the normalised rows themselves, written by the first column tile (PrdGemm.ln_out)
     float* lo = (LN && g.ln_out && tile_n == 0 && m0 + row < g.M) ? g.ln_out + (size_t)(m0 + row) * g.ldlo + 4 * seg : nullptr;
@@ -643,7 +662,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
 #pragma unroll
             for (int w = 0; w < 4 * KG; ++w) v += red[(w * 16 + q) * 64 + lane];
             const int m = m0 + drow32(q, hi);
-            if (m < g.M && n < g.N) epilogue_store(g, g1, g2, m, n, v * H2_INV_WSCALE, C);
+            if (m < g.M && n < g.N) epilogue_store(g, g1, g2, m, n, v * (H2_INV_WSCALE * inv_asc), C);
         }
     }
 }
@@ -658,6 +677,12 @@ static int launch_ring(const PrdGemm& g, dim3 grid, hipStream_t stream) {
     });
     if (g.a_ln) hipLaunchKernelGGL((gemm_ring_kernel<D, KG, true>), grid, dim3(256 * KG), lds, stream, g);
     else hipLaunchKernelGGL((gemm_ring_kernel<D, KG, false>), grid, dim3(256 * KG), lds, stream, g);
+    return (int)hipGetLastError();
+}
+
+static int launch_ring_bkn(const PrdGemm& g, dim3 grid, hipStream_t stream) {      // B as [K][N]: P V of SPAttention (K = keys)
+    const size_t lds = (size_t)2 * 4 * 32 * 64 * 2 + 1024;
+    hipLaunchKernelGGL((gemm_ring_kernel<8, 1, false, true>), grid, dim3(256), lds, stream, g);
     return (int)hipGetLastError();
 }
 
@@ -945,7 +970,14 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
         return (int)hipGetLastError();
     }
     // gemm mode 1, latency-bound node-row linears (fewer 64x64 tiles than that): 32x32 tiles with a deep operand ring
-    if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 && batches == 1) {
+    // (batched, e.g. the per-head logits / P V of SPAttention: same kernel, blockIdx.y = batch; without the fused LayerNorm)
+    if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && g.b_kn && (g.K % 64) == 0 && g.K <= 512 && tiles64 < 2048 && !g.a_ln && g.N >= 4 &&
+        (g.ldb & 3) == 0 && !((g.arith >> 8) & (1 << 17))) {
+        dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
+        return launch_ring_bkn(g, grid, stream);
+    }
+    if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 &&
+        (batches == 1 || (!g.a_ln && !((g.arith >> 8) & (1 << 17))))) {
         const int nch = g.K / 64;
         dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
         const bool many = (long)grid.x * grid.y > 1024;         // throughput regime: one group per workgroup, more workgroups per CU

@@ -73,7 +73,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
          addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
          mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0,
          colscale=None, tile_hint=0, a_ln=False, ln_out=None, c2=None, n_split=0, rowmask_cols=0, rscale=None,
-         slab=False, wsum=None, out_ln=None):
+         slab=False, wsum=None, out_ln=None, a_scale=0.0):
     """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h)."""
     g = PrdGemm()
     g.A, g.B, g.C = _off(A, a_off), _off(B, b_off), _off(Cout, c_off)
@@ -98,6 +98,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
         g.ws, g.ws_bytes = dptr(wsb), wsb.numel() * 4
     g.wsum = dptr(wsum)
     g.out_ln, g.ldol = dptr(out_ln), (out_ln.shape[-1] if out_ln is not None else 0)
+    g.a_scale = float(a_scale)
     g.arith = lib().prd_get_gemm_mode() | (lib().prd_get_tune() << 8)
     import ctypes
     check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
@@ -683,7 +684,7 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
          colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15))
     softmax_rows_(logits, N)
     gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
-         sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L)
+         sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L, a_scale=1024.0)   # probabilities: see PrdGemm.a_scale
     return linear(o, wo, bo, resid=resid, rscale=rscale)
 
 

@@ -155,6 +155,41 @@ def test_operand_ring_gemm_edges(M, N, K, gemm_mode):
         assert rel_l2(out.cpu(), O.ln(x).double() @ w.double().t() + b.double()) < 5e-6
 
 
+@pytest.mark.parametrize("Nk,c", [(320, 512), (128, 96), (192, 70)])
+def test_ring_gemm_batched_and_kn(Nk, c):
+    """The operand-ring kernel with a batch grid and with B given as [K][N] (split-16 arithmetic): SPAttention's per-head
+    logits q k^T + bias and P V with the gate (models/AF2_modules.py:613-628) at its own width (c = 512, 320 keys) and at ragged
+    widths, against fp64."""
+    from protein_redesign_amd import _lib
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(1) == 0
+    try:
+        g = torch.Generator().manual_seed(Nk + c)
+        b, H, N = 2, 4, Nk
+        L = 4 * H * c
+        qkvg = torch.randn(b, N, L, generator=g) / math.sqrt(c) * 3
+        bias = torch.randn(b, H, N, N, generator=g)
+        q = qkvg[..., :H * c].view(b, N, H, c).double()
+        k = qkvg[..., H * c:2 * H * c].view(b, N, H, c).double()
+        v = qkvg[..., 2 * H * c:3 * H * c].view(b, N, H, c).double()
+        gate = qkvg[..., 3 * H * c:].view(b, N, H, c).double()
+        want_logits = torch.einsum("bihc,bjhc->bhij", q, k) + bias.double()
+        ldp = N
+        logits = torch.empty(b, H, N, ldp, device=DEV)
+        dq = cu(qkvg)
+        ops.gemm(dq, dq, logits, N, N, c, L, L, ldp, b_off=H * c, G1=b, G2=H, sa=(N * L, c), sb=(N * L, c),
+                 sc=(H * N * ldp, N * ldp), addmat=cu(bias), sad=(H * N * N, N * N), ldadd=N)
+        assert rel_l2(logits.cpu(), want_logits) < 2e-6
+        P_ = torch.softmax(want_logits, -1)
+        want_o = (torch.einsum("bhij,bjhc->bihc", P_, v) * gate).reshape(b, N, H * c)
+        o = torch.empty(b, N, H * c, device=DEV)
+        ops.gemm(cu(P_.float()), dq, o, N, c, N, ldp, L, H * c, b_off=2 * H * c, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
+                 sc=(N * H * c, c), b_kn=True, mulmat=dq, mul_off=3 * H * c, smu=(N * L, c), ldmul=L, a_scale=1024.0)
+        assert rel_l2(o.cpu(), want_o) < 2e-6
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(320, 2048, 512), (320, 512, 2048), (173, 516, 1024), (2560, 512, 2048), (96, 2048, 512), (100, 960, 1152)])
 def test_k_slab_gemm(M, N, K):
     """The K-slab path of the node-row linears (gemm_slab_kernel + gemm_slab_reduce_kernel: 160 x 64 tiles of one 128-wide K slab
