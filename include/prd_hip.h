@@ -57,8 +57,8 @@ int prd_version(void);
  *      transition / block tail, outer-linear, pair_init, OPM), the triangle-multiplication contraction, Q*K^T and P*V of the
  *      triangle attention and the node-row linears of the single track (prd_gemm with one batch, K a multiple of 64 or 32).
  *      Weight images stay the size of the fp32 ones.  The first-generation short-row attention core (PRD_TUNE_TA_VARIANT 10) uses
- *      bf16 x 3 by truncation (24 bits, 6 products) for Q*K^T.  The single-track attention core, SPAttention's batched
- *      logits / P*V GEMMs, pair_bias and the coordinate head run fp32 MFMA in either mode.
+ *      bf16 x 3 by truncation (24 bits, 6 products) for Q*K^T.  The single-track attention core and pair_bias run fp32 MFMA / FMA in
+ *      either mode.
  *      OPERAND RANGE: fp16 holds magnitudes up to 65504 (a larger operand becomes +-inf, the result NaN -- loudly wrong, never
  *      silently saturated) and keeps a normal lo part down to |x| ~ 0.25 (2^-12 |x| >= 6.1e-5); below that the lo part is
  *      subnormal and the operand carries an ABSOLUTE error of 2^-25 ~ 3e-8 instead of a relative 2^-24.  LayerNorm-ed rows
@@ -337,7 +337,7 @@ int prd_block_tail(float* pair, const float* og, const float* wo, const float* b
 /* coordinate head (modules.py:403 + model.py:364-372): symmetrise, LN -> Linear -> ReLU -> Linear(1),
  * eps_raw[b,N,3] = sum_j m_i m_j w_ij (z_i - z_j) rsqrt(|z_i - z_j|^2 + 1e-4)  (mean not yet removed) */
 int prd_coord_head(float* eps_raw, const float* pair, const float* z, const float* mask,
-                   const float* w1, const float* b1, const float* w2, int b, int N, int P, hipStream_t stream);
+                   const float* w1, const float* b1, const float* w2, int b, int N, int P, int arith, hipStream_t stream);
 /* remove_mean (utils.py:32-36) applied to eps_raw -> noise_pred */
 int prd_remove_mean(float* out, const float* x, const float* mask, int b, int N, int D, hipStream_t stream);
 /* reverse-diffusion update (model.py:405-420): z <- (z - w_t eps)/sqrt(alpha_t) [+ sqrt(beta_t) remove_mean(noise)],

@@ -79,7 +79,7 @@ SIGNATURES = {
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, ci, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, ci, vp],
     "prd_single_attn_core": [vp, vp, ci, vp, vp] + [ci] * 4 + [vp],
-    "prd_coord_head": [vp] * 7 + [ci] * 3 + [vp],
+    "prd_coord_head": [vp] * 7 + [ci] * 4 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
     "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
@@ -97,7 +97,7 @@ GEMM_MODES = {"fp32": 0, "split16": 1, "bf16x3": 1}      # "bf16x3": earlier nam
 DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (env PRD_GEMM_MODE overrides)
 
 # entry points that take the arithmetic as their last argument before the stream ...
-_ARITH_BEFORE_STREAM = ("prd_pair_head", "prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
+_ARITH_BEFORE_STREAM = ("prd_coord_head", "prd_pair_head", "prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
                         "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain")
 # ... and the queries that take it as their last argument
 _ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes",
@@ -224,8 +224,9 @@ def row_gemm_description(b3: bool) -> str:
     if b3:
         return ("split16: fp32 operands split into fp16 hi + lo (both rounded to nearest: 24 bits; 3 products hi*hi + hi*lo + lo*hi) "
                 "and multiplied on the fp16 MFMA pipe with fp32 accumulation -- the row GEMMs of the pair track, the node-row "
-                "linears of the single track, the triangle-multiplication contraction, Q*K^T and P*V of the triangle attention; "
-                "the single-track attention core, SPAttention's batched GEMMs, pair_bias and the coordinate head run fp32 MFMA.  "
+                "linears of the single track (incl. SPAttention's logits / P*V), the coordinate head, the triangle-multiplication contraction, "
+                "Q*K^T and P*V of the triangle attention; "
+                "the single-track attention core and pair_bias run fp32 MFMA / FMA.  "
                 "Parity tolerances are the same as in fp32 mode (PRD_GEMM_MODE=fp32)")
     return "fp32-mfma"
 

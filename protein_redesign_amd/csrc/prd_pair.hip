@@ -1115,17 +1115,18 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
 // ------------------------------------------------------------------------------------------------
 // coordinate head: one workgroup per (b,i); 4 waves split the j blocks; fixed-order reduction
 // ------------------------------------------------------------------------------------------------
-template <int P>
+template <int P, bool B3>                // B3: the hidden layer on the fp16 matrix pipe (split operands; prd_common.h: rowgemm_h2)
 __global__ __launch_bounds__(WG) void coord_head_kernel(float* __restrict__ eps, const float* __restrict__ pair,
                                                         const float* __restrict__ z, const float* __restrict__ mask,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, int b, int N) {
     constexpr int NB = P / 32, KH = P / 2;
-    __shared__ __attribute__((aligned(16))) float W1l[P * (P + 4)];
+    __shared__ __attribute__((aligned(16))) float W1l[P * (P + 4)];      // B3: hi | lo planes of P x P fp16 (the same bytes + padding)
     __shared__ __attribute__((aligned(16))) float b1l[P];
     __shared__ __attribute__((aligned(16))) float w2l[P];
     __shared__ float red[4][3];
-    stage_weight_cll<P>(W1l, w1, P, P, threadIdx.x, WG);
+    if (B3) stage_weight_h2<P>(reinterpret_cast<u32x4*>(W1l), w1, P, P, threadIdx.x, WG, H2_WSCALE);
+    else stage_weight_cll<P>(W1l, w1, P, P, threadIdx.x, WG);
     stage_vec_cll(b1l, b1, P, threadIdx.x, WG);
     stage_vec_cll(w2l, w2, P, threadIdx.x, WG);
     __syncthreads();
@@ -1148,10 +1149,17 @@ __global__ __launch_bounds__(WG) void coord_head_kernel(float* __restrict__ eps,
             ln_cll<KH>(a);
             f32x16 acc[NB];
             zero_acc(acc);
-            rowgemm<P, NB>(W1l, a, acc, r, hi);
+            constexpr float ASC = B3 ? H2_INV_WSCALE : 1.0f;
+            if (B3) {
+                u32x4 xs[2][P / 16];
+                split2h_cll<KH>(a, xs);
+                rowgemm_h2<P, NB>(reinterpret_cast<const u32x4*>(W1l), P, 0, xs, acc, r, hi);
+            } else {
+                rowgemm<P, NB>(W1l, a, acc, r, hi);
+            }
             float wsum = 0.f;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) wsum += fmaxf(acc[s >> 4][s & 15] + b1l[hi * KH + s], 0.f) * w2l[hi * KH + s];
+            for (int s = 0; s < KH; ++s) wsum += fmaxf(acc[s >> 4][s & 15] * ASC + b1l[hi * KH + s], 0.f) * w2l[hi * KH + s];
             wsum = xhalf_sum(wsum);
             const float* zj = z + ((long)bb * N + jj) * 3;
             const float d0 = zi0 - zj[0], d1 = zi1 - zj[1], d2 = zi2 - zj[2];
@@ -1935,12 +1943,16 @@ extern "C" int prd_block_tail(float* pair, const float* og, const float* wo, con
 }
 
 extern "C" int prd_coord_head(float* eps_raw, const float* pair, const float* z, const float* mask,
-                              const float* w1, const float* b1, const float* w2, int b, int N, int P, hipStream_t stream) {
+                              const float* w1, const float* b1, const float* w2, int b, int N, int P, int arith, hipStream_t stream) {
+    PRD_SPLIT_ARITH(arith);
     if (!eps_raw || !pair || !z || !mask || !w1 || !b1 || !w2 || b <= 0 || N <= 0) return PRD_ERR_ARG;
     PRD_CHECK_P(P);
     const int grid = grid_for((long)b * N, 1, 2048);
-    if (P == 64) hipLaunchKernelGGL(coord_head_kernel<64>, dim3(grid), dim3(WG), 0, stream, eps_raw, pair, z, mask, w1, b1, w2, b, N);
-    else hipLaunchKernelGGL(coord_head_kernel<32>, dim3(grid), dim3(WG), 0, stream, eps_raw, pair, z, mask, w1, b1, w2, b, N);
+    const bool b3 = arith == PRD_ARITH_SPLIT16;
+#define PRD_CH(PP, BB) hipLaunchKernelGGL((coord_head_kernel<PP, BB>), dim3(grid), dim3(WG), 0, stream, eps_raw, pair, z, mask, w1, b1, w2, b, N)
+    if (P == 64) { if (b3) PRD_CH(64, true); else PRD_CH(64, false); }
+    else { if (b3) PRD_CH(32, true); else PRD_CH(32, false); }
+#undef PRD_CH
     return (int)hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ int main(void) {
     EXPECT(prd_single_attn_core(p, p, 256, p, p, 1, 8, 2, 32, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_single_attn_core(p, p, 200, p, p, 1, 8, 4, 16, s), PRD_ERR_ALIGN);                    /* qkvg row pitch below 4 H c */
     EXPECT(prd_block_tail(p, p, p, p, p, p, p, p, 0, 0, p, 1, 8, 64, 4, 0, A1, s), PRD_ERR_ARG);   /* bias_out without bias weights */
-    EXPECT(prd_coord_head(p, p, p, p, p, p, 0, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_coord_head(p, p, p, p, p, p, 0, 1, 8, 64, A1, s), PRD_ERR_ARG);
     EXPECT(prd_remove_mean(p, p, p, 1, 8, 65, s), PRD_ERR_ARG);
     EXPECT(prd_reverse_update(p, p, ibuf, p, p, p, p, 0, 1, 8, 21, 10, s), PRD_ERR_ARG);
     EXPECT(prd_static_pair(p, p, p, p, ibuf, ibuf, ibuf, ibuf, p, p, p, p, p, 7, 32, 1, 8, 62, s), PRD_ERR_ALIGN);
