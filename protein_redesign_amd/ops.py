@@ -681,7 +681,9 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     logits = torch.empty(b, H, N, ldp, device=x_normed.device, dtype=F32)
     gemm(qkvg, qkvg, logits, N, N, c, L, L, ldp, b_off=HC, G1=b, G2=H, sa=(N * L, c), sb=(N * L, c),
          sc=(H * N * ldp, N * ldp), addmat=bias, sad=(H * N * N, N * N), ldadd=N,
-         colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15))
+         colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15),
+         tile_hint=32)      # fp32 MFMA in either arithmetic: a softmax follows, and with full-strength weights (|logit| ~ 50) the split
+    #                         operands' 2^-22 shows in the gradients of q / k at the 1e-4 level (tests/test_training_gpu.py)
     softmax_rows_(logits, N)
     gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
          sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L, a_scale=1024.0)   # probabilities: see PrdGemm.a_scale

@@ -697,8 +697,9 @@ def test_free_running_trajectory_vs_yardstick(golden, name, gemm_mode):
       * final positions and logits within 4 x delta_ref of the fp64 run."""
     import os
     from tools.trajectory_conditioning import GOLDEN, free_run, rel
-    if not (os.path.exists(os.path.join(GOLDEN, name + ".npz")) and os.path.exists(os.path.join(GOLDEN, name + "_f64.npz"))):
-        pytest.skip(f"{name}: yardstick fixture not generated (oracle/gen_yardstick.py)")
+    # a committed fixture that is missing is a FAILURE, not a skip: deleting or renaming a golden must not silently remove coverage
+    assert os.path.exists(os.path.join(GOLDEN, name + ".npz")) and os.path.exists(os.path.join(GOLDEN, name + "_f64.npz")), \
+        f"{name}: yardstick fixture missing (oracle/gen_golden.py / oracle/gen_yardstick.py)"
     case, f32 = golden(name)
     _, f64 = golden(name + "_f64")
     steps = [int(v) for v in f64["seg_step"]]
@@ -719,8 +720,15 @@ def test_free_running_trajectory_vs_yardstick(golden, name, gemm_mode):
     gmean = math.exp(sum(math.log(max(r_, 1e-12)) for r_ in ratios) / len(ratios))
     assert gmean <= 2.0, (name, gmean)
     if "traj_pos_f64" in f64:
-        assert rel(pos, f64["traj_pos_f64"]) <= 4 * rel(f32["traj_pos"], f64["traj_pos_f64"])
-        assert rel(logits, f64["traj_logits_f64"]) <= 4 * rel(f32["traj_logits"], f64["traj_logits_f64"])
+        # the bound is a multiple of the reference's own fp32-vs-fp64 distance: it only says something where that distance is
+        # small (a delta_ref of order 1 -- a saturated softmax flipping -- would let any output pass)
+        dpos, dlog = rel(f32["traj_pos"], f64["traj_pos_f64"]), rel(f32["traj_logits"], f64["traj_logits_f64"])
+        assert dpos < 0.1, (name, "the reference's own final positions differ by", dpos, "between fp32 and fp64: fixture not usable")
+        assert rel(pos, f64["traj_pos_f64"]) <= 4 * dpos
+        if dlog < 0.1:
+            assert rel(logits, f64["traj_logits_f64"]) <= 4 * dlog
+        else:
+            print(f"\n{name}: final logits not compared (reference fp32 vs fp64 differ by {dlog:.2e})")
 
 
 @pytest.mark.parametrize("name", ["cfg1_t200", "cfg1_t1000", "cfg1_t200_random", "cfg2_t1000"])
@@ -734,8 +742,8 @@ def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
     the free-running deviation is printed for the record."""
     import os
     from protein_redesign_amd.diffusion_model import ReverseDiffusion
-    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")):
-        pytest.skip(f"{name}: fixture not generated (oracle/gen_yardstick.py; BASELINE configs[1] at its own shape and length)")
+    assert os.path.exists(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")), \
+        f"{name}: fixture missing (oracle/gen_golden.py / oracle/gen_yardstick.py)"
     case, z, args, model, params = golden_case(golden, name)
     one = batch_to(synthetic_batch([tuple(case["traj_sample"])], esm_dim=args["esm_dim"], seed=case["batch_seed"] + 500), DEV)
     loop = ReverseDiffusion(model, one, [NoiseSource(NOISE_SEED, 0)])
@@ -748,16 +756,19 @@ def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
     # T = 1000 with untrained weights: the positions blow up to 1e4 and the sequence softmax saturates -- a handful of segments
     # amplify a 1e-6 perturbation beyond 1e-4 in the reference itself.)
     seg_bound = {}
+    SEG_CAP = 1e-2                                       # no segment-wise twin may relax a bound beyond this
     twin = os.path.join(os.path.dirname(__file__), "golden", name + "_segf64.npz")
     if os.path.exists(twin):
         y = np.load(twin)
-        for q, k0 in enumerate(int(v) for v in y["seg_start"]):
+        for q, k0 in enumerate(int(v) for v in (y["seg_start"] if "seg_start" in y else [])):
             k = steps.index(k0)
             if k + 1 < len(steps):
-                seg_bound[k0] = (3 * rel_l2(seg_z[k + 1:k + 2], y["end_z_f64"][q:q + 1]), 3 * rel_l2(seg_s[k + 1:k + 2], y["end_seq_t_f64"][q:q + 1]))
+                seg_bound[k0] = (min(SEG_CAP, 3 * rel_l2(seg_z[k + 1:k + 2], y["end_z_f64"][q:q + 1])),
+                                 min(SEG_CAP, 3 * rel_l2(seg_s[k + 1:k + 2], y["end_seq_t_f64"][q:q + 1])))
         if "final_pos_f64" in y:                         # the last segment ends in the loop's results (positions, masked logits)
-            seg_bound[int(y["final_start"])] = (3 * rel_l2(z["traj_pos"], y["final_pos_f64"]), 3 * rel_l2(z["traj_logits"], y["final_logits_f64"]))
-    worst = 0.0
+            seg_bound[int(y["final_start"])] = (min(SEG_CAP, 3 * rel_l2(z["traj_pos"], y["final_pos_f64"])),
+                                                min(SEG_CAP, 3 * rel_l2(z["traj_logits"], y["final_logits_f64"])))
+    worst, relaxed = 0.0, []
     with torch.inference_mode():
         for k, start in enumerate(steps):
             end = steps[k + 1] if k + 1 < len(steps) else args["num_steps"]
@@ -772,10 +783,10 @@ def test_trajectory_segments_vs_reference_golden(golden, name, gemm_mode):
             worst = max(worst, ez, es)
             bz, bs = seg_bound.get(start, (0.0, 0.0))
             assert ez < max(TRAJ_TOL, bz) and es < max(TRAJ_TOL, bs), (start, end, ez, es, bz, bs)
-        loop.restart(0, seg_z[0:1], seg_s[0:1])
-        loop.run()
-        pos, _ = loop.result()
-    print(f"\n{name} [{gemm_mode}]: worst segment rel-L2 {worst:.2e}; free-running final positions vs reference {rel_l2(pos.cpu(), z['traj_pos']):.2e}")
+            if ez >= TRAJ_TOL or es >= TRAJ_TOL:         # passed only because of its segment-wise twin: keep it visible
+                relaxed.append((start, f"{ez:.1e}/{bz:.1e}", f"{es:.1e}/{bs:.1e}"))
+    print(f"\n{name} [{gemm_mode}]: worst segment rel-L2 {worst:.2e}; segments above {TRAJ_TOL:g} admitted by their fp64 twin "
+          f"(start, z dev/bound, seq dev/bound): {relaxed if relaxed else 'none'}")
 
 
 @pytest.mark.parametrize("name", ["small32", "small64", "cfg1"])
