@@ -331,8 +331,9 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
     float* Ql = Wl + 64 * (P + 4);               // [npad][17]   (scaled by 1/sqrt(c))
     float* Kl = Ql + npad * TB_PITCH;
     float* Vl = Kl + npad * TB_PITCH;
-    float* Gl = Vl + npad * TB_PITCH;            // sigmoid gate
-    float* Dl = Gl + npad * TB_PITCH;            // dog, then do = dog * gate
+    // (the sigmoid gate of the row does not live in LDS: it is parked in the d(gate) slot of dqkvg -- which this workgroup
+    // overwrites with the gradient afterwards -- so that rows up to 416 positions fit, BASELINE configs[3] draws N <= 384)
+    float* Dl = Vl + npad * TB_PITCH;            // dog, then do = dog * gate
     float* Ml = Dl + npad * TB_PITCH;            // [npad] running max
     float* Ll = Ml + npad;                       // [npad] softmax denominator
     float* El = Ll + npad;                       // [npad] delta = do . o
@@ -383,8 +384,13 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
                 Vl[v * TB_PITCH + 8 + 4 * hi + e] = z * a0[0][12 + e];
                 Ql[v * TB_PITCH + 4 * hi + e] = z * a1[0][e];
                 Ql[v * TB_PITCH + 8 + 4 * hi + e] = z * a1[0][4 + e];
-                Gl[v * TB_PITCH + 4 * hi + e] = z * sigmoidf_(a1[0][8 + e] + bg[h * C + 4 * hi + e]);
-                Gl[v * TB_PITCH + 8 + 4 * hi + e] = z * sigmoidf_(a1[0][12 + e] + bg[h * C + 8 + 4 * hi + e]);
+            }
+            if (valid) {
+                float* gp = dqkvg + row_pos(v) * (4 * HC) + 3 * HC + h * C;
+                *reinterpret_cast<float4*>(gp + 4 * hi) = make_float4(sigmoidf_(a1[0][8] + bg[h * C + 4 * hi]), sigmoidf_(a1[0][9] + bg[h * C + 4 * hi + 1]),
+                                                                      sigmoidf_(a1[0][10] + bg[h * C + 4 * hi + 2]), sigmoidf_(a1[0][11] + bg[h * C + 4 * hi + 3]));
+                *reinterpret_cast<float4*>(gp + 8 + 4 * hi) = make_float4(sigmoidf_(a1[0][12] + bg[h * C + 8 + 4 * hi]), sigmoidf_(a1[0][13] + bg[h * C + 8 + 4 * hi + 1]),
+                                                                          sigmoidf_(a1[0][14] + bg[h * C + 8 + 4 * hi + 2]), sigmoidf_(a1[0][15] + bg[h * C + 8 + 4 * hi + 3]));
             }
             if (hi == 0) kml[v] = (valid && mu * mask[(long)bb * N + v] >= 0.5f) ? 1.f : 0.f;
         }
@@ -447,7 +453,10 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
                     for (int e = 0; e < 4; ++e) o = mfma16(Vl[(k0 + 16 * j + 4 * g4 + e) * TB_PITCH + ql], sv[j][e], o);      // o^T[ch][query]
             }
             const float il = 1.0f / rows4_sum(l_run);
-            const float4 gv = *reinterpret_cast<const float4*>(Gl + q * TB_PITCH + 4 * g4);
+            float* outp = dqkvg + row_pos(qok ? q : 0) * (4 * HC) + h * C + 4 * g4;
+            // the gate parked there by the projection phase (another wave of this workgroup: ordered by the barrier above, and a
+            // CU's L1 sees the CU's own stores)
+            const float4 gv = qok ? *reinterpret_cast<const float4*>(outp + 3 * HC) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 dg = *reinterpret_cast<const float4*>(Dl + q * TB_PITCH + 4 * g4);
             const float gvv[4] = {gv.x, gv.y, gv.z, gv.w}, dgv[4] = {dg.x, dg.y, dg.z, dg.w};
             float dov[4], dgp[4], dsum = 0.f;
@@ -459,7 +468,6 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
                 dsum += dov[e] * oe;
             }
             const float delta = rows4_sum(dsum);
-            float* outp = dqkvg + row_pos(qok ? q : 0) * (4 * HC) + h * C + 4 * g4;
             if (qok) *reinterpret_cast<float4*>(outp + 3 * HC) = make_float4(dgp[0], dgp[1], dgp[2], dgp[3]);
             *reinterpret_cast<float4*>(Dl + q * TB_PITCH + 4 * g4) = make_float4(dov[0], dov[1], dov[2], dov[3]);   // pass B reads do
             if (g4 == 0) { Ml[q] = m_run; Ll[q] = il; El[q] = delta; }
@@ -863,8 +871,8 @@ extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float
     if (!dqkvg || !dog || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 32);
-    const size_t lds = ((size_t)64 * (P + 4) + (size_t)5 * npad * TB_PITCH + 4 * (size_t)npad) * sizeof(float);
-    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;          // rows beyond N ~ 400: not in this first cut
+    const size_t lds = ((size_t)64 * (P + 4) + (size_t)4 * npad * TB_PITCH + 4 * (size_t)npad) * sizeof(float);
+    if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;          // rows beyond N = 416: not in this cut
     const long nwork = (long)b * N * H;
     const int grid = (int)(nwork < 256 ? nwork : 256);
     const int nthreads = 512;                                   // 8 waves: two per SIMD cover each other's dependent MFMA chains

@@ -218,8 +218,9 @@ class TriAttnFn(torch.autograd.Function):
         return (dpair, None, None, None, None, None, *grads)
 
 
-TRI_ATTN_BWD_MAX_N = 352        # prd_tri_attn_bwd_core keeps q, k, v, gate, do of a row (padded to 32) and the head's weights in LDS:
-                                # exactly 160 KB at N = 352 (pitch 20 floats: 16-byte aligned rows); longer rows recompute through torch_ref
+TRI_ATTN_BWD_MAX_N = 416        # prd_tri_attn_bwd_core keeps q, k, v, do of a row (padded to 32) and the head's weights in LDS (the gate is
+                                # parked in its own output slot): 156 KB at N = 416 (pitch 20 floats); BASELINE configs[3] draws N <= 384.
+                                # Longer rows recompute through torch_ref
 
 
 def tri_attn_update(ta, pair: torch.Tensor, mask: torch.Tensor, residual: bool = False) -> torch.Tensor:

@@ -818,14 +818,23 @@ def test_batched_sampling_equals_single_samples(golden):
 
 
 def _full_size_case(na, nr, num_blocks, seed):
-    args = make_args(single_dim=512, pair_dim=64, num_blocks=num_blocks, num_steps=1000, mask_prob=0.3)
+    import gen_oracle_fixtures as GF                   # oracle/gen_oracle_fixtures.py: the case recipe shared with the fixture generator
+    args, params, pb, z, seq_t, t = GF.full_size_inputs(na, nr, num_blocks, seed)
     model, params = build(args, seed=seed)
-    N = na + nr
-    batch = synthetic_batch([(na, nr)], seed=0)
-    pb = O.prepare_batch(batch, 0.3, [NoiseSource(NOISE_SEED, 0).randperm(nr)])
-    g = torch.Generator().manual_seed(8)
-    z, seq_t, t = torch.randn(1, N, 3, generator=g), torch.randn(1, N, 21, generator=g), torch.tensor([500])
     return args, model, params, pb, z, seq_t, t
+
+
+_ORACLE_STEPS = {}
+
+
+def _stored_oracle_step(key):
+    """(noise_pred, seq_pred) of the CPU oracle for a large single-step case, from tests/golden/oracle_steps.npz (written by
+    oracle/gen_oracle_fixtures.py from the same seeds): minutes of host time per suite run otherwise.  A missing entry fails."""
+    import gen_oracle_fixtures as GF
+    if not _ORACLE_STEPS:
+        _ORACLE_STEPS.update(GF.load())
+    assert key + "_eps" in _ORACLE_STEPS, f"tests/golden/oracle_steps.npz has no entry {key}: run oracle/gen_oracle_fixtures.py {key}"
+    return torch.from_numpy(_ORACLE_STEPS[key + "_eps"]), torch.from_numpy(_ORACLE_STEPS[key + "_logits"])
 
 
 @pytest.mark.parametrize("num_blocks", [1, 4])
@@ -833,7 +842,7 @@ def test_full_size_step_vs_oracle(num_blocks, gemm_mode):
     """BASELINE configs[1] shape (N=320, S=512, P=64).  num_blocks = 4 is exactly the network the bench replays."""
     args, model, params, pb, z, seq_t, t = _full_size_case(64, 256, num_blocks, seed=4)
     with torch.inference_mode():
-        want = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
+        want = _stored_oracle_step(f"n320_b{num_blocks}_s4")
         dpb = batch_to(pb, DEV)
         got = model.sample_step(dpb, cu(z), cu(seq_t), dpb["residue_and_atom_mask"], cu(t))
     assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2
@@ -848,7 +857,7 @@ def test_long_sequence_step_vs_oracle(na, nr, gemm_mode):
     size where the 32-bit index arithmetic of a row kernel passes 2^28 elements."""
     args, model, params, pb, z, seq_t, t = _full_size_case(na, nr, 1, seed=7)
     with torch.inference_mode():
-        want = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
+        want = _stored_oracle_step(f"n{na + nr}_b1_s7")
         dpb = batch_to(pb, DEV)
         got = model.sample_step(dpb, cu(z), cu(seq_t), dpb["residue_and_atom_mask"], cu(t))
     assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2
@@ -885,17 +894,12 @@ def test_chunked_and_resident_long_row_cores_agree(setup, ending):
     assert rel_l2(resident.cpu(), chunked.cpu()) < OP_TOL
 
 
-_CFG4_ORACLE = {}
-
-
 def test_long_sequence_four_blocks_vs_oracle(gemm_mode):
     """BASELINE configs[4] at its own depth: N = 769 and all FOUR folding blocks (the graph `bench.py --residues 768 --atoms 1`
-    replays) against the oracle; the oracle's step is evaluated once and shared by the two arithmetic modes."""
+    replays) against the oracle's step (stored: tests/golden/oracle_steps.npz)."""
     args, model, params, pb, z, seq_t, t = _full_size_case(1, 768, 4, seed=11)
     with torch.inference_mode():
-        if "want" not in _CFG4_ORACLE:
-            _CFG4_ORACLE["want"] = O.network_step(params, args, pb, z, seq_t, pb["residue_and_atom_mask"], t)
-        want = _CFG4_ORACLE["want"]
+        want = _stored_oracle_step("n769_b4_s11")
         dpb = batch_to(pb, DEV)
         got = model.sample_step(dpb, cu(z), cu(seq_t), dpb["residue_and_atom_mask"], cu(t))
     assert rel_l2(got[0].cpu(), want[0]) < BLOCK_TOL * 2

@@ -41,6 +41,8 @@ def algorithmic(N, P, S, H=4, c=16):
         "outer_linear_res_h2_kernel": (N * N * S * P + 4 * N * S * P, 2 * U),       # symmetric half of 2 N^2 S P
         "outer_linear_ks_kernel": (N * N * S * P + 4 * N * S * P, 2 * U),
         "pair_init_h2_kernel": (2 * N * N * 256 * P, 2 * U),
+        # pair_init + OPM tail + the two first bias heads in one row pass: static pair in, pair out (+ 2 x [H,N,N] outputs)
+        "pair_head_h2_kernel": (2 * N * N * 256 * P + 2 * N * N * (S // 4) * P + 2 * 2 * N * N * P * H, 2 * U + 2 * H * N * N * 4),
         "opm_pair_h2_kernel": (2 * N * N * (S // 4) * P, 2 * U),
         "coord_head_kernel": (2 * N * N * P * P + 2 * N * N * P, 2 * U),
         "pair_bias_kernel": (2 * 2 * N * N * P * H, U),
