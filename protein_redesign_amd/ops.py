@@ -652,7 +652,8 @@ def project_qkvg(x_normed, packed, HC: int, ln_a: bool = False) -> torch.Tensor:
 
 def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int, *,
                            key_mask: bool, resid: Optional[torch.Tensor], ln_a: bool = False,
-                           qkvg: Optional[torch.Tensor] = None, rscale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           qkvg: Optional[torch.Tensor] = None, rscale: Optional[torch.Tensor] = None,
+                           out_ln: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Multi-head gated attention over the node axis with an additive [b,H,N,N] bias.
 
     Covers reference modules.py:185-225 (c = head_dim, key mask filled with -2**15, q pre-scaled by
@@ -661,7 +662,8 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     ``ln_a``: ``x_normed`` is the raw input and its (affine-free) LayerNorm is fused into the q|k|v|g projection.
     ``qkvg``: the projection, if the caller already computed it (``project_qkvg``, e.g. on a side stream).
     ``rscale``: per-column factor of ``resid`` (an affine-LayerNorm-ed residual given as the plain normalised rows x gamma, with
-    beta folded into ``bo`` by the caller)."""
+    beta folded into ``bo`` by the caller).  ``out_ln``: buffer for LN(result) (no affine) -- only with an output projection that takes
+    the K-slab path (``slab_ok(b N, S_out, H c)``), whose reduce launch holds whole output rows."""
     b, N, S = x_normed.shape
     HC = H * c
     w, pbias, colscale = packed
@@ -687,7 +689,7 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     softmax_rows_(logits, N)
     gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
          sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L, a_scale=1024.0)   # probabilities: see PrdGemm.a_scale
-    return linear(o, wo, bo, resid=resid, rscale=rscale)
+    return linear(o, wo, bo, resid=resid, rscale=rscale, slab=slab_ok(b * N, wo.shape[0], HC), out_ln=out_ln)
 
 
 def project_many(single, packed, P_first: int, *, act: int, act_from: int, xhat=None):

@@ -422,9 +422,18 @@ class Denoiser(nn.Module):
                                                 (ab0.weight, ab0.bias, None, None))
             else:
                 spa_bias, bias = spa.bias_from_pair(pair), None
-        single = spa.attend(mn, qkvg, spa_bias, normed_only=normed_only)
+        # SPAttention's output projection (2048 -> 512) runs on the K-slab path where it qualifies; its reduce launch also writes
+        # LN(single), with which the first block's q|k|v|gate projection starts (no LayerNorm prologue there)
+        b_, N_, S_ = mn.shape
+        xhat0 = None
+        if blocks and _MERGE_PROJ and S_ <= 512 and ops.slab_ok(b_ * N_, spa.mha.linear_o.weight.shape[0], spa.no_heads * spa.c_hidden):
+            xhat0 = torch.empty_like(mn)
+        single = spa.attend(mn, qkvg, spa_bias, normed_only=normed_only, out_ln=xhat0)
         holder = [None]             # spare pair buffer of the fused attention form (the residual stream alternates between two)
         qkvg, extra = None, {}
+        if xhat0 is not None:
+            sa0 = blocks[0].single_attn
+            qkvg = ops.project_qkvg(xhat0, sa0.packed(), sa0.num_heads * sa0.head_dim)
         for i, block in enumerate(blocks):
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
             extra = {}
