@@ -112,7 +112,9 @@ typedef struct PrdGemm {
     const float* mulmat; long long smu1, smu2; int ldmul;
     const float* resid; long long sr1, sr2; int ldr;
     int tile_hint;                  /* 0 = automatic; 32 / 64 / 128 force the workgroup tile */
-    int a_ln;                       /* 1: A rows are LayerNorm-ed over K on the fly (no affine, eps 1e-5, biased variance) --
+    int a_ln;                       /* 2: the A rows go through a row SOFTMAX over K on the fly (split-16 arithmetic, b_kn, K % 64 == 0,
+                                       K <= 512: SPAttention's softmax inside its P V product; PRD_ERR_UNSUPPORTED elsewhere).
+                                       1: A rows are LayerNorm-ed over K on the fly (no affine, eps 1e-5, biased variance) --
                                        nn.LayerNorm(K, elementwise_affine=False) fused into the linear that follows it
                                        (reference modules.py:296,306).  Needs !b_kn, K % 4 == 0 and K <= 512 (32x32 K-split tile), or -- gemm mode 1,
                                        fewer than 512 tiles of 64x64, one batch -- K % 64 == 0 and K <= 1024 (operand-ring kernel);

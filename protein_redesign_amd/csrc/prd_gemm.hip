@@ -538,6 +538,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
     // PrdGemm.a_scale: an exact power of two on the A operand while it is split (small operands -- probabilities -- would lose
     // their lo part to the fp16 subnormal range), taken back out of the accumulator
     const float asc = (g.a_scale > 0.f && !LN) ? g.a_scale : 1.0f, inv_asc = 1.0f / asc;
+    float ascr = asc;                                   // per-row factor of the A operand (a_ln = 2: includes 1 / softmax denominator)
     float4 ra[D][NJ], rb[D][NJ];
 #define PRD_GR_LOAD(SLOT, CI)                                                                            \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
@@ -583,11 +584,34 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
         }
         rz = 1.0f / sqrtf(s2 / (float)g.K + 1e-5f);
     }
+    if (BKN && g.a_ln == 2) {
+        // PrdGemm.a_ln = 2: row SOFTMAX of the A rows over K (the whole row is in the ring: K <= 64 D) -- SPAttention's softmax
+        // rides in its P V product (models/AF2_modules.py:613-628) instead of a launch of its own that rewrites the logits
+        constexpr float L2E = 1.4426950408889634f;
+        float m = -INFINITY;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (d < myn) m = fmaxf(m, fmaxf(fmaxf(ra[d][j].x, ra[d][j].y), fmaxf(ra[d][j].z, ra[d][j].w)));
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+        float ssum = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                ra[d][j].x = __builtin_amdgcn_exp2f((ra[d][j].x - m) * L2E); ra[d][j].y = __builtin_amdgcn_exp2f((ra[d][j].y - m) * L2E);
+                ra[d][j].z = __builtin_amdgcn_exp2f((ra[d][j].z - m) * L2E); ra[d][j].w = __builtin_amdgcn_exp2f((ra[d][j].w - m) * L2E);
+                ssum += d < myn ? (ra[d][j].x + ra[d][j].y) + (ra[d][j].z + ra[d][j].w) : 0.f;
+            }
+        ssum += __shfl_xor(ssum, 1); ssum += __shfl_xor(ssum, 2); ssum += __shfl_xor(ssum, 4);
+        ascr = asc / ssum;
+    }
 #define PRD_GR_STAGE(SLOT, ST, CI)                                                                       \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
         float4 a = ra[SLOT][j];                                                                          \
         const float4 b = rb[SLOT][j];                                                                    \
-        if (!LN) { a.x *= asc; a.y *= asc; a.z *= asc; a.w *= asc; }                                     \
+        if (!LN) { a.x *= ascr; a.y *= ascr; a.z *= ascr; a.w *= ascr; }                                 \
         if (LN) {                                                                                        \
             a.x = (a.x - mean) * rz; a.y = (a.y - mean) * rz; a.z = (a.z - mean) * rz; a.w = (a.w - mean) * rz; \
             if (lo) *reinterpret_cast<float4*>(lo + (kg + KG * (CI)) * KCH + 32 * j) = a;               \
@@ -971,11 +995,12 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     }
     // gemm mode 1, latency-bound node-row linears (fewer 64x64 tiles than that): 32x32 tiles with a deep operand ring
     // (batched, e.g. the per-head logits / P V of SPAttention: same kernel, blockIdx.y = batch; without the fused LayerNorm)
-    if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && g.b_kn && (g.K % 64) == 0 && g.K <= 512 && tiles64 < 2048 && !g.a_ln && g.N >= 4 &&
-        (g.ldb & 3) == 0 && !((g.arith >> 8) & (1 << 17))) {
+    if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && g.b_kn && (g.K % 64) == 0 && g.K <= 512 && tiles64 < 2048 && (g.a_ln == 0 || g.a_ln == 2) &&
+        g.N >= 4 && (g.ldb & 3) == 0 && !((g.arith >> 8) & (1 << 17))) {
         dim3 grid(prd_ceil_div(g.M, 32) * prd_ceil_div(g.N, 32), batches);
         return launch_ring_bkn(g, grid, stream);
     }
+    if (g.a_ln == 2) return PRD_ERR_UNSUPPORTED;        // the fused row softmax exists in that kernel only
     if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 64) == 0 && tiles64 < 512 &&
         (batches == 1 || (!g.a_ln && !((g.arith >> 8) & (1 << 17))))) {
         const int nch = g.K / 64;

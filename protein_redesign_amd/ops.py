@@ -73,8 +73,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
          addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
          mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0,
          colscale=None, tile_hint=0, a_ln=False, ln_out=None, c2=None, n_split=0, rowmask_cols=0, rscale=None,
-         slab=False, wsum=None, out_ln=None, a_scale=0.0):
-    """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h)."""
+         slab=False, wsum=None, out_ln=None, a_scale=0.0, unsupported_ok=False):
+    """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h).  ``a_ln`` may be 2 (row softmax of A, see the header);
+    with ``unsupported_ok`` a PRD_ERR_UNSUPPORTED shape returns None instead of raising (the caller falls back)."""
     g = PrdGemm()
     g.A, g.B, g.C = _off(A, a_off), _off(B, b_off), _off(Cout, c_off)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.G1, g.G2 = M, N, K, lda, ldb, ldc, G1, G2
@@ -89,7 +90,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.resid = (_off(resid, res_off) if resid is not None else None)
     g.sr1, g.sr2, g.ldr = sr[0], sr[1], ldr
     g.colscale, g.tile_hint = dptr(colscale), tile_hint
-    g.a_ln = 1 if a_ln else 0
+    g.a_ln = int(a_ln) if a_ln in (1, 2) else (1 if a_ln else 0)
     g.ln_out, g.ldlo = dptr(ln_out), (ln_out.shape[-1] if ln_out is not None else 0)
     g.C2, g.ldc2, g.n_split = dptr(c2), (c2.shape[-1] if c2 is not None else 0), n_split
     g.rowmask_cols, g.rscale = rowmask_cols, dptr(rscale)
@@ -101,7 +102,10 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.a_scale = float(a_scale)
     g.arith = lib().prd_get_gemm_mode() | (lib().prd_get_tune() << 8)
     import ctypes
-    check(lib().prd_gemm(ctypes.byref(g), stream()), "prd_gemm")
+    code = lib().prd_gemm(ctypes.byref(g), stream())
+    if unsupported_ok and code == -3:
+        return None
+    check(code, "prd_gemm")
     return Cout
 
 
@@ -686,9 +690,12 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
          colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15),
          tile_hint=32)      # fp32 MFMA in either arithmetic: a softmax follows, and with full-strength weights (|logit| ~ 50) the split
     #                         operands' 2^-22 shows in the gradients of q / k at the 1e-4 level (tests/test_training_gpu.py)
-    softmax_rows_(logits, N)
-    gemm(logits, qkvg, o, N, c, N, ldp, L, HC, b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
-         sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC, smu=(N * L, c), ldmul=L, a_scale=1024.0)   # probabilities: see PrdGemm.a_scale
+    pv = dict(b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c), sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC,
+              smu=(N * L, c), ldmul=L, a_scale=1024.0)                                                        # probabilities: see PrdGemm.a_scale
+    # the row softmax rides in the P V product where the library has that form (a_ln = 2); else its own launch
+    if ldp != N or gemm(logits, qkvg, o, N, c, N, ldp, L, HC, a_ln=2, unsupported_ok=True, **pv) is None:
+        softmax_rows_(logits, N)
+        gemm(logits, qkvg, o, N, c, N, ldp, L, HC, **pv)
     return linear(o, wo, bo, resid=resid, rscale=rscale, slab=slab_ok(b * N, wo.shape[0], HC), out_ln=out_ln)
 
 

@@ -186,6 +186,11 @@ def test_ring_gemm_batched_and_kn(Nk, c):
         ops.gemm(cu(P_.float()), dq, o, N, c, N, ldp, L, H * c, b_off=2 * H * c, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
                  sc=(N * H * c, c), b_kn=True, mulmat=dq, mul_off=3 * H * c, smu=(N * L, c), ldmul=L, a_scale=1024.0)
         assert rel_l2(o.cpu(), want_o) < 2e-6
+        # the row softmax inside the product (PrdGemm.a_ln = 2): the A operand is the LOGITS
+        o2 = torch.empty(b, N, H * c, device=DEV)
+        ops.gemm(cu(want_logits.float()), dq, o2, N, c, N, ldp, L, H * c, b_off=2 * H * c, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c),
+                 sc=(N * H * c, c), b_kn=True, mulmat=dq, mul_off=3 * H * c, smu=(N * L, c), ldmul=L, a_scale=1024.0, a_ln=2)
+        assert rel_l2(o2.cpu(), want_o) < 3e-6
     finally:
         assert _lib.lib().prd_set_gemm_mode(prev) == 0
 
