@@ -134,6 +134,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 16
     if geti("PRD_GEMM_BRING", 1) == 0:
         t |= 1 << 17
+    if geti("PRD_TA2_XCD8", 1) == 0:
+        t |= 1 << 20
     return t
 
 
@@ -149,7 +151,7 @@ class _Library:
         self._wrapped = {}
 
     def prd_set_tune(self, tune: int) -> int:
-        if tune < 0 or tune >= (1 << 20):
+        if tune < 0 or tune >= (1 << 22):
             return -1
         self._tune = int(tune)
         return 0

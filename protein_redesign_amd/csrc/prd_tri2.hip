@@ -1357,6 +1357,10 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
     if (per_head < 1) per_head = 1;
     const long rounds = (rows_total + per_head - 1) / per_head;
     per_head = (rows_total + rounds - 1) / rounds;
+    // a multiple of 8 rows in flight per head (never more rounds: per_head <= cap = 64 either way): the kernels then keep the four
+    // head-workgroups of a row on ONE XCD, whose L2 serves three of the four reads of the row.  (N = 769: 60 -> 64 rows in flight.)
+    if (per_head >= 8 && !((tune >> 20) & 1)) per_head = (per_head + 7) / 8 * 8;      // (PRD_TUNE_TA2_NO_XCD8: A/B switch)
+    if (per_head > cap) per_head = cap;
     const int grid = (int)(per_head * H);
     constexpr int NWV = 12;                             // nqb <= 12 query blocks, one wave each
     const int flags_env = PRD_TGET_TA2_FLAGS(tune);     // A/B switch: kernel flags given by the caller (-1: per-kernel default)
