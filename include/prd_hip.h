@@ -354,12 +354,16 @@ int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pr
  * noise_pred = remove_mean(eps_raw); z, seq_t advanced as in prd_reverse_update; t <- t - 1; and the NEXT step's inputs
  * ebeta_next[b,P] = time embedding of t - 1 (prd_time_embed) and single_next[b,N,S] = prd_single_init of the new seq_t.
  * sync: one int32, zero before the first launch, owned by the caller and shared only by stream-ordered launches (the last
- * workgroup to arrive advances t and resets it).  n_cls must be 21 (20 residue types + 'X'), time_dim <= 512 and even. */
-int prd_step_boundary(float* z, float* seq_t, int64_t* t, const float* eps_raw, const float* seq_pred,
+ * workgroup to arrive advances t and resets it).  n_cls must be 21 (20 residue types + 'X'), time_dim <= 512 and even.
+ * seq_h != NULL: seq_pred is an OUTPUT -- the sequence head's last layer (model.py:117-122: Linear(S_h, 21, bias = False) with
+ * weight w_seq [21, S_h]) is applied here to its ReLU hidden units seq_h [b,N,S_h] (row pitch ldh), instead of a GEMM launch of
+ * its own; seq_h == NULL: seq_pred is read. */
+int prd_step_boundary(float* z, float* seq_t, int64_t* t, const float* eps_raw, float* seq_pred,
                       const float* noise, const float* mask, const float* coef,
                       float* single_next, const float* static_single, const float* residue_mask, const float* w_rt,
                       float* ebeta_next, const float* freqs, const float* w_beta, int* sync,
-                      int b, int N, int n_cls, int num_steps, int S, int P, int time_dim, hipStream_t stream);
+                      int b, int N, int n_cls, int num_steps, int S, int P, int time_dim,
+                      const float* seq_h, int ldh, const float* w_seq, int S_h, hipStream_t stream);
 
 /* bytes of scratch an operator needs: op = "tri_mul" | "tri_attn" */
 size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P);

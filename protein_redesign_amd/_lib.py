@@ -82,7 +82,7 @@ SIGNATURES = {
     "prd_coord_head": [vp] * 7 + [ci] * 4 + [vp],
     "prd_remove_mean": [vp] * 3 + [ci] * 3 + [vp],
     "prd_reverse_update": [vp] * 8 + [ci] * 4 + [vp],
-    "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp],
+    "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp, ci, vp, ci] + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 7 + [vp],
     "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 7 + [vp],
     "prd_tri_attn_v2_form": [ci, ci, ci],

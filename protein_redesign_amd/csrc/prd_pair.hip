@@ -1273,12 +1273,14 @@ constexpr int SB_NODES = 8;
 template <int NCLS>
 __global__ __launch_bounds__(256) void step_boundary_kernel(
     float* __restrict__ z, float* __restrict__ seq_t, int64_t* __restrict__ t, const float* __restrict__ eps_raw,
-    const float* __restrict__ seq_pred, const float* __restrict__ noise, const float* __restrict__ mask, const float* __restrict__ coef,
+    float* __restrict__ seq_pred, const float* __restrict__ noise, const float* __restrict__ mask, const float* __restrict__ coef,
     float* __restrict__ single_next, const float* __restrict__ stat, const float* __restrict__ rm, const float* __restrict__ w_rt,
     float* __restrict__ ebeta_next, const float* __restrict__ freqs, const float* __restrict__ w_beta, int* __restrict__ sync,
-    int b, int N, int num_steps, int S, int P, int TD, int nblk, int neb) {
+    int b, int N, int num_steps, int S, int P, int TD, int nblk, int neb,
+    const float* __restrict__ seq_h, int ldh, const float* __restrict__ w_seq, int Sh) {
     constexpr int ncls = NCLS, CPL = (NCLS + 7) / 8;      // classes per lane in the 8-lanes-per-node softmax
     __shared__ float red[4][8];
+    __shared__ float lg[SB_NODES][NCLS + 3];      // seq_h given: the logits of the workgroup's nodes (computed here)
     __shared__ float mean[8];
     __shared__ float xs[SB_NODES][NCLS + 3];     // LayerNorm-ed new seq_t of the workgroup's nodes
     __shared__ float feat[512];
@@ -1324,10 +1326,42 @@ __global__ __launch_bounds__(256) void step_boundary_kernel(
                 if (lane == 0) red[wave][d] = s7[d];
             }
         }
+        if (seq_h) {
+            // the sequence head's LAST layer (model.py:117-122: Linear(S, 21, bias=False) on the ReLU hidden units seq_h) for the
+            // workgroup's 8 nodes: 32 threads per node, 16 hidden units each per 512, shuffle reduction -- instead of a GEMM launch
+            // of its own for 0.007 GF.  The logits are also written to seq_pred (the loop returns them after the last step).
+            const int n = tid >> 5, part = tid & 31, i = i0 + n;
+            const bool ok = i < N;
+            const float* hr = seq_h + ((long)bb * N + (ok ? i : 0)) * ldh;
+            float acc[NCLS];
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) acc[c] = 0.f;
+            for (int k = 4 * part; k < Sh; k += 128) {
+                const float4 hv = *reinterpret_cast<const float4*>(hr + k);
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w_seq + (long)c * Sh + k);
+                    acc[c] += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) acc[c] += __shfl_xor(acc[c], o);
+            }
+            if (part == 0) {
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) {
+                    lg[n][c] = acc[c];
+                    if (ok) seq_pred[((long)bb * N + i) * ncls + c] = acc[c];
+                }
+            }
+            __syncthreads();
+        }
         if (tid < 8 * SB_NODES) {   // seq_t: 2 softmax - 1 and its LayerNorm; 8 lanes per node, classes l, l+8, ...
             const int n = tid >> 3, l = tid & 7, i = i0 + n;
             const bool ok = i < N;
-            const float* lp = seq_pred + ((long)bb * N + (ok ? i : 0)) * ncls;
+            const float* lp = seq_h ? &lg[n][0] : seq_pred + ((long)bb * N + (ok ? i : 0)) * ncls;
             float v[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) v[q] = (l + 8 * q < ncls) ? lp[l + 8 * q] : -INFINITY;
@@ -1970,17 +2004,20 @@ extern "C" int prd_reverse_update(float* z, float* seq_t, int64_t* t, const floa
     return (int)hipGetLastError();
 }
 
-extern "C" int prd_step_boundary(float* z, float* seq_t, int64_t* t, const float* eps_raw, const float* seq_pred,
+extern "C" int prd_step_boundary(float* z, float* seq_t, int64_t* t, const float* eps_raw, float* seq_pred,
                                  const float* noise, const float* mask, const float* coef,
                                  float* single_next, const float* static_single, const float* residue_mask, const float* w_rt,
                                  float* ebeta_next, const float* freqs, const float* w_beta, int* sync,
-                                 int b, int N, int n_cls, int num_steps, int S, int P, int time_dim, hipStream_t stream) {
+                                 int b, int N, int n_cls, int num_steps, int S, int P, int time_dim,
+                                 const float* seq_h, int ldh, const float* w_seq, int S_h, hipStream_t stream) {
     if (!z || !seq_t || !t || !eps_raw || !seq_pred || !noise || !mask || !coef || !single_next || !static_single || !residue_mask ||
         !w_rt || !ebeta_next || !freqs || !w_beta || !sync || b <= 0 || N <= 0 || S <= 0 || P <= 0) return PRD_ERR_ARG;
     if (n_cls != 21 || time_dim <= 0 || time_dim > 512 || (time_dim & 1)) return PRD_ERR_UNSUPPORTED;    // 20 residue types + 'X'
+    if (seq_h && (!w_seq || S_h <= 0)) return PRD_ERR_ARG;
+    if (seq_h && ((S_h & 3) || (ldh & 3) || ldh < S_h)) return PRD_ERR_ALIGN;
     const int nblk = prd_ceil_div(N, SB_NODES), neb = prd_ceil_div(P, 4);
     hipLaunchKernelGGL(step_boundary_kernel<21>, dim3(b * (nblk + neb)), dim3(256), 0, stream, z, seq_t, t, eps_raw, seq_pred, noise, mask, coef,
                        single_next, static_single, residue_mask, w_rt, ebeta_next, freqs, w_beta, sync, b, N, num_steps, S, P,
-                       time_dim, nblk, neb);
+                       time_dim, nblk, neb, seq_h, ldh, w_seq, S_h);
     return (int)hipGetLastError();
 }

@@ -432,9 +432,10 @@ class ProteinReDiffModel(_Base):
         eb = ops.time_embed(t.contiguous(), self.embed_beta[0].weight, self.embed_beta[1].weight, self.num_steps)
         return single, eb
 
-    def _network(self, batch, z, seq_t, mask, t, static=None, step_inputs=None, raw_noise=False):
+    def _network(self, batch, z, seq_t, mask, t, static=None, step_inputs=None, raw_noise=False, defer_seq_head=False):
         """``step_inputs`` = (single, ebeta) if already computed; ``raw_noise``: return the coordinate head's output before
-        remove_mean (the step-boundary kernel removes the mean itself)."""
+        remove_mean (the step-boundary kernel removes the mean itself); ``defer_seq_head``: return the sequence head's HIDDEN units
+        instead of the logits (the step-boundary kernel applies the last layer itself)."""
         if static is None:
             static = self._static_inputs(batch)
         rm = batch["residue_mask"].contiguous()
@@ -457,7 +458,7 @@ class ProteinReDiffModel(_Base):
         with side.fork():
             if h is None:
                 h = ops.linear(single, sm[1].weight, sm[1].bias, act=1, ln_a=True)    # LayerNorm (no affine) fused into the linear
-            seq_pred = ops.linear(h, sm[3].weight)
+            seq_pred = h if defer_seq_head else ops.linear(h, sm[3].weight)
         wr = self.weight_radial
         eps_raw = ops.coord_head(pair, z, mask, wr[1].weight, wr[1].bias, wr[3].weight)
         noise_pred = eps_raw if raw_noise else ops.remove_mean(eps_raw, mask)
@@ -530,6 +531,7 @@ class ReverseDiffusion:
         import os
         self.fused_boundary = os.environ.get("PRD_FUSED_BOUNDARY", "1") != "0"
         self.sync = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._seq_pred_buf = None               # logits of the last step (written by the step-boundary kernel)
         self.single_in, self.eb_in = m._step_inputs(self.static, self.seq_t, self.rm, self.t)
 
     def _refresh_step_inputs(self):
@@ -565,12 +567,15 @@ class ReverseDiffusion:
             noise_pred, seq_pred = m._network(self.batch, self.z, self.seq_t, self.mask, self.t, static=self.static)
             ops.reverse_update_(self.z, self.seq_t, self.t, noise_pred, seq_pred, self.noise, self.mask, m._coef, self.T)
             return seq_pred
-        eps_raw, seq_pred = m._network(self.batch, self.z, self.seq_t, self.mask, self.t, static=self.static,
-                                       step_inputs=(self.single_in, self.eb_in), raw_noise=True)
-        ops.step_boundary_(self.z, self.seq_t, self.t, eps_raw, seq_pred, self.noise, self.mask, m._coef, self.T,
+        eps_raw, seq_h = m._network(self.batch, self.z, self.seq_t, self.mask, self.t, static=self.static,
+                                    step_inputs=(self.single_in, self.eb_in), raw_noise=True, defer_seq_head=True)
+        if self._seq_pred_buf is None:
+            self._seq_pred_buf = torch.empty(*self.seq_t.shape, device=self.seq_t.device, dtype=torch.float32)
+        ops.step_boundary_(self.z, self.seq_t, self.t, eps_raw, self._seq_pred_buf, self.noise, self.mask, m._coef, self.T,
                            self.single_in, self.static["single"], self.rm, m.embed_residue_type[1].weight,
-                           self.eb_in, m.embed_beta[0].weight, m.embed_beta[1].weight, self.sync)
-        return seq_pred
+                           self.eb_in, m.embed_beta[0].weight, m.embed_beta[1].weight, self.sync,
+                           seq_h=seq_h, w_seq=m.seq_mlp[3].weight)
+        return self._seq_pred_buf
 
     @torch.inference_mode()
     def step(self):

@@ -113,15 +113,16 @@ _GEMM_WS = {}
 
 
 def gemm_workspace(device, nbytes: int) -> torch.Tensor:
-    """Persistent per-device scratch of the K-slab GEMM path (partial tiles; at most a few tens of MB).  One buffer per device
-    is enough: the launches that use it are ordered on one stream, and a captured graph keeps the address."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """Persistent scratch of the K-slab GEMM path (partial tiles; at most a few tens of MB), one buffer per (device, stream): the
+    launches that use it are ordered on that stream, and a captured graph keeps the address."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)     # per stream: launches on different streams must not share partials
     buf = _GEMM_WS.get(key)
     n = max(1, (nbytes + 3) // 4)
     if buf is None or buf.numel() < n:
         if buf is not None and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("gemm workspace would have to grow during graph capture; run one eager step first")
-        buf = _GEMM_WS[key] = torch.empty(n, device=f"cuda:{key}", dtype=F32)
+        buf = _GEMM_WS[key] = torch.empty(n, device=f"cuda:{dev}", dtype=F32)
     return buf
 
 
@@ -543,14 +544,18 @@ def reverse_update_(z, seq_t, t, noise_pred, seq_pred, noise, mask, coef, num_st
 
 
 def step_boundary_(z, seq_t, t, eps_raw, seq_pred, noise, mask, coef, num_steps: int, single_next, static_single, residue_mask,
-                   w_rt, ebeta_next, freqs, w_beta, sync):
-    """Reverse update + the next step's single / time-embedding inputs in one launch (prd_hip.h: prd_step_boundary)."""
+                   w_rt, ebeta_next, freqs, w_beta, sync, seq_h=None, w_seq=None):
+    """Reverse update + the next step's single / time-embedding inputs in one launch (prd_hip.h: prd_step_boundary).
+    ``seq_h`` (+ ``w_seq``): the sequence head's hidden units -- its last layer then runs inside this launch and ``seq_pred`` is
+    written instead of read."""
     b, N, _ = z.shape
     P, TD = w_beta.shape
+    hp, ldh = row_block(seq_h) if seq_h is not None else (None, 0)
     check(lib().prd_step_boundary(dptr(z), dptr(seq_t), dptr(t, torch.int64), dptr(eps_raw), dptr(seq_pred), dptr(noise), dptr(mask),
                                   dptr(coef), dptr(single_next), dptr(static_single), dptr(residue_mask), dptr(w_rt),
                                   dptr(ebeta_next), dptr(freqs), dptr(w_beta), dptr(sync, torch.int32), b, N, seq_pred.shape[-1],
-                                  num_steps, static_single.shape[-1], P, TD, stream()), "prd_step_boundary")
+                                  num_steps, static_single.shape[-1], P, TD, hp, ldh, dptr(w_seq),
+                                  (seq_h.shape[-1] if seq_h is not None else 0), stream()), "prd_step_boundary")
 
 
 def tri_attn_stats_floats(b: int, N: int, P: int, H: int = 4) -> int:

@@ -84,7 +84,8 @@ int main(void) {
     /* entries added in round 2: null / unsupported arguments are refused before any HIP call */
     EXPECT(prd_atom_embed(0, ibuf, p, p, (const int*)ibuf, 9, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_single_init(0, p, p, p, p, 8, 64, 21, s), PRD_ERR_ARG);
-    EXPECT(prd_step_boundary(0, p, ibuf, p, p, p, p, p, p, p, p, p, p, p, p, (int*)ibuf, 1, 8, 21, 10, 64, 64, 256, s), PRD_ERR_ARG);
+    EXPECT(prd_step_boundary(0, p, ibuf, p, p, p, p, p, p, p, p, p, p, p, p, (int*)ibuf, 1, 8, 21, 10, 64, 64, 256, 0, 0, 0, 0, s), PRD_ERR_ARG);
+    EXPECT(prd_step_boundary(p, p, ibuf, p, p, p, p, p, p, p, p, p, p, p, p, (int*)ibuf, 1, 8, 21, 10, 64, 64, 256, p, 62, p, 64, s), PRD_ERR_ALIGN);   /* hidden rows closer than their width */
     EXPECT(prd_pair_transition(0, p, p, p, p, p, 1, 1, 8, 64, 0, A1, s), PRD_ERR_ARG);
     EXPECT(prd_pair_transition(p, p, p, p, p, p, 1, 1, 8, 48, 0, A0, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_out(0, p, p, p, p, 1, 1, 8, 64, 0, A1, s), PRD_ERR_ARG);
