@@ -511,7 +511,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
 //     the L2-miss latency once per chunk.
 // Here eight lanes read one 128-byte line of a row (4x fewer tag accesses), a group of four waves keeps D chunks of 64 k in
 // flight in registers (16 KB each), splits fp16 hi | lo while staging a chunk into LDS in the MFMA operand layout (16-byte
-// columns XOR-swizzled by row), and -- for long K -- KG groups take every KG-th chunk with their own LDS stages.  The four
+// columns XOR-swizzled by row >> 1: a row is 128 bytes, two rows share a 256-byte bank line, so the sixteen rows of a ds_read_b128
+// group are (row & 1) x (slot ^ (row >> 1) & 7) = sixteen different 16-byte slots, and the extra ^ 4 (row & 1) puts the two rows of
+// a 16-lane ds_write_b64 group on different 64-byte halves of the 128-byte write bank line; round 3 XORed with row & 7, which put
+// rows r and r + 8 on one read slot: 45-50 % of the kernel's LDS cycles were conflicts), and -- for long K -- KG groups take every KG-th chunk with their own LDS stages.  The four
 // waves of a group each take one 16-wide k-step of a chunk; partial tiles are merged in LDS in a fixed order.  LayerNorm
 // statistics come from the ring itself (the whole row is in flight: K <= 64 D KG), so the first load is the only exposed one.
 template <int D, int KG, bool LN, bool BKN = false>      // BKN: B is given as [K][N] (row pitch ldb) -- staged transposed, 2 bytes at a time
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
             if (lo) *reinterpret_cast<float4*>(lo + (kg + KG * (CI)) * KCH + 32 * j) = a;               \
         }                                                                                                \
         unsigned h0, l0, h1, l1;                                                                         \
-        unsigned char* d_ = mysm + (ST) * STAGE + row * (KCH * 2) + (((4 * j + (seg >> 1)) ^ (row & 7)) << 4) + (seg & 1) * 8; \
+        unsigned char* d_ = mysm + (ST) * STAGE + row * (KCH * 2) + (((4 * j + (seg >> 1)) ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) << 4) + (seg & 1) * 8; \
         split2h(a.x, a.y, h0, l0); split2h(a.z, a.w, h1, l1);                                            \
         *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};                                                   \
         *reinterpret_cast<u32x2*>(d_ + PL) = u32x2{l0, l1};                                              \
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
                 const int nl = bn4 - n0 + e;                                                             \
                 if (nl >= 0 && nl < 32) {                                                                \
-                    unsigned char* t_ = mysm + (ST) * STAGE + 2 * PL + nl * (KCH * 2) + ((((kl >> 3)) ^ (nl & 7)) << 4) + (kl & 7) * 2; \
+                    unsigned char* t_ = mysm + (ST) * STAGE + 2 * PL + nl * (KCH * 2) + ((((kl >> 3)) ^ (((nl >> 1) & 7) ^ ((nl & 1) << 2))) << 4) + (kl & 7) * 2; \
                     *reinterpret_cast<unsigned short*>(t_) = (unsigned short)hh[e];                      \
                     *reinterpret_cast<unsigned short*>(t_ + PL) = (unsigned short)ll[e];                 \
                 }                                                                                        \
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_ring_kernel(PrdGemm g) {
 #define PRD_GR_MFMA(ST)                                                                                  \
     {                                                                                                    \
         const int col = 2 * wave + hi;                   /* wave w takes k-step w of the chunk */        \
-        const unsigned char* a_ = mysm + (ST) * STAGE + r * (KCH * 2) + ((col ^ (r & 7)) << 4);         \
+        const unsigned char* a_ = mysm + (ST) * STAGE + r * (KCH * 2) + ((col ^ (((r >> 1) & 7) ^ ((r & 1) << 2))) << 4);         \
         const u32x4 ah = *reinterpret_cast<const u32x4*>(a_), al = *reinterpret_cast<const u32x4*>(a_ + PL); \
         const u32x4 bh = *reinterpret_cast<const u32x4*>(a_ + 2 * PL), bl = *reinterpret_cast<const u32x4*>(a_ + 3 * PL); \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bh), acc, 0, 0, 0); \
