@@ -254,6 +254,13 @@ int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const float* dAB,
 int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float* pair, const float* mask, const float* wq,
                           const float* wk, const float* wv, const float* wg, const float* bg, int ending,
                           int b, int N, int P, int H, int c, hipStream_t stream);
+/* The same gradients in split-16 arithmetic on the 16-bit matrix pipe (tri_attn_bwd_core_v2_kernel, csrc/prd_tri2.hip), for rows of
+ * up to 384 positions.  Takes, besides dog, the gated head outputs og [b,N,N,64] of the forward (prd_tri_attn_core: the softmax
+ * statistics are recomputed, do . o = dog . og is not).  prd_tri_attn_bwd_core_v2_supported: 1 when (N, P) is served. */
+int prd_tri_attn_bwd_core_v2_supported(int N, int P);
+int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
+                             const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, int ending,
+                             int b, int N, int P, int H, int c, hipStream_t stream);
 /* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x). */
 int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream);
 /* Weight gradient of a linear applied at every pair position (autograd of nn.Linear over [b,N,N,*] activations, e.g.

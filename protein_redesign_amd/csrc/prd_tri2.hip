@@ -1299,6 +1299,458 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Triangle attention BACKWARD core in split-16 arithmetic (the fp32-MFMA form is tri_attn_bwd_core_kernel, prd_bwd.hip; the
+// reference reaches this through autograd of modules.py:236-243 -> 185-225).  One persistent workgroup of 12 waves per CU; a
+// work item is one (pair row, head); wave w owns the 32-position block w of the row: it projects it, sweeps it as QUERIES
+// (pass A: d q) and as KEYS (pass B: d k, d v).  Given  dog = d(gated head output)  and the saved  og = gate * o  of the forward:
+//
+//   phase 1   LayerNorm + split of the block's rows, then four row GEMMs on the 32x32x16 fp16 MFMA:
+//               [K|Q] unswapped : lane (position, hi) gets its 8 K and 8 Q channels = the B operands of the logit products and,
+//                                 stored as fp16 hi | lo planes, their A operands (K rows now, Q rows after pass A)
+//               [V|G] unswapped : V rows likewise (A operand of dP = do V^T), and the gate of the position:
+//                                 do = dog * gate,  delta = sum_c dog_c og_c (= do . o),  d gate_pre = dog og (1 - gate)
+//               [K|Q] swapped   : lane (channel, hi) gets 16 positions of one channel = the position-major A operands
+//                                 [X_hi; X_lo] of the products that contract over positions (dq = dS^T K, dk = dS Q)
+//               [G|G] swapped   : the gate by channel, for do^T = (dog gate)^T, the A operand of dv = P^T do
+//   sweep 0   softmax statistics of the block's queries (logits only): lse_q
+//   pass A    per 32-key tile: S^T = K Q^T - lse, dP^T = V do^T - delta (both constants ride in the accumulator), p = 2^S,
+//             dS = p dP, split, dq^T += [K^T_hi; K^T_lo] dS  (two MFMAs per 16 keys give all four hi/lo products)
+//   pass B    Q rows / do rows replace K rows / V rows in LDS (from the registers they were left in); per 32-query tile:
+//             S, dP again with the lane's key as the B operand, p and dS split, dk^T += [Q^T; ..] dS, dv^T += [do^T; ..] p
+//
+// Scaling (all by powers of two, taken out at the stores): probabilities x 2^5; do of position q x 2^e_q with e_q from the
+// largest |do_q| (gradients are tiny and fp16 has 5 exponent bits); pass B folds 2^(E - e_q), E = min_q e_q, into the
+// probability exponent so that every dS, p of a key column carries the common factor 2^(5 + E).
+struct B2Lds { unsigned krow, vrow, kt, qt, dt, lse, mq, cq, delta, esc, kadd, flag, bias, red, total, plane; };
+
+__host__ __device__ inline B2Lds b2_layout(int P, int NP) {
+    B2Lds L;
+    unsigned off = 64u * (unsigned)P * 4u;              // weight image: rows K | Q | V | G, fp16 hi | lo planes
+    L.plane = (unsigned)NP * 16u;
+    L.krow = off; off += 4u * L.plane;                  // hi planes (lane half 0 | 1), lo planes; Q rows in pass B
+    L.vrow = off; off += 4u * L.plane;                  // V rows; do rows in pass B
+    L.kt = off; off += (unsigned)NP * 64u;              // [tile][16-key half][hi][m = plane * 16 + channel][8 fp16]
+    L.qt = off; off += (unsigned)NP * 64u;
+    L.dt = off; off += (unsigned)NP * 64u;
+    L.lse = off; off += (unsigned)NP * 4u;              // m + c of the query (accumulator preload), and the two terms apart:
+    L.mq = off; off += (unsigned)NP * 4u;               // a replaced logit is (fill - m) - c, exact where fill = m (fully masked row)
+    L.cq = off; off += (unsigned)NP * 4u;
+    L.delta = off; off += (unsigned)NP * 4u;
+    L.esc = off; off += (unsigned)NP * 4u;
+    L.kadd = off; off += (unsigned)NP * 4u;
+    L.flag = off; off += 64u;
+    L.bias = off; off += 64u;
+    L.red = off; off += 64u;
+    L.total = off;
+    return L;
+}
+
+constexpr float B2_PSHIFT = 5.0f;
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
+    float* __restrict__ dqkvg, const float* __restrict__ dog, const float* __restrict__ ogs, const float* __restrict__ pair,
+    const float* __restrict__ mask, const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const B2Lds L = b2_layout(P, NP);
+    u32x4* Wb = reinterpret_cast<u32x4*>(lds);
+    float* biasl = reinterpret_cast<float*>(lds + L.bias);
+    int* redl = reinterpret_cast<int*>(lds + L.red);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const int nqb = NP / 32;
+    const int rstride = gridDim.x / H;
+    int h, slot;
+    if ((rstride & 7) == 0) {                           // the H heads of one row on one XCD
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        h = idx % H;
+        slot = (idx / H) * 8 + xcd;
+    } else {
+        h = blockIdx.x % H;
+        slot = blockIdx.x / H;
+    }
+    const float sc = 0.25f * LOG2E_2;
+    stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
+    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
+    if (tid < 16) biasl[tid] = H2_WSCALE * NEG_LOG2E * bg[h * C + tid];
+    const int nrows = b * N;
+    const float inv16 = H2_INV_WSCALE;
+    const unsigned kl_rel = 2u * L.plane;
+    const bool active = wave < nqb;
+    const int blk = wave;
+    const unsigned krow_lane = L.krow + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
+    const unsigned vrow_lane = L.vrow + (unsigned)hi * L.plane + (unsigned)r * 16u;
+    const unsigned tlane = (unsigned)hi * 512u + (unsigned)r * 16u;                      // + region + 2048 t (+ 1024: second half)
+    f32x16 zero;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+
+    for (int bu = slot; bu < nrows; bu += rstride) {
+        const int bb = bu / N, u = bu - bb * N;
+        auto row_pos = [&](int v) -> long { return ending ? (long)((bb * N + v) * N + u) : (long)(bu * N + v); };
+        __syncthreads();                                // the previous item is done with the LDS (first pass: the weight image)
+        u32x4 kh4 = {0u, 0u, 0u, 0u}, kl4 = kh4, qh4 = kh4, ql4 = kh4, vh4 = kh4, vl4 = kh4, dh4 = kh4, dl4 = kh4;
+        float delta_s = 0.f;
+        int e_q = 127;
+        const int v = blk * 32 + r;
+        const bool valid = active && v < N;
+        // ================= phase 1 =================
+        if (active) {
+            int r1 = r, hi1 = hi;                       // opaque (see tri_attn_core_v2_kernel)
+            asm volatile("" : "+v"(r1), "+v"(hi1));
+            auto wop = [&](int wrow, int s_, u32x4& wh, u32x4& wl) {
+                const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi1);
+                wh = Wb[(size_t)wrow * (P / 8) + slot_];
+                wl = Wb[(size_t)(64 + wrow) * (P / 8) + slot_];
+            };
+            float x[KH];
+            load_row_cll<P>(pair + row_pos(valid ? v : 0) * P, hi1, valid, x);
+            const float mu = mask[bu];
+            const float mk = valid ? mask[bb * N + v] : 0.f;
+            // the lane's 8 channels {4hi+e, 8+4hi+e} of dog and og (issued early: consumed after the second GEMM)
+            float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, o0 = g0, o1 = g0;
+            if (valid) {
+                const float* dp_ = dog + row_pos(v) * HC + h * C + 4 * hi1;
+                const float* op_ = ogs + row_pos(v) * HC + h * C + 4 * hi1;
+                g0 = *reinterpret_cast<const float4*>(dp_);
+                g1 = *reinterpret_cast<const float4*>(dp_ + 8);
+                o0 = *reinterpret_cast<const float4*>(op_);
+                o1 = *reinterpret_cast<const float4*>(op_ + 8);
+            }
+            ln_cll_p<KH>(x);
+            u32x4 xs[2][P / 16];
+            split2h_rn_cll<KH>(x, xs);
+            {   // logit override of masked / padded keys + tile flag
+                const bool keep = valid && (mu * mk >= 0.5f);
+                if (hi1 == 0) reinterpret_cast<float*>(lds + L.kadd)[v] = keep ? 0.f : (v < N ? -32768.0f * LOG2E_2 : -INFINITY);
+                const bool any_override = __any(!keep);
+                if (lane == 0) reinterpret_cast<int*>(lds + L.flag)[blk] = any_override ? 1 : 0;
+            }
+            {   // [K|Q] unswapped
+                f32x16 acc = zero;
+#pragma unroll
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 wh, wl;
+                    wop(r1, s_, wh, wl);
+                    acc = mfma_h(wh, xs[0][s_], acc);
+                    acc = mfma_h(wh, xs[1][s_], acc);
+                    acc = mfma_h(wl, xs[0][s_], acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+                split8_rn(acc, 0, kh4, kl4);
+                split8_rn(acc, 8, qh4, ql4);
+                const unsigned po = L.krow + (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
+                *reinterpret_cast<u32x4*>(lds + po) = kh4;
+                *reinterpret_cast<u32x4*>(lds + po + kl_rel) = kl4;
+            }
+            float gate8[8];
+            {   // [V|G] unswapped
+                f32x16 acc = zero;
+                {
+                    const float4 b0 = *reinterpret_cast<const float4*>(biasl + 4 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 + 4 * hi1);
+                    acc[8] = b0.x; acc[9] = b0.y; acc[10] = b0.z; acc[11] = b0.w;
+                    acc[12] = b1.x; acc[13] = b1.y; acc[14] = b1.z; acc[15] = b1.w;
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 wh, wl;
+                    wop(32 + r1, s_, wh, wl);
+                    acc = mfma_h(wh, xs[0][s_], acc);
+                    acc = mfma_h(wh, xs[1][s_], acc);
+                    acc = mfma_h(wl, xs[0][s_], acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+                split8_rn(acc, 0, vh4, vl4);
+                const unsigned po = L.vrow + (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
+                *reinterpret_cast<u32x4*>(lds + po) = vh4;
+                *reinterpret_cast<u32x4*>(lds + po + kl_rel) = vl4;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gate8[e] = gate_from_scaled(acc[8 + e]);
+            }
+            {   // do, delta, d(gate pre-activation), the position's exponent
+                const float dg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                float dov[8], dgp[8], dsum = 0.f, mx = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = dg[e] * ov[e];
+                    dsum += t;
+                    dgp[e] = t * (1.0f - gate8[e]);
+                    dov[e] = dg[e] * gate8[e];
+                    mx = __builtin_fmaxf(mx, __builtin_fabsf(dov[e]));
+                }
+                dsum = xhalf_add(dsum);
+                mx = xhalf_max(mx);
+                e_q = (mx > 0.f && mx < 3.0e38f) ? -__builtin_amdgcn_frexp_expf(mx) : 127;
+                if (e_q > 126) e_q = (mx > 0.f && mx < 3.0e38f) ? 126 : 127;
+                if (valid) {
+                    float* gp = dqkvg + row_pos(v) * (4 * HC) + 3 * HC + h * C + 4 * hi1;
+                    *reinterpret_cast<float4*>(gp) = make_float4(dgp[0], dgp[1], dgp[2], dgp[3]);
+                    *reinterpret_cast<float4*>(gp + 8) = make_float4(dgp[4], dgp[5], dgp[6], dgp[7]);
+                }
+                const int es = e_q == 127 ? 0 : e_q;
+                delta_s = __builtin_ldexpf(dsum, es);
+                f32x16 d16 = zero;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d16[e] = __builtin_ldexpf(dov[e], es);
+                split8_rn(d16, 0, dh4, dl4);
+                if (hi1 == 0) reinterpret_cast<int*>(lds + L.esc)[v] = es;
+            }
+            {   // [K|Q] swapped: lane n < 16 = K channel n, n >= 16 = Q channel n - 16, registers = positions
+                f32x16 acc = zero;
+#pragma unroll
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 wh, wl;
+                    wop(r1, s_, wh, wl);
+                    acc = mfma_h(xs[0][s_], wh, acc);
+                    acc = mfma_h(xs[1][s_], wh, acc);
+                    acc = mfma_h(xs[0][s_], wl, acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+                u32x4 h0, l0, h1, l1;
+                split8_rn(acc, 0, h0, l0);
+                split8_rn(acc, 8, h1, l1);
+                const unsigned base = (r1 < 16 ? L.kt : L.qt) + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)(r1 & 15) * 16u;
+                *reinterpret_cast<u32x4*>(lds + base) = h0;
+                *reinterpret_cast<u32x4*>(lds + base + 1024u) = h1;
+                *reinterpret_cast<u32x4*>(lds + base + 256u) = l0;
+                *reinterpret_cast<u32x4*>(lds + base + 256u + 1024u) = l1;
+            }
+            {   // [G|G] swapped -> do^T: lanes 0-15 keep the hi parts, lanes 16-31 the lo parts of the same 16 channels
+                const int ch = r1 & 15;
+                float dgt[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int pv = blk * 32 + 8 * (j >> 2) + 4 * hi1 + (j & 3);
+                    dgt[j] = pv < N ? dog[row_pos(pv) * HC + h * C + ch] : 0.f;
+                }
+                f32x16 acc;
+                {
+                    const float bch = biasl[ch];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = bch;
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 wh, wl;
+                    wop(48 + ch, s_, wh, wl);
+                    acc = mfma_h(xs[0][s_], wh, acc);
+                    acc = mfma_h(xs[1][s_], wh, acc);
+                    acc = mfma_h(xs[0][s_], wl, acc);
+                }
+                __builtin_amdgcn_wave_barrier();        // esc[] of this block was written by this wave (LDS is in order per wave)
+                asm volatile("" ::: "memory");
+                const int* escl = reinterpret_cast<const int*>(lds + L.esc) + blk * 32 + 4 * hi1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int4 e4 = *reinterpret_cast<const int4*>(escl + 8 * g);
+                    const int ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[4 * g + e] = __builtin_ldexpf(dgt[4 * g + e] * gate_from_scaled(acc[4 * g + e] * inv16), ev[e]);
+                }
+                u32x4 h0, l0, h1, l1;
+                split8_rn(acc, 0, h0, l0);
+                split8_rn(acc, 8, h1, l1);
+                const bool lo_lane = r1 >= 16;
+                u32x4 s0, s1;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? l0[w] : h0[w]; s1[w] = lo_lane ? l1[w] : h1[w]; }
+                const unsigned base = L.dt + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
+                *reinterpret_cast<u32x4*>(lds + base) = s0;
+                *reinterpret_cast<u32x4*>(lds + base + 1024u) = s1;
+            }
+        }
+        {   // E = min over the positions of the row
+            int em = e_q;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int o_ = __shfl_xor(em, off);
+                em = o_ < em ? o_ : em;
+            }
+            if (lane == 0) redl[wave] = active ? em : 127;
+        }
+        __syncthreads();
+        int E = 127;
+        for (int w = 0; w < nqb; ++w) { const int t = redl[w]; E = t < E ? t : E; }
+        if (E == 127) E = 0;                            // no gradient anywhere in the row: every product below is zero
+        const int es_q = e_q == 127 ? 0 : e_q;
+        unsigned fmask;
+        {
+            const int f = lane < nqb ? reinterpret_cast<const int*>(lds + L.flag)[lane] : 0;
+            fmask = (unsigned)__ballot(f != 0);
+        }
+        if (active) {
+            // ================= sweep 0: lse of the block's queries =================
+            float m_run = -1e30f, l_run = 0.f;
+            for (int t = 0; t < nqb; ++t) {
+                const KOp k = load_k(lds, krow_lane + 512u * t, kl_rel);
+                f32x16 s = qk_tile(k, qh4, ql4, zero);
+                if ((fmask >> t) & 1) mask_tile_at(lds, L.kadd, t, hi, 0.f, s);
+                const float m_new = max2f(m_run, xhalf_max(max16_mfma(s)));
+                l_run *= __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    t0 += __builtin_amdgcn_exp2f(s[j] - m_new);
+                    t1 += __builtin_amdgcn_exp2f(s[j + 1] - m_new);
+                }
+                l_run += t0 + t1;
+            }
+            const float cA = __builtin_amdgcn_logf(xhalf_add(l_run)) - B2_PSHIFT;
+            // ================= pass A: dq of the block's queries =================
+            const float mrefA = m_run + cA;
+            f32x16 nl, nd, o;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { nl[e] = -mrefA; nd[e] = -delta_s; o[e] = 0.f; }
+            for (int t = 0; t < nqb; ++t) {
+                const KOp k = load_k(lds, krow_lane + 512u * t, kl_rel);
+                const KOp vv = load_k(lds, vrow_lane + 512u * t, kl_rel);
+                f32x16 s = qk_tile(k, qh4, ql4, nl);
+                const f32x16 dp = qk_tile(vv, dh4, dl4, nd);
+                const u32x4 va0 = *reinterpret_cast<const u32x4*>(lds + L.kt + tlane + 2048u * t);
+                const u32x4 va1 = *reinterpret_cast<const u32x4*>(lds + L.kt + tlane + 2048u * t + 1024u);
+                const bool fl = (fmask >> t) & 1;
+                if (fl) {                               // replaced logits: (fill - m) - c, exact where fill = m
+                    const float* kadd = reinterpret_cast<const float*>(lds + L.kadd) + 32 * t + 4 * hi;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 ka = *reinterpret_cast<const float4*>(kadd + 8 * g);
+                        s[4 * g + 0] = ka.x == 0.f ? s[4 * g + 0] : (ka.x - m_run) - cA;
+                        s[4 * g + 1] = ka.y == 0.f ? s[4 * g + 1] : (ka.y - m_run) - cA;
+                        s[4 * g + 2] = ka.z == 0.f ? s[4 * g + 2] : (ka.z - m_run) - cA;
+                        s[4 * g + 3] = ka.w == 0.f ? s[4 * g + 3] : (ka.w - m_run) - cA;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s[j] = __builtin_amdgcn_exp2f(s[j]) * dp[j];
+                if (fl) {                               // no gradient through a replaced logit (masked or padded key)
+                    const float* kadd = reinterpret_cast<const float*>(lds + L.kadd) + 32 * t + 4 * hi;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 ka = *reinterpret_cast<const float4*>(kadd + 8 * g);
+                        s[4 * g + 0] = ka.x == 0.f ? s[4 * g + 0] : 0.f;
+                        s[4 * g + 1] = ka.y == 0.f ? s[4 * g + 1] : 0.f;
+                        s[4 * g + 2] = ka.z == 0.f ? s[4 * g + 2] : 0.f;
+                        s[4 * g + 3] = ka.w == 0.f ? s[4 * g + 3] : 0.f;
+                    }
+                }
+                u32x4 h0, l0, h1, l1;
+                split8_rn(s, 0, h0, l0);
+                split8_rn(s, 8, h1, l1);
+                o = mfma_h(va0, h0, o);
+                o = mfma_h(va1, h1, o);
+                o = mfma_h(va0, l0, o);
+                o = mfma_h(va1, l1, o);
+            }
+            if (valid) {
+                const float f = __builtin_ldexpf(0.25f, -es_q - (int)B2_PSHIFT);
+                float* dst = dqkvg + row_pos(v) * (4 * HC) + h * C + 4 * hi;
+                *reinterpret_cast<float4*>(dst) = make_float4(f * (o[0] + o[8]), f * (o[1] + o[9]), f * (o[2] + o[10]), f * (o[3] + o[11]));
+                *reinterpret_cast<float4*>(dst + 8) = make_float4(f * (o[4] + o[12]), f * (o[5] + o[13]), f * (o[6] + o[14]), f * (o[7] + o[15]));
+            }
+            if (hi == 0) {
+                const float cB = cA - (e_q == 127 ? 0.f : (float)(E - es_q));     // (no gradient at q: do' = 0 whatever the factor)
+                reinterpret_cast<float*>(lds + L.lse)[v] = m_run + cB;
+                reinterpret_cast<float*>(lds + L.mq)[v] = m_run;
+                reinterpret_cast<float*>(lds + L.cq)[v] = cB;
+                reinterpret_cast<float*>(lds + L.delta)[v] = delta_s;
+            }
+        }
+        __syncthreads();                                // K rows, V rows are free
+        if (active) {
+            const unsigned po = L.krow + (unsigned)hi * L.plane + (unsigned)(blk * 32 + r) * 16u;
+            *reinterpret_cast<u32x4*>(lds + po) = qh4;
+            *reinterpret_cast<u32x4*>(lds + po + kl_rel) = ql4;
+            const unsigned pv = L.vrow + (unsigned)hi * L.plane + (unsigned)(blk * 32 + r) * 16u;
+            *reinterpret_cast<u32x4*>(lds + pv) = dh4;
+            *reinterpret_cast<u32x4*>(lds + pv + kl_rel) = dl4;
+        }
+        __syncthreads();
+        if (active) {
+            // ================= pass B: dk, dv of the block's keys =================
+            const float ka = reinterpret_cast<const float*>(lds + L.kadd)[v];
+            const bool kover = ka != 0.f;
+            f32x16 ok, ov;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ok[e] = 0.f; ov[e] = 0.f; }
+            for (int t = 0; t < nqb; ++t) {
+                const KOp qa = load_k(lds, krow_lane + 512u * t, kl_rel);
+                const KOp da = load_k(lds, vrow_lane + 512u * t, kl_rel);
+                f32x16 s, dp;                           // accumulators start at -lse_q, -delta_q of the register's query
+                const float* lp = reinterpret_cast<const float*>(lds + L.lse) + 32 * t + 4 * hi;
+                {
+                    const float* dp_ = reinterpret_cast<const float*>(lds + L.delta) + 32 * t + 4 * hi;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 a = *reinterpret_cast<const float4*>(lp + 8 * g), d = *reinterpret_cast<const float4*>(dp_ + 8 * g);
+                        s[4 * g] = -a.x; s[4 * g + 1] = -a.y; s[4 * g + 2] = -a.z; s[4 * g + 3] = -a.w;
+                        dp[4 * g] = -d.x; dp[4 * g + 1] = -d.y; dp[4 * g + 2] = -d.z; dp[4 * g + 3] = -d.w;
+                    }
+                }
+                s = qk_tile(qa, kh4, kl4, s);
+                dp = qk_tile(da, vh4, vl4, dp);
+                if (kover) {                            // the lane's key is masked / padded: its logit is a constant
+                    const float* mp = reinterpret_cast<const float*>(lds + L.mq) + 32 * t + 4 * hi;
+                    const float* cp = reinterpret_cast<const float*>(lds + L.cq) + 32 * t + 4 * hi;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 a = *reinterpret_cast<const float4*>(mp + 8 * g), c4 = *reinterpret_cast<const float4*>(cp + 8 * g);
+                        s[4 * g] = (ka - a.x) - c4.x; s[4 * g + 1] = (ka - a.y) - c4.y;
+                        s[4 * g + 2] = (ka - a.z) - c4.z; s[4 * g + 3] = (ka - a.w) - c4.w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    s[j] = __builtin_amdgcn_exp2f(s[j]);
+                    dp[j] = kover ? 0.f : s[j] * dp[j];
+                }
+                {
+                    const u32x4 va0 = *reinterpret_cast<const u32x4*>(lds + L.dt + tlane + 2048u * t);
+                    const u32x4 va1 = *reinterpret_cast<const u32x4*>(lds + L.dt + tlane + 2048u * t + 1024u);
+                    u32x4 h0, l0, h1, l1;
+                    split8_rn(s, 0, h0, l0);
+                    split8_rn(s, 8, h1, l1);
+                    ov = mfma_h(va0, h0, ov);
+                    ov = mfma_h(va1, h1, ov);
+                    ov = mfma_h(va0, l0, ov);
+                    ov = mfma_h(va1, l1, ov);
+                }
+                {
+                    const u32x4 va0 = *reinterpret_cast<const u32x4*>(lds + L.qt + tlane + 2048u * t);
+                    const u32x4 va1 = *reinterpret_cast<const u32x4*>(lds + L.qt + tlane + 2048u * t + 1024u);
+                    u32x4 h0, l0, h1, l1;
+                    split8_rn(dp, 0, h0, l0);
+                    split8_rn(dp, 8, h1, l1);
+                    ok = mfma_h(va0, h0, ok);
+                    ok = mfma_h(va1, h1, ok);
+                    ok = mfma_h(va0, l0, ok);
+                    ok = mfma_h(va1, l1, ok);
+                }
+            }
+            if (valid) {
+                const float fv = __builtin_ldexpf(1.0f, -E - (int)B2_PSHIFT);
+                const float fk = fv * 0.6931471805599453f;          // Q rows carry log2(e)
+                float* dst = dqkvg + row_pos(v) * (4 * HC) + HC + h * C + 4 * hi;
+                *reinterpret_cast<float4*>(dst) = make_float4(fk * (ok[0] + ok[8]), fk * (ok[1] + ok[9]), fk * (ok[2] + ok[10]), fk * (ok[3] + ok[11]));
+                *reinterpret_cast<float4*>(dst + 8) = make_float4(fk * (ok[4] + ok[12]), fk * (ok[5] + ok[13]), fk * (ok[6] + ok[14]), fk * (ok[7] + ok[15]));
+                *reinterpret_cast<float4*>(dst + HC) = make_float4(fv * (ov[0] + ov[8]), fv * (ov[1] + ov[9]), fv * (ov[2] + ov[10]), fv * (ov[3] + ov[11]));
+                *reinterpret_cast<float4*>(dst + HC + 8) = make_float4(fv * (ov[4] + ov[12]), fv * (ov[5] + ov[13]), fv * (ov[6] + ov[14]), fv * (ov[7] + ov[15]));
+            }
+        }
+    }
+}
+
 size_t v2l_lds_bytes(int N, int P, bool* share_out = nullptr) {
     const int NP = prd_round_up(N, 32), nqb = NP / 32, rem = nqb % 12, G = rem ? 12 / rem : 0;
     const size_t base = (size_t)64 * P * 4 + (size_t)NP * (2 * 32 + 64 + 4) + 128 + 64;
@@ -1405,6 +1857,39 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
         PRD2_SET_LDS((tri_attn_core_v2_kernel<32, NWV>));
         hipLaunchKernelGGL((tri_attn_core_v2_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
                            NP, H, ending, flags);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- backward core, split-16 arithmetic (tri_attn_bwd_core_v2_kernel) ----
+extern "C" int prd_tri_attn_bwd_core_v2_supported(int N, int P) {
+    if (N <= 0 || (P != 32 && P != 64)) return 0;
+    const int NP = prd_round_up(N, 32);
+    return (NP / 32 <= 12 && b2_layout(P, NP).total <= 160u * 1024u) ? 1 : 0;
+}
+
+extern "C" int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
+                                        const float* wq, const float* wk, const float* wv, const float* wg, const float* bg,
+                                        int ending, int b, int N, int P, int H, int c, hipStream_t stream) {
+    if (!dqkvg || !dog || !og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
+    if (!prd_tri_attn_bwd_core_v2_supported(N, P)) return PRD_ERR_UNSUPPORTED;
+    if ((long)b * N * N > 0x7fffffffL / 4) return PRD_ERR_UNSUPPORTED;      // 32-bit position arithmetic in the kernel
+    const int NP = prd_round_up(N, 32);
+    const size_t lds = b2_layout(P, NP).total;
+    const long rows_total = (long)b * N, cap = 256 / H;
+    long per_head = cap < rows_total ? cap : rows_total;
+    if (per_head >= 8) per_head = per_head / 8 * 8;     // the heads of a row on one XCD
+    const int grid = (int)(per_head * H);
+    constexpr int NWV = 12;
+    if (P == 64) {
+        PRD2_SET_LDS((tri_attn_bwd_core_v2_kernel<64, NWV>));
+        hipLaunchKernelGGL((tri_attn_bwd_core_v2_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, dqkvg, dog, og, pair, mask, wq, wk, wv,
+                           wg, bg, b, N, NP, H, ending);
+    } else {
+        PRD2_SET_LDS((tri_attn_bwd_core_v2_kernel<32, NWV>));
+        hipLaunchKernelGGL((tri_attn_bwd_core_v2_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, dqkvg, dog, og, pair, mask, wq, wk, wv,
+                           wg, bg, b, N, NP, H, ending);
     }
     return (int)hipGetLastError();
 }

@@ -7,6 +7,7 @@ and enqueues HIP kernels on the current torch stream.  Weight tensors are passed
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -397,6 +398,9 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
     return dpair, grads
 
 
+TRI_ATTN_BWD_V2 = os.environ.get("PRD_TRI_ATTN_BWD_V2", "1") != "0"      # 0: the fp32-MFMA backward core in split-16 mode too (A/B measurements)
+
+
 def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=None):
     """Gradients of the TriangleAttention update (ops.tri_attn with residual=False) with respect to ``pair`` and its seven weight
     tensors on the hand-written backward (csrc/prd_bwd.hip): out-projection backward (row GEMM) -> attention core backward per
@@ -411,8 +415,12 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
         og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending)
     dog = linear(dy, wo.t().contiguous())                                                         # d og = dy W_o
     dqkvg = torch.empty(b, N, N, 4, HC, device=dev, dtype=F32)
-    check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
-                                      int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core")
+    if lib().prd_get_gemm_mode() == 1 and TRI_ATTN_BWD_V2 and lib().prd_tri_attn_bwd_core_v2_supported(N, P) == 1:
+        check(lib().prd_tri_attn_bwd_core_v2(dptr(dqkvg), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg),
+                                             dptr(bg), int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core_v2")
+    else:
+        check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
+                                          int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core")
     wcat_t = torch.cat([wq, wk, wv, wg], dim=0).t().contiguous()                                  # [P, 4 HC]
     dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat_t)                                             # gradient of LN(pair)
     dpair = torch.empty_like(pair)

@@ -164,6 +164,45 @@ def test_triangle_attention_backward_kernels(mode, P, b, N, gemm_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ending", [False, True])
+@pytest.mark.parametrize("P,b,N,gscale", [(64, 2, 45, 1.0), (32, 1, 100, 1e-6), (64, 1, 320, 1e-4), (64, 1, 384, 1e3), (64, 2, 33, 0.0)])
+def test_triangle_attention_backward_core_split16_vs_fp32(P, b, N, gscale, ending):
+    """prd_tri_attn_bwd_core_v2 (16-bit matrix pipe, split operands, power-of-two scaling of the incoming gradient) against
+    prd_tri_attn_bwd_core (fp32 MFMA) on the same inputs: d(W_q x) | d(W_k x) | d(W_v x) | d(gate), for gradients of very
+    different magnitude (the scaling is per position), positions that receive no gradient at all, masked keys, a fully masked row."""
+    from protein_redesign_amd import ops
+    from protein_redesign_amd._lib import check, dptr, lib, stream
+    g = torch.Generator().manual_seed(7 * N + P)
+    H, c = 4, 16
+    pair = torch.randn(b, N, N, P, generator=g).to(DEV)
+    mask = torch.ones(b, N)
+    mask[b - 1, N - 7:] = 0
+    mask[0, 3] = 0
+    mask = mask.to(DEV)
+    wq, wk, wv, wg = [(torch.randn(64, P, generator=g) / math.sqrt(P)).to(DEV) for _ in range(4)]
+    bg = (torch.randn(64, generator=g) / 4).to(DEV)
+    dog = torch.randn(b, N, N, 64, generator=g) * gscale
+    dog *= torch.logspace(-4, 0, N).view(1, 1, N, 1)            # four decades between the positions of a row
+    dog[:, :, 5] = 0                                            # a position without gradient
+    dog = dog.to(DEV)
+    og = ops.tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending)
+    a = torch.full((b, N, N, 4, 64), float("nan"), device=DEV)
+    r = torch.full((b, N, N, 4, 64), float("nan"), device=DEV)
+    assert lib().prd_tri_attn_bwd_core_v2_supported(N, P) == 1
+    check(lib().prd_tri_attn_bwd_core_v2(dptr(a), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
+                                         int(ending), b, N, P, H, c, stream()), "v2")
+    check(lib().prd_tri_attn_bwd_core(dptr(r), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
+                                      int(ending), b, N, P, H, c, stream()), "fp32")
+    assert torch.isfinite(a).all()
+    for k, name in enumerate(["dq", "dk", "dv", "dgate"]):
+        x, y = a[..., k, :].double(), r[..., k, :].double()
+        if gscale == 0.0:
+            assert float(x.abs().max()) == 0.0 and float(y.abs().max()) == 0.0, name
+        else:
+            assert float((x - y).norm() / y.norm()) < 3e-6, (name, float((x - y).norm() / y.norm()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows,O,I", [(40 * 40 * 2, 64, 64), (102400, 256, 64), (20000, 64, 256), (9001, 128, 128), (8192, 256, 256),
                                       (102400, 4, 64), (20001, 1, 64), (9000, 12, 128)])
 def test_linear_weight_gradient_kernel(rows, O, I):

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Times the triangle-attention backward cores (fp32 MFMA vs split-16) on one shape: tools/bwd_core_bench.py [b N]."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from protein_redesign_amd import ops
+from protein_redesign_amd._lib import check, dptr, lib, stream
+
+b, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2, 320)
+P, H, c = 64, 4, 16
+g = torch.Generator().manual_seed(0)
+pair = torch.randn(b, N, N, P, generator=g).cuda()
+mask = torch.ones(b, N).cuda()
+wq, wk, wv, wg = [(torch.randn(64, P, generator=g) / math.sqrt(P)).cuda() for _ in range(4)]
+bg = torch.zeros(64).cuda()
+dog = (torch.randn(b, N, N, 64, generator=g) * 1e-3).cuda()
+og = ops.tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=False)
+out = torch.empty(b, N, N, 4, 64, device="cuda")
+
+
+def v2():
+    check(lib().prd_tri_attn_bwd_core_v2(dptr(out), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
+                                         0, b, N, P, H, c, stream()), "v2")
+
+
+def v1():
+    check(lib().prd_tri_attn_bwd_core(dptr(out), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
+                                      0, b, N, P, H, c, stream()), "v1")
+
+
+for name, fn in (("fp32", v1), ("split16", v2)):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{name}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us  (b={b}, N={N})")
