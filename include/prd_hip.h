@@ -255,12 +255,13 @@ int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float* pair, con
                           const float* wk, const float* wv, const float* wg, const float* bg, int ending,
                           int b, int N, int P, int H, int c, hipStream_t stream);
 /* The same gradients in split-16 arithmetic on the 16-bit matrix pipe (tri_attn_bwd_core_v2_kernel, csrc/prd_tri2.hip), for rows of
- * up to 384 positions.  Takes, besides dog, the gated head outputs og [b,N,N,64] of the forward (prd_tri_attn_core: the softmax
- * statistics are recomputed, do . o = dog . og is not).  prd_tri_attn_bwd_core_v2_supported: 1 when (N, P) is served. */
+ * up to 384 positions.  Takes, besides dog, the gated head outputs og [b,N,N,64] of the forward (do . o = dog . og is not
+ * recomputed) and, optionally, the softmax statistics lse [b*N,H,N,2] that prd_tri_attn_core_v2_lse wrote in the forward
+ * (null: recomputed by one more sweep over the logits).  prd_tri_attn_bwd_core_v2_supported: 1 when (N, P) is served. */
 int prd_tri_attn_bwd_core_v2_supported(int N, int P);
 int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
-                             const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, int ending,
-                             int b, int N, int P, int H, int c, hipStream_t stream);
+                             const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, const float* lse,
+                             int ending, int b, int N, int P, int H, int c, hipStream_t stream);
 /* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x). */
 int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream);
 /* Weight gradient of a linear applied at every pair position (autograd of nn.Linear over [b,N,N,*] activations, e.g.
@@ -320,6 +321,11 @@ int prd_tri_attn_v2_form(int N, int P, int tune);
 int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
                          const float* wv, const float* wg, const float* bg, int ending,
                          int b, int N, int P, int H, int c, int tune, hipStream_t stream);
+/* prd_tri_attn_core_v2 that also writes, for rows of up to 384 positions, the softmax statistics of every query:
+ * lse [b*N rows][H][N][2] = (m, log2 l) with l = sum over the keys of 2^(logit log2(e) - m); lse may be null. */
+int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair, const float* mask, const float* wq, const float* wk,
+                             const float* wv, const float* wg, const float* bg, int ending,
+                             int b, int N, int P, int H, int c, int tune, hipStream_t stream);
 /* Triangle attention core whose input row is `pair + og_in W_o^T + b_o`: the residual update of the PREVIOUS triangle attention
  * (its output projection, modules.py:339-340) is applied while the row is loaded, and written to `pair_out` -- which must not
  * alias `pair` -- by the workgroups of head 0, instead of a separate prd_tri_attn_out launch.  gemm mode 1, short rows only

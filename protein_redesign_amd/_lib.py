@@ -71,7 +71,7 @@ SIGNATURES = {
     "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 5 + [vp],
     "prd_tri_attn_bwd_core": [vp] * 9 + [ci] * 6 + [vp],
     "prd_tri_attn_bwd_core_v2_supported": [ci, ci],
-    "prd_tri_attn_bwd_core_v2": [vp] * 10 + [ci] * 6 + [vp],
+    "prd_tri_attn_bwd_core_v2": [vp] * 11 + [ci] * 6 + [vp],
     "prd_ln_rows_bwd": [vp, vp, vp, cll, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
     "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],
@@ -87,6 +87,7 @@ SIGNATURES = {
     "prd_step_boundary": [vp] * 16 + [ci] * 7 + [vp, ci, vp, ci] + [vp],
     "prd_tri_attn_core": [vp] * 8 + [ci] * 7 + [vp],
     "prd_tri_attn_core_v2": [vp] * 8 + [ci] * 7 + [vp],
+    "prd_tri_attn_core_v2_lse": [vp] * 9 + [ci] * 7 + [vp],
     "prd_tri_attn_v2_form": [ci, ci, ci],
     "prd_tri_attn_core_chunked": [vp] * 8 + [ci] * 6 + [vp, cz, vp],
     "prd_tri_attn_stats_bytes": [ci] * 5,
@@ -105,7 +106,7 @@ _ARITH_BEFORE_STREAM = ("prd_coord_head", "prd_pair_head", "prd_pair_init", "prd
 _ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes",
                "prd_gemm_slab_ok", "prd_pair_head_supported")
 # entry points without an arithmetic that still dispatch between kernel generations: the PRD_TUNE_* switch word alone
-_TUNE_BEFORE_STREAM = ("prd_tri_attn_core_v2",)
+_TUNE_BEFORE_STREAM = ("prd_tri_attn_core_v2", "prd_tri_attn_core_v2_lse")
 _TUNE_LAST = ("prd_tri_attn_v2_supported", "prd_tri_attn_v2_form")
 
 

@@ -276,7 +276,8 @@ template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
-    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags) {
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags,
+    float* __restrict__ lse_out) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     constexpr float VSCALE = H2_WSCALE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -533,10 +534,14 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
             work_rem -= T1 - T0;
         };
         // gate, normalise, store the 32 queries of block qb (l = the lane's part of the row sum)
-        auto finish = [&](int qb, const float (&o)[8], float l) {
+        auto finish = [&](int qb, const float (&o)[8], float l, float mref) {
             const float ltot = xhalf_add(l);
             const int v = 32 * qb + r;
             if (v < N) {
+                // log2-domain log-sum-exp of the query's logits, for the backward core (prd_tri_attn_bwd_core_v2)
+                // (two terms: a fully masked row has m = the fill value -32768 log2(e), whose sum with log2(l) is not exact)
+                if (lse_out && hi == 0)
+                    *reinterpret_cast<float2*>(lse_out + (((long)bu * H + h) * N + v) * 2) = make_float2(mref, __builtin_amdgcn_logf(ltot));
                 const float il = 1.0f / (VSCALE * ltot);
                 const float* gp = Gl + (size_t)(v * 2 + hi) * 8;
                 const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
         if (owner) {
             float o8[8], lsum, mref;
             if (own_t1 > 0) run_piece(wave, 0, own_t1, o8, lsum, mref);
-            if (!group_owner) finish(wave, o8, lsum);
+            if (!group_owner) finish(wave, o8, lsum, mref);
             else if (own_t1 > 0) put_partial((nhelp + 1) * gi, o8, lsum, mref);
         } else if (helper) {
             const int T0 = qtile(m4 + hj), T1 = qtile(m4 + hj + 1);
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
                 }
-                finish(wave, o, l);
+                finish(wave, o, l, M);
             }
         }
         PRD2_STAMP(5);
@@ -640,7 +645,8 @@ template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
-    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags) {
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags,
+    float* __restrict__ lse_out) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     constexpr float VSCALE = H2_WSCALE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -796,10 +802,12 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         }
     };
 
-    auto finish = [&](const RowIx& row, int qb, const float (&o)[8], float l, const float (&g)[8]) {
+    auto finish = [&](const RowIx& row, int qb, const float (&o)[8], float l, const float (&g)[8], float mref) {
         const float ltot = xhalf_add(l);
         const int v = 32 * qb + r;
         if (v < N) {
+            if (lse_out && hi == 0)
+                *reinterpret_cast<float2*>(lse_out + (((long)row.bu * H + h) * N + v) * 2) = make_float2(mref, __builtin_amdgcn_logf(ltot));
             const float il = 1.0f / (VSCALE * ltot);
             float* dst = og + row_pos(row, v) * HC + h * C + 4 * hi;
             *reinterpret_cast<float4*>(dst) = make_float4(g[0] * (o[0] * il), g[1] * (o[1] * il), g[2] * (o[2] * il), g[3] * (o[3] * il));
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         const float* gp = reinterpret_cast<const float*>(lds + L.gs + (unsigned)(gpar * m4 + gi) * 2048u) + (r * 2 + hi) * 8;
         const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
         const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        finish(row, wave, o, l, g);
+        finish(row, wave, o, l, g, M);
     };
 
     RowIx rcur = make_row(slot < nrows ? slot : 0), rprev = rcur;
@@ -922,7 +930,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         if (owner) {
             float o8[8], lsum = 0.f, mref = 0.f;
             if (own_t1 > 0) run_piece(qh4, ql4, 0, own_t1, o8, lsum, mref);
-            if (!group_owner) finish(rcur, wave, o8, lsum, gate);
+            if (!group_owner) finish(rcur, wave, o8, lsum, gate, mref);
             else if (own_t1 > 0) put_partial((nhelp + 1) * gi, o8, lsum, mref);
         } else if (helper) {
             const int T0 = qtile(m4 + hj), T1 = qtile(m4 + hj + 1);
@@ -1352,7 +1360,8 @@ template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
     float* __restrict__ dqkvg, const float* __restrict__ dog, const float* __restrict__ ogs, const float* __restrict__ pair,
     const float* __restrict__ mask, const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
-    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending) {
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending,
+    const float* __restrict__ lse_in) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const B2Lds L = b2_layout(P, NP);
@@ -1393,7 +1402,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 
     for (int bu = slot; bu < nrows; bu += rstride) {
         const int bb = bu / N, u = bu - bb * N;
-        auto row_pos = [&](int v) -> long { return ending ? (long)((bb * N + v) * N + u) : (long)(bu * N + v); };
+        const int pos0 = ending ? bb * N * N + u : bu * N, pstride = ending ? N : 1;       // positions of the row: pos0 + v * pstride
+        auto row_pos = [&](int v) -> long { return (long)(pos0 + v * pstride); };
         __syncthreads();                                // the previous item is done with the LDS (first pass: the weight image)
         u32x4 kh4 = {0u, 0u, 0u, 0u}, kl4 = kh4, qh4 = kh4, ql4 = kh4, vh4 = kh4, vl4 = kh4, dh4 = kh4, dl4 = kh4;
         float delta_s = 0.f;
@@ -1531,7 +1541,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int pv = blk * 32 + 8 * (j >> 2) + 4 * hi1 + (j & 3);
-                    dgt[j] = pv < N ? dog[row_pos(pv) * HC + h * C + ch] : 0.f;
+                    const float t = dog[row_pos(pv < N ? pv : N - 1) * HC + h * C + ch];       // unconditional loads, all in flight
+                    dgt[j] = pv < N ? t : 0.f;
                 }
                 f32x16 acc;
                 {
@@ -1590,8 +1601,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
             fmask = (unsigned)__ballot(f != 0);
         }
         if (active) {
-            // ================= sweep 0: lse of the block's queries =================
-            float m_run = -1e30f, l_run = 0.f;
+            // ================= sweep 0: lse of the block's queries (unless the forward kept it) =================
+            float m_run = -1e30f, l_run = 0.f, cA;
+            if (lse_in) {
+                const float2 ml = valid ? *reinterpret_cast<const float2*>(lse_in + (((long)bu * H + h) * N + v) * 2) : make_float2(0.f, 0.f);
+                m_run = ml.x;
+                cA = ml.y - B2_PSHIFT;
+            } else {
             for (int t = 0; t < nqb; ++t) {
                 const KOp k = load_k(lds, krow_lane + 512u * t, kl_rel);
                 f32x16 s = qk_tile(k, qh4, ql4, zero);
@@ -1607,7 +1623,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
                 }
                 l_run += t0 + t1;
             }
-            const float cA = __builtin_amdgcn_logf(xhalf_add(l_run)) - B2_PSHIFT;
+            cA = __builtin_amdgcn_logf(xhalf_add(l_run)) - B2_PSHIFT;
+            }
             // ================= pass A: dq of the block's queries =================
             const float mrefA = m_run + cA;
             f32x16 nl, nd, o;
@@ -1622,6 +1639,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
                 const u32x4 va1 = *reinterpret_cast<const u32x4*>(lds + L.kt + tlane + 2048u * t + 1024u);
                 const bool fl = (fmask >> t) & 1;
                 if (fl) {                               // replaced logits: (fill - m) - c, exact where fill = m
+                    asm volatile("" ::: "memory");      // (a real branch: flagged tiles are rare, the selects are not free)
                     const float* kadd = reinterpret_cast<const float*>(lds + L.kadd) + 32 * t + 4 * hi;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -1635,6 +1653,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 #pragma unroll
                 for (int j = 0; j < 16; ++j) s[j] = __builtin_amdgcn_exp2f(s[j]) * dp[j];
                 if (fl) {                               // no gradient through a replaced logit (masked or padded key)
+                    asm volatile("" ::: "memory");
                     const float* kadd = reinterpret_cast<const float*>(lds + L.kadd) + 32 * t + 4 * hi;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -1661,10 +1680,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
             }
             if (hi == 0) {
                 const float cB = cA - (e_q == 127 ? 0.f : (float)(E - es_q));     // (no gradient at q: do' = 0 whatever the factor)
-                reinterpret_cast<float*>(lds + L.lse)[v] = m_run + cB;
+                reinterpret_cast<float*>(lds + L.lse)[v] = -(m_run + cB);         // negated: they start the accumulators of pass B
                 reinterpret_cast<float*>(lds + L.mq)[v] = m_run;
                 reinterpret_cast<float*>(lds + L.cq)[v] = cB;
-                reinterpret_cast<float*>(lds + L.delta)[v] = delta_s;
+                reinterpret_cast<float*>(lds + L.delta)[v] = -delta_s;
             }
         }
         __syncthreads();                                // K rows, V rows are free
@@ -1694,13 +1713,14 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 a = *reinterpret_cast<const float4*>(lp + 8 * g), d = *reinterpret_cast<const float4*>(dp_ + 8 * g);
-                        s[4 * g] = -a.x; s[4 * g + 1] = -a.y; s[4 * g + 2] = -a.z; s[4 * g + 3] = -a.w;
-                        dp[4 * g] = -d.x; dp[4 * g + 1] = -d.y; dp[4 * g + 2] = -d.z; dp[4 * g + 3] = -d.w;
+                        s[4 * g] = a.x; s[4 * g + 1] = a.y; s[4 * g + 2] = a.z; s[4 * g + 3] = a.w;
+                        dp[4 * g] = d.x; dp[4 * g + 1] = d.y; dp[4 * g + 2] = d.z; dp[4 * g + 3] = d.w;
                     }
                 }
                 s = qk_tile(qa, kh4, kl4, s);
                 dp = qk_tile(da, vh4, vl4, dp);
                 if (kover) {                            // the lane's key is masked / padded: its logit is a constant
+                    asm volatile("" ::: "memory");
                     const float* mp = reinterpret_cast<const float*>(lds + L.mq) + 32 * t + 4 * hi;
                     const float* cp = reinterpret_cast<const float*>(lds + L.cq) + 32 * t + 4 * hi;
 #pragma unroll
@@ -1713,7 +1733,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     s[j] = __builtin_amdgcn_exp2f(s[j]);
-                    dp[j] = kover ? 0.f : s[j] * dp[j];
+                    dp[j] = s[j] * dp[j];
                 }
                 {
                     const u32x4 va0 = *reinterpret_cast<const u32x4*>(lds + L.dt + tlane + 2048u * t);
@@ -1740,7 +1760,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
             }
             if (valid) {
                 const float fv = __builtin_ldexpf(1.0f, -E - (int)B2_PSHIFT);
-                const float fk = fv * 0.6931471805599453f;          // Q rows carry log2(e)
+                const float fk = kover ? 0.f : fv * 0.6931471805599453f;      // Q rows carry log2(e); no gradient through a replaced logit
                 float* dst = dqkvg + row_pos(v) * (4 * HC) + HC + h * C + 4 * hi;
                 *reinterpret_cast<float4*>(dst) = make_float4(fk * (ok[0] + ok[8]), fk * (ok[1] + ok[9]), fk * (ok[2] + ok[10]), fk * (ok[3] + ok[11]));
                 *reinterpret_cast<float4*>(dst + 8) = make_float4(fk * (ok[4] + ok[12]), fk * (ok[5] + ok[13]), fk * (ok[6] + ok[14]), fk * (ok[7] + ok[15]));
@@ -1792,12 +1812,15 @@ extern "C" int prd_tri_attn_v2_form(int N, int P, int tune) {
     return (!PRD_TGET_TA2_NO_V3(tune) && v3_lds_bytes(N, P) <= 160 * 1024) ? 2 : 1;
 }
 
-extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
-                                    const float* wv, const float* wg, const float* bg, int ending,
-                                    int b, int N, int P, int H, int c, int tune, hipStream_t stream) {
+// lse (may be null; short rows only): [b * N rows][H][N][2] = (m, log2 l) of every query: reference and log2 of the sum of
+// 2^(logit - m) in the log2 domain, kept by the training forward for prd_tri_attn_bwd_core_v2
+extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair, const float* mask, const float* wq, const float* wk,
+                                        const float* wv, const float* wg, const float* bg, int ending,
+                                        int b, int N, int P, int H, int c, int tune, hipStream_t stream) {
     if (!og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0 || tune < 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     if (!prd_tri_attn_v2_supported(N, P, tune)) return PRD_ERR_UNSUPPORTED;
+    if (lse && N > V2_MAXN) return PRD_ERR_UNSUPPORTED;
     if ((long)b * N * N > 0x7fffffffL / 2) return PRD_ERR_UNSUPPORTED;      // 32-bit position arithmetic in the kernel
     const int NP = prd_round_up(N, 32);
     const bool long_rows = N > V2_MAXN;
@@ -1841,24 +1864,30 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
         if (P == 64) {
             PRD2_SET_LDS((tri_attn_core_v3_kernel<64, NWV>));
             hipLaunchKernelGGL((tri_attn_core_v3_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                               NP, H, ending, flags);
+                               NP, H, ending, flags, lse);
         } else {
             PRD2_SET_LDS((tri_attn_core_v3_kernel<32, NWV>));
             hipLaunchKernelGGL((tri_attn_core_v3_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                               NP, H, ending, flags);
+                               NP, H, ending, flags, lse);
         }
         return (int)hipGetLastError();
     }
     if (P == 64) {
         PRD2_SET_LDS((tri_attn_core_v2_kernel<64, NWV>));
         hipLaunchKernelGGL((tri_attn_core_v2_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                           NP, H, ending, flags);
+                           NP, H, ending, flags, lse);
     } else {
         PRD2_SET_LDS((tri_attn_core_v2_kernel<32, NWV>));
         hipLaunchKernelGGL((tri_attn_core_v2_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                           NP, H, ending, flags);
+                           NP, H, ending, flags, lse);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* mask, const float* wq, const float* wk,
+                                    const float* wv, const float* wg, const float* bg, int ending,
+                                    int b, int N, int P, int H, int c, int tune, hipStream_t stream) {
+    return prd_tri_attn_core_v2_lse(og, nullptr, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, tune, stream);
 }
 
 // ---- backward core, split-16 arithmetic (tri_attn_bwd_core_v2_kernel) ----
@@ -1870,7 +1899,7 @@ extern "C" int prd_tri_attn_bwd_core_v2_supported(int N, int P) {
 
 extern "C" int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
                                         const float* wq, const float* wk, const float* wv, const float* wg, const float* bg,
-                                        int ending, int b, int N, int P, int H, int c, hipStream_t stream) {
+                                        const float* lse, int ending, int b, int N, int P, int H, int c, hipStream_t stream) {
     if (!dqkvg || !dog || !og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     if (!prd_tri_attn_bwd_core_v2_supported(N, P)) return PRD_ERR_UNSUPPORTED;
@@ -1885,11 +1914,11 @@ extern "C" int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const fl
     if (P == 64) {
         PRD2_SET_LDS((tri_attn_bwd_core_v2_kernel<64, NWV>));
         hipLaunchKernelGGL((tri_attn_bwd_core_v2_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, dqkvg, dog, og, pair, mask, wq, wk, wv,
-                           wg, bg, b, N, NP, H, ending);
+                           wg, bg, b, N, NP, H, ending, lse);
     } else {
         PRD2_SET_LDS((tri_attn_bwd_core_v2_kernel<32, NWV>));
         hipLaunchKernelGGL((tri_attn_bwd_core_v2_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, dqkvg, dog, og, pair, mask, wq, wk, wv,
-                           wg, bg, b, N, NP, H, ending);
+                           wg, bg, b, N, NP, H, ending, lse);
     }
     return (int)hipGetLastError();
 }

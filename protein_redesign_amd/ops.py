@@ -401,7 +401,7 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
 TRI_ATTN_BWD_V2 = os.environ.get("PRD_TRI_ATTN_BWD_V2", "1") != "0"      # 0: the fp32-MFMA backward core in split-16 mode too (A/B measurements)
 
 
-def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=None):
+def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=None, lse=None):
     """Gradients of the TriangleAttention update (ops.tri_attn with residual=False) with respect to ``pair`` and its seven weight
     tensors on the hand-written backward (csrc/prd_bwd.hip): out-projection backward (row GEMM) -> attention core backward per
     (row, head) -> projections backward (row GEMM) -> LayerNorm backward.  Weight gradients: slab reductions over all N^2 rows
@@ -412,12 +412,14 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
     dev = pair.device
     dy = dy.contiguous()
     if og is None:                                                                              # forward recompute: gated head outputs
-        og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending)
+        lse = torch.empty(b * N, H, N, 2, device=dev, dtype=F32) if tri_attn_lse_supported(N, P) else None
+        og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending, lse=lse)
     dog = linear(dy, wo.t().contiguous())                                                         # d og = dy W_o
     dqkvg = torch.empty(b, N, N, 4, HC, device=dev, dtype=F32)
     if lib().prd_get_gemm_mode() == 1 and TRI_ATTN_BWD_V2 and lib().prd_tri_attn_bwd_core_v2_supported(N, P) == 1:
         check(lib().prd_tri_attn_bwd_core_v2(dptr(dqkvg), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg),
-                                             dptr(bg), int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core_v2")
+                                             dptr(bg), dptr(lse) if lse is not None else None, int(ending), b, N, P, H, c, stream()),
+              "prd_tri_attn_bwd_core_v2")
     else:
         check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
                                           int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core")
@@ -571,12 +573,26 @@ def tri_attn_stats_floats(b: int, N: int, P: int, H: int = 4) -> int:
     return lib().prd_tri_attn_stats_bytes(b, N, P, H) // 4
 
 
-def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None, stats=None) -> torch.Tensor:
+def tri_attn_lse_supported(N: int, P: int) -> bool:
+    """True when the forward core can keep the softmax statistics of its queries for prd_tri_attn_bwd_core_v2 (split-16 mode, rows
+    of up to 384 positions: the second-generation short-row kernels)."""
+    return (lib().prd_get_gemm_mode() == 1 and lib().prd_tri_attn_v2_form(N, P) in (1, 2)
+            and lib().prd_tri_attn_bwd_core_v2_supported(N, P) == 1 and TRI_ATTN_BWD_V2)
+
+
+def tri_attn_core(pair, mask, wts, H: int, c: int, *, ending: bool, og=None, stats=None, lse=None) -> torch.Tensor:
     """First launch of tri_attn alone: og[b,N,N,64]; wts = (q.w, k.w, v.w, gate.w, gate.b).  Rows beyond the LDS (N > 960) run
-    key-chunked and need ``stats`` (tri_attn_stats_floats; allocated here if not given)."""
+    key-chunked and need ``stats`` (tri_attn_stats_floats; allocated here if not given).  ``lse`` [b*N, H, N, 2] (only where
+    tri_attn_lse_supported): receives (m, log2 l) of every query, which the split-16 backward core then does not recompute."""
     b, N, _, P = pair.shape
     if og is None:
         og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
+    if lse is not None:
+        if not tri_attn_lse_supported(N, P) or lse.numel() != b * N * H * N * 2:
+            raise ValueError("tri_attn_core: lse is kept by the split-16 short-row kernels only, as [b*N, H, N, 2]")
+        check(lib().prd_tri_attn_core_v2_lse(dptr(og), dptr(lse), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
+                                             b, N, P, H, c, stream()), "prd_tri_attn_core_v2_lse")
+        return og
     nst = tri_attn_stats_floats(b, N, P, H)
     if nst:
         if stats is None:
@@ -603,6 +619,17 @@ def tri_attn_core_v2(pair, mask, wts, H: int, c: int, *, ending: bool, og=None) 
         og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
     check(lib().prd_tri_attn_core_v2(dptr(og), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
                                      b, N, P, H, c, stream()), "prd_tri_attn_core_v2")
+    return og
+
+
+def tri_attn_core_v2_lse(pair, mask, wts, H: int, c: int, *, ending: bool, lse, og=None) -> torch.Tensor:
+    """prd_tri_attn_core_v2_lse called directly (split-16 arithmetic whatever the gemm mode): og, and (m, log2 l) of every query
+    into ``lse`` [b*N, H, N, 2]."""
+    b, N, _, P = pair.shape
+    if og is None:
+        og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
+    check(lib().prd_tri_attn_core_v2_lse(dptr(og), dptr(lse), dptr(pair), dptr(mask), *[dptr(w) for w in wts], int(ending),
+                                         b, N, P, H, c, stream()), "prd_tri_attn_core_v2_lse")
     return og
 
 

@@ -197,22 +197,27 @@ class TriAttnFn(torch.autograd.Function):
         ctx.residual = residual
         with torch.no_grad():
             p, w = pair.detach().contiguous(), [x.detach() for x in wts]
-            og = ops.tri_attn_core(p, mask, w[:5], H, c, ending=ending)
+            # without per-block checkpointing the gated head outputs (64 floats per pair position) and the softmax statistics of
+            # the queries (2 floats per query and head) are kept for the backward instead of being recomputed by a second core launch
+            ctx.keep_og = not USE_CHECKPOINT
+            b, N, _, P = p.shape
+            lse = (torch.empty(b * N, H, N, 2, device=p.device, dtype=torch.float32)
+                   if ctx.keep_og and p.is_cuda and ops.tri_attn_lse_supported(N, P) else None)
+            og = ops.tri_attn_core(p, mask, w[:5], H, c, ending=ending, lse=lse)
             out = ops.tri_attn_out(p, og, w[5], w[6], residual=residual)
-        # without per-block checkpointing the gated head outputs (64 floats per pair position) are kept for the backward
-        # instead of being recomputed by a second core launch
-        ctx.keep_og = not USE_CHECKPOINT
-        ctx.save_for_backward(pair, mask, *wts, *([og] if ctx.keep_og else []))
+        ctx.has_lse = lse is not None
+        ctx.save_for_backward(pair, mask, *wts, *([og] if ctx.keep_og else []), *([lse] if ctx.has_lse else []))
         return out
 
     @staticmethod
     def backward(ctx, dy):
         saved = list(ctx.saved_tensors)
+        lse = saved.pop() if ctx.has_lse else None
         og = saved.pop() if ctx.keep_og else None
         pair, mask, *wts = saved
         ending, H, c = ctx.cfg
         with torch.no_grad():
-            dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, og=og)
+            dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, og=og, lse=lse)
             if ctx.residual:
                 dpair = dpair.add_(dy)
         return (dpair, None, None, None, None, None, *grads)

@@ -143,8 +143,10 @@ int main(void) {
     EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, A1, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(0, p, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(p, p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row beyond the LDS */
-    EXPECT(prd_tri_attn_bwd_core_v2(0, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
-    EXPECT(prd_tri_attn_bwd_core_v2(p, p, p, p, p, p, p, p, p, p, 0, 1, 385, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);  /* more than 12 blocks */
+    EXPECT(prd_tri_attn_bwd_core_v2(0, p, p, p, p, p, p, p, p, p, 0, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_attn_bwd_core_v2(p, p, p, p, p, p, p, p, p, p, 0, 0, 1, 385, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);  /* more than 12 blocks */
+    EXPECT(prd_tri_attn_core_v2_lse(0, 0, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, 0, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_attn_core_v2_lse(p, p, p, p, p, p, p, p, p, 0, 1, 769, 64, 4, 16, 0, s), PRD_ERR_UNSUPPORTED);       /* statistics: short rows only */
     EXPECT(prd_tri_attn_bwd_core_v2_supported(384, 64), 1);
     EXPECT(prd_tri_attn_bwd_core_v2_supported(385, 64), 0);
     EXPECT(prd_ln_rows_bwd(0, p, p, 8, 64, s), PRD_ERR_ARG);

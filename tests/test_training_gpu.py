@@ -185,21 +185,23 @@ def test_triangle_attention_backward_core_split16_vs_fp32(P, b, N, gscale, endin
     dog *= torch.logspace(-4, 0, N).view(1, 1, N, 1)            # four decades between the positions of a row
     dog[:, :, 5] = 0                                            # a position without gradient
     dog = dog.to(DEV)
-    og = ops.tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending)
-    a = torch.full((b, N, N, 4, 64), float("nan"), device=DEV)
+    lse = torch.empty(b * N, H, N, 2, device=DEV)
+    og = ops.tri_attn_core_v2_lse(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending, lse=lse)
     r = torch.full((b, N, N, 4, 64), float("nan"), device=DEV)
     assert lib().prd_tri_attn_bwd_core_v2_supported(N, P) == 1
-    check(lib().prd_tri_attn_bwd_core_v2(dptr(a), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
-                                         int(ending), b, N, P, H, c, stream()), "v2")
     check(lib().prd_tri_attn_bwd_core(dptr(r), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
                                       int(ending), b, N, P, H, c, stream()), "fp32")
-    assert torch.isfinite(a).all()
-    for k, name in enumerate(["dq", "dk", "dv", "dgate"]):
-        x, y = a[..., k, :].double(), r[..., k, :].double()
-        if gscale == 0.0:
-            assert float(x.abs().max()) == 0.0 and float(y.abs().max()) == 0.0, name
-        else:
-            assert float((x - y).norm() / y.norm()) < 3e-6, (name, float((x - y).norm() / y.norm()))
+    for stats in (None, lse):                                   # statistics recomputed in the kernel / kept by the forward
+        a = torch.full((b, N, N, 4, 64), float("nan"), device=DEV)
+        check(lib().prd_tri_attn_bwd_core_v2(dptr(a), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
+                                             dptr(stats) if stats is not None else None, int(ending), b, N, P, H, c, stream()), "v2")
+        assert torch.isfinite(a).all()
+        for k, name in enumerate(["dq", "dk", "dv", "dgate"]):
+            x, y = a[..., k, :].double(), r[..., k, :].double()
+            if gscale == 0.0:
+                assert float(x.abs().max()) == 0.0 and float(y.abs().max()) == 0.0, name
+            else:
+                assert float((x - y).norm() / y.norm()) < 3e-6, (name, stats is not None, float((x - y).norm() / y.norm()))
 
 
 @pytest.mark.gpu

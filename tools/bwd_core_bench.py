@@ -18,13 +18,18 @@ mask = torch.ones(b, N).cuda()
 wq, wk, wv, wg = [(torch.randn(64, P, generator=g) / math.sqrt(P)).cuda() for _ in range(4)]
 bg = torch.zeros(64).cuda()
 dog = (torch.randn(b, N, N, 64, generator=g) * 1e-3).cuda()
-og = ops.tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=False)
+lse = torch.empty(b * N, H, N, 2, device="cuda")
+og = ops.tri_attn_core_v2_lse(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=False, lse=lse)
 out = torch.empty(b, N, N, 4, 64, device="cuda")
 
 
-def v2():
+def v2(stats=None):
     check(lib().prd_tri_attn_bwd_core_v2(dptr(out), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
-                                         0, b, N, P, H, c, stream()), "v2")
+                                         dptr(stats) if stats is not None else None, 0, b, N, P, H, c, stream()), "v2")
+
+
+def v2s():
+    v2(lse)
 
 
 def v1():
@@ -32,7 +37,7 @@ def v1():
                                       0, b, N, P, H, c, stream()), "v1")
 
 
-for name, fn in (("fp32", v1), ("split16", v2)):
+for name, fn in (("fp32", v1), ("split16", v2), ("split16 + kept statistics", v2s)):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
