@@ -224,8 +224,13 @@ int prd_tri_mul(float* out, const float* pair, const float* mask, const float* w
 /* ---- backward of TriangleMultiplication (autograd of modules.py:262-274; used by training.py) -------------------------------
  * The contraction of prd_tri_mul alone: O[b][d][i][j] = sum_k A[b][d][i][k] B[b][d][j][k], operands channel-major
  * AB[b][2P][N][ldn] (A = channels 0..P-1, B = channels P..2P-1, ldn = round_up(N,32), zero padded), O[b][P][N][ldn].
- * The backward calls it on transposed operands for dA and dB. */
+ * The backward calls it on transposed operands for dA and dB (P = 128 is accepted for its two contractions stacked). */
 int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, int arith, hipStream_t stream);
+/* The operands of both gradient contractions stacked for ONE prd_tri_mul_contract call with 2P channel pairs:
+ * ops[b][4P][N][ldn] = dO | dO^T | B^T | A^T by channel block (dO already in block 0: prd_tri_mul_out_bwd with
+ * dO_batch_channels = 4P); A, B = the forward operands AB[b][2P][N][ldn].  prd_tri_mul_contract(dAB, ops, b, N, 2P) then yields
+ * dAB[b][2P][N][ldn] = dA | dB.  Padding columns N..ldn of all four blocks are zeroed here. */
+int prd_tri_mul_bwd_operands(float* ops, const float* AB, int b, int N, int P, hipStream_t stream);
 /* TriangleMultiplication "outgoing" followed by "incoming", in place on `pair` (both residual updates of modules.py:336-337),
  * PRD_ARITH_SPLIT16 only (prd_tri_mul_chain_supported): five launches instead of six -- the output stage of the first module and the
  * projection stage of the second run as one row pass down the columns (the outgoing contraction stores its result transposed
@@ -237,10 +242,14 @@ int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outg
 /* Output stage backward.  dy = gradient of the update [b,N,N,P]; O = contraction output (channel-major, as left in prd_tri_mul's
  * workspace); w_*_t = the transposed weights [in][out].  Writes dz = dy * gate and dgp = d(pre-activation of the output gate)
  * (row layout [b,N,N,P]; dW_out = dz^T LN(O), dW_ogate = dgp^T LN(pair) are left to the caller's BLAS), dO (channel-major) and
- * dx1 = W_ogate^T dgp (row layout), the output-gate path of the gradient of LN(pair). */
+ * dx1 = W_ogate^T dgp (row layout), the output-gate path of the gradient of LN(pair).
+ * x_out, lo_out (either may be null): LN(pair) and LN(O) in row layout [b,N,N,P], the inputs of those weight gradients (the kernel
+ * has both in registers).  dO_batch_channels: channel planes between the batches of dO (0 = P, i.e. dO[b][P][N][ldn]; 4P when dO
+ * is block 0 of prd_tri_mul_bwd_operands' buffer). */
 int prd_tri_mul_out_bwd(float* dz, float* dgp, float* dO, float* dx1, const float* dy, const float* pair, const float* O,
                         const float* w_out, const float* b_out, const float* w_ogate, const float* b_ogate,
-                        const float* w_out_t, const float* w_ogate_t, int b, int N, int P, hipStream_t stream);
+                        const float* w_out_t, const float* w_ogate_t, float* x_out, float* lo_out, int dO_batch_channels,
+                        int b, int N, int P, hipStream_t stream);
 /* Projection stage backward.  dAB = gradient of the operands (channel-major [b][2P][N][ldn]); writes dpair [b,N,N,P] (gradient of
  * the update with respect to its input pair tensor), and dpp / dpg = d(pre-activations of ab_proj / ab_gate) in row layout
  * [b,N,N,2P] by pair position (dW_proj = dpp^T LN(pair), dW_gate = dpg^T LN(pair) are left to the caller's BLAS). */
@@ -257,11 +266,12 @@ int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float* pair, con
 /* The same gradients in split-16 arithmetic on the 16-bit matrix pipe (tri_attn_bwd_core_v2_kernel, csrc/prd_tri2.hip), for rows of
  * up to 384 positions.  Takes, besides dog, the gated head outputs og [b,N,N,64] of the forward (do . o = dog . og is not
  * recomputed) and, optionally, the softmax statistics lse [b*N,H,N,2] that prd_tri_attn_core_v2_lse wrote in the forward
- * (null: recomputed by one more sweep over the logits).  prd_tri_attn_bwd_core_v2_supported: 1 when (N, P) is served. */
+ * (null: recomputed by one more sweep over the logits).  x_out (may be null): receives LN(pair) [b,N,N,P], the input of the
+ * projections' weight gradients.  prd_tri_attn_bwd_core_v2_supported: 1 when (N, P) is served. */
 int prd_tri_attn_bwd_core_v2_supported(int N, int P);
 int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
                              const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, const float* lse,
-                             int ending, int b, int N, int P, int H, int c, hipStream_t stream);
+                             float* x_out, int ending, int b, int N, int P, int H, int c, hipStream_t stream);
 /* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x). */
 int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream);
 /* Weight gradient of a linear applied at every pair position (autograd of nn.Linear over [b,N,N,*] activations, e.g.

@@ -67,11 +67,12 @@ SIGNATURES = {
     "prd_tri_attn_core_fused_supported": [ci, ci, ci],
     "prd_tri_attn_core_fused": [vp] * 12 + [ci] * 6 + [vp],
     "prd_tri_mul_chain": [vp, vp, vp, vp, ci, ci, ci, vp, cz, ci, vp],
-    "prd_tri_mul_out_bwd": [vp] * 13 + [ci] * 3 + [vp],
+    "prd_tri_mul_out_bwd": [vp] * 15 + [ci] * 4 + [vp],
+    "prd_tri_mul_bwd_operands": [vp, vp, ci, ci, ci, vp],
     "prd_tri_mul_proj_bwd": [vp] * 13 + [ci] * 5 + [vp],
     "prd_tri_attn_bwd_core": [vp] * 9 + [ci] * 6 + [vp],
     "prd_tri_attn_bwd_core_v2_supported": [ci, ci],
-    "prd_tri_attn_bwd_core_v2": [vp] * 11 + [ci] * 6 + [vp],
+    "prd_tri_attn_bwd_core_v2": [vp] * 12 + [ci] * 6 + [vp],
     "prd_ln_rows_bwd": [vp, vp, vp, cll, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
     "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],

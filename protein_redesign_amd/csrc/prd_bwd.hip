@@ -57,7 +57,8 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
     float* __restrict__ dz_out, float* __restrict__ dgp_out, float* __restrict__ dO, float* __restrict__ dx1,
     const float* __restrict__ dy, const float* __restrict__ pair, const float* __restrict__ O,
     const float* __restrict__ wo, const float* __restrict__ bo, const float* __restrict__ wog, const float* __restrict__ bog,
-    const float* __restrict__ woT, const float* __restrict__ wogT, int b, int N, int ldn) {
+    const float* __restrict__ woT, const float* __restrict__ wogT, int b, int N, int ldn,
+    float* __restrict__ x_out, float* __restrict__ lo_out, int dO_bch) {
     constexpr int KH = P / 2, NB = P / 32, WSZ = P * (P + 4);
     extern __shared__ __attribute__((aligned(16))) float smem_b1[];
     float* Wol = smem_b1;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
         float x[KH], g[KH];
         load_row_cll<P>(pair + off, hi, valid, x);
         ln_cll<KH>(x);
+        if (x_out) store_row_cll<P>(x_out + off, hi, valid, x);        // LN(pair) rows for the caller's weight gradients
         {
             f32x16 ag[NB];
             zero_acc(ag);
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
             for (int s = 0; s < KH; ++s) lo[s] = buf_load(ro, lane_o, (unsigned)(8 * (s >> 2) + (s & 3)) * cbytes);
         }
         const float rstd_o = ln_cll_rstd<KH>(lo);
+        if (lo_out) store_row_cll<P>(lo_out + off, hi, valid, lo);      // LN(O) rows, likewise
         float dz[KH], dgp[KH];
         {
             f32x16 az[NB];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
             for (int s = 0; s < KH; ++s) dlo[s] = a[s >> 4][s & 15];
             ln_cll_bwd<KH>(dlo, lo, rstd_o);
             {
-                const prd_rsrc rdo = make_rsrc(dO + (((long)bb * P) * N + i) * ldn + vb * 32);
+                const prd_rsrc rdo = make_rsrc(dO + (((long)bb * dO_bch) * N + i) * ldn + vb * 32);
 #pragma unroll
                 for (int s = 0; s < KH; ++s) buf_store(dlo[s], rdo, lane_o, (unsigned)(8 * (s >> 2) + (s & 3)) * cbytes);
             }
@@ -817,12 +820,85 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restr
         });                                                                                                     \
     } while (0)
 
+// Operands of the two gradient contractions of TriangleMultiplication as ONE stacked contraction (prd_tri_mul_contract with 2P
+// channel pairs): ops [b][4P][N][ldn] = dO | dO^T | B^T | A^T by channel block, so that
+//   out[c]     = dO[c]   (B^T[c])^T  = dA[c]      (dA[i][k] = sum_j dO[i][j] B[j][k])
+//   out[P + c] = dO^T[c] (A^T[c])^T  = dB[c]      (dB[j][k] = sum_i dO[i][j] A[i][k])
+// lands directly in the channel-major dAB the projection-stage backward reads.  dO is already in block 0 (written there by
+// prd_tri_mul_out_bwd); this kernel writes the three transposes through 64 x 64 LDS tiles (coalesced on both sides) and zeroes
+// the padding columns N .. ldn of every block, dO's included.
+__global__ __launch_bounds__(256) void tri_mul_bwd_operands_kernel(float* __restrict__ ops, const float* __restrict__ AB,
+                                                                   int N, int ldn, int P, int T, long ntask) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x, cl = 4 * (t & 15), rl = t >> 4;
+    for (long task = blockIdx.x; task < ntask; task += gridDim.x) {
+        long q = task;
+        const int src = (int)(q % 3); q /= 3;
+        const int tj = (int)(q % T); q /= T;
+        const int ti = (int)(q % T); q /= T;
+        const int c = (int)(q % P);
+        const int bb = (int)(q / P);
+        const size_t plane = (size_t)N * ldn;
+        const float* S = src == 0 ? ops + ((size_t)bb * 4 * P + c) * plane
+                       : AB + ((size_t)bb * 2 * P + (src == 1 ? P : 0) + c) * plane;
+        float* D = ops + ((size_t)bb * 4 * P + (size_t)(src + 1) * P + c) * plane;
+        const int i0 = 64 * ti, j0 = 64 * tj;
+        __syncthreads();                                // the previous task's tile has been read
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = i0 + rl + 16 * k, col = j0 + cl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < N) {
+                const float* sp = S + (size_t)row * ldn + col;
+                if (col + 3 < N) v = *reinterpret_cast<const float4*>(sp);
+                else {
+                    if (col < N) v.x = sp[0];
+                    if (col + 1 < N) v.y = sp[1];
+                    if (col + 2 < N) v.z = sp[2];
+                }
+                if (src == 0 && col + 3 >= N && col < ldn) {      // dO's own padding columns
+                    float* zp = ops + ((size_t)bb * 4 * P + c) * plane + (size_t)row * ldn + col;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e >= N && col + e < ldn) zp[e] = 0.f;
+                }
+            }
+            tile[rl + 16 * k][cl] = v.x;
+            tile[rl + 16 * k][cl + 1] = v.y;
+            tile[rl + 16 * k][cl + 2] = v.z;
+            tile[rl + 16 * k][cl + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = j0 + rl + 16 * k, col = i0 + cl;    // D[row][col] = S[col][row]
+            if (row < N && col < ldn) {
+                const float4 v = make_float4(tile[cl][rl + 16 * k], tile[cl + 1][rl + 16 * k], tile[cl + 2][rl + 16 * k], tile[cl + 3][rl + 16 * k]);
+                *reinterpret_cast<float4*>(D + (size_t)row * ldn + col) = v;
+            }
+        }
+    }
+}
+
+extern "C" int prd_tri_mul_bwd_operands(float* ops, const float* AB, int b, int N, int P, hipStream_t stream) {
+    if (!ops || !AB || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
+    const int ldn = prd_round_up(N, 32), T = prd_ceil_div(ldn, 64);
+    const long ntask = (long)b * P * T * T * 3;
+    const int grid = (int)(ntask < 256 * 8 ? ntask : 256 * 8);
+    hipLaunchKernelGGL(tri_mul_bwd_operands_kernel, dim3(grid), dim3(256), 0, stream, ops, AB, N, ldn, P, T, ntask);
+    return (int)hipGetLastError();
+}
+
 extern "C" int prd_tri_mul_out_bwd(float* dz, float* dgp, float* dO, float* dx1, const float* dy, const float* pair, const float* O,
                                    const float* w_out, const float* b_out, const float* w_ogate, const float* b_ogate,
-                                   const float* w_out_t, const float* w_ogate_t, int b, int N, int P, hipStream_t stream) {
+                                   const float* w_out_t, const float* w_ogate_t, float* x_out, float* lo_out, int dO_batch_channels,
+                                   int b, int N, int P, hipStream_t stream) {
     if (!dz || !dgp || !dO || !dx1 || !dy || !pair || !O || !w_out || !b_out || !w_ogate || !b_ogate || !w_out_t || !w_ogate_t ||
         b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
+    if (dO_batch_channels == 0) dO_batch_channels = P;
+    if (dO_batch_channels < P) return PRD_ERR_ARG;
     constexpr int NWB = 8;
     const int ldn = prd_round_up(N, 32);
     const size_t lds = ((size_t)4 * P * (P + 4) + 2 * P) * sizeof(float);
@@ -830,11 +906,11 @@ extern "C" int prd_tri_mul_out_bwd(float* dz, float* dgp, float* dO, float* dx1,
     if (P == 64) {
         PRD_BWD_SET_LDS((tri_mul_out_bwd_kernel<64, NWB>));
         hipLaunchKernelGGL((tri_mul_out_bwd_kernel<64, NWB>), dim3(grid), dim3(NWB * 64), lds, stream, dz, dgp, dO, dx1, dy, pair, O, w_out,
-                           b_out, w_ogate, b_ogate, w_out_t, w_ogate_t, b, N, ldn);
+                           b_out, w_ogate, b_ogate, w_out_t, w_ogate_t, b, N, ldn, x_out, lo_out, dO_batch_channels);
     } else {
         PRD_BWD_SET_LDS((tri_mul_out_bwd_kernel<32, NWB>));
         hipLaunchKernelGGL((tri_mul_out_bwd_kernel<32, NWB>), dim3(grid), dim3(NWB * 64), lds, stream, dz, dgp, dO, dx1, dy, pair, O, w_out,
-                           b_out, w_ogate, b_ogate, w_out_t, w_ogate_t, b, N, ldn);
+                           b_out, w_ogate, b_ogate, w_out_t, w_ogate_t, b, N, ldn, x_out, lo_out, dO_batch_channels);
     }
     return (int)hipGetLastError();
 }

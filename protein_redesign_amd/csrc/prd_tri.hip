@@ -2315,7 +2315,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
 extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int P, int arith, hipStream_t stream) {
     PRD_SPLIT_ARITH(arith);
     if (!O || !AB || b <= 0 || N <= 0) return PRD_ERR_ARG;
-    if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
+    if (P != 32 && P != 64 && P != 128) return PRD_ERR_UNSUPPORTED;     // 2 x 64: the stacked gradient contractions of the backward
     const int ldn = prd_round_up(N, 32);
     if (arith == PRD_ARITH_SPLIT16) {
         const int tl = prd_ceil_div(N, TMS_T);

@@ -1361,7 +1361,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
     float* __restrict__ dqkvg, const float* __restrict__ dog, const float* __restrict__ ogs, const float* __restrict__ pair,
     const float* __restrict__ mask, const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending,
-    const float* __restrict__ lse_in) {
+    const float* __restrict__ lse_in, float* __restrict__ x_out) {
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const B2Lds L = b2_layout(P, NP);
@@ -1434,6 +1434,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
                 o1 = *reinterpret_cast<const float4*>(op_ + 8);
             }
             ln_cll_p<KH>(x);
+            if (x_out && h == 0) store_row_cll<P>(x_out + row_pos(valid ? v : 0) * P, hi1, valid, x);    // LN(pair) for the weight gradients
             u32x4 xs[2][P / 16];
             split2h_rn_cll<KH>(x, xs);
             {   // logit override of masked / padded keys + tile flag
@@ -1899,7 +1900,7 @@ extern "C" int prd_tri_attn_bwd_core_v2_supported(int N, int P) {
 
 extern "C" int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
                                         const float* wq, const float* wk, const float* wv, const float* wg, const float* bg,
-                                        const float* lse, int ending, int b, int N, int P, int H, int c, hipStream_t stream) {
+                                        const float* lse, float* x_out, int ending, int b, int N, int P, int H, int c, hipStream_t stream) {
     if (!dqkvg || !dog || !og || !pair || !mask || !wq || !wk || !wv || !wg || !bg || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     if (!prd_tri_attn_bwd_core_v2_supported(N, P)) return PRD_ERR_UNSUPPORTED;
@@ -1914,11 +1915,11 @@ extern "C" int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const fl
     if (P == 64) {
         PRD2_SET_LDS((tri_attn_bwd_core_v2_kernel<64, NWV>));
         hipLaunchKernelGGL((tri_attn_bwd_core_v2_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, dqkvg, dog, og, pair, mask, wq, wk, wv,
-                           wg, bg, b, N, NP, H, ending, lse);
+                           wg, bg, b, N, NP, H, ending, lse, x_out);
     } else {
         PRD2_SET_LDS((tri_attn_bwd_core_v2_kernel<32, NWV>));
         hipLaunchKernelGGL((tri_attn_bwd_core_v2_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, dqkvg, dog, og, pair, mask, wq, wk, wv,
-                           wg, bg, b, N, NP, H, ending, lse);
+                           wg, bg, b, N, NP, H, ending, lse, x_out);
     }
     return (int)hipGetLastError();
 }

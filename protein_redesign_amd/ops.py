@@ -363,25 +363,18 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
     O = ws[2 * unit:].view(b, P, N, ldn)
     dy = dy.contiguous()
     dz, dgp, dx1 = torch.empty_like(pair), torch.empty_like(pair), torch.empty_like(pair)
-    dO = torch.zeros(b, P, N, ldn, device=dev, dtype=F32)
+    x, lo = torch.empty_like(pair), torch.empty_like(pair)       # LN(pair), LN(O) by pair position: inputs of the weight gradients
+    # dA[i][k] = sum_j dO[i][j] B^T[k][j];  dB[j][k] = sum_i dO^T[j][i] A^T[k][i]: one contraction over the stacked operands
+    # dO | dO^T | B^T | A^T (dO written in place by the output-stage backward, the transposes by prd_tri_mul_bwd_operands)
+    ops4 = torch.empty(b, 4 * P, N, ldn, device=dev, dtype=F32)
     woT, wogT = wo.t().contiguous(), wog.t().contiguous()
-    check(lib().prd_tri_mul_out_bwd(dptr(dz), dptr(dgp), dptr(dO), dptr(dx1), dptr(dy), dptr(pair), dptr(O), dptr(wo), dptr(bo),
-                                    dptr(wog), dptr(bog), dptr(woT), dptr(wogT), b, N, P, stream()), "prd_tri_mul_out_bwd")
-
-    def transposed(t):                                   # [b, C, N, ldn] (valid [.., :N, :N]) -> [b, C, N, ldn] with the two node axes swapped
-        out = torch.zeros_like(t)
-        out[..., :N] = t[..., :N].transpose(-1, -2)
-        return out
-
-    A, B = AB[:, :P], AB[:, P:]
+    check(lib().prd_tri_mul_out_bwd(dptr(dz), dptr(dgp), dptr(ops4), dptr(dx1), dptr(dy), dptr(pair), dptr(O), dptr(wo), dptr(bo),
+                                    dptr(wog), dptr(bog), dptr(woT), dptr(wogT), dptr(x), dptr(lo), 4 * P, b, N, P, stream()),
+          "prd_tri_mul_out_bwd")
+    check(lib().prd_tri_mul_bwd_operands(dptr(ops4), dptr(AB), b, N, P, stream()), "prd_tri_mul_bwd_operands")
     dAB = torch.empty(b, 2 * P, N, ldn, device=dev, dtype=F32)
-    # dA[i][k] = sum_j dO[i][j] B^T[k][j];  dB[j][k] = sum_i dO^T[j][i] A^T[k][i]
-    ops_a = torch.cat([dO, transposed(B)], dim=1).contiguous()
-    ops_b = torch.cat([transposed(dO), transposed(A)], dim=1).contiguous()
-    dA, dB = torch.empty(b, P, N, ldn, device=dev, dtype=F32), torch.empty(b, P, N, ldn, device=dev, dtype=F32)
-    check(lib().prd_tri_mul_contract(dptr(dA), dptr(ops_a), b, N, P, stream()), "prd_tri_mul_contract")
-    check(lib().prd_tri_mul_contract(dptr(dB), dptr(ops_b), b, N, P, stream()), "prd_tri_mul_contract")
-    dAB[:, :P], dAB[:, P:] = dA, dB
+    check(lib().prd_tri_mul_contract(dptr(dAB), dptr(ops4), b, N, 2 * P, stream()), "prd_tri_mul_contract")
+    del ops4
     dpair = torch.empty_like(pair)
     dpp = torch.empty(b, N, N, 2 * P, device=dev, dtype=F32)
     dpg = torch.empty(b, N, N, 2 * P, device=dev, dtype=F32)
@@ -389,9 +382,8 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
     check(lib().prd_tri_mul_proj_bwd(dptr(dpair), dptr(dpp), dptr(dpg), dptr(dAB), dptr(dx1), dptr(pair), dptr(mask), dptr(wp),
                                      dptr(bp), dptr(wg), dptr(bg), dptr(wpT), dptr(wgT), int(incoming), b, N, P, stream()),
           "prd_tri_mul_proj_bwd")
-    # weight gradients: dW = dOut^T In over all rows (linear_wgrad); LN(pair), LN(O) recomputed by the LayerNorm kernel
-    x = layer_norm(pair.contiguous()).view(-1, P)
-    lo = layer_norm(O[..., :N].permute(0, 2, 3, 1).contiguous()).view(-1, P)
+    # weight gradients: dW = dOut^T In over all rows (linear_wgrad)
+    x, lo = x.view(-1, P), lo.view(-1, P)
     dz2, dgp2, dpp2, dpg2 = dz.view(-1, P), dgp.view(-1, P), dpp.view(-1, 2 * P), dpg.view(-1, 2 * P)
     grads = (*linear_wgrad(dpp2, x, bias=True), *linear_wgrad(dpg2, x, bias=True), *linear_wgrad(dz2, lo, bias=True),
              *linear_wgrad(dgp2, x, bias=True))
@@ -416,9 +408,11 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
         og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending, lse=lse)
     dog = linear(dy, wo.t().contiguous())                                                         # d og = dy W_o
     dqkvg = torch.empty(b, N, N, 4, HC, device=dev, dtype=F32)
+    x = None
     if lib().prd_get_gemm_mode() == 1 and TRI_ATTN_BWD_V2 and lib().prd_tri_attn_bwd_core_v2_supported(N, P) == 1:
+        x = torch.empty_like(pair)                                                                # LN(pair), left by the core
         check(lib().prd_tri_attn_bwd_core_v2(dptr(dqkvg), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg),
-                                             dptr(bg), dptr(lse) if lse is not None else None, int(ending), b, N, P, H, c, stream()),
+                                             dptr(bg), dptr(lse) if lse is not None else None, dptr(x), int(ending), b, N, P, H, c, stream()),
               "prd_tri_attn_bwd_core_v2")
     else:
         check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
@@ -427,7 +421,7 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
     dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat_t)                                             # gradient of LN(pair)
     dpair = torch.empty_like(pair)
     check(lib().prd_ln_rows_bwd(dptr(dpair), dptr(dxn), dptr(pair), b * N * N, P, stream()), "prd_ln_rows_bwd")
-    x = layer_norm(pair.contiguous()).view(-1, P)
+    x = (x if x is not None else layer_norm(pair.contiguous())).view(-1, P)
     d2 = dqkvg.view(-1, 4, HC)
     dy2 = dy.view(-1, P)
     dw4, db4 = linear_wgrad(dqkvg.view(-1, 4 * HC), x, bias=True)                                # d W_q | W_k | W_v | W_g stacked [4 HC, P]

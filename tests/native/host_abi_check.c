@@ -139,12 +139,15 @@ int main(void) {
     EXPECT(prd_tri_attn_core_v2(0, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, 0, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_core_v2(p, p, p, p, p, p, p, p, 0, 1, 1100, 64, 4, 16, 0, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_attn_core_fused(p, p, p, p, p, p, p, p, p, p, p, p, 1, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);   /* pair_out aliases pair */
-    EXPECT(prd_tri_mul_out_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_out_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 0, 0, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_out_bwd(p, p, p, p, p, p, p, p, p, p, p, p, p, 0, 0, 32, 1, 8, 64, s), PRD_ERR_ARG);     /* batch pitch below P */
+    EXPECT(prd_tri_mul_bwd_operands(0, p, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_mul_bwd_operands(p, p, 1, 8, 48, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_tri_mul_proj_bwd(0, p, p, p, p, p, p, p, p, p, p, p, p, 0, 1, 8, 64, A1, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(0, p, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_bwd_core(p, p, p, p, p, p, p, p, p, 0, 1, 100000, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);   /* row beyond the LDS */
-    EXPECT(prd_tri_attn_bwd_core_v2(0, p, p, p, p, p, p, p, p, p, 0, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
-    EXPECT(prd_tri_attn_bwd_core_v2(p, p, p, p, p, p, p, p, p, p, 0, 0, 1, 385, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);  /* more than 12 blocks */
+    EXPECT(prd_tri_attn_bwd_core_v2(0, p, p, p, p, p, p, p, p, p, 0, 0, 0, 1, 8, 64, 4, 16, s), PRD_ERR_ARG);
+    EXPECT(prd_tri_attn_bwd_core_v2(p, p, p, p, p, p, p, p, p, p, 0, 0, 0, 1, 385, 64, 4, 16, s), PRD_ERR_UNSUPPORTED);  /* more than 12 blocks */
     EXPECT(prd_tri_attn_core_v2_lse(0, 0, p, p, p, p, p, p, p, 0, 1, 8, 64, 4, 16, 0, s), PRD_ERR_ARG);
     EXPECT(prd_tri_attn_core_v2_lse(p, p, p, p, p, p, p, p, p, 0, 1, 769, 64, 4, 16, 0, s), PRD_ERR_UNSUPPORTED);       /* statistics: short rows only */
     EXPECT(prd_tri_attn_bwd_core_v2_supported(384, 64), 1);

@@ -194,7 +194,7 @@ def test_triangle_attention_backward_core_split16_vs_fp32(P, b, N, gscale, endin
     for stats in (None, lse):                                   # statistics recomputed in the kernel / kept by the forward
         a = torch.full((b, N, N, 4, 64), float("nan"), device=DEV)
         check(lib().prd_tri_attn_bwd_core_v2(dptr(a), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
-                                             dptr(stats) if stats is not None else None, int(ending), b, N, P, H, c, stream()), "v2")
+                                             dptr(stats) if stats is not None else None, None, int(ending), b, N, P, H, c, stream()), "v2")
         assert torch.isfinite(a).all()
         for k, name in enumerate(["dq", "dk", "dv", "dgate"]):
             x, y = a[..., k, :].double(), r[..., k, :].double()

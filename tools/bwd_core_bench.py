@@ -25,7 +25,7 @@ out = torch.empty(b, N, N, 4, 64, device="cuda")
 
 def v2(stats=None):
     check(lib().prd_tri_attn_bwd_core_v2(dptr(out), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
-                                         dptr(stats) if stats is not None else None, 0, b, N, P, H, c, stream()), "v2")
+                                         dptr(stats) if stats is not None else None, None, 0, b, N, P, H, c, stream()), "v2")
 
 
 def v2s():
