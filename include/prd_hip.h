@@ -145,6 +145,8 @@ typedef struct PrdGemm {
                                        (operand-ring kernel, split-16 arithmetic) and the accumulator divided by it -- for A operands
                                        far below 1 (softmax probabilities: P V of SPAttention), whose lo part would otherwise fall
                                        into the fp16 subnormal range (see OPERAND RANGE above).  Ignored by the fp32 kernels. */
+    int mul_pos;                    /* with mulmat: v = mulmat[g][m][n] > 0 ? v : 0 instead of the product (the ReLU mask of a backward pass,
+                                       read from the recomputed activations) */
 } PrdGemm;
 size_t prd_gemm_slab_workspace(int M, int N, int K);
 int prd_gemm_slab_ok(int M, int N, int K, int arith);   /* 1 when a PrdGemm of this shape with `ws` set takes the K-slab path */
@@ -272,8 +274,9 @@ int prd_tri_attn_bwd_core_v2_supported(int N, int P);
 int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
                              const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, const float* lse,
                              float* x_out, int ending, int b, int N, int P, int H, int c, hipStream_t stream);
-/* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x). */
-int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream);
+/* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x) (+ res[row][c] when res is given:
+ * the gradient that bypasses the update through its residual connection). */
+int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, const float* res, long long rows, int C, hipStream_t stream);
 /* Weight gradient of a linear applied at every pair position (autograd of nn.Linear over [b,N,N,*] activations, e.g.
  * modules.py:262-274, 321-326): dw[O][I] = sum over rows of dy[row][0..O) (x) x[row][0..I); row pitches lddy / ldx floats (for O > 16: even, and dy / x
  * 8-byte aligned -- PRD_ERR_ALIGN otherwise).

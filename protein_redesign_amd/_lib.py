@@ -38,6 +38,7 @@ class PrdGemm(C.Structure):
         ("wsum", vp),
         ("out_ln", vp), ("ldol", ci),
         ("a_scale", cf),
+        ("mul_pos", ci),
     ]
 
 
@@ -73,7 +74,7 @@ SIGNATURES = {
     "prd_tri_attn_bwd_core": [vp] * 9 + [ci] * 6 + [vp],
     "prd_tri_attn_bwd_core_v2_supported": [ci, ci],
     "prd_tri_attn_bwd_core_v2": [vp] * 12 + [ci] * 6 + [vp],
-    "prd_ln_rows_bwd": [vp, vp, vp, cll, ci, vp],
+    "prd_ln_rows_bwd": [vp, vp, vp, vp, cll, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
     "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],
     "prd_embed_wgrad_workspace": [cll, ci, ci],

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(512) void tri_attn_bwd_core_kernel(
 
 // d/dx of LayerNorm (no affine) over the last axis: one wave per row, C a multiple of 64
 __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy, const float* __restrict__ x,
-                                                          long rows, int C) {
+                                                          const float* __restrict__ res, long rows, int C) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -589,9 +589,34 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dx
     for (int c = lane; c < C; c += 64) { const float y = (xr[c] - mean) * rstd; s1 += gr[c]; s2 += gr[c] * y; }
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     const float m1 = s1 / C, m2 = s2 / C;
-    for (int c = lane; c < C; c += 64) { const float y = (xr[c] - mean) * rstd; dx[row * C + c] = rstd * (gr[c] - m1 - y * m2); }
+    for (int c = lane; c < C; c += 64) {
+        const float y = (xr[c] - mean) * rstd;
+        dx[row * C + c] = rstd * (gr[c] - m1 - y * m2) + (res ? res[row * C + c] : 0.f);
+    }
 }
 
+
+// The same for rows of 64 channels (the pair track): 16 lanes x float4 per row, four rows per wave, reductions inside a DPP row --
+// the row kernel above moves 4 bytes per lane and load and spends six LDS-crossbar shuffles per reduction (74 us for the 157 MB of
+// a b = 2, N = 320 call; this form runs at the speed of the three streams).  res (may be null): added to the result (the
+// residual path of the update whose backward this is).
+__global__ __launch_bounds__(256) void ln_rows_bwd64_kernel(float* __restrict__ dx, const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ res, long rows) {
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= rows) return;
+    const long off = row * 64 + 4 * (threadIdx.x & 15);
+    const float4 xv = *reinterpret_cast<const float4*>(x + off), gv = *reinterpret_cast<const float4*>(dy + off);
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) rv = *reinterpret_cast<const float4*>(res + off);
+    const float mean = row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 64);
+    const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+    const float rstd = 1.0f / sqrtf(row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 64) + 1e-5f);
+    const float y0 = d0 * rstd, y1 = d1 * rstd, y2 = d2 * rstd, y3 = d3 * rstd;
+    const float m1 = row16_sum((gv.x + gv.y) + (gv.z + gv.w)) * (1.0f / 64);
+    const float m2 = row16_sum((gv.x * y0 + gv.y * y1) + (gv.z * y2 + gv.w * y3)) * (1.0f / 64);
+    *reinterpret_cast<float4*>(dx + off) = make_float4(rstd * (gv.x - m1 - y0 * m2) + rv.x, rstd * (gv.y - m1 - y1 * m2) + rv.y,
+                                                       rstd * (gv.z - m1 - y2 * m2) + rv.z, rstd * (gv.w - m1 - y3 * m2) + rv.w);
+}
 
 // ---- weight gradient of a pair-position linear: dW[o][i] = sum_rows dy[row][o] * x[row][i] --------------------------------
 // rows = b N N (2e5 at N = 320), O, I <= 256: a reduction over a huge K with a tiny output, for which the BLAS picks an
@@ -962,9 +987,13 @@ extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float
     return (int)hipGetLastError();
 }
 
-extern "C" int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, long long rows, int C, hipStream_t stream) {
+extern "C" int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, const float* res, long long rows, int C, hipStream_t stream) {
     if (!dx || !dy || !x || rows <= 0 || C <= 0) return PRD_ERR_ARG;
-    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dx, dy, x, (long)rows, C);
+    const bool al16 = ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+    if (C == 64 && al16)
+        hipLaunchKernelGGL(ln_rows_bwd64_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, dx, dy, x, res, (long)rows);
+    else
+        hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dx, dy, x, res, (long)rows, C);
     return (int)hipGetLastError();
 }
 

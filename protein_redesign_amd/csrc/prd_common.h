@@ -64,6 +64,14 @@ PRD_DEV int drow32(int q, int hi) { return (q & 3) + 8 * (q >> 2) + 4 * hi; }
 PRD_DEV int cll_ch(int s, int hi) { return 8 * (s >> 2) + 4 * hi + (s & 3); }
 
 PRD_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+// sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1: no LDS crossbar), result in every lane of the row
+PRD_DEV float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
 
 // ---- row load / store in CLL ------------------------------------------------------------------
 template <int C>

@@ -24,7 +24,10 @@ PRD_DEV void epilogue_store(const PrdGemm& g, int g1, int g2, int m, int n, floa
     if (act == 1) v = fmaxf(v, 0.f);
     else if (act == 2) v = sigmoidf_(v);
     if (g.rowmask && (g.rowmask_cols <= 0 || n < g.rowmask_cols)) v *= g.rowmask[g1 * g.srm1 + m];
-    if (g.mulmat) v *= g.mulmat[g1 * g.smu1 + g2 * g.smu2 + (size_t)m * g.ldmul + n];
+    if (g.mulmat) {
+        const float mv = g.mulmat[g1 * g.smu1 + g2 * g.smu2 + (size_t)m * g.ldmul + n];
+        v = g.mul_pos ? (mv > 0.f ? v : 0.f) : v * mv;
+    }
     if (g.resid) {
         const float rv = g.resid[g1 * g.sr1 + g2 * g.sr2 + (size_t)m * g.ldr + n];
         v += g.rscale ? rv * g.rscale[n] : rv;
@@ -916,6 +919,24 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
     }
 }
 
+// rows of 64 channels (the pair track): 16 lanes x float4 per row, four rows per wave, reductions inside a DPP row
+__global__ __launch_bounds__(256) void ln_rows64_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int ldx, int ldy) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), c4 = 4 * (threadIdx.x & 15);
+    if (row >= rows) return;
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c4);
+    const float mean = row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 64);
+    const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+    const float rstd = 1.0f / sqrtf(row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 64) + 1e-5f);
+    float4 t = make_float4(d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd);
+    if (gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c4), bt = *reinterpret_cast<const float4*>(beta + c4);
+        t = make_float4(t.x * g.x + bt.x, t.y * g.y + bt.y, t.z * g.z + bt.z, t.w * g.w + bt.w);
+    }
+    *reinterpret_cast<float4*>(y + (size_t)row * ldy + c4) = t;
+}
+
 // ---- softmax rows (in place), one wave per row, zero-fills [n, ld) ---------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int rows, int n, int ld) {
     const int lane = threadIdx.x & 63;
@@ -1053,6 +1074,12 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
 extern "C" int prd_ln_rows(const float* x, float* y, const float* gamma, const float* beta,
                            int rows, int C, int ldx, int ldy, hipStream_t stream) {
     if (!x || !y || rows <= 0 || C <= 0 || (gamma && !beta)) return PRD_ERR_ARG;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
+                        reinterpret_cast<uintptr_t>(beta)) & 15) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0;
+    if (C == 64 && al16 && rows >= 4096) {              // the pair-track calls of the training path
+        hipLaunchKernelGGL(ln_rows64_kernel, dim3(prd_ceil_div(rows, 16)), dim3(256), 0, stream, x, y, gamma, beta, rows, ldx, ldy);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(ln_rows_kernel, dim3(prd_ceil_div(rows, 4)), dim3(256), 0, stream, x, y, gamma, beta, rows, C, ldx, ldy);
     return (int)hipGetLastError();
 }

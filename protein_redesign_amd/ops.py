@@ -74,7 +74,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
          addmat=None, sad=(0, 0), ldadd=0, colmask=None, scm1=0, fill=0.0, rowmask=None, srm1=0,
          mulmat=None, mul_off=0, smu=(0, 0), ldmul=0, resid=None, res_off=0, sr=(0, 0), ldr=0,
          colscale=None, tile_hint=0, a_ln=False, ln_out=None, c2=None, n_split=0, rowmask_cols=0, rscale=None,
-         slab=False, wsum=None, out_ln=None, a_scale=0.0, unsupported_ok=False):
+         slab=False, wsum=None, out_ln=None, a_scale=0.0, mul_pos=False, unsupported_ok=False):
     """Raw batched GEMM + epilogue (see PrdGemm in include/prd_hip.h).  ``a_ln`` may be 2 (row softmax of A, see the header);
     with ``unsupported_ok`` a PRD_ERR_UNSUPPORTED shape returns None instead of raising (the caller falls back)."""
     g = PrdGemm()
@@ -101,6 +101,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, a_off=0, b_off=0, c_off=0, G1=1,
     g.wsum = dptr(wsum)
     g.out_ln, g.ldol = dptr(out_ln), (out_ln.shape[-1] if out_ln is not None else 0)
     g.a_scale = float(a_scale)
+    g.mul_pos = int(mul_pos)
     g.arith = lib().prd_get_gemm_mode() | (lib().prd_get_tune() << 8)
     import ctypes
     code = lib().prd_gemm(ctypes.byref(g), stream())
@@ -135,21 +136,26 @@ def slab_ok(M: int, N: int, K: int) -> bool:
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = 0,
            alpha: float = 1.0, resid: Optional[torch.Tensor] = None, rowmask: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, ln_a: bool = False, rscale: Optional[torch.Tensor] = None,
-           slab: bool = False, wsum: Optional[torch.Tensor] = None, out_ln: Optional[torch.Tensor] = None) -> torch.Tensor:
+           slab: bool = False, wsum: Optional[torch.Tensor] = None, out_ln: Optional[torch.Tensor] = None,
+           ln_a_out: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(alpha * x W^T + bias) [* rowmask] [+ resid] for x [..., K], W [N, K]; ``ln_a``: x is LayerNorm-ed
-    (no affine) inside the GEMM instead of by a separate launch."""
+    (no affine) inside the GEMM instead of by a separate launch, and with ``ln_a_out`` [rows, K] the normalised rows are
+    written there as well; ``relu_mask`` [rows, N]: y is zeroed where relu_mask <= 0 (the ReLU backward from recomputed activations)."""
     K = x.shape[-1]
     M = x.numel() // K
     N = w.shape[0]
     if ln_a and not ln_fusable(K):
         x, ln_a = layer_norm(x.contiguous()), False
+        if ln_a_out is not None:
+            ln_a_out.copy_(x.view_as(ln_a_out))
     if out is None:
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
     a, lda = x, K
     if not x.is_contiguous():          # a column block of a wider GEMM output
         a, lda = row_block(x)
     gemm(a, w, out, M, N, K, lda, w.stride(0), N, alpha=alpha, bias=bias, act=act,
-         rowmask=rowmask, resid=resid, ldr=N, a_ln=ln_a, rscale=rscale, slab=slab, wsum=wsum, out_ln=out_ln)
+         rowmask=rowmask, resid=resid, ldr=N, a_ln=ln_a, rscale=rscale, slab=slab, wsum=wsum, out_ln=out_ln,
+         ln_out=ln_a_out if ln_a else None, mulmat=relu_mask, ldmul=N, mul_pos=relu_mask is not None)
     return out
 
 
@@ -393,8 +399,9 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
 TRI_ATTN_BWD_V2 = os.environ.get("PRD_TRI_ATTN_BWD_V2", "1") != "0"      # 0: the fp32-MFMA backward core in split-16 mode too (A/B measurements)
 
 
-def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=None, lse=None):
-    """Gradients of the TriangleAttention update (ops.tri_attn with residual=False) with respect to ``pair`` and its seven weight
+def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=None, lse=None, residual: bool = False):
+    """Gradients of the TriangleAttention update (ops.tri_attn with residual=False; ``residual``: of pair + update, i.e. dy is added
+    to the pair gradient) with respect to ``pair`` and its seven weight
     tensors on the hand-written backward (csrc/prd_bwd.hip): out-projection backward (row GEMM) -> attention core backward per
     (row, head) -> projections backward (row GEMM) -> LayerNorm backward.  Weight gradients: slab reductions over all N^2 rows
     (linear_wgrad)."""
@@ -420,7 +427,7 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
     wcat_t = torch.cat([wq, wk, wv, wg], dim=0).t().contiguous()                                  # [P, 4 HC]
     dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat_t)                                             # gradient of LN(pair)
     dpair = torch.empty_like(pair)
-    check(lib().prd_ln_rows_bwd(dptr(dpair), dptr(dxn), dptr(pair), b * N * N, P, stream()), "prd_ln_rows_bwd")
+    check(lib().prd_ln_rows_bwd(dptr(dpair), dptr(dxn), dptr(pair), dptr(dy) if residual else None, b * N * N, P, stream()), "prd_ln_rows_bwd")
     x = (x if x is not None else layer_norm(pair.contiguous())).view(-1, P)
     d2 = dqkvg.view(-1, 4, HC)
     dy2 = dy.view(-1, P)
@@ -432,11 +439,11 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
 WGRAD_MIN_ROWS = 8192
 
 
-def ln_rows_bwd(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """dx of nn.LayerNorm(C, elementwise_affine=False) over the rows of x2 [rows, C] (prd_ln_rows_bwd)."""
+def ln_rows_bwd(dy2: torch.Tensor, x2: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx of nn.LayerNorm(C, elementwise_affine=False) over the rows of x2 [rows, C] (prd_ln_rows_bwd), plus ``res`` if given."""
     rows, Cn = x2.shape
     dx = torch.empty_like(x2)
-    check(lib().prd_ln_rows_bwd(dptr(dx), dptr(dy2), dptr(x2), rows, Cn, stream()), "prd_ln_rows_bwd")
+    check(lib().prd_ln_rows_bwd(dptr(dx), dptr(dy2), dptr(x2), dptr(res), rows, Cn, stream()), "prd_ln_rows_bwd")
     return dx
 
 

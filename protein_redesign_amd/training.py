@@ -85,17 +85,14 @@ class PairTransitionFn(torch.autograd.Function):
         with torch.no_grad():
             x2 = x.detach().contiguous().view(-1, P)
             dy2 = dy.contiguous().view(-1, P)
-            h = ops.linear(x2, w1, b1, act=1, ln_a=True)                       # [rows, HID]
-            g = ops.linear(dy2, w2.t().contiguous())                           # dy W2
-            g.mul_(h > 0)
+            xn = torch.empty_like(x2)
+            h = ops.linear(x2, w1, b1, act=1, ln_a=True, ln_a_out=xn)          # [rows, HID]; LN(x) rows on the side
+            g = ops.linear(dy2, w2.t().contiguous(), relu_mask=h)              # (dy W2) * [h > 0]
             dxn = ops.linear(g, w1.t().contiguous())                           # [rows, P]
-            dx = ops.ln_rows_bwd(dxn, x2)
+            dx = ops.ln_rows_bwd(dxn, x2, res=dy2 if ctx.residual else None)   # (+ dy: the residual path)
             dw2, db2 = ops.linear_wgrad(dy2, h, bias=True)
-            xn = ops.layer_norm(x2)
             dw1, db1 = ops.linear_wgrad(g, xn, bias=True)
             dx = dx.view_as(x)
-            if ctx.residual:
-                dx = dx.add_(dy)
         return dx, dw1, db1, dw2, db2, None
 
 
@@ -217,9 +214,8 @@ class TriAttnFn(torch.autograd.Function):
         pair, mask, *wts = saved
         ending, H, c = ctx.cfg
         with torch.no_grad():
-            dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, og=og, lse=lse)
-            if ctx.residual:
-                dpair = dpair.add_(dy)
+            dpair, grads = ops.tri_attn_backward(dy, pair.detach().contiguous(), mask, [w.detach() for w in wts], H, c, ending=ending, og=og, lse=lse,
+                                                 residual=ctx.residual)
         return (dpair, None, None, None, None, None, *grads)
 
 

@@ -152,7 +152,7 @@ int main(void) {
     EXPECT(prd_tri_attn_core_v2_lse(p, p, p, p, p, p, p, p, p, 0, 1, 769, 64, 4, 16, 0, s), PRD_ERR_UNSUPPORTED);       /* statistics: short rows only */
     EXPECT(prd_tri_attn_bwd_core_v2_supported(384, 64), 1);
     EXPECT(prd_tri_attn_bwd_core_v2_supported(385, 64), 0);
-    EXPECT(prd_ln_rows_bwd(0, p, p, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_ln_rows_bwd(0, p, p, 0, 8, 64, s), PRD_ERR_ARG);
     EXPECT((int)(prd_linear_wgrad_workspace(102400, 256, 64) != (size_t)200 * (256 * 64 + 256) * 4), 0);
     EXPECT((int)prd_linear_wgrad_workspace(0, 256, 64), 0);
     EXPECT(prd_linear_wgrad(0, p, p, p, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
