@@ -282,10 +282,13 @@ int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, const float* res
  * 8-byte aligned -- PRD_ERR_ALIGN otherwise).
  * I a multiple of 64, O a multiple of 64 or at most 16 (the attention-bias / coordinate-head linears), both at most 256.
  * db (optional, NULL = skip): the bias gradient db[O] = sum over rows of dy, from the same pass over dy.
- * ws: prd_linear_wgrad_workspace(rows, O, I) bytes of slab partials. */
+ * ws: prd_linear_wgrad_workspace(rows, O, I) bytes of slab partials.
+ * arith: PRD_ARITH_FP32 = fp32 MFMA; PRD_ARITH_SPLIT16 (wide form) = fp16 hi | lo operands on the 16-bit matrix pipe, dy scaled by a
+ * running power of two per wave (gradients have no fixed magnitude; csrc/prd_bwd.hip linear_wgrad_h2_kernel).  db is summed in
+ * fp32 either way. */
 size_t prd_linear_wgrad_workspace(long long rows, int O, int I);
 int prd_linear_wgrad(float* dw, float* db, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
-                     float* ws, size_t ws_bytes, hipStream_t stream);
+                     float* ws, size_t ws_bytes, int arith, hipStream_t stream);
 /* Gradient of a small embedding table applied at every pair position (modules.py:35-71: bond-type, bond-distance and
  * relative-position tables): dtable[card][C] = sum over rows of dy[row][0..C) into row idx[row] (int64; indices outside
  * [0, card) are ignored).  card <= 128, C <= 64.  ws: prd_embed_wgrad_workspace(rows, card, C) bytes. */

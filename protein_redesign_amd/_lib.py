@@ -76,7 +76,7 @@ SIGNATURES = {
     "prd_tri_attn_bwd_core_v2": [vp] * 12 + [ci] * 6 + [vp],
     "prd_ln_rows_bwd": [vp, vp, vp, vp, cll, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
-    "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, vp],
+    "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, ci, vp],
     "prd_embed_wgrad_workspace": [cll, ci, ci],
     "prd_embed_wgrad": [vp, vp, vp, cll, ci, ci, ci, vp, cz, vp],
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, ci, vp],
@@ -103,7 +103,8 @@ DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (e
 
 # entry points that take the arithmetic as their last argument before the stream ...
 _ARITH_BEFORE_STREAM = ("prd_coord_head", "prd_pair_head", "prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
-                        "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain")
+                        "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain",
+                        "prd_linear_wgrad")
 # ... and the queries that take it as their last argument
 _ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes",
                "prd_gemm_slab_ok", "prd_pair_head_supported")

@@ -720,6 +720,155 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(float* __restrict__ p
     }
 }
 
+// The same slab reduction on the 16-bit matrix pipe (gemm mode 1): v_mfma_f32_32x32x16_f16 takes SIXTEEN rows per instruction
+// where the fp32 form takes two, and the three split products hi*hi, hi*lo, lo*hi still leave a 64x64 block at 12 matrix
+// instructions per 16 rows instead of 32 twice as long ones.  Lane (r, hi) loads dy[row0 + 8 hi + u][o0 + 2r + ea] and
+// x[row0 + 8 hi + u][i0 + 2r + eb], u < 8: its eight values of one column ARE the eight contraction entries an operand lane
+// holds, so the rows go from the float2 loads through the hi | lo split straight into the MFMA, no LDS.
+// Range: x (activations) is O(1); dy is a gradient of unknown magnitude and fp16 has five exponent bits, so dy is multiplied by
+// a wave-uniform power of two `cur` before the split and the accumulators carry that factor.  `cur` is set from the first
+// non-zero 16-row group (largest |dy| -> [64, 128)) and lowered, with the accumulators rescaled, whenever a group would
+// pass 2^14: groups far below the running scale lose relative precision exactly in proportion to how little they contribute.
+template <int NBLK>
+__global__ __launch_bounds__(256) void linear_wgrad_h2_kernel(float* __restrict__ part, const float* __restrict__ dy, const float* __restrict__ x,
+                                                              long rows, int O, int I, int lddy, int ldx, int rows_per_wg, int want_db) {
+    constexpr int WPB = 4 / NBLK, U = 8;
+    __shared__ float red[WPB > 1 ? 4 : 1][64][64];
+    __shared__ float redb[4][2][32];
+    const int pn = O * I + (want_db ? O : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+    const int ibn = I / 64;
+    const int blk = blockIdx.y * NBLK + wave / WPB, sub = wave % WPB;
+    const int ob = blk / ibn, ib = blk - ob * ibn;
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    const float* dyp = dy + ob * 64 + 2 * r;
+    const float* xp = x + ib * 64 + 2 * r;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[ea][eb][q] = 0.f;
+    float sdb0 = 0.f, sdb1 = 0.f;
+    float cur = 0.f;                                        // the power of two dy is multiplied by (0: not set yet)
+    float2 ca[U], cb[U], na[U], nb[U];
+    auto load = [&](float2 (&a)[U], float2 (&b)[U], long row) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = row + 8 * hi + u;
+            const long rc = rr < r1 ? rr : r1 - 1;          // clamped (rows past the slab are multiplied by zero)
+            const float z = rr < r1 ? 1.f : 0.f;
+            const float2 t = *reinterpret_cast<const float2*>(dyp + rc * lddy);
+            a[u] = make_float2(t.x * z, t.y * z);
+            b[u] = *reinterpret_cast<const float2*>(xp + rc * ldx);
+        }
+    };
+    auto mfma_h = [](u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    };
+    const long step = 2L * U * WPB;
+    long row = r0 + 2L * U * sub;
+    if (row < r1) load(ca, cb, row);
+    for (; row < r1; row += step) {
+        const long nx = row + step;
+        load(na, nb, nx < r1 ? nx : row);                   // unconditional prefetch (the last one re-reads the current group)
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(ca[u].x), __builtin_fabsf(ca[u].y)));
+            sdb0 += ca[u].x;
+            sdb1 += ca[u].y;
+        }
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o_));
+        mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
+        if (mx > 0.f && mx < 3.0e38f && (cur == 0.f || mx * cur > 16384.f)) {      // wave-uniform; rare after the first group
+            int e = 7 - __builtin_amdgcn_frexp_expf(mx);    // mx * 2^e in [64, 128)
+            e = e > 120 ? 120 : (e < -120 ? -120 : e);
+            const float nw = __builtin_ldexpf(1.0f, e);
+            if (cur != 0.f) {
+                const float f = nw / cur;                   // a power of two: exact
+#pragma unroll
+                for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+                    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc[ea][eb][q] *= f;
+            }
+            cur = nw;
+        }
+        u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned h, l;
+            split2h(ca[2 * w].x * cur, ca[2 * w + 1].x * cur, h, l); ah[0][w] = h; al[0][w] = l;
+            split2h(ca[2 * w].y * cur, ca[2 * w + 1].y * cur, h, l); ah[1][w] = h; al[1][w] = l;
+            split2h(cb[2 * w].x, cb[2 * w + 1].x, h, l); bh[0][w] = h; bl[0][w] = l;
+            split2h(cb[2 * w].y, cb[2 * w + 1].y, h, l); bh[1][w] = h; bl[1][w] = l;
+        }
+#pragma unroll
+        for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                acc[ea][eb] = mfma_h(ah[ea], bh[eb], acc[ea][eb]);
+                acc[ea][eb] = mfma_h(ah[ea], bl[eb], acc[ea][eb]);
+                acc[ea][eb] = mfma_h(al[ea], bh[eb], acc[ea][eb]);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { ca[u] = na[u]; cb[u] = nb[u]; }
+    }
+    {   // back to the scale of dy
+        const float inv = cur != 0.f ? 1.0f / cur : 0.f;
+#pragma unroll
+        for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ea][eb][q] *= inv;
+    }
+    if (WPB > 1) {                                          // merge the waves of a block (fixed order)
+        if (sub > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[wave][e * 16 + q][lane] = acc[e >> 1][e & 1][q];
+        }
+        __syncthreads();
+        if (sub == 0) {
+#pragma unroll
+            for (int w = 1; w < WPB; ++w)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[e >> 1][e & 1][q] += red[wave + w][e * 16 + q][lane];
+        }
+    }
+    if (want_db && ib == 0) {
+        sdb0 += __shfl_xor(sdb0, 32);
+        sdb1 += __shfl_xor(sdb1, 32);
+        if (hi == 0) { redb[wave][0][r] = sdb0; redb[wave][1][r] = sdb1; }
+    }
+    if (want_db) __syncthreads();
+    if (want_db && ib == 0 && sub == 0 && hi == 0) {
+        float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) { b0 += redb[wave + w][0][r]; b1 += redb[wave + w][1][r]; }
+        *reinterpret_cast<float2*>(part + (size_t)blockIdx.x * pn + (size_t)O * I + ob * 64 + 2 * r) = make_float2(b0, b1);
+    }
+    if (sub == 0) {
+        float* pt = part + (size_t)blockIdx.x * pn;
+#pragma unroll
+        for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = ob * 64 + 2 * drow32(q, hi) + ea;
+                *reinterpret_cast<float2*>(pt + (size_t)o * I + ib * 64 + 2 * r) = make_float2(acc[ea][0][q], acc[ea][1][q]);
+            }
+    }
+}
+
 // The same reduction for a NARROW output side (O <= 16: the attention-bias and coordinate-head linears, modules.py:300-304,
 // model.py:364-369): one lane per input column, the O values of dy per row broadcast, rows dealt to slabs and to the four waves.
 template <int OMAX>
@@ -1008,7 +1157,9 @@ extern "C" size_t prd_linear_wgrad_workspace(long long rows, int O, int I) {
 }
 
 extern "C" int prd_linear_wgrad(float* dw, float* db, const float* dy, const float* x, long long rows, int O, int I, int lddy, int ldx,
-                                float* ws, size_t ws_bytes, hipStream_t stream) {
+                                float* ws, size_t ws_bytes, int arith, hipStream_t stream) {
+    PRD_SPLIT_ARITH(arith);
+    (void)tune;
     if (!dw || !dy || !x || !ws || rows <= 0 || O <= 0 || I <= 0) return PRD_ERR_ARG;
     const bool narrow = O <= 16;
     if ((!narrow && (O % 64)) || (I % 64) || O > 256 || I > 256) return PRD_ERR_UNSUPPORTED;
@@ -1029,7 +1180,11 @@ extern "C" int prd_linear_wgrad(float* dw, float* db, const float* dy, const flo
         const int nblk = (O / 64) * (I / 64);
         const int per = (nblk % 4 == 0) ? 4 : ((nblk % 2 == 0) ? 2 : 1);     // 64x64 blocks per workgroup
         dim3 grid((unsigned)slabs, nblk / per);
-        if (per == 4) hipLaunchKernelGGL(linear_wgrad_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+        if (arith == PRD_ARITH_SPLIT16) {
+            if (per == 4) hipLaunchKernelGGL(linear_wgrad_h2_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+            else if (per == 2) hipLaunchKernelGGL(linear_wgrad_h2_kernel<2>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+            else hipLaunchKernelGGL(linear_wgrad_h2_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
+        } else if (per == 4) hipLaunchKernelGGL(linear_wgrad_kernel<4>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
         else if (per == 2) hipLaunchKernelGGL(linear_wgrad_kernel<2>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
         else hipLaunchKernelGGL(linear_wgrad_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
     }

@@ -155,14 +155,14 @@ int main(void) {
     EXPECT(prd_ln_rows_bwd(0, p, p, 0, 8, 64, s), PRD_ERR_ARG);
     EXPECT((int)(prd_linear_wgrad_workspace(102400, 256, 64) != (size_t)200 * (256 * 64 + 256) * 4), 0);
     EXPECT((int)prd_linear_wgrad_workspace(0, 256, 64), 0);
-    EXPECT(prd_linear_wgrad(0, p, p, p, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
-    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 96, 64, 96, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);       /* O neither <= 16 nor a multiple of 64 */
-    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 65, 64, p, 1 << 20, s), PRD_ERR_ALIGN);            /* odd row pitch */
-    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
-    EXPECT(prd_linear_wgrad(p, p, p + 1, p, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ALIGN);        /* dy 4-byte aligned only: the wide kernel loads 8 bytes */
-    EXPECT(prd_linear_wgrad(p, p, p, p + 1, 100, 64, 64, 64, 64, p, 1 << 20, s), PRD_ERR_ALIGN);
-    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p + 1, 1 << 20, s), PRD_ERR_ALIGN);        /* partials workspace */
-    EXPECT(prd_linear_wgrad(p, p, p + 1, p, 100, 4, 64, 4, 64, p, 16, s), PRD_ERR_WORKSPACE);            /* narrow form: scalar loads, no alignment demand */
+    EXPECT(prd_linear_wgrad(0, p, p, p, 100, 64, 64, 64, 64, p, 1 << 20, 0, s), PRD_ERR_ARG);
+    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 96, 64, 96, 64, p, 1 << 20, 0, s), PRD_ERR_UNSUPPORTED);       /* O neither <= 16 nor a multiple of 64 */
+    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 65, 64, p, 1 << 20, 0, s), PRD_ERR_ALIGN);            /* odd row pitch */
+    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p, 16, 0, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_linear_wgrad(p, p, p + 1, p, 100, 64, 64, 64, 64, p, 1 << 20, 0, s), PRD_ERR_ALIGN);        /* dy 4-byte aligned only: the wide kernel loads 8 bytes */
+    EXPECT(prd_linear_wgrad(p, p, p, p + 1, 100, 64, 64, 64, 64, p, 1 << 20, 0, s), PRD_ERR_ALIGN);
+    EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p + 1, 1 << 20, 0, s), PRD_ERR_ALIGN);        /* partials workspace */
+    EXPECT(prd_linear_wgrad(p, p, p + 1, p, 100, 4, 64, 4, 64, p, 16, 0, s), PRD_ERR_WORKSPACE);            /* narrow form: scalar loads, no alignment demand */
     EXPECT(prd_embed_wgrad(0, (const long long*)ibuf, p, 100, 8, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
     EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 200, 64, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);   /* more than 128 table rows */
     EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 8, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);

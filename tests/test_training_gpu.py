@@ -164,6 +164,53 @@ def test_triangle_attention_backward_kernels(mode, P, b, N, gemm_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("O,I", [(256, 64), (64, 256), (64, 64), (128, 64)])
+@pytest.mark.parametrize("profile", ["tiny", "huge", "rising", "falling", "spike", "zeros_then_data", "all_zero"])
+def test_linear_weight_gradient_range_of_the_gradient(O, I, profile):
+    """The split-16 weight-gradient kernel multiplies dy by a running power of two per wave (fp16 has five exponent bits, gradients no
+    fixed magnitude).  Gradients of 1e-30 and 1e+20, magnitudes that rise or fall by sixty octaves along the rows of a slab (the
+    scale is lowered on the fly / stays where the large rows put it), a single row 2^40 above the rest, leading all-zero rows, an
+    all-zero gradient: the result against a float64 reduction, relative to the largest entry of dW."""
+    from protein_redesign_amd import _lib, ops
+    rows = 24000
+    g = torch.Generator().manual_seed(O + I + len(profile))
+    dy = torch.randn(rows, O, generator=g, dtype=torch.float64)
+    x = torch.randn(rows, I, generator=g)
+    t = torch.linspace(0, 1, rows, dtype=torch.float64).view(-1, 1)
+    if profile == "tiny":
+        dy = dy * 1e-30
+    elif profile == "huge":
+        dy = dy * 1e20
+    elif profile == "rising":
+        dy = dy * torch.exp2(-30 + 60 * ((t * 32) % 1.0))        # sixty octaves up inside every ~750-row stretch (slabs are ~94 rows)
+    elif profile == "falling":
+        dy = dy * torch.exp2(30 - 60 * ((t * 32) % 1.0))
+    elif profile == "spike":
+        dy[rows // 2 + 5] *= 2.0 ** 40
+    elif profile == "zeros_then_data":
+        dy[:4000] = 0
+    elif profile == "all_zero":
+        dy = dy * 0
+    dy = dy.float().cuda()
+    x = x.cuda()
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES["split16"]) == 0
+    try:
+        got, db = ops.linear_wgrad(dy, x, bias=True)
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+    want = dy.double().t() @ x.double()
+    wantb = dy.double().sum(0)
+    assert torch.isfinite(got).all() and torch.isfinite(db).all()
+    if profile == "all_zero":
+        assert float(got.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+        return
+    assert float((got.double() - want).norm() / want.norm()) < 2e-6
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-6
+    assert float((db.double() - wantb).norm() / wantb.norm()) < 2e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ending", [False, True])
 @pytest.mark.parametrize("P,b,N,gscale", [(64, 2, 45, 1.0), (32, 1, 100, 1e-6), (64, 1, 320, 1e-4), (64, 1, 384, 1e3), (64, 2, 33, 0.0)])
 def test_triangle_attention_backward_core_split16_vs_fp32(P, b, N, gscale, ending):
@@ -207,9 +254,9 @@ def test_triangle_attention_backward_core_split16_vs_fp32(P, b, N, gscale, endin
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,O,I", [(40 * 40 * 2, 64, 64), (102400, 256, 64), (20000, 64, 256), (9001, 128, 128), (8192, 256, 256),
                                       (102400, 4, 64), (20001, 1, 64), (9000, 12, 128)])
-def test_linear_weight_gradient_kernel(rows, O, I):
-    """prd_linear_wgrad (slab partials on fp32 MFMA + ordered reduction) against a float64 reduction; also through strided views
-    (a column slice of a wider tensor, as the attention backward passes them)."""
+def test_linear_weight_gradient_kernel(rows, O, I, gemm_mode):
+    """prd_linear_wgrad (slab partials on fp32 MFMA, or in split-16 mode on the 16-bit matrix pipe, + ordered reduction) against a
+    float64 reduction; also through strided views (a column slice of a wider tensor, as the attention backward passes them)."""
     from protein_redesign_amd import ops
     g = torch.Generator().manual_seed(rows + O)
     wide = torch.randn(rows, O + 64, generator=g).cuda()

@@ -46,7 +46,8 @@ def main():
     rows.sort(key=lambda r: -r[0])
     tot = sum(r[0] for r in rows)
     print(f"total self device time {tot / 1e3:.2f} ms")
-    for t, n, k, sh, st in rows[:45]:
+    rows = [r for r in rows if r[2].startswith("aten::") or "Backward" in r[2] or "Fn" in r[2]]
+    for t, n, k, sh, st in rows[:60]:
         print(f"{t / 1e3:8.3f} ms {n:4d}  {k[:40]:40s} {sh:70s} {' <- '.join(x.split('/')[-1][:60] for x in st)}")
 
 
