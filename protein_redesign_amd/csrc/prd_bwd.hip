@@ -781,10 +781,12 @@ __global__ __launch_bounds__(256) void linear_wgrad_h2_kernel(float* __restrict_
             sdb0 += ca[u].x;
             sdb1 += ca[u].y;
         }
+        // (the test is per lane, one ballot; the wave maximum is only formed when some lane asks for a new scale)
+        if (__any(mx > 0.f && mx < 3.0e38f && (cur == 0.f || mx * cur > 16384.f))) {      // rare after the first group
+            mx = mx < 3.0e38f ? mx : 0.f;
 #pragma unroll
-        for (int o_ = 32; o_ > 0; o_ >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o_));
-        mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
-        if (mx > 0.f && mx < 3.0e38f && (cur == 0.f || mx * cur > 16384.f)) {      // wave-uniform; rare after the first group
+            for (int o_ = 32; o_ > 0; o_ >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o_));
+            mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
             int e = 7 - __builtin_amdgcn_frexp_expf(mx);    // mx * 2^e in [64, 128)
             e = e > 120 ? 120 : (e < -120 ? -120 : e);
             const float nw = __builtin_ldexpf(1.0f, e);

@@ -231,7 +231,11 @@ def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int
     sa = 1.0 / math.sqrt(len(atom_tabs))
     acc = 0.0
     for f, tab in enumerate(atom_tabs):
-        acc = acc + sa * F.embedding(batch["atom_feats"][..., f], tab)
+        idx = batch["atom_feats"][..., f]
+        # on the GPU with a backward coming: one-hot @ table (its table gradient is a small dense GEMM; torch's embedding backward
+        # sorts and scatter-adds: 58 us per table for 640 rows)
+        acc = acc + sa * ((F.one_hot(idx, tab.shape[0]).to(tab.dtype) @ tab) if (idx.is_cuda and torch.is_grad_enabled() and tab.requires_grad)
+                          else F.embedding(idx, tab))
     single = am.unsqueeze(-1) * acc + rm.unsqueeze(-1) * (
         torch.relu(F.linear(ln(seq_t), w_rt)) + F.linear(ln(batch["residue_esm"]), w_esm))
     sb = 1.0 / math.sqrt(len(bond_tabs))
