@@ -115,15 +115,18 @@ _GEMM_WS = {}
 
 
 def gemm_workspace(device, nbytes: int) -> torch.Tensor:
-    """Persistent scratch of the K-slab GEMM path (partial tiles; at most a few tens of MB), one buffer per (device, stream): the
-    launches that use it are ordered on that stream, and a captured graph keeps the address."""
+    """Scratch of the K-slab GEMM path (partial tiles; at most a few tens of MB).  Eager launches: one persistent buffer per
+    (device, stream) -- the launches that use it are ordered on that stream.  Under graph capture: a fresh tensor per call from the
+    capturing graph's own memory pool (the allocator reuses it between the GEMMs of the captured step, which are ordered on the
+    capture stream, and the graph keeps the addresses alive exactly as long as it exists; a cached buffer would outlive the graph
+    it was carved from)."""
     dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    n = max(1, (nbytes + 3) // 4)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, device=f"cuda:{dev}", dtype=F32)
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)     # per stream: launches on different streams must not share partials
     buf = _GEMM_WS.get(key)
-    n = max(1, (nbytes + 3) // 4)
     if buf is None or buf.numel() < n:
-        if buf is not None and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("gemm workspace would have to grow during graph capture; run one eager step first")
         buf = _GEMM_WS[key] = torch.empty(n, device=f"cuda:{dev}", dtype=F32)
     return buf
 
