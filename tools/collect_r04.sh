@@ -47,6 +47,12 @@ python tools/op_bench.py > $OUT/${TAG}_op_bench.txt 2>&1
 python tools/train_bench.py > $OUT/${TAG}_train_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_train_trace -o t -- python3 tools/train_bench.py --steps 3 --warmup 2 > gpurun_out/${TAG}_train_trace.log 2>&1
 python tools/rocprof_summary.py $(db gpurun_out/${TAG}_train_trace) $OUT/${TAG}_train_kernel_stats.txt > /dev/null
+PRD_TRI_ATTN_BWD_V2=0 python tools/train_bench.py > $OUT/${TAG}_train_bench_fp32_bwd_core.txt 2>&1      # same-box A/B: the fp32-MFMA backward core
+python tools/train_op_profile.py > $OUT/${TAG}_train_op_profile.txt 2>&1
+python tools/bwd_core_bench.py 2 320 > $OUT/${TAG}_bwd_core_bench.txt 2>&1
+python tools/bwd_core_bench.py 1 384 >> $OUT/${TAG}_bwd_core_bench.txt 2>&1
+bash tools/bwd_pmc.sh ${TAG} > /dev/null 2>&1
+cp gpurun_out/${TAG}_bwd_pmc.txt $OUT/${TAG}_bwd_core_pmc.txt
 python tools/trajectory_conditioning.py > $OUT/${TAG}_trajectory.txt 2>&1
 ls -la $OUT
 rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_pmc_* gpurun_out/${TAG}_n769_trace gpurun_out/${TAG}_n769_pmc_* gpurun_out/${TAG}_train_trace
