@@ -14,6 +14,7 @@
 // Same "lane owns a pair row" scheme as the forward row kernels (prd_common.h); fp32 MFMA row GEMMs (gradients are not on the
 // sampling hot path); the transposed weights are passed in by the caller.
 #include "prd_common.h"
+#include <type_traits>
 #include "../../include/prd_hip.h"
 #include <mutex>
 
@@ -1134,6 +1135,123 @@ extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float
     } else {
         PRD_BWD_SET_LDS(tri_attn_bwd_core_kernel<32>);
         hipLaunchKernelGGL(tri_attn_bwd_core_kernel<32>, dim3(grid), dim3(nthreads), lds, stream, dqkvg, dog, pair, mask, wq, wk, wv, wg, bg, b, N, npad, H, ending);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- a linear at every pair position as a ROW kernel (the GEMMs of the training backward with 2e5 rows and K, N <= 256) --------
+// prd_gemm's tile kernels give one 64 x 64 tile (one K chunk!) to a workgroup: at K = 64 that is a load -> split -> LDS -> MFMA ->
+// store chain without anything to overlap it with, 2 TB/s for K = 64 -> N = 256.  Here the weights (<= 64 KB as fp16 hi | lo) stay
+// in LDS for the life of a persistent workgroup and every wave streams 32-row blocks through them: y = act(LN?(x) W^T + bias),
+// optionally zeroed where mask_pos <= 0 (the ReLU backward from recomputed activations).  Shapes: (K, OUT) = (64, 64), (64, 256),
+// (256, 64).  (A fused LayerNorm-backward tail for the 256 -> 64 form was measured no faster than this kernel + ln_rows_bwd64 --
+// 77.8 vs 47.6 + 30 us -- and is not built.)
+namespace {
+template <int K, int NW>
+__global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
+    float* __restrict__ out, float* __restrict__ xn_out, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ mask_pos, long rows, int OUT, int ln_in, int act) {
+    extern __shared__ __attribute__((aligned(16))) float smem_pl[];
+    u32x4* Wimg = reinterpret_cast<u32x4*>(smem_pl);
+    float* bl = smem_pl + (size_t)OUT * K;
+    const int NT = NW * 64;
+    if (OUT == 64) stage_weight_h2<K>(Wimg, w, 64, K, threadIdx.x, NT, H2_WSCALE);
+    else stage_weight_h2<K>(Wimg, w, 256, K, threadIdx.x, NT, H2_WSCALE);
+    stage_vec_cll(bl, bias, OUT, threadIdx.x, NT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long ntask = (rows + 31) / 32;
+    WaveTasks tasks(nullptr, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        const long row = task * 32 + r;
+        const bool valid = row < rows;
+        const long rowc = valid ? row : 0;
+        if constexpr (K == 64) {
+            float xv[32];
+            load_row_cll<64>(x + rowc * 64, hi, valid, xv);
+            if (ln_in) {
+                ln_cll<32>(xv);
+                if (xn_out) store_row_cll<64>(xn_out + rowc * 64, hi, valid, xv);
+            }
+            u32x4 ps[2][4];
+            split2h_cll<32>(xv, ps);
+            for (int j = 0; j < OUT / 64; ++j) {
+                f32x16 acc[2];
+                zero_acc(acc);
+                rowgemm_h2<64, 2>(Wimg, OUT, 64 * j, ps, acc, r, hi);
+                float y[32];
+#pragma unroll
+                for (int s_ = 0; s_ < 32; ++s_) {
+                    float v = acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bl[hi * (OUT / 2) + 32 * j + s_];
+                    y[s_] = act == 1 ? fmaxf(v, 0.f) : v;
+                }
+                if (mask_pos) {
+                    float m[32];
+                    load_row_cll<64>(mask_pos + rowc * OUT + 64 * j, hi, valid, m);
+#pragma unroll
+                    for (int s_ = 0; s_ < 32; ++s_) y[s_] = m[s_] > 0.f ? y[s_] : 0.f;
+                }
+                store_row_cll<64>(out + rowc * OUT + 64 * j, hi, valid, y);
+            }
+        } else {                                        // K = 256 -> 64 outputs, the row in four 64-channel pieces
+            f32x16 acc[2];
+            zero_acc(acc);
+            auto piece = [&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                float xv[32];
+                load_row_cll<64>(x + rowc * 256 + 64 * c, hi, valid, xv);
+                u32x4 ps[2][4];
+                split2h_cll<32>(xv, ps);
+                rowgemm_h2_part<256, 2, 4 * c, 4 * c + 4>(Wimg, 64, 0, ps, acc, r, hi);
+            };
+            piece(std::integral_constant<int, 0>{});
+            piece(std::integral_constant<int, 1>{});
+            piece(std::integral_constant<int, 2>{});
+            piece(std::integral_constant<int, 3>{});
+            float y[32];
+#pragma unroll
+            for (int s_ = 0; s_ < 32; ++s_) {
+                const float v = acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bl[hi * 32 + s_];
+                y[s_] = act == 1 ? fmaxf(v, 0.f) : v;
+            }
+            if (mask_pos) {
+                float m[32];
+                load_row_cll<64>(mask_pos + rowc * 64, hi, valid, m);
+#pragma unroll
+                for (int s_ = 0; s_ < 32; ++s_) y[s_] = m[s_] > 0.f ? y[s_] : 0.f;
+            }
+            store_row_cll<64>(out + rowc * 64, hi, valid, y);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int prd_pair_linear_supported(int K, int OUT, int arith) {
+    if (arith < 0 || (arith & 0xff) != PRD_ARITH_SPLIT16) return 0;
+    return ((K == 64 && (OUT == 64 || OUT == 256)) || (K == 256 && OUT == 64)) ? 1 : 0;
+}
+
+extern "C" int prd_pair_linear(float* out, const float* x, const float* w, const float* bias, long long rows, int K, int OUT,
+                               int ln_in, float* xn_out, int act, const float* mask_pos, int arith, hipStream_t stream) {
+    if (!out || !x || !w || rows <= 0 || act < 0 || act > 1) return PRD_ERR_ARG;
+    if (!prd_pair_linear_supported(K, OUT, arith)) return PRD_ERR_UNSUPPORTED;
+    if ((ln_in && K != 64) || (xn_out && !ln_in)) return PRD_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xn_out) |
+         reinterpret_cast<uintptr_t>(mask_pos)) & 15)
+        return PRD_ERR_ALIGN;
+    constexpr int NWP = 8;
+    const size_t lds = ((size_t)OUT * K + OUT) * sizeof(float);
+    const long ntask = (rows + 31) / 32;
+    const int grid = grid_for(ntask, NWP, 256);          // one persistent workgroup per CU (the register budget allows two waves per SIMD)
+    if (K == 64) {
+        PRD_BWD_SET_LDS((pair_linear_rows_kernel<64, NWP>));
+        hipLaunchKernelGGL((pair_linear_rows_kernel<64, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, out, xn_out, x, w, bias, mask_pos,
+                           (long)rows, OUT, ln_in, act);
+    } else {
+        PRD_BWD_SET_LDS((pair_linear_rows_kernel<256, NWP>));
+        hipLaunchKernelGGL((pair_linear_rows_kernel<256, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, out, xn_out, x, w, bias, mask_pos,
+                           (long)rows, OUT, ln_in, act);
     }
     return (int)hipGetLastError();
 }

@@ -416,7 +416,9 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
     if og is None:                                                                              # forward recompute: gated head outputs
         lse = torch.empty(b * N, H, N, 2, device=dev, dtype=F32) if tri_attn_lse_supported(N, P) else None
         og = tri_attn_core(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=ending, lse=lse)
-    dog = linear(dy, wo.t().contiguous())                                                         # d og = dy W_o
+    dog = pair_linear(dy.view(-1, P), wo.t())                                                     # d og = dy W_o
+    if dog is None:
+        dog = linear(dy, wo.t().contiguous())
     dqkvg = torch.empty(b, N, N, 4, HC, device=dev, dtype=F32)
     x = None
     if lib().prd_get_gemm_mode() == 1 and TRI_ATTN_BWD_V2 and lib().prd_tri_attn_bwd_core_v2_supported(N, P) == 1:
@@ -428,7 +430,9 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
         check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
                                           int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core")
     wcat_t = torch.cat([wq, wk, wv, wg], dim=0).t().contiguous()                                  # [P, 4 HC]
-    dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat_t)                                             # gradient of LN(pair)
+    dxn = pair_linear(dqkvg.view(-1, 4 * HC), wcat_t)                                            # gradient of LN(pair)
+    if dxn is None:
+        dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat_t)
     dpair = torch.empty_like(pair)
     check(lib().prd_ln_rows_bwd(dptr(dpair), dptr(dxn), dptr(pair), dptr(dy) if residual else None, b * N * N, P, stream()), "prd_ln_rows_bwd")
     x = (x if x is not None else layer_norm(pair.contiguous())).view(-1, P)
@@ -440,6 +444,24 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
 
 
 WGRAD_MIN_ROWS = 8192
+
+
+PAIR_LINEAR = os.environ.get("PRD_PAIR_LINEAR", "1") != "0"      # 0: the activation-gradient GEMMs of the backward through prd_gemm (A/B)
+
+
+def pair_linear(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ln_in: bool = False,
+                xn_out: Optional[torch.Tensor] = None, act: int = 0, relu_mask: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """act(LN?(x2) w^T + bias) over the rows of x2 [rows, K] on the row kernel prd_pair_linear (weights resident in LDS, rows
+    streamed), with ``relu_mask`` zeroed where relu_mask <= 0.  Returns None where the row kernel does not serve the call (shape,
+    arithmetic, few rows, strided input): the caller then uses ``linear``."""
+    rows, K = x2.shape
+    OUT = w.shape[0]
+    if not (PAIR_LINEAR and x2.is_cuda and x2.is_contiguous() and rows >= WGRAD_MIN_ROWS and lib().prd_pair_linear_supported(K, OUT) == 1):
+        return None
+    out = torch.empty(rows, OUT, device=x2.device, dtype=F32)
+    check(lib().prd_pair_linear(dptr(out), dptr(x2), dptr(w.contiguous()), dptr(bias), rows, K, OUT, int(ln_in), dptr(xn_out), act,
+                                dptr(relu_mask), stream()), "prd_pair_linear")
+    return out
 
 
 def ln_rows_bwd(dy2: torch.Tensor, x2: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:

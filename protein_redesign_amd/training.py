@@ -86,10 +86,17 @@ class PairTransitionFn(torch.autograd.Function):
             x2 = x.detach().contiguous().view(-1, P)
             dy2 = dy.contiguous().view(-1, P)
             xn = torch.empty_like(x2)
-            h = ops.linear(x2, w1, b1, act=1, ln_a=True, ln_a_out=xn)          # [rows, HID]; LN(x) rows on the side
-            g = ops.linear(dy2, w2.t().contiguous(), relu_mask=h)              # (dy W2) * [h > 0]
-            dxn = ops.linear(g, w1.t().contiguous())                           # [rows, P]
-            dx = ops.ln_rows_bwd(dxn, x2, res=dy2 if ctx.residual else None)   # (+ dy: the residual path)
+            res = dy2 if ctx.residual else None                                # (+ dy: the residual path)
+            h = ops.pair_linear(x2, w1, b1, ln_in=True, xn_out=xn, act=1)      # [rows, HID]; LN(x) rows on the side
+            if h is None:
+                h = ops.linear(x2, w1, b1, act=1, ln_a=True, ln_a_out=xn)
+            g = ops.pair_linear(dy2, w2.t(), relu_mask=h)                      # (dy W2) * [h > 0]
+            if g is None:
+                g = ops.linear(dy2, w2.t().contiguous(), relu_mask=h)
+            dxn = ops.pair_linear(g, w1.t())                                   # [rows, P]
+            if dxn is None:
+                dxn = ops.linear(g, w1.t().contiguous())
+            dx = ops.ln_rows_bwd(dxn, x2, res=res)
             dw2, db2 = ops.linear_wgrad(dy2, h, bias=True)
             dw1, db1 = ops.linear_wgrad(g, xn, bias=True)
             dx = dx.view_as(x)

@@ -153,6 +153,13 @@ int main(void) {
     EXPECT(prd_tri_attn_bwd_core_v2_supported(384, 64), 1);
     EXPECT(prd_tri_attn_bwd_core_v2_supported(385, 64), 0);
     EXPECT(prd_ln_rows_bwd(0, p, p, 0, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_linear(0, p, p, p, 100, 64, 64, 0, 0, 0, 0, 1, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 128, 0, 0, 0, 0, 1, s), PRD_ERR_UNSUPPORTED);        /* (K, OUT) not served */
+    EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, s), PRD_ERR_UNSUPPORTED);          /* fp32 arithmetic: the caller's GEMM */
+    EXPECT(prd_pair_linear(p, p, p, p, 100, 256, 64, 1, 0, 0, 0, 1, s), PRD_ERR_ARG);                 /* LayerNorm of 256-wide rows */
+    EXPECT(prd_pair_linear(p, p + 1, p, p, 100, 64, 64, 0, 0, 0, 0, 1, s), PRD_ERR_ALIGN);
+    EXPECT(prd_pair_linear_supported(256, 64, 1), 1);
+    EXPECT(prd_pair_linear_supported(256, 256, 1), 0);
     EXPECT((int)(prd_linear_wgrad_workspace(102400, 256, 64) != (size_t)200 * (256 * 64 + 256) * 4), 0);
     EXPECT((int)prd_linear_wgrad_workspace(0, 256, 64), 0);
     EXPECT(prd_linear_wgrad(0, p, p, p, 100, 64, 64, 64, 64, p, 1 << 20, 0, s), PRD_ERR_ARG);

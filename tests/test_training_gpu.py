@@ -164,6 +164,48 @@ def test_triangle_attention_backward_kernels(mode, P, b, N, gemm_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows", [8192 + 7, 204800])
+@pytest.mark.parametrize("case", ["64to64", "64to256_ln_relu", "64to256_mask", "256to64"])
+def test_pair_position_linear_row_kernel(case, rows):
+    """prd_pair_linear (weights resident in LDS, rows streamed, split-16 arithmetic) against float64: the activation-gradient GEMMs of
+    the attention / transition backward with their fused neighbours -- LayerNorm of the input rows (and the normalised rows as a
+    side output), bias + ReLU, the ReLU mask from recomputed activations; a row count that is not a multiple of the 32-row task,
+    and one where every wave runs several tasks; bit-identical between runs."""
+    from protein_redesign_amd import _lib, ops
+    g = torch.Generator().manual_seed(len(case) + rows)
+    K, OUT = (256, 64) if case.startswith("256") else ((64, 256) if "256" in case else (64, 64))
+    x = torch.randn(rows, K, generator=g) * 1.7 + 0.3
+    w = torch.randn(OUT, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(OUT, generator=g) * 0.1 if "relu" in case else None
+    hmask = torch.randn(rows, OUT, generator=g).clamp_min(0) if "mask" in case else None
+    xd = x.double()
+    if "ln" in case:
+        xd = torch.nn.functional.layer_norm(xd, (K,))
+    want = xd @ w.double().t() + (bias.double() if bias is not None else 0)
+    if "relu" in case:
+        want = want.clamp_min(0)
+    if hmask is not None:
+        want = want * (hmask.double() > 0)
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES["split16"]) == 0
+    try:
+        xn = torch.empty(rows, K, device=DEV) if "ln_relu" in case else None
+        dev_args = (x.to(DEV), w.to(DEV), bias.to(DEV) if bias is not None else None)
+        kw = dict(ln_in="ln_relu" in case, xn_out=xn, act=1 if "relu" in case else 0, relu_mask=hmask.to(DEV) if hmask is not None else None)
+        got = ops.pair_linear(*dev_args, **kw)
+        assert got is not None and got.shape == (rows, OUT)
+        for _ in range(3):
+            assert torch.equal(got, ops.pair_linear(*dev_args, **kw))
+        assert _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES["fp32"]) == 0
+        assert ops.pair_linear(x.to(DEV), w.to(DEV)) is None           # fp32 arithmetic: the caller's GEMM path
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+    assert float((got.double().cpu() - want).norm() / want.norm()) < 2e-6
+    if xn is not None:
+        assert float((xn.double().cpu() - xd).norm() / xd.norm()) < 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("O,I", [(256, 64), (64, 256), (64, 64), (128, 64)])
 @pytest.mark.parametrize("profile", ["tiny", "huge", "rising", "falling", "spike", "zeros_then_data", "all_zero"])
 def test_linear_weight_gradient_range_of_the_gradient(O, I, profile):

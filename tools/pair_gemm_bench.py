@@ -38,3 +38,16 @@ for K, N, ln in ((64, 64, False), (64, 256, False), (64, 256, True), (256, 64, F
         except Exception as e:  # noqa: BLE001
             line += f"  hint {th}: {type(e).__name__}"
     print(line)
+
+print("row kernel (prd_pair_linear):")
+for K, N, ln in ((64, 64, False), (64, 256, False), (64, 256, True), (256, 64, False)):
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    t = bench(lambda: ops.pair_linear(x, w, ln_in=ln))
+    print(f"K={K:3d} N={N:3d} ln={int(ln)}: {t:6.1f} us")
+x = torch.randn(M, 256, generator=g).cuda()
+w = (torch.randn(64, 256, generator=g) / 16).cuda()
+dy = torch.randn(M, 64, generator=g).cuda()
+h = torch.randn(M, 256, generator=g).cuda()
+w2 = (torch.randn(256, 64, generator=g) / 8).cuda()
+print(f"K= 64 N=256 + ReLU mask: {bench(lambda: ops.pair_linear(dy, w2, relu_mask=h)):6.1f} us")
