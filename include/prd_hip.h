@@ -274,6 +274,9 @@ int prd_tri_attn_bwd_core_v2_supported(int N, int P);
 int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
                              const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, const float* lse,
                              float* x_out, int ending, int b, int N, int P, int H, int c, hipStream_t stream);
+/* out[b][i][p][j] = dy[b][i][j][p] + dy[b][j][i][p] (dy [b,N,N,P] -> out [b,N,P,N]): the symmetrised, transposed gradient the
+ * backward of the outer-linear update (modules.py:283-287) contracts with LN(single) over j.  P in {32, 64}. */
+int prd_sym_transpose(float* out, const float* dy, int b, int N, int P, hipStream_t stream);
 /* A linear at every pair position as a row kernel (the activation-gradient GEMMs of the training backward: 2e5 rows, K and OUT
  * at most 256; autograd of nn.Linear over [b,N,N,*], modules.py:236-243, 321-326): out[row][0..OUT) = act(LN?(x[row]) W^T + bias),
  * W [OUT][K] as in nn.Linear.  ln_in: LayerNorm (no affine) of the x rows first (K = 64), xn_out (optional) receives them.

@@ -1057,6 +1057,57 @@ __global__ __launch_bounds__(256) void tri_mul_bwd_operands_kernel(float* __rest
     }
 }
 
+// out[b][i][p][j] = dy[b][i][j][p] + dy[b][j][i][p]: the symmetrised gradient of the outer-linear update (modules.py:283-287:
+// out[i][j] depends on x_i x_j and on u_i - u_j) in the [b, N P, N] row layout its backward GEMM contracts over j.  One workgroup
+// per (b, i, 64 positions j): both reads are 4 P-byte rows, the transpose goes through a 64 x 65 LDS tile.
+__global__ __launch_bounds__(256) void sym_transpose_kernel(float* __restrict__ out, const float* __restrict__ dy, int N, int P, int T, long ntask) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x, c4 = 4 * (t & 15), rl = t >> 4;
+    for (long task = blockIdx.x; task < ntask; task += gridDim.x) {
+        const int tj = (int)(task % T);
+        const long bi = task / T;                       // b * N + i
+        const long bb = bi / N;
+        const int i = (int)(bi - bb * N), j0 = 64 * tj;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jl = rl + 16 * k, j = j0 + jl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < N && c4 < P) {
+                const float4 a = *reinterpret_cast<const float4*>(dy + (bi * N + j) * P + c4);
+                const float4 c = *reinterpret_cast<const float4*>(dy + ((bb * N + j) * N + i) * P + c4);
+                v = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+            }
+            tile[jl][c4] = v.x; tile[jl][c4 + 1] = v.y; tile[jl][c4 + 2] = v.z; tile[jl][c4 + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pl = rl + 16 * k, j = j0 + c4;    // out[(bi P + pl) N + j .. j + 3]
+            if (pl < P && j < N) {
+                float* dst = out + (bi * P + pl) * N + j;
+                const float v[4] = {tile[c4][pl], tile[c4 + 1][pl], tile[c4 + 2][pl], tile[c4 + 3][pl]};
+                if (j + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j + e < N) dst[e] = v[e];
+            }
+        }
+    }
+}
+
+extern "C" int prd_sym_transpose(float* out, const float* dy, int b, int N, int P, hipStream_t stream) {
+    if (!out || !dy || b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dy)) & 15) return PRD_ERR_ALIGN;
+    const int T = prd_ceil_div(N, 64);
+    const long ntask = (long)b * N * T;
+    const int grid = (int)(ntask < 256 * 8 ? ntask : 256 * 8);
+    hipLaunchKernelGGL(sym_transpose_kernel, dim3(grid), dim3(256), 0, stream, out, dy, N, P, T, ntask);
+    return (int)hipGetLastError();
+}
+
 extern "C" int prd_tri_mul_bwd_operands(float* ops, const float* AB, int b, int N, int P, hipStream_t stream) {
     if (!ops || !AB || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;

@@ -131,6 +131,12 @@ def gemm_workspace(device, nbytes: int) -> torch.Tensor:
     return buf
 
 
+def split16_gemm_ok(M: int, N: int, K: int) -> bool:
+    """True when an unbatched [M, K] x [N, K]^T GEMM lands on the split-16 tile kernel (gemm_h2: split-16 mode, K a multiple of 32,
+    at least 512 tiles of 64 x 64) -- otherwise the fp32 tile kernel would run, and for large shapes the BLAS is the better fallback."""
+    return lib().prd_get_gemm_mode() == 1 and K % 32 == 0 and ((M + 63) // 64) * ((N + 63) // 64) >= 512
+
+
 def slab_ok(M: int, N: int, K: int) -> bool:
     """True when a linear of this shape takes the K-slab path (prd_hip.h: prd_gemm_slab_ok) in the current arithmetic."""
     return lib().prd_gemm_slab_ok(M, N, K) == 1
@@ -444,6 +450,14 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
 
 
 WGRAD_MIN_ROWS = 8192
+
+
+def sym_transpose(dy: torch.Tensor) -> torch.Tensor:
+    """[b, N, N, P] -> [b, N, P, N]: out[b,i,p,j] = dy[b,i,j,p] + dy[b,j,i,p] (prd_sym_transpose)."""
+    b, N, _, P = dy.shape
+    out = torch.empty(b, N, P, N, device=dy.device, dtype=F32)
+    check(lib().prd_sym_transpose(dptr(out), dptr(dy), b, N, P, stream()), "prd_sym_transpose")
+    return out
 
 
 PAIR_LINEAR = os.environ.get("PRD_PAIR_LINEAR", "1") != "0"      # 0: the activation-gradient GEMMs of the backward through prd_gemm (A/B)

@@ -148,9 +148,18 @@ class OuterLinearFn(torch.autograd.Function):
             s2 = single.detach().contiguous()
             x = ops.layer_norm(s2)
             w1, w2 = w[:, :S], w[:, S:]
-            dyt = dy.transpose(1, 2)
-            dsym = (dy + dyt).permute(0, 1, 3, 2).reshape(b, N * P, N)
-            T = torch.bmm(dsym, x).view(b, N, P, S)
+            if dy.is_cuda and P in (32, 64) and LIBRARY_BWD:
+                dsym = ops.sym_transpose(dy.contiguous()).view(b, N * P, N)     # (dy + dy^T)[b, i, p, j] in one pass
+            else:
+                dsym = (dy + dy.transpose(1, 2)).permute(0, 1, 3, 2).reshape(b, N * P, N)
+            if dy.is_cuda and ops.split16_gemm_ok(N * P, S, N):                 # the split-16 tile GEMM, one launch per complex
+                xt = x.transpose(1, 2).contiguous()                             # [b, S, N]: B as [N_out][K]
+                T = torch.empty(b, N * P, S, device=dy.device, dtype=torch.float32)
+                for bb in range(b):
+                    ops.gemm(dsym[bb], xt[bb], T[bb], N * P, S, N, N, N, S)
+                T = T.view(b, N, P, S)
+            else:
+                T = torch.bmm(dsym, x).view(b, N, P, S)
             du = dy.sum(2) - dy.sum(1)                                          # [b, N, P]
             dx = (T * w1).sum(dim=2) + du @ w2
             dw1 = 0.5 * (T * x.unsqueeze(2)).sum(dim=(0, 1))

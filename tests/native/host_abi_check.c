@@ -158,6 +158,8 @@ int main(void) {
     EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, s), PRD_ERR_UNSUPPORTED);          /* fp32 arithmetic: the caller's GEMM */
     EXPECT(prd_pair_linear(p, p, p, p, 100, 256, 64, 1, 0, 0, 0, 1, s), PRD_ERR_ARG);                 /* LayerNorm of 256-wide rows */
     EXPECT(prd_pair_linear(p, p + 1, p, p, 100, 64, 64, 0, 0, 0, 0, 1, s), PRD_ERR_ALIGN);
+    EXPECT(prd_sym_transpose(0, p, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_sym_transpose(p, p, 1, 8, 48, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_pair_linear_supported(256, 64, 1), 1);
     EXPECT(prd_pair_linear_supported(256, 256, 1), 0);
     EXPECT((int)(prd_linear_wgrad_workspace(102400, 256, 64) != (size_t)200 * (256 * 64 + 256) * 4), 0);

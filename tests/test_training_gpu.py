@@ -164,6 +164,19 @@ def test_triangle_attention_backward_kernels(mode, P, b, N, gemm_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,N,P", [(2, 45, 64), (1, 130, 32), (2, 320, 64)])
+def test_symmetrised_transpose_kernel(b, N, P):
+    """prd_sym_transpose: out[b,i,p,j] = dy[b,i,j,p] + dy[b,j,i,p] (the operand of the outer-linear backward's GEMM), bit-exact
+    against the torch expression; N not a multiple of 4 / of the 64-position tile."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(N + P)
+    dy = torch.randn(b, N, N, P, generator=g).to(DEV)
+    want = (dy + dy.transpose(1, 2)).permute(0, 1, 3, 2).contiguous()
+    got = ops.sym_transpose(dy)
+    assert got.shape == (b, N, P, N) and torch.equal(got, want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows", [8192 + 7, 204800])
 @pytest.mark.parametrize("case", ["64to64", "64to256_ln_relu", "64to256_mask", "256to64"])
 def test_pair_position_linear_row_kernel(case, rows):
