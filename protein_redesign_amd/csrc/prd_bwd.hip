@@ -890,20 +890,39 @@ __global__ __launch_bounds__(256) void linear_wgrad_narrow_kernel(float* __restr
     float acc[OMAX];
 #pragma unroll
     for (int o = 0; o < OMAX; ++o) acc[o] = 0.f;
-    constexpr int U = 8;
+    constexpr int U = OMAX <= 4 ? 32 : 8;                  // rows in flight per wave: 256 B each -- the narrow form is a pure stream of x
+    const bool vec4 = O == 4 && lddy == 4 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
     for (long row = r0 + (long)U * wave; row < r1; row += 4 * U) {
         float xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = (row + u < r1) ? x[(row + u) * ldx + i] : 0.f;
+        for (int u = 0; u < U; ++u) {                           // unconditional loads from clamped rows (all in flight); rows past the slab x 0
+            const long rc = row + u < r1 ? row + u : r1 - 1;
+            xv[u] = x[rc * ldx + i] * (row + u < r1 ? 1.f : 0.f);
+        }
+        if (OMAX == 4 && vec4) {                                // the four values of a row in one 16-byte broadcast load
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 d4 = *reinterpret_cast<const float4*>(dy + (row + u < r1 ? row + u : r1 - 1) * 4);
+                const float z = row + u < r1 ? 1.f : 0.f;
+                const float dv[4] = {d4.x * z, d4.y * z, d4.z * z, d4.w * z};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    acc[o] += dv[o] * xv[u];
+                    sdb[o] += dv[o];
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float* dr = dy + (row + u < r1 ? row + u : r1 - 1) * lddy;         // wave-uniform address: a broadcast load
+            const float z = row + u < r1 ? 1.f : 0.f;
 #pragma unroll
             for (int o = 0; o < OMAX; ++o)
                 if (o < O) {
-                    const float dv = dr[o];
+                    const float dv = dr[o] * z;
                     acc[o] += dv * xv[u];
-                    sdb[o] += (row + u < r1) ? dv : 0.f;        // the same value in every lane
+                    sdb[o] += dv;                                // the same value in every lane
                 }
         }
     }
