@@ -164,6 +164,37 @@ def test_triangle_attention_backward_kernels(mode, P, b, N, gemm_mode):
 
 
 @pytest.mark.gpu
+def test_pair_track_backward_is_bit_reproducible(gemm_mode):
+    """The hand-written backward of the pair-track operators at the training shape (2 complexes of N = 320: every persistent
+    workgroup runs several tasks) gives bit-identical gradients when repeated -- no atomics, fixed reduction orders, and no
+    timing-dependent result anywhere (a fused LayerNorm-backward tail that failed exactly this check was not shipped)."""
+    from protein_redesign_amd import ops
+    b, N, P, H, c = 2, 320, 64, 4, 16
+    g = torch.Generator().manual_seed(5)
+    pair = torch.randn(b, N, N, P, generator=g).to(DEV)
+    dy = (torch.randn(b, N, N, P, generator=g) * 1e-3).to(DEV)
+    mask = torch.ones(b, N)
+    mask[1, N - 9:] = 0
+    mask = mask.to(DEV)
+
+    def w(*shape):
+        return (torch.randn(*shape, generator=g) / math.sqrt(shape[-1] if len(shape) == 2 else 16.0)).to(DEV)
+
+    ta = [w(64, P), w(64, P), w(64, P), w(64, P), w(64), w(P, 64), w(P)]
+    tm = [w(2 * P, P), w(2 * P), w(2 * P, P), w(2 * P), w(P, P), w(P), w(P, P), w(P)]
+
+    def run():
+        d1, g1 = ops.tri_attn_backward(dy, pair, mask, ta, H, c, ending=False, residual=True)
+        d2, g2 = ops.tri_mul_backward(dy, pair, mask, tm, incoming=True)
+        return [d1, *g1, d2, *g2]
+
+    first = [t.clone() for t in run()]
+    for _ in range(3):
+        for k, (a, r) in enumerate(zip(run(), first)):
+            assert torch.equal(a, r), f"output {k} differs between runs"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("b,N,P", [(2, 45, 64), (1, 130, 32), (2, 320, 64)])
 def test_symmetrised_transpose_kernel(b, N, P):
     """prd_sym_transpose: out[b,i,p,j] = dy[b,i,j,p] + dy[b,j,i,p] (the operand of the outer-linear backward's GEMM), bit-exact
