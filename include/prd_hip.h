@@ -302,10 +302,15 @@ int prd_linear_wgrad(float* dw, float* db, const float* dy, const float* x, long
                      float* ws, size_t ws_bytes, int arith, hipStream_t stream);
 /* Gradient of a small embedding table applied at every pair position (modules.py:35-71: bond-type, bond-distance and
  * relative-position tables): dtable[card][C] = sum over rows of dy[row][0..C) into row idx[row] (int64; indices outside
- * [0, card) are ignored).  card <= 128, C <= 64.  ws: prd_embed_wgrad_workspace(rows, card, C) bytes. */
+ * [0, card) are ignored).  card <= 128, C <= 64.  row_scale (optional) [rows]: dy[row] is multiplied by it (the mask factors the
+ * lookup is multiplied by in the forward).  ws: prd_embed_wgrad_workspace(rows, card, C) bytes. */
 size_t prd_embed_wgrad_workspace(long long rows, int card, int C);
-int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, long long rows, int card, int C, int lddy,
-                    float* ws, size_t ws_bytes, hipStream_t stream);
+int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, const float* row_scale, long long rows, int card, int C,
+                    int lddy, float* ws, size_t ws_bytes, hipStream_t stream);
+/* rbf[b][i][j][0..R) = mask[b][i] mask[b][j] exp(-(R-1)/2 (|z_i - z_j| - centers[r])^2): the radial-basis rows of the pair distances
+ * (modules.py:73-82, model.py:352-356) materialised for the weight gradient of the distance embedding (dW = dy^T rbf through
+ * prd_linear_wgrad); R a multiple of 4. */
+int prd_rbf_rows(float* out, const float* z, const float* centers, const float* mask, int b, int N, int R, hipStream_t stream);
 
 /* TriangleAttention (modules.py:236-243 -> 185-225): out = (residual ? pair : 0) + update(pair).
  * ws: b * N * N * 64 floats. */

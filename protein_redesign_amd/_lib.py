@@ -81,7 +81,8 @@ SIGNATURES = {
     "prd_linear_wgrad_workspace": [cll, ci, ci],
     "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, ci, vp],
     "prd_embed_wgrad_workspace": [cll, ci, ci],
-    "prd_embed_wgrad": [vp, vp, vp, cll, ci, ci, ci, vp, cz, vp],
+    "prd_embed_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, vp, cz, vp],
+    "prd_rbf_rows": [vp, vp, vp, vp, ci, ci, ci, vp],
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, ci, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, ci, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, ci, vp],

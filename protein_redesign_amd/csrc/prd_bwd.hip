@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_narrow_kernel(float* __restr
 // same long-K, tiny-output GEMM as the linear weight gradients (475 us per table); here a wave keeps a private [card][C] table in
 // LDS (lane = channel, one row at a time: no conflicts, fixed order), the four waves and then the slabs are summed in order.
 __global__ __launch_bounds__(256) void embed_wgrad_kernel(float* __restrict__ part, const long long* __restrict__ idx, const float* __restrict__ dy,
-                                                          long rows, int card, int C, int lddy, int rows_per_wg) {
+                                                          const float* __restrict__ row_scale, long rows, int card, int C, int lddy, int rows_per_wg) {
     extern __shared__ float etab[];                          // [4 waves][card][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* mine = etab + (size_t)wave * card * 64;
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void embed_wgrad_kernel(float* __restrict__ pa
         for (int u = 0; u < U; ++u) {
             const long rr = row + u < r1 ? row + u : r1 - 1;
             c[u] = (int)idx[rr];                             // wave-uniform
-            v[u] = (row + u < r1 && lane < C) ? dy[rr * lddy + lane] : 0.f;
+            v[u] = (row + u < r1 && lane < C) ? dy[rr * lddy + lane] * (row_scale ? row_scale[rr] : 1.0f) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -1114,6 +1114,40 @@ __global__ __launch_bounds__(256) void sym_transpose_kernel(float* __restrict__ 
             }
         }
     }
+}
+
+// rbf[b][i][j][r] = mask_i mask_j exp(-scale (|z_i - z_j| - center_r)^2), scale = (R - 1) / 2: the radial-basis features of
+// the pair distances (modules.py:73-82, model.py:352-356) as rows, for the weight gradient of the distance embedding
+// (prd_pair_init generates them on the fly and never stores them).  One thread per (pair position, four centres).
+__global__ __launch_bounds__(256) void rbf_rows_kernel(float* __restrict__ out, const float* __restrict__ z, const float* __restrict__ centers,
+                                                       const float* __restrict__ mask, long npos, int N, int R) {
+    const int r4 = R / 4;
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= npos * r4) return;
+    const long pos = tid / r4;
+    const int q = (int)(tid - pos * r4);
+    const long bi = pos / N;
+    const int j = (int)(pos - bi * N);
+    const long bb = bi / N;
+    const float* zi = z + bi * 3;
+    const float* zj = z + (bb * N + j) * 3;
+    const float dx = zi[0] - zj[0], dy = zi[1] - zj[1], dz = zi[2] - zj[2];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float m = mask[bi] * mask[bb * N + j];
+    const float scale = (R - 1) * 0.5f;
+    const float4 c = *reinterpret_cast<const float4*>(centers + 4 * q);
+    const float a0 = dist - c.x, a1 = dist - c.y, a2 = dist - c.z, a3 = dist - c.w;
+    *reinterpret_cast<float4*>(out + pos * R + 4 * q) =
+        make_float4(m * expf(-scale * a0 * a0), m * expf(-scale * a1 * a1), m * expf(-scale * a2 * a2), m * expf(-scale * a3 * a3));
+}
+
+extern "C" int prd_rbf_rows(float* out, const float* z, const float* centers, const float* mask, int b, int N, int R, hipStream_t stream) {
+    if (!out || !z || !centers || !mask || b <= 0 || N <= 0 || R <= 0) return PRD_ERR_ARG;
+    if (R % 4) return PRD_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(centers)) & 15) return PRD_ERR_ALIGN;
+    const long npos = (long)b * N * N, nthr = npos * (R / 4);
+    hipLaunchKernelGGL(rbf_rows_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, out, z, centers, mask, npos, N, R);
+    return (int)hipGetLastError();
 }
 
 extern "C" int prd_sym_transpose(float* out, const float* dy, int b, int N, int P, hipStream_t stream) {
@@ -1387,8 +1421,8 @@ extern "C" size_t prd_embed_wgrad_workspace(long long rows, int card, int C) {
     return (size_t)wgrad_slabs(rows) * card * C * sizeof(float);
 }
 
-extern "C" int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, long long rows, int card, int C, int lddy,
-                               float* ws, size_t ws_bytes, hipStream_t stream) {
+extern "C" int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, const float* row_scale, long long rows, int card, int C,
+                               int lddy, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (!dtable || !idx || !dy || !ws || rows <= 0 || card <= 0 || C <= 0 || lddy < C) return PRD_ERR_ARG;
     if (C > 64 || card > 128) return PRD_ERR_UNSUPPORTED;
     if (ws_bytes < prd_embed_wgrad_workspace(rows, card, C)) return PRD_ERR_WORKSPACE;
@@ -1397,7 +1431,7 @@ extern "C" int prd_embed_wgrad(float* dtable, const long long* idx, const float*
     const size_t lds = (size_t)4 * card * 64 * sizeof(float);
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)embed_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    hipLaunchKernelGGL(embed_wgrad_kernel, dim3((unsigned)slabs), dim3(256), lds, stream, ws, idx, dy, (long)rows, card, C, lddy, rows_per_wg);
+    hipLaunchKernelGGL(embed_wgrad_kernel, dim3((unsigned)slabs), dim3(256), lds, stream, ws, idx, dy, row_scale, (long)rows, card, C, lddy, rows_per_wg);
     const int n = card * C;
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dtable, (float*)nullptr, ws, n, n, (int)slabs);
     return (int)hipGetLastError();

@@ -508,14 +508,24 @@ def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor, bias: bool = False):
     return (dw, dy2.sum(0)) if bias else dw
 
 
-def embed_wgrad(idx: torch.Tensor, dy2: torch.Tensor, card: int) -> torch.Tensor:
-    """dtable [card, C] = scatter-sum of the rows of dy2 [rows, C] by idx [rows] (int64): the gradient of a small embedding table
-    looked up at every pair position (prd_embed_wgrad; card <= 128, C <= 64, contiguous inputs)."""
+def rbf_rows(z: torch.Tensor, centers: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """[b, N, N, R] radial-basis rows of the pair distances times mask_i mask_j (prd_rbf_rows)."""
+    b, N, _ = z.shape
+    R_ = centers.numel()
+    out = torch.empty(b, N, N, R_, device=z.device, dtype=F32)
+    check(lib().prd_rbf_rows(dptr(out), dptr(z.contiguous()), dptr(centers), dptr(mask.contiguous()), b, N, R_, stream()), "prd_rbf_rows")
+    return out
+
+
+def embed_wgrad(idx: torch.Tensor, dy2: torch.Tensor, card: int, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dtable [card, C] = scatter-sum of the rows of dy2 [rows, C] (times ``scale`` [rows] if given) by idx [rows] (int64): the
+    gradient of a small embedding table looked up at every pair position (prd_embed_wgrad; card <= 128, C <= 64, contiguous inputs)."""
     rows, Cn = dy2.shape
     dt = torch.empty(card, Cn, device=dy2.device, dtype=F32)
     nbytes = lib().prd_embed_wgrad_workspace(rows, card, Cn)
     ws = torch.empty(nbytes // 4, device=dy2.device, dtype=F32)
-    check(lib().prd_embed_wgrad(dptr(dt), dptr(idx, torch.int64), dptr(dy2), rows, card, Cn, Cn, dptr(ws), nbytes, stream()), "prd_embed_wgrad")
+    check(lib().prd_embed_wgrad(dptr(dt), dptr(idx, torch.int64), dptr(dy2), dptr(scale), rows, card, Cn, Cn, dptr(ws), nbytes, stream()),
+          "prd_embed_wgrad")
     return dt
 
 

@@ -223,10 +223,8 @@ def single_pair_attention(single, pair, gm, bm, gz, bz, wz, wq, wk, wv, wg, bg, 
     return m + F.linear((o * gate).reshape(b_, n, -1), wo, bo)
 
 
-def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int, max_relpos: int,
-                atom_tabs: Sequence[torch.Tensor], bond_tabs: Sequence[torch.Tensor], bd_tab, rp_tab, w_rt, w_esm,
-                centers, w_dist, freqs, w_beta):
-    """model.py:332-361: single and pair inputs of the trunk."""
+def input_stage_single(batch, seq_t, atom_tabs: Sequence[torch.Tensor], w_rt, w_esm):
+    """model.py:332-345: the single half of the input stage (atom feature tables, residue type and ESM projections)."""
     am, rm = batch["atom_mask"], batch["residue_mask"]
     sa = 1.0 / math.sqrt(len(atom_tabs))
     acc = 0.0
@@ -236,8 +234,16 @@ def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int
         # sorts and scatter-adds: 58 us per table for 640 rows)
         acc = acc + sa * ((F.one_hot(idx, tab.shape[0]).to(tab.dtype) @ tab) if (idx.is_cuda and torch.is_grad_enabled() and tab.requires_grad)
                           else F.embedding(idx, tab))
-    single = am.unsqueeze(-1) * acc + rm.unsqueeze(-1) * (
+    return am.unsqueeze(-1) * acc + rm.unsqueeze(-1) * (
         torch.relu(F.linear(ln(seq_t), w_rt)) + F.linear(ln(batch["residue_esm"]), w_esm))
+
+
+def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int, max_relpos: int,
+                atom_tabs: Sequence[torch.Tensor], bond_tabs: Sequence[torch.Tensor], bd_tab, rp_tab, w_rt, w_esm,
+                centers, w_dist, freqs, w_beta):
+    """model.py:332-361: single and pair inputs of the trunk."""
+    am, rm = batch["atom_mask"], batch["residue_mask"]
+    single = input_stage_single(batch, seq_t, atom_tabs, w_rt, w_esm)
     sb = 1.0 / math.sqrt(len(bond_tabs))
     bacc = 0.0
     for f, tab in enumerate(bond_tabs):

@@ -11,6 +11,7 @@ fp32 throughout (the reference trains under fp16 autocast, train.py:37; parity i
 """
 from __future__ import annotations
 
+import math
 import os
 
 from typing import Callable, Dict, Optional, Sequence, Tuple
@@ -33,6 +34,7 @@ USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
 # 0: the backward of the pair transition, the attention bias and the outer-linear through the torch restatement (HipOp), as in
 # round 2 -- A/B measurements only
 LIBRARY_BWD = os.environ.get("PRD_LIBRARY_BWD", "1") != "0"
+INPUT_STAGE_BWD = os.environ.get("PRD_INPUT_STAGE_BWD", "1") != "0"     # 0: the input stage's backward through its torch restatement (A/B)
 # 1: the residual adds of a folding block's pair updates ride in the kernels' own residual paths (pair + update written by the
 # operator, dy added to its input gradient) instead of eight torch adds over the pair tensor per block; 0: A/B measurements
 FUSED_RESIDUAL = os.environ.get("PRD_TRAIN_FUSED_RESIDUAL", "1") != "0"
@@ -63,6 +65,79 @@ class HipOp(torch.autograd.Function):
             grads = torch.autograd.grad([o for o, _ in pairs], wrt, [g.contiguous() for _, g in pairs], allow_unused=True)
         it = iter(grads)
         return (None, None) + tuple(next(it) if i.requires_grad else None for i in ins)
+
+
+class InputStageFn(torch.autograd.Function):
+    """The input stage (model.py:332-361) with a hand-written backward of its PAIR half.  Forward: the HIP input kernels.  Backward:
+    the single half (a few [b, N, S] operators) through its torch restatement; the pair half without an autograd graph over
+    [b, N, N, *] tensors -- the three kinds of small tables (bond features, bond distance, relative position) by the slab scatter-sum
+    prd_embed_wgrad with the forward's mask factors as a row scale, the distance embedding's weight as dy^T rbf with the radial-basis
+    rows materialised once by prd_rbf_rows (they do not depend on a parameter), the time-embedding term from the masked sum of dy.
+    (The torch restatement recomputed and differentiated a dozen [b, N, N, 64 / 256] tensors: 2.05 ms of a 25 ms step.)"""
+
+    @staticmethod
+    def forward(ctx, fwd: Callable, meta: dict, z, seq_t, *params):
+        ctx.meta = meta
+        ctx.save_for_backward(z, seq_t, *params)
+        with torch.no_grad():
+            return fwd(z.detach(), seq_t.detach(), *[p.detach() for p in params])
+
+    @staticmethod
+    def backward(ctx, dsingle, dpair):
+        m = ctx.meta
+        batch, mask, t, na, nb = m["batch"], m["mask"], m["t"], m["na"], m["nb"]
+        z, seq_t, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad[2:]
+        atom_tabs, bond_tabs = params[:na], params[na:na + nb]
+        bd_tab, rp_tab, w_rt, w_esm, centers, w_dist, freqs, w_beta = params[na + nb:]
+        grads = [None] * (2 + len(params))
+        # ---- single half: torch restatement of [b, N, S]-sized operators ----
+        if dsingle is not None:
+            with torch.enable_grad():
+                s_in = seq_t.detach().requires_grad_(True) if need[1] else seq_t.detach()
+                a_in = [p.detach().requires_grad_(True) for p in atom_tabs]
+                wr, we = w_rt.detach().requires_grad_(True), w_esm.detach().requires_grad_(True)
+                single = R.input_stage_single(batch, s_in, a_in, wr, we)
+                wrt = ([s_in] if need[1] else []) + a_in + [wr, we]
+                g = list(torch.autograd.grad(single, wrt, dsingle.contiguous(), allow_unused=True))
+            if need[1]:
+                grads[1] = g.pop(0)
+            for k in range(na):
+                grads[2 + k] = g[k]
+            grads[2 + na + nb + 2], grads[2 + na + nb + 3] = g[na], g[na + 1]
+        # ---- pair half ----
+        if dpair is not None:
+            with torch.no_grad():
+                b, N = mask.shape
+                P = dpair.shape[-1]
+                dyp = dpair.contiguous()
+                dy2 = dyp.view(-1, P)
+                am, rm = batch["atom_mask"], batch["residue_mask"]
+                am2 = am.unsqueeze(-1) * am.unsqueeze(-2)
+                ri, ci = batch["residue_index"], batch["residue_chain_index"]
+                rel = (ri.unsqueeze(-1) - ri.unsqueeze(-2)).clamp(min=-m["max_relpos"], max=m["max_relpos"]) + m["max_relpos"]
+                s_rel = (rm.unsqueeze(-1) * rm.unsqueeze(-2) * (ci.unsqueeze(-1) == ci.unsqueeze(-2)).float()).contiguous().view(-1)
+                s_bond = (am2 * batch["bond_mask"] * (1.0 / math.sqrt(nb))).contiguous().view(-1)
+                for f in range(nb):
+                    grads[2 + na + f] = ops.embed_wgrad(batch["bond_feats"][..., f].contiguous().view(-1), dy2, bond_tabs[f].shape[0], scale=s_bond)
+                grads[2 + na + nb] = ops.embed_wgrad(batch["bond_distance"].clamp(max=m["max_bond_distance"]).contiguous().view(-1), dy2,
+                                                     bd_tab.shape[0], scale=am2.contiguous().view(-1))
+                grads[2 + na + nb + 1] = ops.embed_wgrad(rel.contiguous().view(-1), dy2, rp_tab.shape[0], scale=s_rel)
+                rbf = ops.rbf_rows(z.detach(), centers.detach(), mask)                    # [b, N, N, R], mask_i mask_j inside
+                grads[2 + na + nb + 5] = ops.linear_wgrad(dy2, rbf.view(-1, rbf.shape[-1]))
+                m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
+                S = (dyp * m2).sum(dim=(1, 2))                                            # [b, P]: gradient of the per-complex time term
+            with torch.enable_grad():
+                fr, wb = freqs.detach().requires_grad_(freqs.requires_grad), w_beta.detach().requires_grad_(True)
+                wx = fr * (t / m["num_steps"])[:, None, None].unsqueeze(-1)
+                sinus = torch.cat([torch.sin(wx), torch.cos(wx)], dim=-1)
+                term = torch.nn.functional.linear(sinus, wb)                             # [b, 1, 1, P]
+                gb = torch.autograd.grad(term, [fr, wb] if fr.requires_grad else [wb], S.view_as(term), allow_unused=True)
+            if fr.requires_grad:
+                grads[2 + na + nb + 6], grads[2 + na + nb + 7] = gb[0], gb[1]
+            else:
+                grads[2 + na + nb + 7] = gb[0]
+        return (None, None, *grads)
 
 
 class PairTransitionFn(torch.autograd.Function):
@@ -365,7 +440,15 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
         pair = ops.pair_init(static["pair"], z_.contiguous(), mask, model.embed_dist[0].center, model.embed_dist[1].weight, eb)
         return single, pair
 
-    single, pair = HipOp.apply(in_hip, in_ref, z, seq_t, *in_params)
+    P_ = model.embed_dist[1].weight.shape[0]
+    hand = (z.is_cuda and LIBRARY_BWD and INPUT_STAGE_BWD and P_ <= 64 and model.embed_dist[0].center.numel() % 4 == 0 and not model.embed_dist[0].center.requires_grad
+            and all(tab.shape[0] <= 128 for tab in (*bond_tabs, model.embed_bond_distance.weight, model.embed_relpos.weight)))
+    if hand:                                            # hand-written backward of the pair half (InputStageFn)
+        meta = dict(batch=batch, mask=mask, t=t, na=na, nb=nb, num_steps=model.num_steps, max_bond_distance=model.max_bond_distance,
+                    max_relpos=model.max_relpos)
+        single, pair = InputStageFn.apply(in_hip, meta, z, seq_t, *in_params)
+    else:
+        single, pair = HipOp.apply(in_hip, in_ref, z, seq_t, *in_params)
 
     # ---- OuterProductUpdate (masked add) and SPAttention (modules.py:394-398) ----
     opm = den.opm

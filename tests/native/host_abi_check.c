@@ -158,6 +158,8 @@ int main(void) {
     EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, s), PRD_ERR_UNSUPPORTED);          /* fp32 arithmetic: the caller's GEMM */
     EXPECT(prd_pair_linear(p, p, p, p, 100, 256, 64, 1, 0, 0, 0, 1, s), PRD_ERR_ARG);                 /* LayerNorm of 256-wide rows */
     EXPECT(prd_pair_linear(p, p + 1, p, p, 100, 64, 64, 0, 0, 0, 0, 1, s), PRD_ERR_ALIGN);
+    EXPECT(prd_rbf_rows(0, p, p, p, 1, 8, 256, s), PRD_ERR_ARG);
+    EXPECT(prd_rbf_rows(p, p, p, p, 1, 8, 30, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_sym_transpose(0, p, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_sym_transpose(p, p, 1, 8, 48, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_pair_linear_supported(256, 64, 1), 1);
@@ -172,9 +174,9 @@ int main(void) {
     EXPECT(prd_linear_wgrad(p, p, p, p + 1, 100, 64, 64, 64, 64, p, 1 << 20, 0, s), PRD_ERR_ALIGN);
     EXPECT(prd_linear_wgrad(p, p, p, p, 100, 64, 64, 64, 64, p + 1, 1 << 20, 0, s), PRD_ERR_ALIGN);        /* partials workspace */
     EXPECT(prd_linear_wgrad(p, p, p + 1, p, 100, 4, 64, 4, 64, p, 16, 0, s), PRD_ERR_WORKSPACE);            /* narrow form: scalar loads, no alignment demand */
-    EXPECT(prd_embed_wgrad(0, (const long long*)ibuf, p, 100, 8, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
-    EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 200, 64, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);   /* more than 128 table rows */
-    EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 100, 8, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
+    EXPECT(prd_embed_wgrad(0, (const long long*)ibuf, p, 0, 100, 8, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
+    EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 0, 100, 200, 64, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);   /* more than 128 table rows */
+    EXPECT(prd_embed_wgrad(p, (const long long*)ibuf, p, 0, 100, 8, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
     EXPECT((int)(prd_embed_wgrad_workspace(102400, 65, 64) != (size_t)200 * 65 * 64 * 4), 0);
     EXPECT((int)(prd_workspace_bytes("tri_mul", 1, 320, 512, 64) != (size_t)3 * 64 * 320 * 320 * 4), 0);
     EXPECT((int)prd_workspace_bytes("nonsense", 1, 320, 512, 64), 0);

@@ -42,7 +42,8 @@ def main():
 
     def label(ref):
         q = getattr(ref, "__qualname__", str(ref))
-        return q.split(".<locals>")[0].replace("_update", "")
+        parts = q.split(".<locals>.")
+        return (parts[0] + ("." + parts[-1] if len(parts) > 1 else "")).replace("_update", "")
 
     for cls in (training.HipOp, training.TriMulFn, training.TriAttnFn):
         of, ob = cls.forward, cls.backward
