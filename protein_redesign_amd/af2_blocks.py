@@ -112,7 +112,8 @@ class SPAttention(nn.Module):
             rscale = ln.weight
         # no mask: the reference builds a mask bias and drops it (AF2_modules.py:447 vs 461-463)
         return ops.gated_attention_single(mn, mn, bias, self._packed(), a.linear_o.weight, bo,
-                                          self.no_heads, self.c_hidden, key_mask=False, resid=mn, qkvg=qkvg, rscale=rscale, out_ln=out_ln)
+                                          self.no_heads, self.c_hidden, key_mask=False, resid=mn, qkvg=qkvg, rscale=rscale, out_ln=out_ln,
+                                          logits_fp32=self.training)
 
     def forward(self, m: torch.Tensor, z: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, N, _ = m.shape

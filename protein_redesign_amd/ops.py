@@ -747,7 +747,7 @@ def project_qkvg(x_normed, packed, HC: int, ln_a: bool = False) -> torch.Tensor:
 def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int, *,
                            key_mask: bool, resid: Optional[torch.Tensor], ln_a: bool = False,
                            qkvg: Optional[torch.Tensor] = None, rscale: Optional[torch.Tensor] = None,
-                           out_ln: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           out_ln: Optional[torch.Tensor] = None, logits_fp32: bool = True) -> torch.Tensor:
     """Multi-head gated attention over the node axis with an additive [b,H,N,N] bias.
 
     Covers reference modules.py:185-225 (c = head_dim, key mask filled with -2**15, q pre-scaled by
@@ -757,7 +757,8 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     ``qkvg``: the projection, if the caller already computed it (``project_qkvg``, e.g. on a side stream).
     ``rscale``: per-column factor of ``resid`` (an affine-LayerNorm-ed residual given as the plain normalised rows x gamma, with
     beta folded into ``bo`` by the caller).  ``out_ln``: buffer for LN(result) (no affine) -- only with an output projection that takes
-    the K-slab path (``slab_ok(b N, S_out, H c)``), whose reduce launch holds whole output rows."""
+    the K-slab path (``slab_ok(b N, S_out, H c)``), whose reduce launch holds whole output rows.  ``logits_fp32`` (wide heads only):
+    the logits on fp32 MFMA in either arithmetic -- what a training forward needs (below); sampling passes False."""
     b, N, S = x_normed.shape
     HC = H * c
     w, pbias, colscale = packed
@@ -778,8 +779,10 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
     gemm(qkvg, qkvg, logits, N, N, c, L, L, ldp, b_off=HC, G1=b, G2=H, sa=(N * L, c), sb=(N * L, c),
          sc=(H * N * ldp, N * ldp), addmat=bias, sad=(H * N * N, N * N), ldadd=N,
          colmask=(mask if key_mask else None), scm1=N, fill=-(2.0 ** 15),
-         tile_hint=32)      # fp32 MFMA in either arithmetic: a softmax follows, and with full-strength weights (|logit| ~ 50) the split
-    #                         operands' 2^-22 shows in the gradients of q / k at the 1e-4 level (tests/test_training_gpu.py)
+         tile_hint=32 if logits_fp32 else 0)
+    # logits_fp32: fp32 MFMA in either arithmetic -- a softmax follows, and with full-strength weights (|logit| ~ 50) the split
+    # operands' 2^-22 shows in the GRADIENTS of q / k at the 1e-4 level (tests/test_training_gpu.py: the backward differentiates an
+    # fp32 restatement); a sampling step has no such consumer and stays inside the 1e-5 parity bound with the split operands
     pv = dict(b_off=2 * HC, G1=b, G2=H, sa=(H * N * ldp, N * ldp), sb=(N * L, c), sc=(N * HC, c), b_kn=True, mulmat=qkvg, mul_off=3 * HC,
               smu=(N * L, c), ldmul=L, a_scale=1024.0)                                                        # probabilities: see PrdGemm.a_scale
     # the row softmax rides in the P V product where the library has that form (a_ln = 2); else its own launch
