@@ -274,6 +274,9 @@ int prd_tri_attn_bwd_core_v2_supported(int N, int P);
 int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
                              const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, const float* lse,
                              float* x_out, int ending, int b, int N, int P, int H, int c, hipStream_t stream);
+/* out[b][i][j][:] = scale (x[b][i][j][:] + x[b][j][i][:]): the pair symmetrisation in front of the heads (modules.py:403) and its
+ * backward.  Not in place; P a multiple of 4. */
+int prd_sym_rows(float* out, const float* x, float scale, int b, int N, int P, hipStream_t stream);
 /* out[b][i][p][j] = dy[b][i][j][p] + dy[b][j][i][p] (dy [b,N,N,P] -> out [b,N,P,N]): the symmetrised, transposed gradient the
  * backward of the outer-linear update (modules.py:283-287) contracts with LN(single) over j.  P in {32, 64}. */
 int prd_sym_transpose(float* out, const float* dy, int b, int N, int P, hipStream_t stream);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "prd_tri_attn_bwd_core_v2": [vp] * 12 + [ci] * 6 + [vp],
     "prd_ln_rows_bwd": [vp, vp, vp, vp, cll, ci, vp],
     "prd_sym_transpose": [vp, vp, ci, ci, ci, vp],
+    "prd_sym_rows": [vp, vp, cf, ci, ci, ci, vp],
     "prd_pair_linear_supported": [ci, ci, ci],
     "prd_pair_linear": [vp, vp, vp, vp, cll, ci, ci, ci, vp, ci, vp, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],

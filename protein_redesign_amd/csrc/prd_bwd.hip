@@ -1150,6 +1150,31 @@ extern "C" int prd_rbf_rows(float* out, const float* z, const float* centers, co
     return (int)hipGetLastError();
 }
 
+// out[b][i][j][:] = scale (x[b][i][j][:] + x[b][j][i][:]): the pair symmetrisation in front of the coordinate head (modules.py:403)
+// and its backward, in the row layout (both reads are whole 4 P-byte rows: no transpose needed).  One thread per float4.
+__global__ __launch_bounds__(256) void sym_rows_kernel(float* __restrict__ out, const float* __restrict__ x, long npos, int N, int P4, float scale) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= npos * P4) return;
+    const long pos = tid / P4;
+    const int q = (int)(tid - pos * P4);
+    const long bi = pos / N;
+    const int j = (int)(pos - bi * N);
+    const long bb = bi / N;
+    const int i = (int)(bi - bb * N);
+    const float4 a = *reinterpret_cast<const float4*>(x + (pos * P4 + q) * 4);
+    const float4 c = *reinterpret_cast<const float4*>(x + ((((bb * N + j) * N + i) * P4) + q) * 4);
+    *reinterpret_cast<float4*>(out + (pos * P4 + q) * 4) = make_float4(scale * (a.x + c.x), scale * (a.y + c.y), scale * (a.z + c.z), scale * (a.w + c.w));
+}
+
+extern "C" int prd_sym_rows(float* out, const float* x, float scale, int b, int N, int P, hipStream_t stream) {
+    if (!out || !x || b <= 0 || N <= 0 || P <= 0) return PRD_ERR_ARG;
+    if (P % 4 || out == x) return PRD_ERR_UNSUPPORTED;                  // (not in place: position (j, i) is read by another thread)
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x)) & 15) return PRD_ERR_ALIGN;
+    const long npos = (long)b * N * N, nthr = npos * (P / 4);
+    hipLaunchKernelGGL(sym_rows_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, out, x, npos, N, P / 4, scale);
+    return (int)hipGetLastError();
+}
+
 extern "C" int prd_sym_transpose(float* out, const float* dy, int b, int N, int P, hipStream_t stream) {
     if (!out || !dy || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;

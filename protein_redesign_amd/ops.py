@@ -452,6 +452,14 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
 WGRAD_MIN_ROWS = 8192
 
 
+def sym_rows(x: torch.Tensor, scale: float = 0.5) -> torch.Tensor:
+    """scale * (x + x.transpose(1, 2)) for x [b, N, N, P] (prd_sym_rows)."""
+    b, N, _, P = x.shape
+    out = torch.empty_like(x)
+    check(lib().prd_sym_rows(dptr(out), dptr(x), float(scale), b, N, P, stream()), "prd_sym_rows")
+    return out
+
+
 def sym_transpose(dy: torch.Tensor) -> torch.Tensor:
     """[b, N, N, P] -> [b, N, P, N]: out[b,i,p,j] = dy[b,i,j,p] + dy[b,j,i,p] (prd_sym_transpose)."""
     b, N, _, P = dy.shape

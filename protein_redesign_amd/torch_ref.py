@@ -265,6 +265,11 @@ def input_stage(batch, z, seq_t, mask, t, num_steps: int, max_bond_distance: int
     return single, pair
 
 
+def seq_head(single, ws1, bs1, ws2):
+    """model.py:371-374: sequence logits."""
+    return F.linear(torch.relu(F.linear(ln(single), ws1, bs1)), ws2)
+
+
 def heads(single, pair, z, mask, wr1, br1, wr2, ws1, bs1, ws2):
     """modules.py:403 (pair symmetrisation) + model.py:364-374: coordinate update and sequence logits."""
     pair = 0.5 * (pair + pair.transpose(1, 2))

@@ -34,6 +34,7 @@ USE_CHECKPOINT = os.environ.get("PRD_TRAIN_CHECKPOINT", "0") == "1"
 # 0: the backward of the pair transition, the attention bias and the outer-linear through the torch restatement (HipOp), as in
 # round 2 -- A/B measurements only
 LIBRARY_BWD = os.environ.get("PRD_LIBRARY_BWD", "1") != "0"
+HEADS_BWD = os.environ.get("PRD_HEADS_BWD", "1") != "0"                 # 0: the heads' backward through the torch restatement (A/B)
 INPUT_STAGE_BWD = os.environ.get("PRD_INPUT_STAGE_BWD", "1") != "0"     # 0: the input stage's backward through its torch restatement (A/B)
 # 1: the residual adds of a folding block's pair updates ride in the kernels' own residual paths (pair + update written by the
 # operator, dy added to its input gradient) instead of eight torch adds over the pair tensor per block; 0: A/B measurements
@@ -138,6 +139,55 @@ class InputStageFn(torch.autograd.Function):
             else:
                 grads[2 + na + nb + 7] = gb[0]
         return (None, None, *grads)
+
+
+class HeadsFn(torch.autograd.Function):
+    """The two heads (modules.py:403 + model.py:364-374) with a hand-written backward of the coordinate head.  Forward: the HIP
+    kernels.  Backward: the sequence head (single-sized) through its torch restatement; the coordinate head without an autograd graph
+    over pair-sized tensors -- psym = (pair + pair^T) / 2 (prd_sym_rows), h = relu(W1 LN(psym) + b1) recomputed by the row kernel,
+    dw[b,i,j] = mask_i mask_j r_ij . d eps_i (r = the unit difference vectors), g = dw w2 [h > 0], dLN = g W1, LayerNorm backward,
+    symmetrisation of the result; weight gradients from the slab reductions."""
+
+    @staticmethod
+    def forward(ctx, fwd: Callable, z, mask, single, pair, *w):
+        ctx.save_for_backward(z, mask, single, pair, *w)
+        with torch.no_grad():
+            return fwd(single.detach(), pair.detach(), *[x.detach() for x in w])
+
+    @staticmethod
+    def backward(ctx, deps, dlogits):
+        z, mask, single, pair, wr1, br1, wr2, ws1, bs1, ws2 = ctx.saved_tensors
+        gs = gp = None
+        gw = [None] * 6
+        if dlogits is not None:
+            with torch.enable_grad():
+                s_in = single.detach().requires_grad_(True)
+                ws = [x.detach().requires_grad_(True) for x in (ws1, bs1, ws2)]
+                g = torch.autograd.grad(R.seq_head(s_in, *ws), [s_in, *ws], dlogits.contiguous())
+            gs, gw[3], gw[4], gw[5] = g
+        if deps is not None:
+            with torch.no_grad():
+                b, N, _, P = pair.shape
+                m = mask.unsqueeze(-1)
+                de = deps - m * (m * deps).sum(dim=1, keepdim=True) / m.sum(dim=1, keepdim=True)      # remove_mean is self-adjoint
+                zij = z.unsqueeze(-2) - z.unsqueeze(-3)
+                r = zij * torch.rsqrt(torch.sum(torch.square(zij), -1, keepdim=True) + 1e-4)
+                dw = (mask.unsqueeze(-1) * mask.unsqueeze(-2)) * (r * de.unsqueeze(2)).sum(-1)         # [b, N, N]
+                psym = ops.sym_rows(pair.detach().contiguous(), 0.5).view(-1, P)
+                xn = torch.empty_like(psym)
+                h = ops.pair_linear(psym, wr1, br1, ln_in=True, xn_out=xn, act=1)
+                if h is None:
+                    h = ops.linear(psym, wr1, br1, act=1, ln_a=True, ln_a_out=xn)
+                dw2 = dw.reshape(-1, 1)
+                gw[2] = (dw2 * h).sum(0, keepdim=True)                                                  # d wr2 [1, HID]
+                g = torch.where(h > 0, dw2 * wr2, torch.zeros((), device=h.device))                     # [rows, HID]
+                dxn = ops.pair_linear(g, wr1.t())
+                if dxn is None:
+                    dxn = ops.linear(g, wr1.t().contiguous())
+                dps = ops.ln_rows_bwd(dxn, psym)
+                gp = ops.sym_rows(dps.view(b, N, N, P), 0.5)
+                gw[0], gw[1] = ops.linear_wgrad(g, xn, bias=True)
+        return (None, None, None, gs, gp, *gw)
 
 
 class PairTransitionFn(torch.autograd.Function):
@@ -499,6 +549,9 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
         h = ops.linear(s_.contiguous(), w[3], w[4], act=1, ln_a=True)
         return eps, ops.linear(h, w[5])
 
+    P_h = pair.shape[-1]
+    if pair.is_cuda and LIBRARY_BWD and HEADS_BWD and P_h % 64 == 0 and wr[1].weight.shape[0] % 64 == 0 and wr[3].weight.shape[0] == 1:
+        return HeadsFn.apply(heads_hip, z, mask, single, pair, *head_params)
     return HipOp.apply(heads_hip, heads_ref, single, pair, *head_params)
 
 
