@@ -209,7 +209,11 @@ def outer_product_update(single, mask, g, bta, w1, b1, w2, b2, wo, bo):
 
 def single_pair_attention(single, pair, gm, bm, gz, bz, wz, wq, wk, wv, wg, bg, wo, bo, heads: int):
     """AF2_modules.py:421-473: unmasked, residual on the LayerNorm-ed input, head width = single_dim."""
-    bias = pair_bias(pair, wz, None, gz, bz)
+    return single_bias_attention(single, pair_bias(pair, wz, None, gz, bz), gm, bm, wq, wk, wv, wg, bg, wo, bo, heads)
+
+
+def single_bias_attention(single, bias, gm, bm, wq, wk, wv, wg, bg, wo, bo, heads: int):
+    """single_pair_attention with the pair bias [b, H, N, N] given."""
     m = ln(single, gm, bm)
     b_, n, _ = m.shape
 

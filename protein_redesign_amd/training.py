@@ -229,26 +229,38 @@ class PairTransitionFn(torch.autograd.Function):
 
 
 class PairBiasFn(torch.autograd.Function):
-    """attn_bias of a folding block (modules.py:300-304): bias[b,h,i,j] = (W LN(pair[b,i,j]) + c)[h].  Backward on the library's
-    kernels: dLN = dbias W (a K = H GEMM), dpair = LN'(dLN; pair), dW | dc = dbias^T LN(pair) from the narrow slab reduction."""
+    """attn_bias of a folding block (modules.py:300-304): bias[b,h,i,j] = (W LN(pair[b,i,j]) + c)[h], and SPAttention's pair bias
+    (AF2_modules.py:454-459): the same with an affine LayerNorm (gamma, beta) and no c.  Backward on the library's kernels:
+    dLN = dbias (W gamma) (a K = H GEMM), dpair = LN'(dLN; pair), dW' | dc' = dbias^T LN(pair) from the narrow slab reduction; with
+    the affine LayerNorm folded as W' = W diag(gamma), c' = c + W beta:  dW = dW' gamma + dc' (x) beta,  dgamma = sum_h W dW',
+    dbeta = W^T dc'."""
 
     @staticmethod
-    def forward(ctx, pair, w, c):
-        ctx.save_for_backward(pair, w)
+    def forward(ctx, pair, w, c, gamma=None, beta=None):
+        ctx.affine = gamma is not None
+        ctx.has_c = c is not None
+        ctx.save_for_backward(pair, w, *([gamma, beta] if ctx.affine else []))
         with torch.no_grad():
-            return ops.pair_bias(pair.detach().contiguous(), w, c)
+            return ops.pair_bias(pair.detach().contiguous(), w, c, gamma, beta) if ctx.affine else ops.pair_bias(pair.detach().contiguous(), w, c)
 
     @staticmethod
     def backward(ctx, dbias):
-        pair, w = ctx.saved_tensors
+        pair, w, *aff = ctx.saved_tensors
         P, H = pair.shape[-1], w.shape[0]
         with torch.no_grad():
             x2 = pair.detach().contiguous().view(-1, P)
             d2 = dbias.permute(0, 2, 3, 1).contiguous().view(-1, H)           # [rows, H]
-            dxn = d2 @ w                                                      # [rows, P]: K = H = 4, not a matrix-pipe shape
+            wf = w * aff[0] if ctx.affine else w                              # W diag(gamma)
+            dxn = d2 @ wf                                                     # [rows, P]: K = H = 4, not a matrix-pipe shape
             dx = ops.ln_rows_bwd(dxn, x2)
-            dw, dc = ops.linear_wgrad(d2, ops.layer_norm(x2), bias=True)
-        return dx.view_as(pair), dw, dc
+            dwf, dcf = ops.linear_wgrad(d2, ops.layer_norm(x2), bias=True)
+            if not ctx.affine:
+                return dx.view_as(pair), dwf, (dcf if ctx.has_c else None), None, None
+            gamma, beta = aff
+            dw = dwf * gamma + dcf.unsqueeze(1) * beta
+            dgamma = (w * dwf).sum(0)
+            dbeta = dcf @ w
+        return dx.view_as(pair), dw, (dcf if ctx.has_c else None), dgamma, dbeta
 
 
 class OuterLinearFn(torch.autograd.Function):
@@ -526,7 +538,22 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
     def spa_hip(s_, p_, *w):
         return spa(s_.contiguous(), p_.contiguous(), mask)
 
-    single = HipOp.apply(spa_hip, spa_ref, single, pair, *spa_params)
+    if pair.is_cuda and LIBRARY_BWD and pair.numel() // pair.shape[-1] >= ops.WGRAD_MIN_ROWS and spa.pair_bias:
+        # the pair bias as its own node with the hand-written backward (PairBiasFn, affine LayerNorm); the attention itself, whose
+        # tensors are single-sized, keeps its torch restatement for the backward
+        spa_bias = PairBiasFn.apply(pair, spa.linear_z[1].weight, None, spa.linear_z[0].weight, spa.linear_z[0].bias)
+        att_params = (spa_params[0], spa_params[1], *spa_params[5:])
+
+        def att_ref(s_, bias_, *w):
+            return R.single_bias_attention(s_, bias_, *w, heads=H)
+
+        def att_hip(s_, bias_, *w):
+            mn, qkvg = spa.project(s_.contiguous())
+            return spa.attend(mn, qkvg, bias_.contiguous())
+
+        single = HipOp.apply(att_hip, att_ref, single, spa_bias, *att_params)
+    else:
+        single = HipOp.apply(spa_hip, spa_ref, single, pair, *spa_params)
 
     # ---- folding blocks, each under activation checkpointing like the reference (modules.py:399-401) ----
     for blk in den.folding_blocks:

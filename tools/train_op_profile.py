@@ -45,7 +45,8 @@ def main():
         parts = q.split(".<locals>.")
         return (parts[0] + ("." + parts[-1] if len(parts) > 1 else "")).replace("_update", "")
 
-    for cls in (training.HipOp, training.TriMulFn, training.TriAttnFn):
+    for cls in (training.HipOp, training.TriMulFn, training.TriAttnFn, training.PairTransitionFn, training.PairBiasFn, training.OuterLinearFn,
+                training.InputStageFn, training.HeadsFn):
         of, ob = cls.forward, cls.backward
 
         def fwd(ctx, *t, _of=of, _cls=cls):
