@@ -274,6 +274,11 @@ int prd_tri_attn_bwd_core_v2_supported(int N, int P);
 int prd_tri_attn_bwd_core_v2(float* dqkvg, const float* dog, const float* og, const float* pair, const float* mask,
                              const float* wq, const float* wk, const float* wv, const float* wg, const float* bg, const float* lse,
                              float* x_out, int ending, int b, int N, int P, int H, int c, hipStream_t stream);
+/* The two reductions of the outer-linear backward over T [R][P][S] (R = b N node rows; T = (dy + dy^T) LN(single), the output of the
+ * backward's GEMM): dx[r][s] = sum_p T[r][p][s] w1[p][s], and dw1_part[c][p][s] = sum over the rows of chunk c (of `chunks` equal
+ * chunks of R) of T[r][p][s] x[r][s] -- the caller adds the chunks (fixed order: no atomics). */
+int prd_outer_linear_bwd_reduce(float* dx, float* dw1_part, int chunks, const float* T, const float* w1, const float* x,
+                                long long R, int P, int S, hipStream_t stream);
 /* out[b][i][j][:] = scale (x[b][i][j][:] + x[b][j][i][:]): the pair symmetrisation in front of the heads (modules.py:403) and its
  * backward.  Not in place; P a multiple of 4. */
 int prd_sym_rows(float* out, const float* x, float scale, int b, int N, int P, hipStream_t stream);

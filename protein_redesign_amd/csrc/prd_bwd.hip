@@ -1166,6 +1166,56 @@ __global__ __launch_bounds__(256) void sym_rows_kernel(float* __restrict__ out, 
     *reinterpret_cast<float4*>(out + (pos * P4 + q) * 4) = make_float4(scale * (a.x + c.x), scale * (a.y + c.y), scale * (a.z + c.z), scale * (a.w + c.w));
 }
 
+// The two reductions of the outer-linear backward over T[r][p][s] (r = (b, i) node rows, p = pair channels, s = single channels;
+// T = (dy + dy^T) LN(single), modules.py:283-287 under autograd):  dx[r][s] = sum_p T[r][p][s] w1[p][s]  and
+// dw1[c][p][s] = sum over the rows of chunk c of T[r][p][s] x[r][s]  (the caller adds the few chunks).  Neither is a GEMM (s is
+// elementwise); torch needs a multiply that writes a T-sized temporary and a sum for each.  One thread per s column, T read
+// once per kernel with unit stride along s.
+__global__ __launch_bounds__(256) void outer_linear_bwd_dx_kernel(float* __restrict__ dx, const float* __restrict__ T, const float* __restrict__ w1,
+                                                                  long R, int P, int S) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= R * S) return;
+    const long r = tid / S;
+    const int s = (int)(tid - r * S);
+    const float* t = T + r * P * S + s;
+    float a0 = 0.f, a1 = 0.f;
+    int p = 0;
+    for (; p + 1 < P; p += 2) {
+        a0 += t[(long)p * S] * w1[(long)p * S + s];
+        a1 += t[(long)(p + 1) * S] * w1[(long)(p + 1) * S + s];
+    }
+    if (p < P) a0 += t[(long)p * S] * w1[(long)p * S + s];
+    dx[tid] = a0 + a1;
+}
+
+__global__ __launch_bounds__(256) void outer_linear_bwd_dw1_kernel(float* __restrict__ part, const float* __restrict__ T, const float* __restrict__ x,
+                                                                   long R, int P, int S, int rows_per_chunk) {
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;          // p * S + s
+    if (col >= (long)P * S) return;
+    const int s = (int)(col % S);
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk < R ? r0 + rows_per_chunk : R;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long r = r0;
+    for (; r + 3 < r1; r += 4) {
+        a0 += T[r * P * S + col] * x[r * S + s];
+        a1 += T[(r + 1) * P * S + col] * x[(r + 1) * S + s];
+        a2 += T[(r + 2) * P * S + col] * x[(r + 2) * S + s];
+        a3 += T[(r + 3) * P * S + col] * x[(r + 3) * S + s];
+    }
+    for (; r < r1; ++r) a0 += T[r * P * S + col] * x[r * S + s];
+    part[(long)blockIdx.y * P * S + col] = (a0 + a1) + (a2 + a3);
+}
+
+extern "C" int prd_outer_linear_bwd_reduce(float* dx, float* dw1_part, int chunks, const float* T, const float* w1, const float* x,
+                                           long long R, int P, int S, hipStream_t stream) {
+    if (!dx || !dw1_part || !T || !w1 || !x || R <= 0 || P <= 0 || S <= 0 || chunks <= 0) return PRD_ERR_ARG;
+    hipLaunchKernelGGL(outer_linear_bwd_dx_kernel, dim3((unsigned)((R * S + 255) / 256)), dim3(256), 0, stream, dx, T, w1, (long)R, P, S);
+    const int rpc = (int)((R + chunks - 1) / chunks);
+    hipLaunchKernelGGL(outer_linear_bwd_dw1_kernel, dim3((unsigned)(((long)P * S + 255) / 256), chunks), dim3(256), 0, stream, dw1_part, T, x,
+                       (long)R, P, S, rpc);
+    return (int)hipGetLastError();
+}
+
 extern "C" int prd_sym_rows(float* out, const float* x, float scale, int b, int N, int P, hipStream_t stream) {
     if (!out || !x || b <= 0 || N <= 0 || P <= 0) return PRD_ERR_ARG;
     if (P % 4 || out == x) return PRD_ERR_UNSUPPORTED;                  // (not in place: position (j, i) is read by another thread)

@@ -452,6 +452,16 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
 WGRAD_MIN_ROWS = 8192
 
 
+def outer_linear_bwd_reduce(T: torch.Tensor, w1: torch.Tensor, x: torch.Tensor, chunks: int = 4):
+    """(dx [R, S] = sum_p T w1,  dw1 [P, S] = sum_r T x) for T [R, P, S], w1 [P, S], x [R, S] (prd_outer_linear_bwd_reduce)."""
+    R_, P, S = T.shape
+    dx = torch.empty(R_, S, device=T.device, dtype=F32)
+    part = torch.empty(chunks, P, S, device=T.device, dtype=F32)
+    check(lib().prd_outer_linear_bwd_reduce(dptr(dx), dptr(part), chunks, dptr(T), dptr(w1.contiguous()), dptr(x.contiguous()), R_, P, S, stream()),
+          "prd_outer_linear_bwd_reduce")
+    return dx, part.sum(0)
+
+
 def sym_rows(x: torch.Tensor, scale: float = 0.5) -> torch.Tensor:
     """scale * (x + x.transpose(1, 2)) for x [b, N, N, P] (prd_sym_rows)."""
     b, N, _, P = x.shape

@@ -298,8 +298,13 @@ class OuterLinearFn(torch.autograd.Function):
             else:
                 T = torch.bmm(dsym, x).view(b, N, P, S)
             du = dy.sum(2) - dy.sum(1)                                          # [b, N, P]
-            dx = (T * w1).sum(dim=2) + du @ w2
-            dw1 = 0.5 * (T * x.unsqueeze(2)).sum(dim=(0, 1))
+            if dy.is_cuda and LIBRARY_BWD:                                      # both reductions over T without T-sized temporaries
+                dxt, dw1 = ops.outer_linear_bwd_reduce(T.reshape(b * N, P, S), w1, x.reshape(b * N, S))
+                dx = dxt.view(b, N, S) + du @ w2
+                dw1 = 0.5 * dw1
+            else:
+                dx = (T * w1).sum(dim=2) + du @ w2
+                dw1 = 0.5 * (T * x.unsqueeze(2)).sum(dim=(0, 1))
             dw2 = du.reshape(-1, P).t() @ x.reshape(-1, S)
             dc = dy.sum(dim=(0, 1, 2))
             dsingle = ops.ln_rows_bwd(dx.reshape(-1, S).contiguous(), s2.view(-1, S)).view_as(single)

@@ -162,6 +162,8 @@ int main(void) {
     EXPECT(prd_rbf_rows(p, p, p, p, 1, 8, 30, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_sym_transpose(0, p, 1, 8, 64, s), PRD_ERR_ARG);
     EXPECT(prd_sym_rows(0, p, 0.5f, 1, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_outer_linear_bwd_reduce(0, p, 4, p, p, p, 16, 64, 512, s), PRD_ERR_ARG);
+    EXPECT(prd_outer_linear_bwd_reduce(p, p, 0, p, p, p, 16, 64, 512, s), PRD_ERR_ARG);
     EXPECT(prd_sym_rows(p, p, 0.5f, 1, 8, 64, s), PRD_ERR_UNSUPPORTED);                                    /* in place */
     EXPECT(prd_sym_transpose(p, p, 1, 8, 48, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_pair_linear_supported(256, 64, 1), 1);

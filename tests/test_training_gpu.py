@@ -195,6 +195,23 @@ def test_pair_track_backward_is_bit_reproducible(gemm_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,P,S", [(90, 32, 64), (640, 64, 512), (301, 64, 130)])
+def test_outer_linear_backward_reductions(R, P, S):
+    """prd_outer_linear_bwd_reduce against float64: dx = sum_p T w1 and dw1 = sum_r T x over T [R, P, S]; repeatable bit for bit."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(R + S)
+    T = torch.randn(R, P, S, generator=g).to(DEV)
+    w1 = torch.randn(P, 2 * S, generator=g).to(DEV)[:, :S]              # a column block, as the backward passes it
+    x = torch.randn(R, S, generator=g).to(DEV)
+    dx, dw1 = ops.outer_linear_bwd_reduce(T, w1, x)
+    wdx = (T.double() * w1.double()).sum(1)
+    wdw = (T.double() * x.double().unsqueeze(1)).sum(0)
+    assert float((dx.double() - wdx).norm() / wdx.norm()) < 1e-6 and float((dw1.double() - wdw).norm() / wdw.norm()) < 1e-6
+    dx2, dw2 = ops.outer_linear_bwd_reduce(T, w1, x)
+    assert torch.equal(dx, dx2) and torch.equal(dw1, dw2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("b,N,P", [(2, 45, 64), (1, 130, 32), (2, 320, 64)])
 def test_symmetrised_transpose_kernel(b, N, P):
     """prd_sym_transpose: out[b,i,p,j] = dy[b,i,j,p] + dy[b,j,i,p] (the operand of the outer-linear backward's GEMM), bit-exact
