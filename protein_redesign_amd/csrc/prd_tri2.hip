@@ -1632,6 +1632,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) { nl[e] = -mrefA; nd[e] = -delta_s; o[e] = 0.f; }
             for (int t = 0; t < nqb; ++t) {
+                v2_prio(nqb - t, nqb);                  // the waves of a SIMD should reach the barrier together (see v2_prio)
                 const KOp k = load_k(lds, krow_lane + 512u * t, kl_rel);
                 const KOp vv = load_k(lds, vrow_lane + 512u * t, kl_rel);
                 f32x16 s = qk_tile(k, qh4, ql4, nl);
@@ -1673,6 +1674,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
                 o = mfma_h(va0, l0, o);
                 o = mfma_h(va1, l1, o);
             }
+            __builtin_amdgcn_s_setprio(0);
             if (valid) {
                 const float f = __builtin_ldexpf(0.25f, -es_q - (int)B2_PSHIFT);
                 float* dst = dqkvg + row_pos(v) * (4 * HC) + h * C + 4 * hi;
@@ -1705,6 +1707,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) { ok[e] = 0.f; ov[e] = 0.f; }
             for (int t = 0; t < nqb; ++t) {
+                v2_prio(nqb - t, nqb);
                 const KOp qa = load_k(lds, krow_lane + 512u * t, kl_rel);
                 const KOp da = load_k(lds, vrow_lane + 512u * t, kl_rel);
                 f32x16 s, dp;                           // accumulators start at -lse_q, -delta_q of the register's query
@@ -1759,6 +1762,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
                     ok = mfma_h(va1, l1, ok);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             if (valid) {
                 const float fv = __builtin_ldexpf(1.0f, -E - (int)B2_PSHIFT);
                 const float fk = kover ? 0.f : fv * 0.6931471805599453f;      // Q rows carry log2(e); no gradient through a replaced logit
