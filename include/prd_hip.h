@@ -315,6 +315,12 @@ int prd_linear_wgrad(float* dw, float* db, const float* dy, const float* x, long
 size_t prd_embed_wgrad_workspace(long long rows, int card, int C);
 int prd_embed_wgrad(float* dtable, const long long* idx, const float* dy, const float* row_scale, long long rows, int card, int C,
                     int lddy, float* ws, size_t ws_bytes, hipStream_t stream);
+/* K <= 8 small tables looked up at the same rows (the input stage's bond-feature, bond-distance and relative-position tables): all
+ * their gradients in one pass over dy.  idx / row_scale / card: HOST arrays of K device pointers / K device pointers (entries or the
+ * whole array may be NULL = no scale) / K cardinalities; dtables [sum card][C] = the K gradients stacked in order.  sum card <= 128,
+ * C <= 64; ws: prd_embed_wgrad_workspace(rows, sum card, C) bytes. */
+int prd_embed_wgrad_multi(float* dtables, const long long* const* idx, const float* const* row_scale, const int* card, int K,
+                          const float* dy, long long rows, int C, int lddy, float* ws, size_t ws_bytes, hipStream_t stream);
 /* rbf[b][i][j][0..R) = mask[b][i] mask[b][j] exp(-(R-1)/2 (|z_i - z_j| - centers[r])^2): the radial-basis rows of the pair distances
  * (modules.py:73-82, model.py:352-356) materialised for the weight gradient of the distance embedding (dW = dy^T rbf through
  * prd_linear_wgrad); R a multiple of 4. */

@@ -85,6 +85,7 @@ SIGNATURES = {
     "prd_embed_wgrad_workspace": [cll, ci, ci],
     "prd_embed_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, vp, cz, vp],
     "prd_rbf_rows": [vp, vp, vp, vp, ci, ci, ci, vp],
+    "prd_embed_wgrad_multi": [vp, vp, vp, vp, ci, vp, cll, ci, ci, vp, cz, vp],
     "prd_tri_attn": [vp] * 10 + [ci] * 7 + [vp, cz, vp, ci, vp],
     "prd_pair_transition": [vp] * 6 + [ci] * 4 + [vp, ci, vp],
     "prd_block_tail": [vp] * 11 + [ci] * 4 + [vp, ci, vp],

@@ -977,6 +977,48 @@ __global__ __launch_bounds__(256) void embed_wgrad_kernel(float* __restrict__ pa
     }
 }
 
+// Several small tables looked up at the same pair positions (the input stage: three bond-feature tables, bond distance,
+// relative position): their gradients in ONE pass over dy -- a wave keeps one private [total rows][64] table in LDS, every row of
+// dy is loaded once and added, times the set's row scale, at the K table rows its K indices name.
+struct EmbedMulti { const long long* idx[8]; const float* scale[8]; int off[8]; int card[8]; int K; int total; };
+__global__ __launch_bounds__(256) void embed_wgrad_multi_kernel(float* __restrict__ part, EmbedMulti em, const float* __restrict__ dy,
+                                                                long rows, int C, int lddy, int rows_per_wg) {
+    extern __shared__ float etabm[];                         // [4 waves][total][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = etabm + (size_t)wave * em.total * 64;
+    for (int e = lane; e < em.total * 64; e += 64) mine[e] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    constexpr int U = 4;
+    for (long row = r0 + (long)U * wave; row < r1; row += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = row + u < r1 ? row + u : r1 - 1;
+            v[u] = (row + u < r1 && lane < C) ? dy[rr * lddy + lane] : 0.f;
+        }
+        for (int k = 0; k < em.K; ++k) {
+            int c[U];
+            float sc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long rr = row + u < r1 ? row + u : r1 - 1;
+                c[u] = (int)em.idx[k][rr];                    // wave-uniform
+                sc[u] = em.scale[k] ? em.scale[k][rr] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c[u] >= 0 && c[u] < em.card[k]) mine[(em.off[k] + c[u]) * 64 + lane] += v[u] * sc[u];
+        }
+    }
+    __syncthreads();
+    float* pt = part + (size_t)blockIdx.x * em.total * C;
+    for (int e = threadIdx.x; e < em.total * 64; e += 256) {
+        const int cc = e >> 6, ch = e & 63;
+        if (ch < C) pt[cc * C + ch] = ((etabm[e] + etabm[(size_t)em.total * 64 + e]) + etabm[(size_t)2 * em.total * 64 + e]) + etabm[(size_t)3 * em.total * 64 + e];
+    }
+}
+
 // 64 elements per workgroup, the slabs dealt in four contiguous quarters to the four waves (eight loads in flight per lane),
 // quarter sums combined in wave order: the summation order is fixed.
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ part,
@@ -1488,6 +1530,35 @@ extern "C" int prd_linear_wgrad(float* dw, float* db, const float* dy, const flo
         else hipLaunchKernelGGL(linear_wgrad_kernel<1>, grid, dim3(256), 0, stream, ws, dy, x, (long)rows, O, I, lddy, ldx, rows_per_wg, want_db);
     }
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dw, db, ws, n, nw, (int)slabs);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_embed_wgrad_multi(float* dtables, const long long* const* idx, const float* const* row_scale, const int* card, int K,
+                                     const float* dy, long long rows, int C, int lddy, float* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!dtables || !idx || !card || !dy || !ws || K <= 0 || rows <= 0 || C <= 0 || lddy < C) return PRD_ERR_ARG;
+    if (K > 8 || C > 64) return PRD_ERR_UNSUPPORTED;
+    EmbedMulti em{};
+    em.K = K;
+    int total = 0;
+    for (int k = 0; k < K; ++k) {
+        if (!idx[k] || card[k] <= 0) return PRD_ERR_ARG;
+        em.idx[k] = idx[k];
+        em.scale[k] = row_scale ? row_scale[k] : nullptr;
+        em.off[k] = total;
+        em.card[k] = card[k];
+        total += card[k];
+    }
+    em.total = total;
+    if (total > 128) return PRD_ERR_UNSUPPORTED;
+    if (ws_bytes < prd_embed_wgrad_workspace(rows, total, C)) return PRD_ERR_WORKSPACE;
+    const long slabs = wgrad_slabs(rows);
+    const int rows_per_wg = (int)((rows + slabs - 1) / slabs);
+    const size_t lds = (size_t)4 * total * 64 * sizeof(float);
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)embed_wgrad_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    hipLaunchKernelGGL(embed_wgrad_multi_kernel, dim3((unsigned)slabs), dim3(256), lds, stream, ws, em, dy, (long)rows, C, lddy, rows_per_wg);
+    const int n = total * C;
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, dtables, (float*)nullptr, ws, n, n, (int)slabs);
     return (int)hipGetLastError();
 }
 

@@ -547,6 +547,24 @@ def embed_wgrad(idx: torch.Tensor, dy2: torch.Tensor, card: int, scale: Optional
     return dt
 
 
+def embed_wgrad_multi(idxs, dy2: torch.Tensor, cards, scales=None):
+    """The gradients of several small tables looked up at the same rows, in one pass over dy2 [rows, C] (prd_embed_wgrad_multi):
+    ``idxs`` int64 [rows] each, ``cards`` their table sizes, ``scales`` optional per-set row factors [rows] (entries may be None).
+    Returns the list of [card_k, C] gradients."""
+    import ctypes
+    K = len(idxs)
+    rows, Cn = dy2.shape
+    total = int(sum(cards))
+    dt = torch.empty(total, Cn, device=dy2.device, dtype=F32)
+    nbytes = lib().prd_embed_wgrad_workspace(rows, total, Cn)
+    ws = torch.empty(nbytes // 4, device=dy2.device, dtype=F32)
+    ip = (ctypes.c_void_p * K)(*[dptr(i, torch.int64) for i in idxs])
+    sp = (ctypes.c_void_p * K)(*[dptr(s) for s in (scales if scales is not None else [None] * K)])
+    cp = (ctypes.c_int * K)(*[int(c) for c in cards])
+    check(lib().prd_embed_wgrad_multi(dptr(dt), ip, sp, cp, K, dptr(dy2), rows, Cn, Cn, dptr(ws), nbytes, stream()), "prd_embed_wgrad_multi")
+    return list(torch.split(dt, [int(c) for c in cards], dim=0))
+
+
 def tri_attn_uses_long_rows(N: int, P: int) -> bool:
     """True when rows of N positions take the re-projecting long-row core kernel (prd_hip.h: prd_tri_attn_variant)."""
     return tri_attn_variant(N, P) >= 1

@@ -119,11 +119,16 @@ class InputStageFn(torch.autograd.Function):
                 rel = (ri.unsqueeze(-1) - ri.unsqueeze(-2)).clamp(min=-m["max_relpos"], max=m["max_relpos"]) + m["max_relpos"]
                 s_rel = (rm.unsqueeze(-1) * rm.unsqueeze(-2) * (ci.unsqueeze(-1) == ci.unsqueeze(-2)).float()).contiguous().view(-1)
                 s_bond = (am2 * batch["bond_mask"] * (1.0 / math.sqrt(nb))).contiguous().view(-1)
-                for f in range(nb):
-                    grads[2 + na + f] = ops.embed_wgrad(batch["bond_feats"][..., f].contiguous().view(-1), dy2, bond_tabs[f].shape[0], scale=s_bond)
-                grads[2 + na + nb] = ops.embed_wgrad(batch["bond_distance"].clamp(max=m["max_bond_distance"]).contiguous().view(-1), dy2,
-                                                     bd_tab.shape[0], scale=am2.contiguous().view(-1))
-                grads[2 + na + nb + 1] = ops.embed_wgrad(rel.contiguous().view(-1), dy2, rp_tab.shape[0], scale=s_rel)
+                idxs = [batch["bond_feats"][..., f].contiguous().view(-1) for f in range(nb)]
+                idxs += [batch["bond_distance"].clamp(max=m["max_bond_distance"]).contiguous().view(-1), rel.contiguous().view(-1)]
+                cards = [tab.shape[0] for tab in (*bond_tabs, bd_tab, rp_tab)]
+                scales = [s_bond] * nb + [am2.contiguous().view(-1), s_rel]
+                if nb + 2 <= 8 and sum(cards) <= 128:           # all table gradients in one pass over dy
+                    tg = ops.embed_wgrad_multi(idxs, dy2, cards, scales)
+                else:
+                    tg = [ops.embed_wgrad(i, dy2, c_, scale=s_) for i, c_, s_ in zip(idxs, cards, scales)]
+                for f in range(nb + 2):
+                    grads[2 + na + f] = tg[f]
                 rbf = ops.rbf_rows(z.detach(), centers.detach(), mask)                    # [b, N, N, R], mask_i mask_j inside
                 grads[2 + na + nb + 5] = ops.linear_wgrad(dy2, rbf.view(-1, rbf.shape[-1]))
                 m2 = (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)

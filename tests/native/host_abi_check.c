@@ -158,6 +158,14 @@ int main(void) {
     EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, s), PRD_ERR_UNSUPPORTED);          /* fp32 arithmetic: the caller's GEMM */
     EXPECT(prd_pair_linear(p, p, p, p, 100, 256, 64, 1, 0, 0, 0, 1, s), PRD_ERR_ARG);                 /* LayerNorm of 256-wide rows */
     EXPECT(prd_pair_linear(p, p + 1, p, p, 100, 64, 64, 0, 0, 0, 0, 1, s), PRD_ERR_ALIGN);
+    {
+        const long long* ids[2] = {(const long long*)ibuf, (const long long*)ibuf};
+        int cards[2] = {8, 200};
+        EXPECT(prd_embed_wgrad_multi(0, ids, 0, cards, 2, p, 100, 64, 64, p, 1 << 20, s), PRD_ERR_ARG);
+        EXPECT(prd_embed_wgrad_multi(p, ids, 0, cards, 2, p, 100, 64, 64, p, 1 << 20, s), PRD_ERR_UNSUPPORTED);      /* more than 128 rows in total */
+        cards[1] = 8;
+        EXPECT(prd_embed_wgrad_multi(p, ids, 0, cards, 2, p, 100, 64, 64, p, 16, s), PRD_ERR_WORKSPACE);
+    }
     EXPECT(prd_rbf_rows(0, p, p, p, 1, 8, 256, s), PRD_ERR_ARG);
     EXPECT(prd_rbf_rows(p, p, p, p, 1, 8, 30, s), PRD_ERR_UNSUPPORTED);
     EXPECT(prd_sym_transpose(0, p, 1, 8, 64, s), PRD_ERR_ARG);

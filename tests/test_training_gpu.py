@@ -195,6 +195,30 @@ def test_pair_track_backward_is_bit_reproducible(gemm_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(40 * 40 * 2, 64), (204800, 64), (9001, 32)])
+def test_multi_table_embedding_gradient(rows, C):
+    """prd_embed_wgrad_multi (several small tables looked up at the same rows, one pass over dy, per-set row scales) against the
+    single-table kernel and a float64 scatter-sum; out-of-range indices are ignored; bit-identical when repeated."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    cards = [5, 6, 2, 8, 65]
+    dy = torch.randn(rows, C, generator=g).to(DEV)
+    idxs = [torch.randint(0, c, (rows,), generator=g).to(DEV) for c in cards]
+    idxs[1][:7] = -1
+    scales = [torch.rand(rows, generator=g).to(DEV), None, torch.rand(rows, generator=g).to(DEV), None, (torch.rand(rows, generator=g) > 0.3).float().to(DEV)]
+    got = ops.embed_wgrad_multi(idxs, dy, cards, scales)
+    for k, c in enumerate(cards):
+        v = dy.double() * (scales[k].double().unsqueeze(1) if scales[k] is not None else 1.0)
+        ok = idxs[k] >= 0
+        want = torch.zeros(c, C, dtype=torch.float64, device=DEV).index_add_(0, idxs[k][ok], v[ok])
+        assert got[k].shape == (c, C) and float((got[k].double() - want).norm() / want.norm()) < 2e-6, k
+        one = ops.embed_wgrad(idxs[k], dy, c, scale=scales[k])
+        assert float((got[k] - one).norm() / one.norm()) < 2e-6
+    again = ops.embed_wgrad_multi(idxs, dy, cards, scales)
+    assert all(torch.equal(a, b_) for a, b_ in zip(got, again))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,P,S", [(90, 32, 64), (640, 64, 512), (301, 64, 130)])
 def test_outer_linear_backward_reductions(R, P, S):
     """prd_outer_linear_bwd_reduce against float64: dx = sum_p T w1 and dw1 = sum_r T x over T [R, P, S]; repeatable bit for bit."""
