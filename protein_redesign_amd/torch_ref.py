@@ -95,8 +95,16 @@ def gated_attention(x, mask, wq, wk, wv, wg, bg, wo, bo, heads: int, head_dim: i
     def split(t):
         return t.reshape(*lead, n, heads, head_dim).transpose(-2, -3)
 
-    q, k, v = split(linear(x, wq)), split(linear(x, wk)), split(linear(x, wv))
-    g = split(torch.sigmoid(linear(x, wg, bg)))
+    if x.is_cuda and torch.is_grad_enabled():
+        # one GEMM for the four projections (and one for each of their gradients): on the GPU this restatement is the BACKWARD of
+        # the single-track attention, a chain of ~35 launch-bound kernels at [b, N, 512] size
+        hc = heads * head_dim
+        qkvg = F.linear(x, torch.cat([wq, wk, wv, wg], dim=0))
+        q, k, v = split(qkvg[..., :hc]), split(qkvg[..., hc:2 * hc]), split(qkvg[..., 2 * hc:3 * hc])
+        g = split(torch.sigmoid(qkvg[..., 3 * hc:] + bg))
+    else:
+        q, k, v = split(linear(x, wq)), split(linear(x, wk)), split(linear(x, wv))
+        g = split(torch.sigmoid(linear(x, wg, bg)))
     logits = torch.matmul((1.0 / math.sqrt(head_dim)) * q, k.transpose(-1, -2))
     if bias is not None:
         logits = logits + bias
@@ -220,10 +228,17 @@ def single_bias_attention(single, bias, gm, bm, wq, wk, wv, wg, bg, wo, bo, head
     def heads_of(t):
         return t.view(b_, n, heads, -1).transpose(-2, -3)
 
-    q, k, v = heads_of(F.linear(m, wq)), heads_of(F.linear(m, wk)), heads_of(F.linear(m, wv))
+    if m.is_cuda and torch.is_grad_enabled():           # one GEMM for the four projections (see gated_attention)
+        hc = wq.shape[0]
+        qkvg = F.linear(m, torch.cat([wq, wk, wv, wg], dim=0))
+        q, k, v = heads_of(qkvg[..., :hc]), heads_of(qkvg[..., hc:2 * hc]), heads_of(qkvg[..., 2 * hc:3 * hc])
+        gate_pre = qkvg[..., 3 * hc:] + bg
+    else:
+        q, k, v = heads_of(F.linear(m, wq)), heads_of(F.linear(m, wk)), heads_of(F.linear(m, wv))
+        gate_pre = F.linear(m, wg, bg)
     a = torch.softmax(torch.matmul(q / math.sqrt(q.shape[-1]), k.transpose(-1, -2)) + bias, dim=-1)
     o = torch.matmul(a, v).transpose(-2, -3)
-    gate = torch.sigmoid(F.linear(m, wg, bg)).view(b_, n, heads, -1)
+    gate = torch.sigmoid(gate_pre).view(b_, n, heads, -1)
     return m + F.linear((o * gate).reshape(b_, n, -1), wo, bo)
 
 
