@@ -989,26 +989,41 @@ __global__ __launch_bounds__(256) void embed_wgrad_multi_kernel(float* __restric
     for (int e = lane; e < em.total * 64; e += 64) mine[e] = 0.f;
     const long r0 = (long)blockIdx.x * rows_per_wg;
     const long r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
-    constexpr int U = 4;
-    for (long row = r0 + (long)U * wave; row < r1; row += 4 * U) {
-        float v[U];
+    // 64 rows per wave and round: the lanes fetch the K indices and scales of 64 rows with coalesced loads (one row per lane) and
+    // hand them out with v_readlane -- a wave-uniform 8-byte load per (row, table) made the single-table form latency-bound
+    const int lc = lane < C ? lane : 0;
+    const float lz = lane < C ? 1.f : 0.f;
+    for (long row0 = r0 + 64L * wave; row0 < r1; row0 += 256) {
+        const long rl = row0 + lane;
+        const bool ok = rl < r1;
+        const long rcl = ok ? rl : r1 - 1;
+        int ci[8];
+        float si[8];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long rr = row + u < r1 ? row + u : r1 - 1;
-            v[u] = (row + u < r1 && lane < C) ? dy[rr * lddy + lane] : 0.f;
+        for (int k = 0; k < 8; ++k) {
+            ci[k] = -1;
+            si[k] = 0.f;
+            if (k < em.K) {
+                ci[k] = ok ? (int)em.idx[k][rcl] : -1;
+                si[k] = em.scale[k] ? em.scale[k][rcl] : 1.0f;
+            }
         }
-        for (int k = 0; k < em.K; ++k) {
-            int c[U];
-            float sc[U];
+        for (int u0 = 0; u0 < 64 && row0 + u0 < r1; u0 += 8) {
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const long rr = row + u < r1 ? row + u : r1 - 1;
-                c[u] = (int)em.idx[k][rr];                    // wave-uniform
-                sc[u] = em.scale[k] ? em.scale[k][rr] : 1.0f;
+            for (int j = 0; j < 8; ++j) {
+                const long rr = row0 + u0 + j;
+                v[j] = dy[(rr < r1 ? rr : r1 - 1) * lddy + lc] * (rr < r1 ? lz : 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (c[u] >= 0 && c[u] < em.card[k]) mine[(em.off[k] + c[u]) * 64 + lane] += v[u] * sc[u];
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < em.K) {
+                        const int c = __builtin_amdgcn_readlane(ci[k], u0 + j);
+                        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, si[k]), u0 + j));
+                        if (c >= 0 && c < em.card[k]) mine[(em.off[k] + c) * 64 + lane] += v[j] * sc;
+                    }
         }
     }
     __syncthreads();
