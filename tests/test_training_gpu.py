@@ -219,6 +219,24 @@ def test_multi_table_embedding_gradient(rows, C):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,N", [(2, 45), (1, 320)])
+def test_radial_basis_rows_and_pair_symmetrisation_kernels(b, N):
+    """prd_rbf_rows against the reference's formula (modules.py:73-82: exp(-(R-1)/2 (|z_i - z_j| - c_r)^2), here times mask_i mask_j)
+    and prd_sym_rows against scale * (x + x^T), bit-exact."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(N)
+    z = (torch.randn(b, N, 3, generator=g) * 0.7).to(DEV)
+    mask = (torch.rand(b, N, generator=g) > 0.2).float().to(DEV)
+    centers = torch.linspace(0.0, 2.0, 256).to(DEV)
+    got = ops.rbf_rows(z, centers, mask)
+    dist = torch.linalg.norm(z.double().unsqueeze(-2) - z.double().unsqueeze(-3), dim=-1)
+    want = torch.exp(-(255 / 2.0) * torch.square(dist.unsqueeze(-1) - centers.double())) * (mask.unsqueeze(-1) * mask.unsqueeze(-2)).unsqueeze(-1)
+    assert got.shape == (b, N, N, 256) and float((got.double() - want).abs().max()) < 2e-5
+    x = torch.randn(b, N, N, 64, generator=g).to(DEV)
+    assert torch.equal(ops.sym_rows(x, 0.5), 0.5 * (x + x.transpose(1, 2)))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,P,S", [(90, 32, 64), (640, 64, 512), (301, 64, 130)])
 def test_outer_linear_backward_reductions(R, P, S):
     """prd_outer_linear_bwd_reduce against float64: dx = sum_p T w1 and dw1 = sum_r T x over T [R, P, S]; repeatable bit for bit."""
