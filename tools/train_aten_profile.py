@@ -47,6 +47,15 @@ def main():
     tot = sum(r[0] for r in rows)
     print(f"total self device time {tot / 1e3:.2f} ms")
     rows = [r for r in rows if r[2].startswith("aten::") or "Backward" in r[2] or "Fn" in r[2]]
+    if "--fills" in sys.argv:           # where the small fills / copies of a step come from: count by operator and shape
+        cnt = {}
+        for e in prof.key_averages(group_by_input_shape=True):
+            if e.key in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::copy_", "aten::clone", "aten::ones_like", "aten::full",
+                         "aten::masked_fill", "aten::one_hot", "aten::contiguous", "aten::cat", "aten::add_", "aten::add", "aten::mul", "aten::sum"):
+                cnt[(e.key, str(e.input_shapes)[:80])] = cnt.get((e.key, str(e.input_shapes)[:80]), 0) + e.count
+        for (k, sh), n in sorted(cnt.items(), key=lambda kv: -kv[1])[:50]:
+            print(f"{n:5d}  {k:22s} {sh}")
+        return
     for t, n, k, sh, st in rows[:60]:
         print(f"{t / 1e3:8.3f} ms {n:4d}  {k[:40]:40s} {sh:70s} {' <- '.join(x.split('/')[-1][:60] for x in st)}")
 
