@@ -245,6 +245,8 @@ int prd_tri_mul_chain(float* pair, const float* mask, const float* const* w_outg
  * workspace); w_*_t = the transposed weights [in][out].  Writes dz = dy * gate and dgp = d(pre-activation of the output gate)
  * (row layout [b,N,N,P]; dW_out = dz^T LN(O), dW_ogate = dgp^T LN(pair) are left to the caller's BLAS), dO (channel-major) and
  * dx1 = W_ogate^T dgp (row layout), the output-gate path of the gradient of LN(pair).
+ * w_out_t / w_ogate_t may be NULL: the kernel then stages the transposed images from w_out / w_ogate read column-wise (no
+ * transposed copy needed); likewise w_proj_t / w_gate_t of prd_tri_mul_proj_bwd.
  * x_out, lo_out (either may be null): LN(pair) and LN(O) in row layout [b,N,N,P], the inputs of those weight gradients (the kernel
  * has both in registers).  dO_batch_channels: channel planes between the batches of dO (0 = P, i.e. dO[b][P][N][ldn]; 4P when dO
  * is block 0 of prd_tri_mul_bwd_operands' buffer). */

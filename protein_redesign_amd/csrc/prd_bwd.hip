@@ -71,8 +71,9 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_bwd_kernel(
     const int NT = NW * 64;
     stage_weight_cll<P>(Wol, wo, P, P, threadIdx.x, NT);
     stage_weight_cll<P>(Wgl, wog, P, P, threadIdx.x, NT);
-    stage_weight_cll<P>(WoTl, woT, P, P, threadIdx.x, NT);
-    stage_weight_cll<P>(WgTl, wogT, P, P, threadIdx.x, NT);
+    // W^T images: from the caller's transposed copies, or (null) straight from W read column-wise
+    if (woT) stage_weight_cll<P>(WoTl, woT, P, P, threadIdx.x, NT); else stage_weight_cll_t<P>(WoTl, wo, P, P, threadIdx.x, NT);
+    if (wogT) stage_weight_cll<P>(WgTl, wogT, P, P, threadIdx.x, NT); else stage_weight_cll_t<P>(WgTl, wog, P, P, threadIdx.x, NT);
     stage_vec_cll(bol, bo, P, threadIdx.x, NT);
     stage_vec_cll(bgl, bog, P, threadIdx.x, NT);
     __syncthreads();
@@ -173,13 +174,15 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_proj_bwd_kernel(
     if (B3) {
         stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wpl), wp, OUT, P, threadIdx.x, NT, H2_WSCALE);
         stage_weight_h2<P>(reinterpret_cast<u32x4*>(Wgl), wg, OUT, P, threadIdx.x, NT, H2_WSCALE);
-        stage_weight_h2<OUT>(reinterpret_cast<u32x4*>(WpTl), wpT, P, OUT, threadIdx.x, NT, H2_WSCALE);
-        stage_weight_h2<OUT>(reinterpret_cast<u32x4*>(WgTl), wgT, P, OUT, threadIdx.x, NT, H2_WSCALE);
+        if (wpT) stage_weight_h2<OUT>(reinterpret_cast<u32x4*>(WpTl), wpT, P, OUT, threadIdx.x, NT, H2_WSCALE);
+        else stage_weight_h2_t<OUT>(reinterpret_cast<u32x4*>(WpTl), wp, P, P, threadIdx.x, NT, H2_WSCALE);
+        if (wgT) stage_weight_h2<OUT>(reinterpret_cast<u32x4*>(WgTl), wgT, P, OUT, threadIdx.x, NT, H2_WSCALE);
+        else stage_weight_h2_t<OUT>(reinterpret_cast<u32x4*>(WgTl), wg, P, P, threadIdx.x, NT, H2_WSCALE);
     } else {
         stage_weight_cll<P>(Wpl, wp, OUT, P, threadIdx.x, NT);
         stage_weight_cll<P>(Wgl, wg, OUT, P, threadIdx.x, NT);
-        stage_weight_cll<OUT>(WpTl, wpT, P, OUT, threadIdx.x, NT);
-        stage_weight_cll<OUT>(WgTl, wgT, P, OUT, threadIdx.x, NT);
+        if (wpT) stage_weight_cll<OUT>(WpTl, wpT, P, OUT, threadIdx.x, NT); else stage_weight_cll_t<OUT>(WpTl, wp, P, P, threadIdx.x, NT);
+        if (wgT) stage_weight_cll<OUT>(WgTl, wgT, P, OUT, threadIdx.x, NT); else stage_weight_cll_t<OUT>(WgTl, wg, P, P, threadIdx.x, NT);
     }
     stage_vec_cll(bpl, bp, OUT, threadIdx.x, NT);
     stage_vec_cll(bgl, bg, OUT, threadIdx.x, NT);
@@ -1307,8 +1310,7 @@ extern "C" int prd_tri_mul_out_bwd(float* dz, float* dgp, float* dO, float* dx1,
                                    const float* w_out, const float* b_out, const float* w_ogate, const float* b_ogate,
                                    const float* w_out_t, const float* w_ogate_t, float* x_out, float* lo_out, int dO_batch_channels,
                                    int b, int N, int P, hipStream_t stream) {
-    if (!dz || !dgp || !dO || !dx1 || !dy || !pair || !O || !w_out || !b_out || !w_ogate || !b_ogate || !w_out_t || !w_ogate_t ||
-        b <= 0 || N <= 0) return PRD_ERR_ARG;
+    if (!dz || !dgp || !dO || !dx1 || !dy || !pair || !O || !w_out || !b_out || !w_ogate || !b_ogate || b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     if (dO_batch_channels == 0) dO_batch_channels = P;
     if (dO_batch_channels < P) return PRD_ERR_ARG;
@@ -1332,7 +1334,7 @@ extern "C" int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const 
                                     const float* mask, const float* w_proj, const float* b_proj, const float* w_gate, const float* b_gate,
                                     const float* w_proj_t, const float* w_gate_t, int incoming, int b, int N, int P, int arith, hipStream_t stream) {
     PRD_SPLIT_ARITH(arith);
-    if (!dpair || !dpp || !dpg || !dAB || !dx1 || !pair || !mask || !w_proj || !b_proj || !w_gate || !b_gate || !w_proj_t || !w_gate_t ||
+    if (!dpair || !dpp || !dpg || !dAB || !dx1 || !pair || !mask || !w_proj || !b_proj || !w_gate || !b_gate ||
         b <= 0 || N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     constexpr int NWB = 8;

@@ -136,6 +136,21 @@ PRD_DEV void ln_cll(float (&x)[KH]) {
 // ---- LDS staging ------------------------------------------------------------------------------
 // W: global [nout][K] (row pitch ldw floats, 16-byte aligned rows) -> Wl: LDS, row pitch K+4,
 // K axis permuted to CLL order: 16-byte group f of a row goes to slot (f&1)*(K/8) + (f>>1).
+// The same image from the TRANSPOSED matrix in memory: Wt [K][nout] (row pitch ldt), i.e. row o of the image is column o of Wt
+// (the backward of a linear multiplies by W^T: no transposed copy of the weights has to be made first).  Consecutive threads
+// take consecutive o: the four scalar loads of a 16-byte group are coalesced across the workgroup.
+template <int K>
+PRD_DEV void stage_weight_cll_t(float* Wl, const float* __restrict__ Wt, int nout, int ldt, int tid, int nthreads, float scale = 1.0f) {
+    constexpr int F = K / 4;
+    const int total = nout * F;
+    for (int idx = tid; idx < total; idx += nthreads) {
+        const int f = idx / nout, o = idx - f * nout;
+        const float* src = Wt + (size_t)(4 * f) * ldt + o;
+        const float4 v = make_float4(src[0], src[ldt], src[2 * (size_t)ldt], src[3 * (size_t)ldt]);
+        *reinterpret_cast<float4*>(Wl + o * (K + 4) + (f & 1) * (K / 2) + (f >> 1) * 4) = make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
+    }
+}
+
 template <int K>
 PRD_DEV void stage_weight_cll(float* Wl, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads, float scale = 1.0f) {
     constexpr int F = K / 4, G = 8;
@@ -458,6 +473,30 @@ PRD_DEV void stage_weight_h2_rows(u32x4* Wh, int nout, int row0, const float* __
 template <int K>
 PRD_DEV void stage_weight_h2(u32x4* Wh, const float* __restrict__ W, int nout, int ldw, int tid, int nthreads, float scale) {
     stage_weight_h2_rows<K>(Wh, nout, 0, W, nout, ldw, tid, nthreads, scale);
+}
+// ... and from the transposed matrix in memory, Wt [K][nout] (see stage_weight_cll_t)
+template <int K>
+PRD_DEV void stage_weight_h2_t(u32x4* Wh, const float* __restrict__ Wt, int nout, int ldt, int tid, int nthreads, float scale) {
+    constexpr int S = K / 16;
+    const int total = nout * S * 2;
+    for (int idx = tid; idx < total; idx += nthreads) {
+        const int rem = idx / nout, o = idx - rem * nout, st = rem >> 1, h = rem & 1;
+        const float* s0 = Wt + (size_t)(16 * st + 4 * h) * ldt + o;        // CLL elements 8st .. 8st+3: k = 16 st + 4 h + e
+        const float* s1 = s0 + (size_t)8 * ldt;                            // 8st+4 .. 8st+7: k = 16 st + 8 + 4 h + e
+        const float v[8] = {scale * s0[0], scale * s0[ldt], scale * s0[2 * (size_t)ldt], scale * s0[3 * (size_t)ldt],
+                            scale * s1[0], scale * s1[ldt], scale * s1[2 * (size_t)ldt], scale * s1[3 * (size_t)ldt]};
+        u32x4 ph, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b;
+            split2h(v[2 * q], v[2 * q + 1], a, b);
+            ph[q] = a;
+            pl[q] = b;
+        }
+        const int slot = h2_slot<K>(o, 2 * st + h);
+        Wh[(size_t)o * (K / 8) + slot] = ph;
+        Wh[(size_t)(nout + o) * (K / 8) + slot] = pl;
+    }
 }
 // NATURAL K order (for operands generated per K step, not rows in CLL): slot j of row o holds W[o][k0 + 8 j .. + 7]; K must be a
 // multiple of 128 (16 | K/8), slot j is stored at j ^ (o & 15).  K step s of lane (r, hi) then covers k = 16 s + 8 hi .. + 7.

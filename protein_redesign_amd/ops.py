@@ -382,9 +382,9 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
     # dA[i][k] = sum_j dO[i][j] B^T[k][j];  dB[j][k] = sum_i dO^T[j][i] A^T[k][i]: one contraction over the stacked operands
     # dO | dO^T | B^T | A^T (dO written in place by the output-stage backward, the transposes by prd_tri_mul_bwd_operands)
     ops4 = torch.empty(b, 4 * P, N, ldn, device=dev, dtype=F32)
-    woT, wogT = wo.t().contiguous(), wog.t().contiguous()
+    # (the transposed weight images are staged from wo / wog / wp / wg read column-wise: no transposed copies)
     check(lib().prd_tri_mul_out_bwd(dptr(dz), dptr(dgp), dptr(ops4), dptr(dx1), dptr(dy), dptr(pair), dptr(O), dptr(wo), dptr(bo),
-                                    dptr(wog), dptr(bog), dptr(woT), dptr(wogT), dptr(x), dptr(lo), 4 * P, b, N, P, stream()),
+                                    dptr(wog), dptr(bog), None, None, dptr(x), dptr(lo), 4 * P, b, N, P, stream()),
           "prd_tri_mul_out_bwd")
     check(lib().prd_tri_mul_bwd_operands(dptr(ops4), dptr(AB), b, N, P, stream()), "prd_tri_mul_bwd_operands")
     dAB = torch.empty(b, 2 * P, N, ldn, device=dev, dtype=F32)
@@ -393,9 +393,8 @@ def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
     dpair = torch.empty_like(pair)
     dpp = torch.empty(b, N, N, 2 * P, device=dev, dtype=F32)
     dpg = torch.empty(b, N, N, 2 * P, device=dev, dtype=F32)
-    wpT, wgT = wp.t().contiguous(), wg.t().contiguous()
     check(lib().prd_tri_mul_proj_bwd(dptr(dpair), dptr(dpp), dptr(dpg), dptr(dAB), dptr(dx1), dptr(pair), dptr(mask), dptr(wp),
-                                     dptr(bp), dptr(wg), dptr(bg), dptr(wpT), dptr(wgT), int(incoming), b, N, P, stream()),
+                                     dptr(bp), dptr(wg), dptr(bg), None, None, int(incoming), b, N, P, stream()),
           "prd_tri_mul_proj_bwd")
     # weight gradients: dW = dOut^T In over all rows (linear_wgrad)
     x, lo = x.view(-1, P), lo.view(-1, P)
