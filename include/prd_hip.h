@@ -291,10 +291,11 @@ int prd_sym_transpose(float* out, const float* dy, int b, int N, int P, hipStrea
  * at most 256; autograd of nn.Linear over [b,N,N,*], modules.py:236-243, 321-326): out[row][0..OUT) = act(LN?(x[row]) W^T + bias),
  * W [OUT][K] as in nn.Linear.  ln_in: LayerNorm (no affine) of the x rows first (K = 64), xn_out (optional) receives them.
  * act: 0 none, 1 ReLU.  mask_pos (optional) [rows][OUT]: the result is zeroed where mask_pos <= 0 (ReLU backward from recomputed
- * activations).  (K, OUT) in {(64,64), (64,256), (256,64)}, split-16 arithmetic (prd_pair_linear_supported); 16-byte aligned row tensors. */
+ * activations).  w_kn = 1: W is given TRANSPOSED in memory, [K][OUT] (the backward of a linear multiplies by the forward's weight
+ * as it lies: no transposed copy).  (K, OUT) in {(64,64), (64,256), (256,64)}, split-16 arithmetic (prd_pair_linear_supported); 16-byte aligned row tensors. */
 int prd_pair_linear_supported(int K, int OUT, int arith);
 int prd_pair_linear(float* out, const float* x, const float* w, const float* bias, long long rows, int K, int OUT,
-                    int ln_in, float* xn_out, int act, const float* mask_pos, int arith, hipStream_t stream);
+                    int ln_in, float* xn_out, int act, const float* mask_pos, int w_kn, int arith, hipStream_t stream);
 /* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x) (+ res[row][c] when res is given:
  * the gradient that bypasses the update through its residual connection). */
 int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, const float* res, long long rows, int C, hipStream_t stream);

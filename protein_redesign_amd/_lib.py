@@ -79,7 +79,7 @@ SIGNATURES = {
     "prd_sym_rows": [vp, vp, cf, ci, ci, ci, vp],
     "prd_outer_linear_bwd_reduce": [vp, vp, ci, vp, vp, vp, cll, ci, ci, vp],
     "prd_pair_linear_supported": [ci, ci, ci],
-    "prd_pair_linear": [vp, vp, vp, vp, cll, ci, ci, ci, vp, ci, vp, ci, vp],
+    "prd_pair_linear": [vp, vp, vp, vp, cll, ci, ci, ci, vp, ci, vp, ci, ci, vp],
     "prd_linear_wgrad_workspace": [cll, ci, ci],
     "prd_linear_wgrad": [vp, vp, vp, vp, cll, ci, ci, ci, ci, vp, cz, ci, vp],
     "prd_embed_wgrad_workspace": [cll, ci, ci],

@@ -1388,12 +1388,13 @@ namespace {
 template <int K, int NW>
 __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
     float* __restrict__ out, float* __restrict__ xn_out, const float* __restrict__ x, const float* __restrict__ w,
-    const float* __restrict__ bias, const float* __restrict__ mask_pos, long rows, int OUT, int ln_in, int act) {
+    const float* __restrict__ bias, const float* __restrict__ mask_pos, long rows, int OUT, int ln_in, int act, int w_kn) {
     extern __shared__ __attribute__((aligned(16))) float smem_pl[];
     u32x4* Wimg = reinterpret_cast<u32x4*>(smem_pl);
     float* bl = smem_pl + (size_t)OUT * K;
     const int NT = NW * 64;
-    if (OUT == 64) stage_weight_h2<K>(Wimg, w, 64, K, threadIdx.x, NT, H2_WSCALE);
+    if (w_kn) stage_weight_h2_t<K>(Wimg, w, OUT, OUT, threadIdx.x, NT, H2_WSCALE);        // w given as [K][OUT]
+    else if (OUT == 64) stage_weight_h2<K>(Wimg, w, 64, K, threadIdx.x, NT, H2_WSCALE);
     else stage_weight_h2<K>(Wimg, w, 256, K, threadIdx.x, NT, H2_WSCALE);
     stage_vec_cll(bl, bias, OUT, threadIdx.x, NT);
     __syncthreads();
@@ -1471,7 +1472,7 @@ extern "C" int prd_pair_linear_supported(int K, int OUT, int arith) {
 }
 
 extern "C" int prd_pair_linear(float* out, const float* x, const float* w, const float* bias, long long rows, int K, int OUT,
-                               int ln_in, float* xn_out, int act, const float* mask_pos, int arith, hipStream_t stream) {
+                               int ln_in, float* xn_out, int act, const float* mask_pos, int w_kn, int arith, hipStream_t stream) {
     if (!out || !x || !w || rows <= 0 || act < 0 || act > 1) return PRD_ERR_ARG;
     if (!prd_pair_linear_supported(K, OUT, arith)) return PRD_ERR_UNSUPPORTED;
     if ((ln_in && K != 64) || (xn_out && !ln_in)) return PRD_ERR_ARG;
@@ -1485,11 +1486,11 @@ extern "C" int prd_pair_linear(float* out, const float* x, const float* w, const
     if (K == 64) {
         PRD_BWD_SET_LDS((pair_linear_rows_kernel<64, NWP>));
         hipLaunchKernelGGL((pair_linear_rows_kernel<64, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, out, xn_out, x, w, bias, mask_pos,
-                           (long)rows, OUT, ln_in, act);
+                           (long)rows, OUT, ln_in, act, w_kn);
     } else {
         PRD_BWD_SET_LDS((pair_linear_rows_kernel<256, NWP>));
         hipLaunchKernelGGL((pair_linear_rows_kernel<256, NWP>), dim3(grid), dim3(NWP * 64), lds, stream, out, xn_out, x, w, bias, mask_pos,
-                           (long)rows, OUT, ln_in, act);
+                           (long)rows, OUT, ln_in, act, w_kn);
     }
     return (int)hipGetLastError();
 }

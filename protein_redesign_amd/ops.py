@@ -434,10 +434,10 @@ def tri_attn_backward(dy, pair, mask, wts, H: int, c: int, *, ending: bool, og=N
     else:
         check(lib().prd_tri_attn_bwd_core(dptr(dqkvg), dptr(dog), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
                                           int(ending), b, N, P, H, c, stream()), "prd_tri_attn_bwd_core")
-    wcat_t = torch.cat([wq, wk, wv, wg], dim=0).t().contiguous()                                  # [P, 4 HC]
-    dxn = pair_linear(dqkvg.view(-1, 4 * HC), wcat_t)                                            # gradient of LN(pair)
+    wcat = torch.cat([wq, wk, wv, wg], dim=0)                                                     # [4 HC, P]
+    dxn = pair_linear(dqkvg.view(-1, 4 * HC), wcat.t())                                          # gradient of LN(pair)
     if dxn is None:
-        dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat_t)
+        dxn = linear(dqkvg.view(b, N, N, 4 * HC), wcat.t().contiguous())
     dpair = torch.empty_like(pair)
     check(lib().prd_ln_rows_bwd(dptr(dpair), dptr(dxn), dptr(pair), dptr(dy) if residual else None, b * N * N, P, stream()), "prd_ln_rows_bwd")
     x = (x if x is not None else layer_norm(pair.contiguous())).view(-1, P)
@@ -490,8 +490,10 @@ def pair_linear(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     if not (PAIR_LINEAR and x2.is_cuda and x2.is_contiguous() and rows >= WGRAD_MIN_ROWS and lib().prd_pair_linear_supported(K, OUT) == 1):
         return None
     out = torch.empty(rows, OUT, device=x2.device, dtype=F32)
-    check(lib().prd_pair_linear(dptr(out), dptr(x2), dptr(w.contiguous()), dptr(bias), rows, K, OUT, int(ln_in), dptr(xn_out), act,
-                                dptr(relu_mask), stream()), "prd_pair_linear")
+    kn = (not w.is_contiguous()) and w.t().is_contiguous()      # a transposed view of a [K, OUT] matrix: staged as it lies in memory
+    wsrc = w.t() if kn else w.contiguous()
+    check(lib().prd_pair_linear(dptr(out), dptr(x2), dptr(wsrc), dptr(bias), rows, K, OUT, int(ln_in), dptr(xn_out), act,
+                                dptr(relu_mask), int(kn), stream()), "prd_pair_linear")
     return out
 
 

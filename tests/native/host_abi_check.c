@@ -153,11 +153,11 @@ int main(void) {
     EXPECT(prd_tri_attn_bwd_core_v2_supported(384, 64), 1);
     EXPECT(prd_tri_attn_bwd_core_v2_supported(385, 64), 0);
     EXPECT(prd_ln_rows_bwd(0, p, p, 0, 8, 64, s), PRD_ERR_ARG);
-    EXPECT(prd_pair_linear(0, p, p, p, 100, 64, 64, 0, 0, 0, 0, 1, s), PRD_ERR_ARG);
-    EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 128, 0, 0, 0, 0, 1, s), PRD_ERR_UNSUPPORTED);        /* (K, OUT) not served */
-    EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, s), PRD_ERR_UNSUPPORTED);          /* fp32 arithmetic: the caller's GEMM */
-    EXPECT(prd_pair_linear(p, p, p, p, 100, 256, 64, 1, 0, 0, 0, 1, s), PRD_ERR_ARG);                 /* LayerNorm of 256-wide rows */
-    EXPECT(prd_pair_linear(p, p + 1, p, p, 100, 64, 64, 0, 0, 0, 0, 1, s), PRD_ERR_ALIGN);
+    EXPECT(prd_pair_linear(0, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, 1, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 128, 0, 0, 0, 0, 0, 1, s), PRD_ERR_UNSUPPORTED);        /* (K, OUT) not served */
+    EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, 0, s), PRD_ERR_UNSUPPORTED);          /* fp32 arithmetic: the caller's GEMM */
+    EXPECT(prd_pair_linear(p, p, p, p, 100, 256, 64, 1, 0, 0, 0, 0, 1, s), PRD_ERR_ARG);                 /* LayerNorm of 256-wide rows */
+    EXPECT(prd_pair_linear(p, p + 1, p, p, 100, 64, 64, 0, 0, 0, 0, 0, 1, s), PRD_ERR_ALIGN);
     {
         const long long* ids[2] = {(const long long*)ibuf, (const long long*)ibuf};
         int cards[2] = {8, 200};

@@ -299,6 +299,9 @@ def test_pair_position_linear_row_kernel(case, rows):
         assert got is not None and got.shape == (rows, OUT)
         for _ in range(3):
             assert torch.equal(got, ops.pair_linear(*dev_args, **kw))
+        # the weight as a transposed view of a [K, OUT] matrix (what the backward of a linear passes): staged as it lies in memory
+        w_view = dev_args[1].t().contiguous().t()
+        assert not w_view.is_contiguous() and torch.equal(got, ops.pair_linear(dev_args[0], w_view, dev_args[2], **kw))
         assert _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES["fp32"]) == 0
         assert ops.pair_linear(x.to(DEV), w.to(DEV)) is None           # fp32 arithmetic: the caller's GEMM path
     finally:
