@@ -419,11 +419,13 @@ class ProteinReDiffModel(_Base):
             "residue_chain_index")}, bond_tabs + [self.embed_bond_distance.weight, self.embed_relpos.weight],
             self.max_bond_distance, self.max_relpos, P)
         tabs = torch.cat([e.weight for e in self.embed_atom_feats.embeddings], dim=0).contiguous()
-        offs, acc = [], 0
-        for n in ATOM_FEATURE_CARDS:
-            offs.append(acc)
-            acc += n
-        offsets = torch.tensor(offs, dtype=torch.int32, device=am.device)
+        offsets = getattr(self, "_atom_table_offsets", None)
+        if offsets is None or offsets.device != am.device:             # constant: uploaded once (not a host copy per call)
+            offs, acc = [], 0
+            for n in ATOM_FEATURE_CARDS:
+                offs.append(acc)
+                acc += n
+            offsets = self._atom_table_offsets = torch.tensor(offs, dtype=torch.int32, device=am.device)
         ss = ops.atom_embed(batch["atom_feats"].contiguous(), am, tabs, offsets, S)
         esm = ops.layer_norm(batch["residue_esm"].contiguous())
         ss = ops.linear(esm, self.embed_residue_esm[1].weight, rowmask=rm, resid=ss)
