@@ -65,7 +65,9 @@ int prd_version(void);
  *      (|x| <= sqrt(C)), their gated / ReLU-ed projections, probabilities (kept x 2^4) and weights (staged x 16) are well
  *      inside; tests/test_split16_range.py drives weights x 50 / x 1e-3 (triangle multiplication), x 30 / x 1e-3 (ReLU hidden
  *      units), logits x 30 / x 400 and inputs x 1e-4 / x 1e4 through both arithmetics.  Activations or weights beyond ~1e4 / below
- *      ~1e-4 in an un-normalised position are out of range for PRD_ARITH_SPLIT16: use PRD_ARITH_FP32.
+ *      ~1e-4 in an un-normalised position are out of range for PRD_ARITH_SPLIT16: use PRD_ARITH_FP32.  The host side does
+ *      that by itself: a sampling loop / optimisation step that ends non-finite under PRD_ARITH_SPLIT16 is run again under
+ *      PRD_ARITH_FP32 (or raises; ProteinReDiffModel.nonfinite_policy), see prd_step_boundary's sync[1].
  * Both arithmetics meet every parity tolerance of tests/ (the GPU suite runs its operator / step / trajectory / gradient tests in both). */
 #define PRD_ARITH_FP32 0
 #define PRD_ARITH_SPLIT16 1
@@ -415,8 +417,13 @@ int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pr
 /* The whole step boundary of the sampling loop in one launch (model.py:373, 405-420 and the next step's model.py:341-346):
  * noise_pred = remove_mean(eps_raw); z, seq_t advanced as in prd_reverse_update; t <- t - 1; and the NEXT step's inputs
  * ebeta_next[b,P] = time embedding of t - 1 (prd_time_embed) and single_next[b,N,S] = prd_single_init of the new seq_t.
- * sync: one int32, zero before the first launch, owned by the caller and shared only by stream-ordered launches (the last
- * workgroup to arrive advances t and resets it).  n_cls must be 21 (20 residue types + 'X'), time_dim <= 512 and even.
+ * sync: TWO int32, zero before the first launch, owned by the caller and shared only by stream-ordered launches: sync[0] is the
+ * arrival counter (the last workgroup to arrive advances t and resets it); sync[1] is a STICKY non-finite flag -- set to 1, never
+ * cleared by the library, as soon as a new coordinate or a new sequence entry is inf / NaN.  The reference is fp32 end to end
+ * (model.py:377-422) and cannot overflow at 65504; under PRD_ARITH_SPLIT16 an out-of-range operand can (OPERAND RANGE above) and
+ * shows up here: the host reads the flag once per sampling loop and re-runs the call under PRD_ARITH_FP32 or fails
+ * (protein_redesign_amd.diffusion_model: ProteinReDiffModel.nonfinite_policy).  n_cls must be 21 (20 residue types + 'X'),
+ * time_dim <= 512 and even.
  * seq_h != NULL: seq_pred is an OUTPUT -- the sequence head's last layer (model.py:117-122: Linear(S_h, 21, bias = False) with
  * weight w_seq [21, S_h]) is applied here to its ReLU hidden units seq_h [b,N,S_h] (row pitch ldh), instead of a GEMM launch of
  * its own; seq_h == NULL: seq_pred is read. */

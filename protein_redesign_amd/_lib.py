@@ -234,6 +234,39 @@ def arith() -> int:
     return lib().prd_get_gemm_mode()
 
 
+ARITH_NAMES = {0: "fp32 (PRD_ARITH_FP32)", 1: "split16 (PRD_ARITH_SPLIT16)"}
+
+
+class arithmetic:
+    """``with arithmetic("fp32"): ...`` -- the operators called inside pass that arithmetic to the library; the previous default
+    comes back on exit (also on an exception).  ``None`` leaves the default alone.  The library itself is stateless (prd_hip.h):
+    this only changes what the Python binding injects, so it is a fresh CALL in another arithmetic, never a re-exec."""
+
+    def __init__(self, mode):
+        if isinstance(mode, str):
+            if mode not in GEMM_MODES:
+                raise ValueError(f"arithmetic must be one of {sorted(GEMM_MODES)}, got {mode!r}")
+            mode = GEMM_MODES[mode]
+        self.mode = mode
+        self.prev = None
+
+    def __enter__(self):
+        if self.mode is not None:
+            self.prev = lib().prd_get_gemm_mode()
+            if lib().prd_set_gemm_mode(self.mode) != 0:
+                raise ValueError(f"invalid arithmetic {self.mode!r}")
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            lib().prd_set_gemm_mode(self.prev)
+        return False
+
+
+class NonFiniteError(RuntimeError):
+    """A sampling loop or an optimisation step produced inf / NaN (see ProteinReDiffModel.nonfinite_policy)."""
+
+
 def row_gemm_description(b3: bool) -> str:
     """What the GEMMs of the pair kernels compute in, for bench.py's JSON line (stated truthfully, not as a precision claim)."""
     if b3:

@@ -99,11 +99,17 @@ class SPAttention(nn.Module):
     def bias_from_pair(self, z: torch.Tensor) -> torch.Tensor:
         return ops.pair_bias(z.contiguous(), self.linear_z[1].weight, None, self.linear_z[0].weight, self.linear_z[0].bias)
 
-    def attend(self, mn: torch.Tensor, qkvg: torch.Tensor, bias: torch.Tensor, normed_only: bool = False, out_ln=None) -> torch.Tensor:
+    def attend(self, mn: torch.Tensor, qkvg: torch.Tensor, bias: torch.Tensor, normed_only: bool = False, out_ln=None,
+               logits_fp32: Optional[bool] = None) -> torch.Tensor:
         """``normed_only``: ``mn`` is the PLAIN normalised input (no affine; Denoiser.project_single's merged projection); the
         residual LN_affine(m) = mn * gamma + beta is then formed in the output projection's epilogue (gamma as the residual's
         column factor, beta added to the bias).  ``out_ln``: buffer that receives LN(result) when the output projection runs on
-        the K-slab path (ops.slab_ok): the first folding block's attention projection starts with it."""
+        the K-slab path (ops.slab_ok): the first folding block's attention projection starts with it.  ``logits_fp32``: the
+        logits on fp32 MFMA in either arithmetic (ops.gated_attention_single) -- what a DIFFERENTIABLE forward needs; the
+        training path passes True explicitly (training.network), None = only while autograd is recording (whatever the
+        module's train / eval flag says: a backward taken on an eval() model must see the same forward)."""
+        if logits_fp32 is None:
+            logits_fp32 = torch.is_grad_enabled()
         a = self.mha
         ln = self.layer_norm_m
         bo, rscale = a.linear_o.bias, None
@@ -113,7 +119,7 @@ class SPAttention(nn.Module):
         # no mask: the reference builds a mask bias and drops it (AF2_modules.py:447 vs 461-463)
         return ops.gated_attention_single(mn, mn, bias, self._packed(), a.linear_o.weight, bo,
                                           self.no_heads, self.c_hidden, key_mask=False, resid=mn, qkvg=qkvg, rscale=rscale, out_ln=out_ln,
-                                          logits_fp32=self.training)
+                                          logits_fp32=bool(logits_fp32))
 
     def forward(self, m: torch.Tensor, z: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, N, _ = m.shape

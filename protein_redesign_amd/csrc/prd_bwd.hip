@@ -1385,6 +1385,22 @@ extern "C" int prd_tri_attn_bwd_core(float* dqkvg, const float* dog, const float
 // (256, 64).  (A fused LayerNorm-backward tail for the 256 -> 64 form was measured no faster than this kernel + ln_rows_bwd64 --
 // 77.8 vs 47.6 + 30 us -- and is not built.)
 namespace {
+// Un-normalised operand rows (gradients: 1e-4 ... 1e-9 per element near a minimum, include/prd_hip.h OPERAND RANGE) are brought to
+// [1, 2) by an EXACT power of two before the fp16 hi | lo split and the factor is taken out of the accumulator again: biased
+// exponent of the largest magnitude of a row piece (both lane halves), clamped so that both factors are normal numbers.
+template <int KH>
+PRD_DEV unsigned row_exp_biased(const float (&x)[KH]) {
+    float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KH; k += 2) { m0 = fmaxf(m0, fabsf(x[k])); m1 = fmaxf(m1, fabsf(x[k + 1])); }
+    float m = fmaxf(m0, m1);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    unsigned eb = (__float_as_uint(m) >> 23) & 255u;
+    return eb < 1u ? 1u : (eb > 253u ? 253u : eb);      // an all-zero (or denormal) row: factor 2^126 of zeros; inf / NaN stay loud
+}
+PRD_DEV float pow2_from_biased(unsigned eb) { return __uint_as_float(eb << 23); }             // 2^(eb - 127)
+PRD_DEV float inv_pow2_from_biased(unsigned eb) { return __uint_as_float((254u - eb) << 23); } // 2^(127 - eb)
+
 template <int K, int NW>
 __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
     float* __restrict__ out, float* __restrict__ xn_out, const float* __restrict__ x, const float* __restrict__ w,
@@ -1408,9 +1424,16 @@ __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
         if constexpr (K == 64) {
             float xv[32];
             load_row_cll<64>(x + rowc * 64, hi, valid, xv);
+            float back = H2_INV_WSCALE;                 // accumulator -> result
             if (ln_in) {
                 ln_cll<32>(xv);
                 if (xn_out) store_row_cll<64>(xn_out + rowc * 64, hi, valid, xv);
+            } else {                                    // a raw row: normalise by a power of two (see row_exp_biased)
+                const unsigned eb = row_exp_biased<32>(xv);
+                const float dn = inv_pow2_from_biased(eb);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) xv[k] *= dn;
+                back = H2_INV_WSCALE * pow2_from_biased(eb);
             }
             u32x4 ps[2][4];
             split2h_cll<32>(xv, ps);
@@ -1421,7 +1444,7 @@ __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
                 float y[32];
 #pragma unroll
                 for (int s_ = 0; s_ < 32; ++s_) {
-                    float v = acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bl[hi * (OUT / 2) + 32 * j + s_];
+                    float v = acc[s_ >> 4][s_ & 15] * back + bl[hi * (OUT / 2) + 32 * j + s_];
                     y[s_] = act == 1 ? fmaxf(v, 0.f) : v;
                 }
                 if (mask_pos) {
@@ -1435,10 +1458,24 @@ __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
         } else {                                        // K = 256 -> 64 outputs, the row in four 64-channel pieces
             f32x16 acc[2];
             zero_acc(acc);
+            // running power-of-two scale of the row over its four pieces: a piece with a larger exponent than any before it
+            // rescales the accumulators (exactly), every piece is split at the scale of the largest so far
+            unsigned eb_run = 1u;
             auto piece = [&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 float xv[32];
                 load_row_cll<64>(x + rowc * 256 + 64 * c, hi, valid, xv);
+                const unsigned eb = row_exp_biased<32>(xv);
+                if (c == 0) eb_run = eb;
+                else if (eb > eb_run) {
+                    const float f = (eb - eb_run) >= 126u ? 0.f : __uint_as_float((127u - (eb - eb_run)) << 23);     // 2^(eb_run - eb)
+#pragma unroll
+                    for (int s_ = 0; s_ < 32; ++s_) acc[s_ >> 4][s_ & 15] *= f;
+                    eb_run = eb;
+                }
+                const float dn = inv_pow2_from_biased(eb_run);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) xv[k] *= dn;
                 u32x4 ps[2][4];
                 split2h_cll<32>(xv, ps);
                 rowgemm_h2_part<256, 2, 4 * c, 4 * c + 4>(Wimg, 64, 0, ps, acc, r, hi);
@@ -1447,10 +1484,11 @@ __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
             piece(std::integral_constant<int, 1>{});
             piece(std::integral_constant<int, 2>{});
             piece(std::integral_constant<int, 3>{});
+            const float back = H2_INV_WSCALE * pow2_from_biased(eb_run);
             float y[32];
 #pragma unroll
             for (int s_ = 0; s_ < 32; ++s_) {
-                const float v = acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bl[hi * 32 + s_];
+                const float v = acc[s_ >> 4][s_ & 15] * back + bl[hi * 32 + s_];
                 y[s_] = act == 1 ? fmaxf(v, 0.f) : v;
             }
             if (mask_pos) {

@@ -1267,8 +1267,10 @@ __global__ __launch_bounds__(256) void reverse_update_kernel(float* __restrict__
 // Workgroups [0, nblk) of a sample own 8 nodes each (a 32-node version ran 42 us: one long chain of dependent L2 round trips
 // per workgroup -- the work has to be wide, not deep); the masked means over all nodes are recomputed by every one of them
 // (N x 7 loads).  Workgroups [nblk, nblk + P/4) compute four time-embedding outputs each.  The step counter is advanced by the
-// LAST workgroup to arrive at `sync` (one int, zero before the first launch; every workgroup reads t before it arrives), which
-// also resets the counter for the next replay of the graph.
+// LAST workgroup to arrive at `sync[0]` (zero before the first launch; every workgroup reads t before it arrives), which
+// also resets the counter for the next replay of the graph.  `sync[1]` is a STICKY flag: set to 1 (never cleared here) when a new
+// coordinate or sequence entry is inf / NaN -- under PRD_ARITH_SPLIT16 that is how an operand beyond the fp16 range shows
+// (prd_hip.h, OPERAND RANGE); the host reads it once per sample() and re-runs the call under PRD_ARITH_FP32 or raises.
 constexpr int SB_NODES = 8;
 template <int NCLS>
 __global__ __launch_bounds__(256) void step_boundary_kernel(
@@ -1388,12 +1390,15 @@ __global__ __launch_bounds__(256) void step_boundary_kernel(
             for (int o = 1; o < 8; o <<= 1) var += __shfl_xor(var, o);
             const float rstd = 1.0f / sqrtf(var / ncls + 1e-5f);
             float* sp = seq_t + ((long)bb * N + (ok ? i : 0)) * ncls;
+            bool bad = false;
 #pragma unroll
             for (int q = 0; q < CPL; ++q)
                 if (l + 8 * q < ncls) {
                     if (ok) sp[l + 8 * q] = v[q];
+                    bad |= ok && !(fabsf(v[q]) <= 1.5f);        // 2 softmax - 1 lies in [-1, 1]: anything else is inf / NaN logits
                     xs[n][l + 8 * q] = ok ? (v[q] - mu) * rstd : 0.f;
                 }
+            if (bad) sync[1] = 1;
         }
         __syncthreads();
         if (tid < 7) mean[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
@@ -1407,6 +1412,7 @@ __global__ __launch_bounds__(256) void step_boundary_kernel(
                 float out = isa * (z[g] - wn * npred);
                 if (tt > 0) out = out + sb * (nz[i * 3 + d] - m * mean[3 + d] / mean[6]);
                 z[g] = out;
+                if (!(fabsf(out) <= 3.0e38f)) sync[1] = 1;      // sticky: inf / NaN coordinates (prd_hip.h, OPERAND RANGE)
             }
         }
         // single input of the next step: thread -> channels c, c + 256, ...; W_rt row in registers; the static-single / mask loads

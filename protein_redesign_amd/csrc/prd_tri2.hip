@@ -59,6 +59,7 @@ namespace {
 constexpr float LOG2E_2 = 1.4426950408889634f;
 constexpr float P_SHIFT = 4.0f;                 // probabilities are 2^(s - max + P_SHIFT)
 constexpr int V2_MAXN = 384;
+constexpr int PRD_V3_DEFAULT_KL = 0;        // key-loop form of tri_attn_core_v3_kernel when the caller gives no flags
 
 PRD_DEV f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -239,6 +240,38 @@ PRD_DEV void exp_split(f32x16& s, float& lsum, bool& big, PBuf& p) {
     lsum += ts;
     split8_rn(s, 0, p.ph0, p.pl0);
     split8_rn(s, 8, p.ph1, p.pl1);
+}
+// the two halves of exp_split apart (key-loop forms 1-3 of tri_attn_core_v3_kernel issue the next tile's Q K^T between them)
+template <bool SUM>
+PRD_DEV void exp_sum(f32x16& s, float& lsum, bool& big) {
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        s[j] = __builtin_amdgcn_exp2f(s[j]);
+        s[j + 1] = __builtin_amdgcn_exp2f(s[j + 1]);
+        if (SUM) { t0 += s[j]; t1 += s[j + 1]; }
+    }
+    if (SUM) {
+        const float ts = t0 + t1;
+        big |= !(ts < 30000.0f);                       // (the fp32 sum stays finite when an fp16 hi part overflows: test it here)
+        lsum += ts;
+    }
+}
+PRD_DEV void split_p(const f32x16& s, PBuf& p) {
+    split8_rn(s, 0, p.ph0, p.pl0);
+    split8_rn(s, 8, p.ph1, p.pl1);
+}
+// Row sum on the matrix pipe: v_mfma_f32_4x4x4_16B_f16 with A = ones adds a lane's OWN four fp16 values (its B operand) to each
+// of its four accumulator registers -- 8 small MFMAs (8 cycles each) per tile for the hi and lo parts of the 16 probabilities
+// instead of 18 v_add_f32.  An overflowed probability (+inf in fp16) makes the sum inf: the piece is then redone online.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+PRD_DEV void rowsum_mfma(const PBuf& p, f32x4& la0, f32x4& la1) {
+    const h16x4 ones = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+#define PRD_SUM4(acc, v, w) acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, __builtin_bit_cast(h16x4, u32x2_t{v[w], v[w + 1]}), acc, 0, 0, 0)
+    PRD_SUM4(la0, p.ph0, 0); PRD_SUM4(la1, p.ph0, 2); PRD_SUM4(la0, p.ph1, 0); PRD_SUM4(la1, p.ph1, 2);
+    PRD_SUM4(la0, p.pl0, 0); PRD_SUM4(la1, p.pl0, 2); PRD_SUM4(la0, p.pl1, 0); PRD_SUM4(la1, p.pl1, 2);
+#undef PRD_SUM4
 }
 PRD_DEV void load_v(const unsigned char* lds, unsigned vaddr, PBuf& p) {
     p.va0 = *reinterpret_cast<const u32x4*>(lds + vaddr);
@@ -641,7 +674,10 @@ PRD_DEV V3Lds v3_layout(int P, int NP) {
     return L;
 }
 
-template <int P, int NW>
+// KL = key-loop form (A/B: PRD_TA2_FLAGS bits 1-2; measured in DESIGN.md 4.3, round 5): 0 the round-3 order (Q K^T, exp + row
+// sum, split, P V); bit 0: the NEXT tile's Q K^T is issued between the exponentials and the split of this one (one more logit
+// tile in registers); bit 1: the row sum on the matrix pipe (rowsum_mfma) instead of 18 v_add_f32
+template <int P, int NW, int KL>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -869,7 +905,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             lsum = 0.f;
             bool big = false;
             if (flags & 1) v2_prio(work_rem, work_tot);
-            {
+            if (KL == 0) {
                 KOp k = load_k(lds, kbase + 512u * T0, kl_rel);
                 f32x16 s0 = qk_tile(k, qh, ql, zero);
                 if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_rel);
@@ -892,7 +928,44 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
                     exp_split(s, lsum, big, p);
                     pv_tile(p, o0);
                 }
+            } else {
+                constexpr bool VSUM = (KL & 2) == 0;    // row sum on the VALU (else: rowsum_mfma)
+                f32x4 la0 = {0.f, 0.f, 0.f, 0.f}, la1 = {0.f, 0.f, 0.f, 0.f};
+                KOp k = load_k(lds, kbase + 512u * T0, kl_rel);
+                f32x16 s = qk_tile(k, qh, ql, zero);
+                if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_rel);
+                if ((fmask >> T0) & 1) mask_tile_at(lds, kaddo, T0, hi, 0.f, s);
+                const float tmax = xhalf_max(max16_mfma(s));
+                mref = tmax - P_SHIFT;
+                f32x16 negm;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { negm[e] = -mref; s[e] -= mref; }
+                for (int t = T0; t < T1; ++t) {
+                    if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
+                    PBuf p;
+                    load_v(lds, vbase + 2048u * t, p);
+                    exp_sum<VSUM>(s, lsum, big);
+                    f32x16 sn;
+                    if ((KL & 1) && t + 1 < T1) {       // the next tile's logits: issued here, consumed one iteration later
+                        sn = qk_tile(k, qh, ql, negm);
+                        if (t + 2 < T1) k = load_k(lds, kbase + 512u * (t + 2), kl_rel);
+                    }
+                    split_p(s, p);
+                    if (!VSUM) rowsum_mfma(p, la0, la1);
+                    pv_tile(p, o0);
+                    if (t + 1 < T1) {
+                        if (!(KL & 1)) {
+                            sn = qk_tile(k, qh, ql, negm);
+                            if (t + 2 < T1) k = load_k(lds, kbase + 512u * (t + 2), kl_rel);
+                        }
+                        s = sn;
+                        if ((fmask >> (t + 1)) & 1) mask_tile_at(lds, kaddo, t + 1, hi, mref, s);
+                    }
+                }
+                if (!VSUM) lsum = la0[0] + la1[0];
             }
+            // (forms with the row sum on the matrix pipe have no per-tile `big` test: an overflowed probability is +inf in fp16
+            // and makes the sum inf)
             if (__any(big || !(lsum < 3.0e38f))) {      // rare: redo the piece with the online update in every tile
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o0[e] = 0.f;
@@ -1866,15 +1939,16 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
     }
     if (v3) {
         const size_t lds3 = v3_lds_bytes(N, P);
-        if (P == 64) {
-            PRD2_SET_LDS((tri_attn_core_v3_kernel<64, NWV>));
-            hipLaunchKernelGGL((tri_attn_core_v3_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                               NP, H, ending, flags, lse);
-        } else {
-            PRD2_SET_LDS((tri_attn_core_v3_kernel<32, NWV>));
-            hipLaunchKernelGGL((tri_attn_core_v3_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, bg, b, N,
-                               NP, H, ending, flags, lse);
-        }
+#define PRD_V3_LAUNCH(PP, KLF)                                                                                                      \
+        do {                                                                                                                      \
+            PRD2_SET_LDS((tri_attn_core_v3_kernel<PP, NWV, KLF>));                                                                \
+            hipLaunchKernelGGL((tri_attn_core_v3_kernel<PP, NWV, KLF>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, \
+                               bg, b, N, NP, H, ending, flags & ~6, lse);                                                         \
+        } while (0)
+        const int kl = flags_env >= 0 ? (flags >> 1) & 3 : PRD_V3_DEFAULT_KL;     // key-loop form (bits 1-2 of PRD_TA2_FLAGS; v3 has no stagger)
+        if (P == 64) { if (kl == 0) PRD_V3_LAUNCH(64, 0); else if (kl == 1) PRD_V3_LAUNCH(64, 1); else if (kl == 2) PRD_V3_LAUNCH(64, 2); else PRD_V3_LAUNCH(64, 3); }
+        else { if (kl == 0) PRD_V3_LAUNCH(32, 0); else if (kl == 1) PRD_V3_LAUNCH(32, 1); else if (kl == 2) PRD_V3_LAUNCH(32, 2); else PRD_V3_LAUNCH(32, 3); }
+#undef PRD_V3_LAUNCH
         return (int)hipGetLastError();
     }
     if (P == 64) {

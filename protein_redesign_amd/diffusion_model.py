@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from .constants import ATOM_FEATURE_CARDS, BOND_FEATURE_CARDS, NUM_RESIDUE_CLASSES
 from .schedule import reverse_coefficients, schedule_tables
 from .synthetic import NoiseSource
@@ -205,6 +205,14 @@ class ProteinReDiffModel(_Base):
         # so different seeds give different samples like in the reference; set an int to pin it regardless of the global seed.
         self.sample_seed = None
         self.use_hip_graph = True               # replay one captured step graph inside sample()
+        # What to do when a sampling loop / optimisation step ends with inf / NaN (the reference is fp32 end to end and cannot
+        # overflow at 65504; the default split-16 arithmetic can -- include/prd_hip.h, OPERAND RANGE):
+        #   "fp32"  (default) run the CALL again under PRD_ARITH_FP32 (a fresh call in this process, with a RuntimeWarning), and keep
+        #           fp32 for this model's later calls; if that is non-finite too -- or the call already ran in fp32 -- raise;
+        #   "raise" raise _lib.NonFiniteError naming the arithmetic;   "off" return whatever came out (no check, no host sync).
+        self.nonfinite_policy = "fp32"
+        self.arithmetic = None                  # None: the process default (_lib); "fp32" / "split16": this model's calls pin it
+        self.arith_fallbacks = 0                # how many calls were repeated in fp32 by the policy above
         self._side = None                       # ops.SideStream of the device the model runs on (created on first use)
         self._sample_counter = 0
 
@@ -331,7 +339,7 @@ class ProteinReDiffModel(_Base):
         self.log("val_loss", loss, on_epoch=True, sync_dist=True, batch_size=x.size(0))
         return loss
 
-    def training_step(self, batch, batch_idx, t=None, noise_z=None, noise_seq=None, sources=None):
+    def training_step(self, batch, batch_idx, t=None, noise_z=None, noise_seq=None, sources=None, check_finite=True):
         """model.py:528-549: mean over the batch of diffusion_loss / node count, differentiable with respect to every trainable
         parameter (training.network: HIP forward, per-operator backward, per-block recompute).  ``t`` / the noises / the mask
         sources may be injected (parity tests); otherwise they are drawn like the reference draws them."""
@@ -348,10 +356,44 @@ class ProteinReDiffModel(_Base):
         num_nodes = (mask > 0.5).sum(-1)
         if t is None:
             t = torch.randint(0, self.num_steps, size=(x.size(0),)).to(x.device)
-        diff_loss = self.diffusion_loss(batch, x, mask, t, noise_z, noise_seq)
-        loss = torch.mean(diff_loss / num_nodes)
+        if noise_z is None:                     # drawn HERE so that a repeated forward (non-finite policy) sees the same noise
+            noise_z = ops.remove_mean(torch.randn_like(x), mask.contiguous())
+        if noise_seq is None:
+            noise_seq = ops.remove_mean(torch.randn_like(batch["residue_one_hot"]), batch["residue_mask"].contiguous())
+
+        def forward_loss():
+            return torch.mean(self.diffusion_loss(batch, x, mask, t, noise_z, noise_seq) / num_nodes)
+
+        with _lib.arithmetic(self.arithmetic):
+            loss = forward_loss()
+        if check_finite and self.nonfinite_policy != "off" and loss.is_cuda and not bool(torch.isfinite(loss.detach())):
+            loss = self._nonfinite_training_step(forward_loss)
         self.log("train_loss", loss, on_step=True, on_epoch=True, sync_dist=True, batch_size=x.size(0))
         return loss
+
+    def _current_arith(self) -> int:
+        return _lib.GEMM_MODES[self.arithmetic] if self.arithmetic is not None else _lib.arith()
+
+    def _nonfinite_training_step(self, forward_loss):
+        """The loss of a training step came out inf / NaN.  Under split-16 arithmetic with policy "fp32": the PROCESS default
+        becomes PRD_ARITH_FP32 from here on (the backward of the returned loss runs after this function returns and reads the
+        default when it runs -- a scoped switch would put the split-16 backward kernels behind an fp32 forward) and the forward is
+        repeated; anything else raises."""
+        import warnings
+        cur = self._current_arith()
+        if cur == 1 and self.nonfinite_policy == "fp32":
+            warnings.warn("training_step: non-finite loss under split-16 arithmetic (an operand beyond the fp16 range: include/prd_hip.h, "
+                          "OPERAND RANGE); switching this process to PRD_ARITH_FP32 and repeating the step", RuntimeWarning, stacklevel=3)
+            self.arithmetic = None
+            _lib.lib().prd_set_gemm_mode(0)
+            self.arith_fallbacks += 1
+            loss = forward_loss()
+            if bool(torch.isfinite(loss.detach())):
+                return loss
+            cur = 0
+        raise _lib.NonFiniteError(f"training_step: non-finite loss under {_lib.ARITH_NAMES[cur]} arithmetic"
+                                  + (" (the fp32 repeat of a non-finite split-16 step)" if self.arith_fallbacks else "")
+                                  + ": the weights / inputs themselves produce inf or NaN")
 
     def predict_step(self, batch, batch_idx):
         with self.ema.average_parameters(self.parameters()):
@@ -487,9 +529,35 @@ class ProteinReDiffModel(_Base):
     def sample(self, batch, sources: Optional[Sequence] = None, batch_idx: Optional[int] = None):
         if sources is None:
             sources = self._sources(batch["atom_mask"].shape[0], batch_idx)
-        loop = ReverseDiffusion(self, batch, sources)
-        loop.run()
-        return loop.result()
+        # the keyed generators are consumed by a loop: remember where they stood so that a repeat draws the same noise
+        states = [s.g.get_state() if hasattr(s, "g") else None for s in sources]
+        with _lib.arithmetic(self.arithmetic):
+            loop = ReverseDiffusion(self, batch, sources)
+            loop.run()
+            cur = _lib.arith()
+            if self.nonfinite_policy == "off" or loop.finite():
+                return loop.result()
+        if cur == 1 and self.nonfinite_policy == "fp32":
+            import warnings
+            warnings.warn(f"sample: inf / NaN after {loop.steps_done} denoising steps under split-16 arithmetic (an operand beyond the "
+                          "fp16 range: include/prd_hip.h, OPERAND RANGE); running the call again under PRD_ARITH_FP32 and keeping fp32 "
+                          "for this model", RuntimeWarning, stacklevel=2)
+            if any(st is None for st in states):
+                raise _lib.NonFiniteError("sample: non-finite under split-16 arithmetic and the noise sources cannot be rewound")
+            for s, st in zip(sources, states):
+                s.g.set_state(st)
+            self.arith_fallbacks += 1
+            self.arithmetic = "fp32"
+            with _lib.arithmetic("fp32"):
+                loop = ReverseDiffusion(self, batch, sources)
+                loop.run()
+                if loop.finite():
+                    return loop.result()
+            cur = 0
+        raise _lib.NonFiniteError(f"sample: inf / NaN coordinates or logits under {_lib.ARITH_NAMES[cur]} arithmetic"
+                                  + (" (the fp32 repeat of a non-finite split-16 call)" if self.arith_fallbacks and cur == 0 else "")
+                                  + (": outside the operand range of the split arithmetic (include/prd_hip.h); set model.arithmetic = 'fp32' "
+                                     "or nonfinite_policy = 'fp32'" if cur == 1 else ": the weights / inputs themselves produce inf or NaN"))
 
 
 class ReverseDiffusion:
@@ -536,7 +604,7 @@ class ReverseDiffusion:
         # inputs of the coming step that the previous step's boundary kernel prepares (single, time embedding)
         import os
         self.fused_boundary = os.environ.get("PRD_FUSED_BOUNDARY", "1") != "0"
-        self.sync = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sync = torch.zeros(2, dtype=torch.int32, device=dev)     # [0] arrival counter, [1] sticky non-finite flag (prd_step_boundary)
         self._seq_pred_buf = None               # logits of the last step (written by the step-boundary kernel)
         self.single_in, self.eb_in = m._step_inputs(self.static, self.seq_t, self.rm, self.t)
 
@@ -602,6 +670,16 @@ class ReverseDiffusion:
     def run(self):
         while self.steps_done < self.T:
             self.step()
+
+    def finite(self) -> bool:
+        """False when the loop produced inf / NaN: the sticky flag the step-boundary kernel keeps (any step, prd_hip.h) or'ed with a
+        check of the current state and logits (covers the un-fused boundary and direct step() use).  ONE host read per call --
+        after the loop, never inside it."""
+        bad = self.sync[1] != 0
+        bad = bad | ~torch.isfinite(self.z).all()
+        if self.seq_pred is not None:
+            bad = bad | ~torch.isfinite(self.seq_pred).all()
+        return not bool(bad)
 
     def result(self):
         """(positions in Angstrom, residue-masked logits) as in model.py:421-422."""

@@ -221,31 +221,64 @@ class PDBDataModule:
             self.train_sampler.set_epoch(epoch)
 
     def _train_sizes(self, ds) -> List[int]:
-        """num_atoms + num_residues of every training complex.  Read from ``<cache>/sizes_index.json`` when it covers the id
-        list; otherwise one pass over the cache, persisted there for the next start-up (best effort: a read-only cache is
-        scanned every time)."""
+        """num_atoms + num_residues of every training complex.  Read from ``<cache>/sizes_index.json`` where an entry's
+        FINGERPRINT -- (mtime_ns, size) of the complex's two cache files -- still matches: a cache that was re-preprocessed
+        (other cropping / featurisation) is re-scanned instead of driving the buckets with stale sizes.  Under an initialised
+        process group rank 0 alone scans and writes the index, the other ranks wait at a barrier and read it (ranks that start
+        together on a shared cache neither scan it N times nor overwrite each other's file).  Best effort on a read-only cache:
+        it is scanned every time."""
         import json
         index_path = self.cache_dir / "sizes_index.json"
-        index: Dict[str, int] = {}
-        if index_path.exists():
+
+        def fingerprint(pid):
+            fp = []
+            for name in ("ligand_data.pt", "protein_data.pt"):
+                try:
+                    st = os.stat(self.cache_dir / pid / name)
+                    fp += [int(st.st_mtime_ns), int(st.st_size)]
+                except OSError:
+                    fp += [0, 0]
+            return fp
+
+        def load():
+            if not index_path.exists():
+                return {}
             try:
                 with open(index_path, "r") as f:
-                    index = {str(k): int(v) for k, v in json.load(f).items()}
-            except (OSError, ValueError):
-                index = {}
-        missing = [i for i, pid in enumerate(ds.pdb_ids) if pid not in index]
-        for i in missing:
-            d = ds[i]
-            index[ds.pdb_ids[i]] = int(d["num_atoms"]) + int(d["num_residues"])
-        if missing:
-            try:
-                tmp = index_path.with_suffix(".json.tmp%d" % os.getpid())
-                with open(tmp, "w") as f:
-                    json.dump(index, f)
-                os.replace(tmp, index_path)
-            except OSError:
-                pass
-        return [index[pid] for pid in ds.pdb_ids]
+                    raw = json.load(f)
+                if not isinstance(raw, dict) or raw.get("version") != 2:
+                    return {}           # round-4 files had no fingerprints: rebuilt once
+                return {str(k): (int(v[0]), [int(x) for x in v[1]]) for k, v in raw["entries"].items()}
+            except (OSError, ValueError, KeyError, TypeError, IndexError):
+                return {}
+
+        def scan_and_store(index):
+            stale = [i for i, pid in enumerate(ds.pdb_ids) if pid not in index or index[pid][1] != fingerprint(pid)]
+            for i in stale:
+                d = ds[i]
+                index[ds.pdb_ids[i]] = (int(d["num_atoms"]) + int(d["num_residues"]), fingerprint(ds.pdb_ids[i]))
+            if stale:
+                try:
+                    tmp = index_path.with_suffix(".json.tmp%d" % os.getpid())
+                    with open(tmp, "w") as f:
+                        json.dump({"version": 2, "entries": {k: [v[0], v[1]] for k, v in index.items()}}, f)
+                    os.replace(tmp, index_path)
+                except OSError:
+                    pass
+            return index
+
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if not distributed:
+            index = scan_and_store(load())
+        else:
+            if torch.distributed.get_rank() == 0:
+                index = scan_and_store(load())
+            torch.distributed.barrier()
+            if torch.distributed.get_rank() != 0:
+                index = load()
+                if any(pid not in index or index[pid][1] != fingerprint(pid) for pid in ds.pdb_ids):
+                    index = scan_and_store(index)       # rank 0 could not write (read-only cache): scan here too
+        return [index[pid][0] for pid in ds.pdb_ids]
 
     def val_dataloader(self):
         return torch.utils.data.DataLoader(PDBDataset(self.cache_dir, self.val_pdb_ids), batch_size=self.batch_size,

@@ -513,7 +513,9 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
         return single, pair
 
     P_ = model.embed_dist[1].weight.shape[0]
-    hand = (z.is_cuda and LIBRARY_BWD and INPUT_STAGE_BWD and P_ <= 64 and model.embed_dist[0].center.numel() % 4 == 0 and not model.embed_dist[0].center.requires_grad
+    # (the hand-written backwards below return no gradient for the coordinates: a caller who differentiates with respect to z --
+    # guidance, a gradient check on the positions -- gets the differentiable torch restatement instead of a silent None)
+    hand = (z.is_cuda and not z.requires_grad and LIBRARY_BWD and INPUT_STAGE_BWD and P_ <= 64 and model.embed_dist[0].center.numel() % 4 == 0 and not model.embed_dist[0].center.requires_grad
             and all(tab.shape[0] <= 128 for tab in (*bond_tabs, model.embed_bond_distance.weight, model.embed_relpos.weight)))
     if hand:                                            # hand-written backward of the pair half (InputStageFn)
         meta = dict(batch=batch, mask=mask, t=t, na=na, nb=nb, num_steps=model.num_steps, max_bond_distance=model.max_bond_distance,
@@ -546,7 +548,10 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
         return R.single_pair_attention(s_, p_, *w, heads=H)
 
     def spa_hip(s_, p_, *w):
-        return spa(s_.contiguous(), p_.contiguous(), mask)
+        s_, p_ = s_.contiguous(), p_.contiguous()
+        mn_, qkvg_ = spa.project(s_)
+        bias_ = spa.bias_from_pair(p_) if spa.pair_bias else torch.zeros(s_.shape[0], spa.no_heads, s_.shape[1], s_.shape[1], device=s_.device)
+        return spa.attend(mn_, qkvg_, bias_, logits_fp32=True)
 
     if pair.is_cuda and LIBRARY_BWD and pair.numel() // pair.shape[-1] >= ops.WGRAD_MIN_ROWS and spa.pair_bias:
         # the pair bias as its own node with the hand-written backward (PairBiasFn, affine LayerNorm); the attention itself, whose
@@ -559,7 +564,7 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
 
         def att_hip(s_, bias_, *w):
             mn, qkvg = spa.project(s_.contiguous())
-            return spa.attend(mn, qkvg, bias_.contiguous())
+            return spa.attend(mn, qkvg, bias_.contiguous(), logits_fp32=True)     # explicit: not inferred from the train / eval flag
 
         single = HipOp.apply(att_hip, att_ref, single, spa_bias, *att_params)
     else:
@@ -587,8 +592,12 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
         return eps, ops.linear(h, w[5])
 
     P_h = pair.shape[-1]
-    if pair.is_cuda and LIBRARY_BWD and HEADS_BWD and P_h % 64 == 0 and wr[1].weight.shape[0] % 64 == 0 and wr[3].weight.shape[0] == 1:
+    if (pair.is_cuda and not z.requires_grad and LIBRARY_BWD and HEADS_BWD and P_h % 64 == 0 and wr[1].weight.shape[0] % 64 == 0
+            and wr[3].weight.shape[0] == 1):
         return HeadsFn.apply(heads_hip, z, mask, single, pair, *head_params)
+    if z.requires_grad:             # the coordinates as an INPUT of the node: the restatement differentiates them too (r_ij and the distances)
+        return HipOp.apply(lambda s_, p_, z_, *w: heads_hip(s_, p_, *w), lambda s_, p_, z_, *w: R.heads(s_, p_, z_, mask, *w),
+                           single, pair, z, *head_params)
     return HipOp.apply(heads_hip, heads_ref, single, pair, *head_params)
 
 
@@ -599,14 +608,33 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
 _FLAT_GRAD_BUFFERS = {}      # (device, numel) -> persistent flat fp32 buffer (no 65 MB allocation per step)
 
 
-def all_reduce_gradients(params: Sequence[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None) -> None:
+def _flat_views(params: Sequence[torch.nn.Parameter]):
+    """(flat buffer, per-parameter views into it, the gradients as flat views).  view(-1), not reshape: a gradient in a
+    non-viewable layout must raise here -- reshape would hand back a COPY and the averaged values would land in a temporary
+    while p.grad stayed un-averaged."""
+    grads = [p.grad.view(-1) for p in params]
+    n = sum(g.numel() for g in grads)
+    key = (grads[0].device, n)
+    flat = _FLAT_GRAD_BUFFERS.get(key)
+    if flat is None:
+        flat = _FLAT_GRAD_BUFFERS[key] = torch.empty(n, device=grads[0].device, dtype=torch.float32)
+    return flat, list(torch.split(flat, [g.numel() for g in grads])), grads
+
+
+def all_reduce_gradients(params: Sequence[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None, slices: int = 1,
+                         on_slice: Optional[Callable[[int, int], None]] = None) -> None:
     """Average the gradients of ``params`` over the ranks of ``group``: ONE all-reduce of the flattened gradient (16.3 M fp32 =
     65 MB for the reference configuration; RCCL over xGMI with backend "nccl" -- a single large message instead of DDP's 25 MB
     buckets: per-link bound rings want few, large collectives) in a persistent buffer.  Every trainable parameter must have a
     gradient on every rank -- the contract of the reference's ``strategy="ddp_find_unused_parameters_false"`` (train.py:38), under
     which DDP raises as well; materialising zeros instead would make Adam decay the moments of a parameter that took no part
     in the step.  A one-rank group still runs the collective (the code path is the same at every world size).  No-op without
-    an initialised process group."""
+    an initialised process group.
+
+    ``slices`` > 1: the flat buffer goes out as that many consecutive all-reduces, all enqueued at once (asynchronously) on the
+    communication stream; ``on_slice(first_param, end_param)`` is called on the compute stream as soon as slice k has come back
+    and been unpacked, i.e. while slices k + 1 ... are still on the wire -- the hook for work that only needs the reduced gradients
+    of those parameters (tools/train_bench.py --overlap measures an optimiser step per slice against the single message)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = dist.get_world_size(group)
@@ -615,32 +643,170 @@ def all_reduce_gradients(params: Sequence[torch.nn.Parameter], group: Optional[d
     if missing:
         raise RuntimeError(f"all_reduce_gradients: {len(missing)} trainable parameter(s) have no gradient (first index "
                            f"{missing[0]}); like DDP with find_unused_parameters=False this is an error")
-    # view(-1), not reshape: a gradient in a non-viewable layout must raise here -- reshape would hand back a COPY and the
-    # averaged values would land in a temporary while p.grad stayed un-averaged
-    grads = [p.grad.view(-1) for p in params]
-    n = sum(g.numel() for g in grads)
-    key = (grads[0].device, n)
-    flat = _FLAT_GRAD_BUFFERS.get(key)
-    if flat is None:
-        flat = _FLAT_GRAD_BUFFERS[key] = torch.empty(n, device=grads[0].device, dtype=torch.float32)
-    views = list(torch.split(flat, [g.numel() for g in grads]))
+    flat, views, grads = _flat_views(params)
     torch._foreach_copy_(views, grads)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if world > 1:
-        flat.div_(world)
-    torch._foreach_copy_(grads, views)
+    if slices <= 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if world > 1:
+            flat.div_(world)
+        torch._foreach_copy_(grads, views)
+        if on_slice is not None:
+            on_slice(0, len(params))
+        return
+    # parameter-aligned slices of about equal size
+    sizes = [g.numel() for g in grads]
+    target, bounds, acc = sum(sizes) / slices, [0], 0
+    for i, n in enumerate(sizes):
+        acc += n
+        if acc >= target * len(bounds) and len(bounds) < slices:
+            bounds.append(i + 1)
+    if bounds[-1] != len(params):
+        bounds.append(len(params))
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    works = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        works.append(dist.all_reduce(flat[offs[a]:offs[b]], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for (a, b), w in zip(zip(bounds[:-1], bounds[1:]), works):
+        w.wait()                                            # stream-level wait for THIS slice only; the later ones stay in flight
+        part = flat[offs[a]:offs[b]]
+        if world > 1:
+            part.div_(world)
+        torch._foreach_copy_(grads[a:b], views[a:b])
+        if on_slice is not None:
+            on_slice(a, b)
+
+
+def _grads_finite(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
+    """0-dim bool on the device: every gradient finite (one multi-tensor norm, no host sync)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    return torch.isfinite(torch.stack(torch._foreach_norm(grads)).sum())
+
+
+class Fitter:
+    """Optimisation driver the way ``train.py`` drives the model through Lightning's Trainer (train.py:34-57, model.py:203-217,
+    528-549), without Lightning: per micro-batch ``training_step`` -> backward of loss / k; per k = ``accumulate_grad_batches``
+    micro-batches (train.py:57; every published training command uses 8 or 10, README.md:136-169) ONE gradient average over the
+    data-parallel ranks -> Adam step -> LinearLR step -> EMA update.  Gradients accumulate locally in ``p.grad`` in between:
+    k times fewer collectives than a step per micro-batch, and the reference's optimiser trajectory.
+
+    Non-finite guard without a host round trip (the model's ``nonfinite_policy``, diffusion_model.py): the optimiser step is
+    SKIPPED ON THE DEVICE when the accumulated loss or any gradient is inf / NaN (fused Adam's ``found_inf``, the GradScaler
+    protocol), the flag is read back one optimiser step LATER -- when it has long been written -- and then the process switches
+    to PRD_ARITH_FP32 (policy "fp32", with a warning; the skipped step is lost, the parameters were never touched) or raises."""
+
+    def __init__(self, model, optimizer, scheduler=None, group: Optional[dist.ProcessGroup] = None, accumulate_grad_batches: int = 1,
+                 reduce_slices: int = 1):
+        if accumulate_grad_batches < 1:
+            raise ValueError("accumulate_grad_batches must be >= 1")
+        self.model, self.optimizer, self.scheduler, self.group = model, optimizer, scheduler, group
+        self.k = int(accumulate_grad_batches)
+        self.reduce_slices = int(reduce_slices)
+        self.micro = 0                      # micro-batches since the last optimiser step
+        self.optimizer_steps = 0
+        self.skipped_steps = 0
+        self._pending = None                # found_inf flag of the previous optimiser step (device tensor), read lazily
+        self._bad_loss = None               # device bool: some micro-batch loss of the running accumulation was non-finite
+        self._params = [p for p in model.parameters() if p.requires_grad]
+        self._device_guard = bool(self._params) and all(p.is_cuda for p in self._params) and \
+            bool(getattr(optimizer, "defaults", {}).get("fused", False))
+
+    def _settle(self):
+        """Read the flag of the PREVIOUS optimiser step (no stall: that step finished long ago) and act on it."""
+        if self._pending is None:
+            return
+        bad, self._pending = bool(self._pending.item() != 0), None
+        if not bad:
+            return
+        self.skipped_steps += 1
+        import warnings
+        from . import _lib
+        pol = getattr(self.model, "nonfinite_policy", "raise")
+        if pol == "fp32" and _lib.arith() == 1:
+            warnings.warn("fit: an optimisation step produced non-finite loss / gradients under split-16 arithmetic (skipped on the "
+                          "device, parameters untouched); switching this process to PRD_ARITH_FP32", RuntimeWarning, stacklevel=3)
+            _lib.lib().prd_set_gemm_mode(0)
+            self.model.arithmetic = None
+            self.model.arith_fallbacks += 1
+            return
+        if pol != "off":
+            raise _lib.NonFiniteError(f"fit: non-finite loss / gradients under {_lib.ARITH_NAMES[_lib.arith()]} arithmetic; the optimiser "
+                                      "step was skipped on the device (parameters untouched)")
+
+    def step(self, batch, batch_idx: int, **step_kwargs) -> torch.Tensor:
+        """One MICRO-batch; the optimiser moves on every k-th call.  Returns the detached loss of the micro-batch."""
+        model, opt = self.model, self.optimizer
+        if self.micro == 0:
+            self._settle()
+            opt.zero_grad(set_to_none=True)
+            self._bad_loss = None
+        guard = self._device_guard and getattr(model, "nonfinite_policy", "off") != "off"
+        loss = model.training_step(batch, batch_idx, check_finite=not guard and getattr(model, "nonfinite_policy", "off") != "off",
+                                   **step_kwargs)
+        (loss / self.k if self.k > 1 else loss).backward()          # Lightning scales the loss by 1 / accumulate_grad_batches
+        if guard:
+            b = ~torch.isfinite(loss.detach())
+            self._bad_loss = b if self._bad_loss is None else (self._bad_loss | b)
+        self.micro += 1
+        if self.micro == self.k:
+            self.finish_accumulation()
+        return loss.detach()
+
+    def finish_accumulation(self) -> None:
+        """Gradient average + optimiser step for the micro-batches accumulated so far (also the end-of-epoch flush of an
+        incomplete group, as Lightning does)."""
+        if self.micro == 0:
+            return
+        model, opt = self.model, self.optimizer
+        all_reduce_gradients(self._params, self.group, slices=self.reduce_slices)
+        guard = self._device_guard and getattr(model, "nonfinite_policy", "off") != "off"
+        if guard:
+            found = (self._bad_loss | ~_grads_finite(self._params)).to(torch.float32).reshape(1)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                dist.all_reduce(found, op=dist.ReduceOp.MAX, group=self.group)       # every rank skips or none does
+            opt.grad_scale, opt.found_inf = None, found         # fused Adam: no update, no step count, when found_inf == 1
+            self._pending = found
+        opt.step()
+        if guard:
+            opt.found_inf = None
+        if self.scheduler is not None:
+            self.scheduler.step()
+        model.ema.update(model.parameters())
+        self.micro = 0
+        self.optimizer_steps += 1
+
+    def fit_epoch(self, loader, epoch: int = 0, max_steps: Optional[int] = None, to_device=None):
+        """All micro-batches of ``loader`` (a PDBDataModule.train_dataloader()); returns the list of detached losses."""
+        losses = []
+        for i, batch in enumerate(loader):
+            if max_steps is not None and self.optimizer_steps >= max_steps:
+                break
+            if to_device is not None:
+                batch = {k: (v.to(to_device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            losses.append(self.step(batch, i))
+        self.finish_accumulation()
+        self._settle()
+        return losses
 
 
 def fit_step(model, batch, batch_idx: int, optimizer, scheduler=None, group: Optional[dist.ProcessGroup] = None,
-             **step_kwargs) -> torch.Tensor:
-    """One optimisation step the way ``train.py`` drives it through Lightning: training_step -> backward -> gradient average
-    over the data-parallel ranks -> Adam step -> LinearLR step -> EMA update (model.py:203-217, 528-549)."""
-    optimizer.zero_grad(set_to_none=True)
+             accumulate_grad_batches: int = 1, **step_kwargs) -> torch.Tensor:
+    """One MICRO-batch of the optimisation the way ``train.py`` drives it through Lightning: training_step -> backward of
+    loss / k; on every k-th micro-batch (``(batch_idx + 1) % k == 0``, k = ``accumulate_grad_batches``, train.py:57) gradient average
+    over the data-parallel ranks -> Adam step -> LinearLR step -> EMA update (model.py:203-217, 528-549).  Stateless convenience
+    form of ``Fitter`` (which adds the device-side non-finite guard); with k = 1 every call is a full optimisation step."""
+    k = int(accumulate_grad_batches)
+    if k < 1:
+        raise ValueError("accumulate_grad_batches must be >= 1")
+    if batch_idx % k == 0:
+        optimizer.zero_grad(set_to_none=True)
     loss = model.training_step(batch, batch_idx, **step_kwargs)
-    loss.backward()
-    all_reduce_gradients(list(model.parameters()), group)
-    optimizer.step()
-    if scheduler is not None:
-        scheduler.step()
-    model.ema.update(model.parameters())
+    (loss / k if k > 1 else loss).backward()
+    if (batch_idx + 1) % k == 0:
+        all_reduce_gradients(list(model.parameters()), group)
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        model.ema.update(model.parameters())
     return loss.detach()

@@ -724,6 +724,21 @@ def test_free_running_trajectory_vs_yardstick(golden, name, gemm_mode):
         assert dev <= 16 * dref, (name, st, dev, dref)
     gmean = math.exp(sum(math.log(max(r_, 1e-12)) for r_ in ratios) / len(ratios))
     assert gmean <= 2.0, (name, gmean)
+    if name == "cfg2_t1000":
+        # The north-star sentence ITSELF (BASELINE.json: "outputs within 1e-4 relative L2 of reference", BASELINE configs[1] at its own
+        # shape and length, free-running): every stored state and the final positions / logits against the reference's own FP32 run.
+        # What this fixture is: near-init weights whose seed tools/conditioning_scan.py picked because the random map CONTRACTS
+        # (delta_ref stays below 1e-4 over all 1000 steps) -- a benign yardstick, the only kind on which a free-running 1e-4 is a
+        # statement about the implementation rather than about chaos (the diverging fixtures above are held to delta_ref instead).
+        worst = 0.0
+        for k, st in enumerate(steps):
+            dev32 = rel(zs[k][0], f32["seg_z"][k].astype(np.float64))
+            worst = max(worst, dev32)
+            assert dev32 <= TRAJ_TOL, (name, "step", st, "vs the reference's fp32 run", dev32)
+        fin_pos, fin_log = rel(pos, f32["traj_pos"].astype(np.float64)), rel(logits, f32["traj_logits"].astype(np.float64))
+        assert fin_pos <= TRAJ_TOL and fin_log <= TRAJ_TOL, (name, fin_pos, fin_log)
+        print(f"\n{name} [{gemm_mode}]: free-running vs the reference fp32 run: worst stored step {worst:.2e}, final positions {fin_pos:.2e}, "
+              f"final logits {fin_log:.2e} (bound {TRAJ_TOL:g})")
     if "traj_pos_f64" in f64:
         # the bound is a multiple of the reference's own fp32-vs-fp64 distance: it only says something where that distance is
         # small (a delta_ref of order 1 -- a saturated softmax flipping -- would let any output pass)
@@ -963,6 +978,35 @@ def test_triangle_attention_long_rows(setup, mode, N, valid, gemm_mode):
     assert rel_l2(got, want) < OP_TOL
     for k in range(len(rows)):                       # no single row may hide behind the aggregate
         assert rel_l2(got[:, k], want[:, k]) < 2 * OP_TOL, rows[k]
+
+
+@pytest.mark.parametrize("mode", ["starting", "ending"])
+def test_triangle_attention_long_rows_whole_tensor(setup, mode, gemm_mode):
+    """One WHOLE-tensor comparison with the oracle per long-row kernel (the row-subset tests above consult the
+    oracle on 16 rows per case): N = 449 -- the split-16 long-row core (tri_attn_core_v2l) and, in fp32 arithmetic, the fp32 long-row
+    kernel -- every row, both orientations, masked tail.  The oracle runs 64 rows at a time (its [rows, H, N, N] logits)."""
+    s = setup
+    P, N, valid = s["P"], 449, 431
+    H, c = s["args"]["num_heads"], s["args"]["head_dim"]
+    assert ops.tri_attn_uses_long_rows(N, P)
+    g = torch.Generator().manual_seed(4490 + (mode == "ending"))
+    pair = torch.randn(1, N, N, P, generator=g)
+    mask = torch.ones(1, N)
+    mask[0, valid:] = 0
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    pfx = f"Denoiser.folding_blocks.0.pair_attn_{mode}"
+    src, msrc = (pair, m2) if mode == "starting" else (pair.transpose(1, 2), m2.transpose(1, 2))
+    want = torch.empty(1, N, N, P)
+    with torch.inference_mode():
+        for r0 in range(0, N, 64):
+            want[:, r0:r0 + 64] = O.gated_attention(s["params"], pfx + ".attn", src[:, r0:r0 + 64].contiguous(), msrc[:, r0:r0 + 64].contiguous(), H, c)
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
+    got = mod.run(cu(pair), cu(mask), residual=False).cpu()
+    if mode == "ending":
+        got = got.transpose(1, 2)
+    assert rel_l2(got, want) < OP_TOL
+    row_err = (got - want).flatten(2).norm(dim=2) / want.flatten(2).norm(dim=2).clamp_min(1e-30)
+    assert float(row_err.max()) < 2 * OP_TOL, int(row_err.argmax())
 
 
 def test_eight_complexes_per_gpu_equal_single_runs(gemm_mode):

@@ -148,7 +148,7 @@ def test_bucket_batch_sampler_pads_a_step_with_distinct_batches():
 
 def test_pdb_datamodule_round_trip(tmp_path):
     """data.py:206-259: id lists + preprocessed cache -> collated batches; the training loader is size-bucketed."""
-    from protein_redesign_amd.pipeline import PDBDataModule
+    from protein_redesign_amd.pipeline import PDBDataModule, PDBDataset
     from protein_redesign_amd.synthetic import synthetic_sample
     ids = [f"c{k:02d}" for k in range(10)]
     cache = tmp_path / "PDB_processed_cache"
@@ -169,11 +169,24 @@ def test_pdb_datamodule_round_trip(tmp_path):
     assert len(list(dm.val_dataloader())) == 1 and len(list(dm.test_dataloader())) == 1
     # the sizes found by the first scan are persisted next to the cache and re-used
     import json
-    index = json.loads((cache / "sizes_index.json").read_text())
+    raw = json.loads((cache / "sizes_index.json").read_text())
+    assert raw["version"] == 2
+    index = {k: v[0] for k, v in raw["entries"].items()}
     assert sorted(index) == sorted(ids[:6]) and all(v > 0 for v in index.values())
     dm2 = PDBDataModule(tmp_path, batch_size=2, num_workers=0, bucket_width=8)
     dm2.setup()
-    assert dm2._train_sizes(type("D", (), {"pdb_ids": ids[:6], "__getitem__": lambda self, i: 1 / 0})()) == [index[p] for p in ids[:6]]
+    no_scan = type("D", (), {"pdb_ids": ids[:6], "__getitem__": lambda self, i: 1 / 0})()
+    assert dm2._train_sizes(no_scan) == [index[p] for p in ids[:6]]
+    # a complex that was re-preprocessed (other cropping) is re-read, not served from the index: the entry's fingerprint is the
+    # (mtime, size) of its cache files
+    d = synthetic_sample(3, 40, esm_dim=8, seed=77)
+    torch.save({kk: v for kk, v in d.items() if kk.startswith(("residue", "num_residues"))}, cache / ids[2] / "protein_data.pt")
+    with pytest.raises(ZeroDivisionError):
+        dm2._train_sizes(no_scan)                                   # the stale entry forces a read of that complex
+    sizes = dm2._train_sizes(PDBDataset(cache, ids[:6]))
+    assert sizes[2] == int(torch.load(cache / ids[2] / "ligand_data.pt", weights_only=False)["num_atoms"]) + 40
+    assert [s_ for k, s_ in enumerate(sizes) if k != 2] == [index[p] for k, p in enumerate(ids[:6]) if k != 2]
+    assert dm2._train_sizes(no_scan) == sizes                       # ... and the refreshed index is persisted
     # free shuffling under data parallelism: disjoint shards per rank (what Lightning's DistributedSampler gives the reference)
     seen = []
     for r in range(2):

@@ -159,3 +159,26 @@ def test_single_transition_hidden_scale(setup, scale, gemm_mode):
     h = ops.linear(cu(s["single"]), (sf[1].weight * scale).contiguous(), (sf[1].bias * scale).contiguous(), act=1, ln_a=True)
     got = ops.linear(h, sf[3].weight, sf[3].bias)
     check(got, w32, w64, scale)
+
+
+@pytest.mark.parametrize("offset", [30.0, -300.0, 0.0])
+def test_single_transition_slab_path_row_offset(offset, gemm_mode):
+    """the K-slab transition applies the fused LayerNorm by linearity, rstd (x W^T - mean rowsum(W)), on RAW
+    rows; with |mean| >> std the subtraction cancels.  Rows with an offset of 30 / 300 standard deviations through
+    ops.transition_single on the slab path (the full-size shape 320 x 512 -> 2048 -> 512), against float64; the bar is the operator
+    tolerance or three times what plain fp32 arithmetic (LayerNorm first, as the reference does) reaches on the same rows."""
+    g = torch.Generator().manual_seed(5)
+    M, S, Hd = 320, 512, 2048
+    x = torch.randn(1, M, S, generator=g) + offset
+    w1, b1 = torch.randn(Hd, S, generator=g) / S ** 0.5, 0.1 * torch.randn(Hd, generator=g)
+    w2, b2 = torch.randn(S, Hd, generator=g) / Hd ** 0.5, 0.1 * torch.randn(S, generator=g)
+
+    def ref(dt):
+        xn = torch.nn.functional.layer_norm(x.to(dt), (S,))
+        return torch.relu(xn @ w1.to(dt).t() + b1.to(dt)) @ w2.to(dt).t() + b2.to(dt)
+
+    want32, want64 = ref(torch.float32), ref(torch.float64)
+    took_slab = ops.slab_ok(M, Hd, S)
+    got = ops.transition_single(cu(x), cu(w1), cu(b1), cu(w2), cu(b2), residual=False, wsum1=cu(w1.sum(1)))
+    assert gemm_mode == "fp32" or took_slab, "the full-size transition must take the K-slab path in split-16 arithmetic"
+    check(got, want32, want64, ("slab transition", offset, gemm_mode))

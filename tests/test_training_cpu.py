@@ -159,3 +159,144 @@ def test_gradient_average_over_two_ranks(tmp_path):
     assert torch.allclose(g0["w"], want_w, rtol=1e-6) and torch.equal(g0["w"], g1["w"]) and torch.equal(g0["b"], g1["b"])
     assert torch.allclose(g0["u"], torch.full((4,), 0.5)) and torch.equal(g0["u"], g1["u"])
     assert g0["raised"] and g1["raised"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# accumulate_grad_batches (train.py:57; README.md:136-169 use 8 / 10): gradients accumulate locally, ONE collective and ONE
+# optimiser step per k micro-batches
+# ---------------------------------------------------------------------------------------------------
+
+class _StubEma:
+    def __init__(self):
+        self.updates = 0
+
+    def update(self, params):
+        self.updates += 1
+
+
+class _StubModel(torch.nn.Module):
+    """What training.Fitter touches of a ProteinReDiffModel: training_step(batch, idx, check_finite=...), parameters(), ema."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.lin = torch.nn.Linear(6, 4)
+        self.ema = _StubEma()
+        self.nonfinite_policy = "raise"
+
+    def training_step(self, batch, batch_idx, check_finite=True):
+        return torch.tanh(self.lin(batch["x"])).square().sum(-1).mean()          # mean over the batch, like model.py:546
+
+
+def _accum_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    dist.all_reduce = counting
+    data = torch.randn(world, 8, 6, generator=torch.Generator().manual_seed(11))[rank]     # 8 samples per rank: two groups of k = 4
+    out = {}
+    for slices in (1, 3):
+        model = _StubModel()
+        opt = torch.optim.SGD(model.parameters(), lr=1.0)                    # lr 1: the parameter change IS the averaged gradient
+        fitter = training.Fitter(model, opt, accumulate_grad_batches=4, reduce_slices=slices)
+        p0 = [p.detach().clone() for p in model.parameters()]
+        calls["n"] = 0
+        for i in range(4):
+            fitter.step({"x": data[i:i + 1]}, i)
+        out[f"delta{slices}"] = [a - b.detach() for a, b in zip(p0, model.parameters())]
+        out[f"calls{slices}"] = calls["n"]
+        out[f"steps{slices}"] = (fitter.optimizer_steps, model.ema.updates)
+        for i in range(4, 7):                                                # an incomplete group: flushed at the end of the epoch
+            fitter.step({"x": data[i:i + 1]}, i)
+        assert fitter.optimizer_steps == 1 and fitter.micro == 3
+        fitter.finish_accumulation()
+        out[f"flush{slices}"] = (fitter.optimizer_steps, fitter.micro)
+    # the stateless form: fit_step with accumulate_grad_batches
+    model = _StubModel()
+    opt = torch.optim.SGD(model.parameters(), lr=1.0)
+    p0 = [p.detach().clone() for p in model.parameters()]
+    for i in range(4):
+        training.fit_step(model, {"x": data[i:i + 1]}, i, opt, accumulate_grad_batches=4)
+    out["delta_fit_step"] = [a - b.detach() for a, b in zip(p0, model.parameters())]
+    torch.save(out, os.path.join(out_dir, f"a{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_over_two_ranks(tmp_path):
+    """k = 4 micro-batches of one sample on each of two gloo ranks == the gradient of the single batch of 4 per rank, averaged over
+    the ranks; ONE all-reduce (or ``reduce_slices`` pieces of it) and ONE optimiser / EMA step per 4 micro-batches."""
+    port = 29200 + (os.getpid() % 500)
+    mp.spawn(_accum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"a{r}.pt")) for r in range(2))
+    data = torch.randn(2, 8, 6, generator=torch.Generator().manual_seed(11))
+    model = _StubModel()
+    want = [torch.zeros_like(p) for p in model.parameters()]
+    for rank in range(2):
+        model.zero_grad()
+        model.training_step({"x": data[rank, :4]}, 0).backward()              # the batch of 4 in one piece
+        for w, p in zip(want, model.parameters()):
+            w += p.grad / 2
+    for key in ("delta1", "delta3", "delta_fit_step"):
+        for got0, got1, w in zip(r0[key], r1[key], want):
+            assert torch.allclose(got0, w, rtol=1e-5, atol=1e-7), key
+            assert torch.equal(got0, got1), key                               # both ranks hold the same averaged gradient
+    assert r0["calls1"] == 1 and 1 < r0["calls3"] <= 3                        # per optimiser step, not per micro-batch (slices are parameter-aligned)
+    assert r0["steps1"] == (1, 1) and r0["flush1"] == (2, 0) and r0["flush3"] == (2, 0)
+
+
+def test_accumulated_micro_batches_on_the_network(golden, monkeypatch):
+    """The same on the real network (CPU stand-ins for the HIP forwards, as in test_backward_wiring_matches_oracle_autograd): with
+    accumulate_grad_batches = 2 the optimiser sees the MEAN of the two micro-batch gradients -- what Lightning's loss / k leaves in
+    p.grad (train.py:57).  (A batch of two is NOT the reference for this network: model.py:515-525 adds the KL and cross-entropy
+    terms summed over the WHOLE batch to every complex's loss, so the loss of a batch is not the mean of its complexes' losses.)"""
+    case, z, args, params, pb = case_inputs(golden, "tiny")
+    from protein_redesign_amd import torch_ref as R
+    monkeypatch.setattr(training, "HipOp", _RefOp)
+    monkeypatch.setattr(training, "tri_mul_update",
+                        lambda tm, pair, mask, residual=False: R.triangle_multiplication(pair, mask, *tm.weights(), incoming=tm.mode == "incoming"))
+    monkeypatch.setattr(training, "tri_attn_update",
+                        lambda ta, pair, mask, residual=False: R.triangle_attention(pair, mask, *ta.attn.weights(), ta.attn.num_heads,
+                                                                                    ta.attn.head_dim, ending=ta.mode == "ending"))
+    sizes = [tuple(s) for s in case["sizes"]]
+    assert len(sizes) >= 2
+    t = torch.from_numpy(z["train_t"])[:2]
+    nz, ns = torch.from_numpy(z["train_noise_z"])[:2], torch.from_numpy(z["train_noise_seq"])[:2]
+
+    def fresh():
+        m = ProteinReDiffModel(args)
+        m.load_state_dict(params)
+        m.nonfinite_policy = "off"
+        return m
+
+    full = synthetic_batch(sizes, esm_dim=args["esm_dim"], seed=case["batch_seed"], n_total=case["n_total"])
+
+    def micro(k):
+        return ({kk: (v[k:k + 1].clone() if torch.is_tensor(v) else v) for kk, v in full.items()},
+                dict(t=t[k:k + 1], noise_z=nz[k:k + 1], noise_seq=ns[k:k + 1], sources=[NoiseSource(NOISE_SEED, 100 + k)]))
+
+    singles = []
+    for k in range(2):
+        m = fresh()
+        b, kw = micro(k)
+        m.training_step(b, k, **kw).backward()
+        singles.append([p.grad for p in m.parameters()])
+    acc = fresh()
+    fitter = training.Fitter(acc, torch.optim.SGD(acc.parameters(), lr=0.0), accumulate_grad_batches=2)
+    for k in range(2):
+        b, kw = micro(k)
+        fitter.step(b, k, **kw)
+    assert fitter.optimizer_steps == 1 and fitter.micro == 0
+    want = [None if g0 is None else (g0 + g1) / 2 for g0, g1 in zip(*singles)]
+    scale = float(torch.cat([w.reshape(-1) for w in want if w is not None]).double().norm())
+    for (name, p), w in zip(acc.named_parameters(), want):
+        if w is None:
+            assert p.grad is None, name
+            continue
+        assert float((p.grad.double() - w.double()).norm()) < 1e-5 * float(w.double().norm()) + 1e-7 * scale, name

@@ -312,6 +312,46 @@ def test_pair_position_linear_row_kernel(case, rows):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1e-6, 1e-9, 1e3, 1e-30])
+@pytest.mark.parametrize("case", ["64to64", "64to256_mask", "256to64", "256to64_spread"])
+def test_pair_position_linear_operand_range(case, scale):
+    """the backward calls prd_pair_linear on RAW gradient rows (dy W2, g W1, d og, dqkvg W), whose entries are
+    1e-4 ... 1e-9 near a minimum; fp16 hi | lo operands carry an absolute 3e-8 error below 6e-5 and flush below 6e-8.  Every 32-row
+    task row is therefore normalised by an exact power of two before the split (per 64-channel piece with a running scale for
+    K = 256) -- held here against float64 at the tolerance of the O(1) test, for rows scaled by 1e-6, 1e-9, 1e3 and 1e-30, with
+    three decades between neighbouring rows, an all-zero row, and (``spread``) eight decades between the four pieces of a row."""
+    from protein_redesign_amd import _lib, ops
+    rows = 8192 + 7
+    g = torch.Generator().manual_seed(len(case) + 17)
+    K, OUT = (256, 64) if case.startswith("256") else ((64, 256) if "256" in case else (64, 64))
+    x = torch.randn(rows, K, generator=g) * scale
+    x[1::3] *= 1e-3                                              # decades between the rows of one 32-row task
+    x[5] = 0.0
+    if "spread" in case:
+        x[:, :64] *= 1e-8
+        x[:, 64:128] *= 1e-4
+        x[7::2, 192:] *= 1e-6                                    # the running scale both rises and stays along a row
+    w = torch.randn(OUT, K, generator=g) / math.sqrt(K)
+    hmask = torch.randn(rows, OUT, generator=g).clamp_min(0) if "mask" in case else None
+    want = x.double() @ w.double().t()
+    if hmask is not None:
+        want = want * (hmask.double() > 0)
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(_lib.GEMM_MODES["split16"]) == 0
+    try:
+        got = ops.pair_linear(x.to(DEV), w.to(DEV), relu_mask=hmask.to(DEV) if hmask is not None else None)
+        assert got is not None and torch.equal(got, ops.pair_linear(x.to(DEV), w.to(DEV), relu_mask=hmask.to(DEV) if hmask is not None else None))
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+    got = got.double().cpu()
+    assert torch.isfinite(got).all() and float(got[5].abs().max()) == 0.0
+    # row by row: a small row must be as accurate as a large one (a whole-tensor norm would only see the large rows)
+    err = (got - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-300)
+    keep = want.norm(dim=1) > 0
+    assert float(err[keep].max()) < 4e-6, (case, scale, float(err[keep].max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("O,I", [(256, 64), (64, 256), (64, 64), (128, 64)])
 @pytest.mark.parametrize("profile", ["tiny", "huge", "rising", "falling", "spike", "zeros_then_data", "all_zero"])
 def test_linear_weight_gradient_range_of_the_gradient(O, I, profile):
@@ -476,3 +516,28 @@ def test_full_size_backward_directional_derivative():
     numeric = (vals[0] - vals[1]) / (2 * eps)
     print(f"\nfull-size directional derivative: analytic {analytic:.6e}  finite difference {numeric:.6e}  loss {float(loss):.4f}")
     assert abs(analytic) > 1.0 and abs(analytic - numeric) <= 5e-3 * abs(analytic)
+
+
+def test_gradient_with_respect_to_the_coordinates(golden, gemm_mode):
+    """the hand-written backwards of the input stage and of the heads return no gradient for z; a caller who needs
+    d loss / d z (guidance, a gradient check on the positions) must get it from the differentiable restatement, not a silent None:
+    d(<eps, a> + <logits, b>) / dz against the oracle's autograd."""
+    case, zf, args, params, pb = case_inputs(golden, "small64")
+    model = hip_model(args, params)
+    dpb = batch_to(pb, DEV)
+    mask = pb["residue_and_atom_mask"]
+    g = torch.Generator().manual_seed(12)
+    b, N = mask.shape
+    z0 = O.remove_mean(torch.randn(b, N, 3, generator=g), mask)
+    seq_t = torch.randn(b, N, 21, generator=g)
+    t = torch.tensor([5] * b)
+    a_, b_ = torch.randn(b, N, 3, generator=g), torch.randn(b, N, 21, generator=g)
+    zo = z0.clone().requires_grad_(True)
+    eps_o, log_o = O.network_step(params, args, pb, zo, seq_t, mask, t)
+    ((eps_o * a_).sum() + (log_o * b_).sum()).backward()
+    zh = z0.to(DEV).requires_grad_(True)
+    eps_h, log_h = model(dpb, zh, seq_t.to(DEV), mask.to(DEV), t.to(DEV))
+    ((eps_h * a_.to(DEV)).sum() + (log_h * b_.to(DEV)).sum()).backward()
+    assert zh.grad is not None
+    assert rel_l2(zh.grad.cpu(), zo.grad) < GRAD_TOL
+    assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
