@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
 #pragma unroll
                 for (int s_ = 0; s_ < 32; ++s_) {
                     float v = acc[s_ >> 4][s_ & 15] * back + bl[hi * (OUT / 2) + 32 * j + s_];
-                    y[s_] = act == 1 ? fmaxf(v, 0.f) : v;
+                    y[s_] = act == 1 ? relu_nan(v) : v;
                 }
                 if (mask_pos) {
                     float m[32];
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(NW * 64) void pair_linear_rows_kernel(
 #pragma unroll
             for (int s_ = 0; s_ < 32; ++s_) {
                 const float v = acc[s_ >> 4][s_ & 15] * back + bl[hi * 32 + s_];
-                y[s_] = act == 1 ? fmaxf(v, 0.f) : v;
+                y[s_] = act == 1 ? relu_nan(v) : v;
             }
             if (mask_pos) {
                 float m[32];

@@ -30,6 +30,11 @@ PRD_DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma
 PRD_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 PRD_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// ReLU that PROPAGATES NaN, like torch.relu in the reference (modules.py:306-326, model.py:110-122): fmaxf / v_max_f32 return the
+// OTHER operand for a NaN, so a non-finite activation -- an operand beyond the fp16 range under PRD_ARITH_SPLIT16 -- would become a
+// silent 0 in the next hidden layer (measured: ab_proj x 1e5 gave finite, WRONG coordinates through the coordinate head's ReLU).
+// NaN < 0 is false: the NaN stays, reaches the outputs and trips the sticky flag of prd_step_boundary.
+PRD_DEV float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 // gate sigmoid on the hardware transcendentals (v_exp_f32 + v_rcp_f32, ~1 ulp each): the gates multiply
 // O(1) values, so their 1e-7 relative error is far inside the 1e-5 operator tolerance
 PRD_DEV float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }

@@ -21,7 +21,7 @@ PRD_DEV void epilogue_store(const PrdGemm& g, int g1, int g2, int m, int n, floa
     if (g.addmat) v += g.addmat[g1 * g.sad1 + g2 * g.sad2 + (size_t)m * g.ldadd + n];
     if (g.colmask && g.colmask[g1 * g.scm1 + n] < 0.5f) v = g.fill;
     const int act = (n >= g.act_from) ? g.act : 0;
-    if (act == 1) v = fmaxf(v, 0.f);
+    if (act == 1) v = relu_nan(v);
     else if (act == 2) v = sigmoidf_(v);
     if (g.rowmask && (g.rowmask_cols <= 0 || n < g.rowmask_cols)) v *= g.rowmask[g1 * g.srm1 + m];
     if (g.mulmat) {
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(128) void gemm_slab_reduce_kernel(PrdGemm g, const 
             if (g.colscale) v *= g.colscale[n + e];
             if (g.bias) v += g.bias[n + e];
             const int act = (n + e >= g.act_from) ? g.act : 0;
-            if (act == 1) v = fmaxf(v, 0.f);
+            if (act == 1) v = relu_nan(v);
             else if (act == 2) v = sigmoidf_(v);
             if (g.rowmask && (g.rowmask_cols <= 0 || n + e < g.rowmask_cols)) v *= g.rowmask[m];
             if (g.resid) { const float rv = g.resid[(size_t)m * g.ldr + n + e]; v += g.rscale ? rv * g.rscale[n + e] : rv; }

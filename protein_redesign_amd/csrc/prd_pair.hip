@@ -127,7 +127,7 @@ __global__ __launch_bounds__(128) void single_init_kernel(float* __restrict__ si
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
         float acc = 0.f;
         for (int k = 0; k < ncls; ++k) acc += xs[k] * w[c * ncls + k];
-        single[row * S + c] = stat[row * S + c] + m * fmaxf(acc, 0.f);
+        single[row * S + c] = stat[row * S + c] + m * relu_nan(acc);
     }
 }
 
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(NW * 64) void pair_transition_kernel(int* queue, fl
             zero_acc(acc);                                                                                          \
             rowgemm<P, HBP>(W1l + (Q) * HBP * 32 * (P + 4), x, acc, r, hi);                                         \
             _Pragma("unroll") for (int s = 0; s < HHP; ++s)                                                         \
-                h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s], 0.f);                             \
+                h[s] = relu_nan(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s]);                             \
             rowgemm_part<HID, NB, (Q) * HHP / 4, ((Q) + 1) * HHP / 4>(W2l, h, acc2, r, hi);                         \
         }
         PRD_PT_PASS(0) PRD_PT_PASS(1) PRD_PT_PASS(2) PRD_PT_PASS(3)
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(NW * 64) void block_tail_kernel(int* queue, float* 
         zero_acc(acc);                                                                                              \
         rowgemm<P, HBP>(W1l + (Q) * HBP * 32 * (P + 4), x, acc, r, hi);                                             \
         _Pragma("unroll") for (int s = 0; s < HHP; ++s)                                                             \
-            h[s] = fmaxf(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s], 0.f);                                 \
+            h[s] = relu_nan(acc[s >> 4][s & 15] + b1l[hi * HH + (Q) * HHP + s]);                                 \
         rowgemm_part<HID, NB, (Q) * HHP / 4, ((Q) + 1) * HHP / 4>(W2l, h, acc2, r, hi);                             \
     }
 
@@ -1032,11 +1032,15 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
         for (int h = 0; h < H; ++h) stage_vec_cll(wbl + h * P, wb + h * P, P, threadIdx.x, NT);
     __syncthreads();
     pt.mark(6);                                         // 6: prologue (weight staging, barrier)
-    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int lane = threadIdx.x & 63, r_w = lane & 31, hi_w = lane >> 5;
     const long ntask = (rows + 31) / 32;
     WaveTasks tasks(nullptr, ntask, NW);
     // (requesting the first task's rows before the weight staging was tried: the staging loop then spills, 38.7 -> 50.9 us)
     for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        // lane coordinates opaque per task: hipcc otherwise hoists lane-dependent 64-bit addresses out of the task loop and, at the
+        // 168-register limit of 12 waves, parks them in scratch (12 B / lane, one reload per task)
+        int r = r_w, hi = hi_w;
+        asm volatile("" : "+v"(r), "+v"(hi));
         const long pos = task * 32 + r;
         const bool valid = pos < rows;
         float raw[KH];
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__(NW * 64) void pair_tail_h2_kernel(float* out, const
             zero_acc(acc);                                                                                          \
             rowgemm_h2<P, HBP>(W1h, HID, (Q) * HBP * 32, xs, acc, r, hi);                                           \
             _Pragma("unroll") for (int s_ = 0; s_ < HHP; ++s_)                                                      \
-                h[s_] = fmaxf(acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + b1l[hi * HH + (Q) * HHP + s_], 0.f);          \
+                h[s_] = relu_nan(acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + b1l[hi * HH + (Q) * HHP + s_]);          \
             u32x4 hs[2][HHP / 8];                                                                                   \
             split2h_cll<HHP>(h, hs);                                                                                \
             rowgemm_h2_part<HID, NB, (Q) * HHP / 8, ((Q) + 1) * HHP / 8>(W2h, P, 0, hs, acc2, r, hi);               \
@@ -1159,7 +1163,7 @@ __global__ __launch_bounds__(WG) void coord_head_kernel(float* __restrict__ eps,
             }
             float wsum = 0.f;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) wsum += fmaxf(acc[s >> 4][s & 15] * ASC + b1l[hi * KH + s], 0.f) * w2l[hi * KH + s];
+            for (int s = 0; s < KH; ++s) wsum += relu_nan(acc[s >> 4][s & 15] * ASC + b1l[hi * KH + s]) * w2l[hi * KH + s];
             wsum = xhalf_sum(wsum);
             const float* zj = z + ((long)bb * N + jj) * 3;
             const float d0 = zi0 - zj[0], d1 = zi1 - zj[1], d2 = zi2 - zj[2];
@@ -1433,7 +1437,7 @@ __global__ __launch_bounds__(256) void step_boundary_kernel(
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < NCLS; ++k) acc += xs[u][k] * w[k];
-                if (i0 + u < N) single_next[((long)bb * N + i0 + u) * S + c] = st8[u] + rm8[u] * fmaxf(acc, 0.f);
+                if (i0 + u < N) single_next[((long)bb * N + i0 + u) * S + c] = st8[u] + rm8[u] * relu_nan(acc);
             }
         }
     }
@@ -1707,24 +1711,30 @@ __global__ __launch_bounds__(512) void outer_linear_ks_kernel(float* out, const 
         T.i0 = ib * 32 + grp * RG;
         return T;
     };
-    const int lrow = lane / LR, lpiece = lane % LR;
-    // epilogue: wave g owns rows 4g .. 4g+3 of the tile; lane = (row 4g + lane / 16, 16-byte piece lane % 16 of the P channels).
-    // For P = 32 (8 pieces per row) the upper half of every 16-lane group idles.
-    const int erow = 4 * wave + (lane >> 4), epiece = lane & 15;
-    const bool elive = epiece < P / 4;
-    const int ech = 4 * (elive ? epiece : 0);
-    // channel ech .. ech+3 sits in accumulator group (ech >> 5) * 4 + ((ech >> 3) & 3) of the lane of row erow with hi = (ech >> 2) & 1
-    const int egrp = (ech >> 5) * 4 + ((ech >> 3) & 3), esrc = erow + 32 * ((ech >> 2) & 1);
-    // The partial tile of (wave, group g) is stored lane-linear EXCEPT that the low four lane bits are XORed with (2 g + hi): the
-    // sixteen lanes of a ds_read_b128 group of the reduction (two tile rows x 8 channel pieces: same low lane bits, all eight
-    // (group, hi) combinations) then read sixteen different 16-byte bank slots.  Unswizzled they hit two slots, 8-way: 67 % of the
-    // kernel's LDS cycles were bank conflicts (profiles/r03_roofline.txt).
-    const int eoff = egrp * 64 + ((esrc & 48) | ((esrc & 15) ^ ((2 * egrp + (esrc >> 5)) & 15)));
-    const float4 bs = *reinterpret_cast<const float4*>(bias + ech);
+    const int lane_w = lane;
     struct Epi { float4 ui, pu, pm; };
     pt.mark(6);                                             // 6: prologue (W1 slice -> registers)
     for (int t = blockIdx.x; t < ntask; t += gridDim.x) {
         const Task T = decode(t);
+        // Lane coordinates opaque per task: the lane-dependent offsets below are a dozen VALU instructions per task; hoisted out of
+        // the task loop they sat in registers next to the W1 slices (256 VGPRs) and eight of them went to scratch (32 B / lane).
+        int lane = lane_w;
+        asm volatile("" : "+v"(lane));
+        const int r = lane & 31, hi = lane >> 5;
+        const int lrow = lane / LR, lpiece = lane % LR;
+        // epilogue: wave g owns rows 4g .. 4g+3 of the tile; lane = (row 4g + lane / 16, 16-byte piece lane % 16 of the P channels).
+        // For P = 32 (8 pieces per row) the upper half of every 16-lane group idles.
+        const int erow = 4 * wave + (lane >> 4), epiece = lane & 15;
+        const bool elive = epiece < P / 4;
+        const int ech = 4 * (elive ? epiece : 0);
+        // channel ech .. ech+3 sits in accumulator group (ech >> 5) * 4 + ((ech >> 3) & 3) of the lane of row erow with hi = (ech >> 2) & 1
+        const int egrp = (ech >> 5) * 4 + ((ech >> 3) & 3), esrc = erow + 32 * ((ech >> 2) & 1);
+        // The partial tile of (wave, group g) is stored lane-linear EXCEPT that the low four lane bits are XORed with (2 g + hi): the
+        // sixteen lanes of a ds_read_b128 group of the reduction (two tile rows x 8 channel pieces: same low lane bits, all eight
+        // (group, hi) combinations) then read sixteen different 16-byte bank slots.  Unswizzled they hit two slots, 8-way: 67 % of the
+        // kernel's LDS cycles were bank conflicts (profiles/r03_roofline.txt).
+        const int eoff = egrp * 64 + ((esrc & 48) | ((esrc & 15) ^ ((2 * egrp + (esrc >> 5)) & 15)));
+        const float4 bs = *reinterpret_cast<const float4*>(bias + ech);
         // ---- x_j slice of the block, once per task: coalesced -> wave-private LDS tile -> row-per-lane operands ----
         {
             float4 xj[NLD];

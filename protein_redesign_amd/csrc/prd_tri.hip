@@ -232,13 +232,17 @@ __global__ __launch_bounds__(NW * 64) void tri_mul_out_proj_kernel(float* pair, 
     stage_vec_cll(bpl, bp, OUT, threadIdx.x, NW * 64, H2_WSCALE);
     stage_vec_cll(bgl, bg, OUT, threadIdx.x, NW * 64, NEG_LOG2E * H2_WSCALE);
     __syncthreads();
-    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int lane = threadIdx.x & 63, r_w = lane & 31, hi_w = lane >> 5;
     const int nvb = ldn / 32;
     const long ntask = (long)b * N * nvb;
     const unsigned cbytes = (unsigned)N * (unsigned)ldn * 4u;              // channel stride of Ot and AB
-    const unsigned lane_off = (unsigned)(4 * hi) * cbytes + (unsigned)r * 4u;
     WaveTasks tasks(nullptr, ntask, NW);
     for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        // lane coordinates opaque per task (as in pair_tail_h2_kernel): lane-dependent addresses hoisted out of the task loop were
+        // parked in scratch at the 168-register limit of 12 waves (12 B / lane)
+        int r = r_w, hi = hi_w;
+        asm volatile("" : "+v"(r), "+v"(hi));
+        const unsigned lane_off = (unsigned)(4 * hi) * cbytes + (unsigned)r * 4u;
         const int ti = (int)task;
         const int vb = ti % nvb, bu = ti / nvb;            // bu = bb * N + u
         const int bb = bu / N, u = bu - bb * N;

@@ -618,9 +618,18 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 float mm[5];
                 bool has[5];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                // (a missing piece reads the slot of a piece that EXISTS, with weight 0: with fewer than four key tiles -- rows of up to
+                // 96 positions -- some helpers have no tile and never write their slot; reading one of those fed whatever the LDS held,
+                // possibly a NaN, into 0 * x: found in round 5 by poisoning the LDS, tools/ubench/lds_poison.hip)
+                int kv = 0;
+#pragma unroll
+                for (int k = 4; k >= 0; --k) {
                     has[k] = k == 0 ? own_t1 > 0 : (k - 1 < nhelp && qtile(m4 + k) > qtile(m4 + k - 1));
-                    const float v_ = part[(size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + 9 * 64 + lane];
+                    if (has[k]) kv = k;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float v_ = part[(size_t)(s0 + (has[k] ? k : kv)) * 640 + 9 * 64 + lane];
                     mm[k] = has[k] ? v_ : -INFINITY;
                 }
                 float M = mm[0];
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
-                    const float* pp = part + (size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + lane;
+                    const float* pp = part + (size_t)(s0 + (has[k] ? k : kv)) * 640 + lane;
                     const float scl = has[k] ? __builtin_amdgcn_exp2f(mm[k] - M) : 0.f;
                     l += scl * pp[8 * 64];
 #pragma unroll
@@ -857,9 +866,15 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         float mm[5];
         bool has[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
+        int kv = 0;                                     // a piece that exists (see tri_attn_core_v2_kernel's merge)
+#pragma unroll
+        for (int k = 4; k >= 0; --k) {
             has[k] = k == 0 ? own_t1 > 0 : (k - 1 < nhelp && qtile(m4 + k) > qtile(m4 + k - 1));
-            const float v_ = part[(size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + 9 * 64 + lane];
+            if (has[k]) kv = k;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float v_ = part[(size_t)(s0 + (has[k] ? k : kv)) * 640 + 9 * 64 + lane];
             mm[k] = has[k] ? v_ : -INFINITY;
         }
         float M = mm[0];
@@ -870,7 +885,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const float* pp = part + (size_t)(s0 + (has[k] ? k : (own_t1 > 0 ? 0 : 1))) * 640 + lane;
+            const float* pp = part + (size_t)(s0 + (has[k] ? k : kv)) * 640 + lane;
             const float scl = has[k] ? __builtin_amdgcn_exp2f(mm[k] - M) : 0.f;
             l += scl * pp[8 * 64];
 #pragma unroll
@@ -1466,14 +1481,19 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
     const unsigned kl_rel = 2u * L.plane;
     const bool active = wave < nqb;
     const int blk = wave;
-    const unsigned krow_lane = L.krow + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
-    const unsigned vrow_lane = L.vrow + (unsigned)hi * L.plane + (unsigned)r * 16u;
-    const unsigned tlane = (unsigned)hi * 512u + (unsigned)r * 16u;                      // + region + 2048 t (+ 1024: second half)
+    const int r_w = r, hi_w = hi;
     f32x16 zero;
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero[e] = 0.f;
 
     for (int bu = slot; bu < nrows; bu += rstride) {
+        // lane coordinates opaque per item: the lane-dependent LDS offsets are three VALU instructions per item; hoisted out of the
+        // item loop, two of the kernel's lane constants went to scratch at the 168-register limit (12 B / lane)
+        int r = r_w, hi = hi_w;
+        asm volatile("" : "+v"(r), "+v"(hi));
+        const unsigned krow_lane = L.krow + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
+        const unsigned vrow_lane = L.vrow + (unsigned)hi * L.plane + (unsigned)r * 16u;
+        const unsigned tlane = (unsigned)hi * 512u + (unsigned)r * 16u;                      // + region + 2048 t (+ 1024: second half)
         const int bb = bu / N, u = bu - bb * N;
         const int pos0 = ending ? bb * N * N + u : bu * N, pstride = ending ? N : 1;       // positions of the row: pos0 + v * pstride
         auto row_pos = [&](int v) -> long { return (long)(pos0 + v * pstride); };

@@ -762,7 +762,7 @@ class Fitter:
         all_reduce_gradients(self._params, self.group, slices=self.reduce_slices)
         guard = self._device_guard and getattr(model, "nonfinite_policy", "off") != "off"
         if guard:
-            found = (self._bad_loss | ~_grads_finite(self._params)).to(torch.float32).reshape(1)
+            found = (self._bad_loss | ~_grads_finite(self._params)).to(torch.float32).reshape(())      # 0-dim, like GradScaler's
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
                 dist.all_reduce(found, op=dist.ReduceOp.MAX, group=self.group)       # every rank skips or none does
             opt.grad_scale, opt.found_inf = None, found         # fused Adam: no update, no step count, when found_inf == 1

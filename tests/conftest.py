@@ -30,3 +30,38 @@ def golden():
         case = json.loads(str(z["case"]))
         return case, z
     return load
+
+
+# ---------------------------------------------------------------------------------------------------
+# PRD_LDS_POISON=1 (debug runs of the GPU suite): fill the LDS of every CU with NaN patterns before EVERY operator call, so that a
+# kernel that reads LDS it never wrote fails deterministically instead of depending on what ran before on the box (round 5: the
+# merge of tri_attn_core_v2 / v3 read the partial slot of a helper wave without tiles for rows shorter than 97 positions).
+# Needs tools/ubench/liblds_poison.so (build line in tools/ubench/lds_poison.hip).
+# ---------------------------------------------------------------------------------------------------
+def _install_lds_poison():
+    import ctypes
+    import types
+    from protein_redesign_amd import ops
+    so = os.path.join(ROOT, "tools", "ubench", "liblds_poison.so")
+    if not os.path.exists(so):
+        raise RuntimeError(f"PRD_LDS_POISON is set but {so} is missing: build it (see tools/ubench/lds_poison.hip)")
+    pois = ctypes.CDLL(so)
+    pois.prd_dbg_poison_lds.argtypes = [ctypes.c_uint, ctypes.c_void_p]
+    skip = {"task_queue", "round_up", "_off", "cached_pack", "row_block", "workspace_bytes", "gemm_workspace", "slab_ok", "ln_fusable",
+            "split16_gemm_ok"}
+
+    def wrap(fn):
+        def w(*a, **k):
+            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                assert pois.prd_dbg_poison_lds(0x7fc00000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+            return fn(*a, **k)
+        w.__wrapped__ = fn
+        return w
+    for name in dir(ops):
+        fn = getattr(ops, name)
+        if isinstance(fn, types.FunctionType) and fn.__module__ == ops.__name__ and name not in skip and not hasattr(fn, "__wrapped__"):
+            setattr(ops, name, wrap(fn))
+
+
+if os.environ.get("PRD_LDS_POISON"):
+    _install_lds_poison()
