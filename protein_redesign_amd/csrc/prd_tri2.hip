@@ -617,7 +617,6 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 const int s0 = (nhelp + 1) * gi;
                 float mm[5];
                 bool has[5];
-#pragma unroll
                 // (a missing piece reads the slot of a piece that EXISTS, with weight 0: with fewer than four key tiles -- rows of up to
                 // 96 positions -- some helpers have no tile and never write their slot; reading one of those fed whatever the LDS held,
                 // possibly a NaN, into 0 * x: found in round 5 by poisoning the LDS, tools/ubench/lds_poison.hip)
@@ -865,7 +864,6 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         const int s0 = (nhelp + 1) * gi;
         float mm[5];
         bool has[5];
-#pragma unroll
         int kv = 0;                                     // a piece that exists (see tri_attn_core_v2_kernel's merge)
 #pragma unroll
         for (int k = 4; k >= 0; --k) {
