@@ -748,6 +748,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     for (int e = 0; e < 8; ++e) gate[e] = 0.f;
 
     // ================= phase 1 of one row into buffer `par`, gate share `gpar` =================
+    int it = 0;                                         // (row iteration: PRD2_STAMP)
     auto phase1 = [&](const RowIx& row, int par, int gpar) {
         if (p1_blk < 0) return;
         const unsigned bufo = L.buf0 + (unsigned)par * L.bufsize;
@@ -768,6 +769,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         ln_cll_p<KH>(x);
         u32x4 xs[2][P / 16];
         split2h_rn_cll<KH>(x, xs);
+        PRD2_STAMP(3);                                  // (timing builds) 3: row arrived, LayerNorm-ed and split
         if (p1_kinds & 1) {
             {   // logit override of masked / padded keys + tile flag
                 const bool keep = valid && (mu * mk >= 0.5f);
@@ -897,12 +899,15 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
 
     RowIx rcur = make_row(slot < nrows ? slot : 0), rprev = rcur;
     if (slot < nrows) phase1(rcur, 0, 0);
-    int it = 0, gpar = 0;                               // gpar = it % 3
+    int gpar = 0;                                       // gpar = it % 3
     for (int bu = slot; bu < nrows; bu += rstride, ++it) {
         const int par = it & 1;
         const unsigned bufo = L.buf0 + (unsigned)par * L.bufsize;
+        PRD2_STAMP(5);                                  // 5: arrival at the barrier
         __syncthreads();
+        PRD2_STAMP(0);                                  // 0: released
         if (it > 0 && group_owner) merge(rprev, par ^ 1, gpar == 0 ? 2 : gpar - 1);
+        PRD2_STAMP(1);                                  // 1: merge of the previous row done
         // ================= phase 2 of row rcur =================
         unsigned fmask;
         {
@@ -1030,6 +1035,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        PRD2_STAMP(2);                                  // 2: key loops done
         // ================= phase 1 of the next row =================
         rprev = rcur;
         const int bun = bu + rstride;
@@ -1037,6 +1043,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             rcur = make_row(bun);
             phase1(rcur, par ^ 1, gpar == 2 ? 0 : gpar + 1);
         }
+        PRD2_STAMP(4);                                  // 4: projection of the next row done
         gpar = gpar == 2 ? 0 : gpar + 1;
     }
     if (it > 0 && m4 > 0) {
