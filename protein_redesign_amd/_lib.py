@@ -147,6 +147,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 16
     if geti("PRD_GEMM_BRING", 1) == 0:
         t |= 1 << 17
+    if geti("PRD_GEMM_XCDCOLS", 1) == 0:
+        t |= 1 << 18
     if geti("PRD_TA2_XCD8", 1) == 0:
         t |= 1 << 20
     return t

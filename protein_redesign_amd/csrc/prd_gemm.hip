@@ -366,7 +366,21 @@ __global__ __launch_bounds__(256 * KG) void gemm_h2_kernel(PrdGemm g) {
     const int r = lane & 31, hi = lane >> 5;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int tiles_n = (g.N + 63) / 64;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    int tile_m, tile_n;
+    if (g.tile_hint == -8) {
+        // (host: PrdGemm.tile_hint is re-used as the launch's block map; -8 = XCD-aware columns)  All row tiles of ONE column tile on
+        // ONE XCD, next to each other in dispatch order: block b runs on XCD b % 8 (observed placement, speed only), so the weight tile
+        // of a column crosses the fabric once and the other row tiles find it in that XCD's L2.  Row-major order (block = tile_m *
+        // tiles_n + tile_n) put the five row tiles of a column of the trunk-head projection (M = 320, N = 8448, 17 MB of weights) on
+        // different XCDs and 132 blocks apart: 54.6 MB of HBM-side traffic for 17 MB of weights (profiles/r04_roofline.txt).
+        const int tiles_m = (g.M + 63) / 64, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile_m = j % tiles_m;
+        tile_n = (j / tiles_m) * 8 + xcd;
+        if (tile_n >= tiles_n) return;                  // (grid rounded up to a multiple of 8 column tiles; uniform per workgroup)
+    } else {
+        tile_m = blockIdx.x / tiles_n;
+        tile_n = blockIdx.x - tile_m * tiles_n;
+    }
     const int m0 = tile_m * 64, n0 = tile_n * 64;
     const int gb = blockIdx.y, g1 = gb / g.G2, g2 = gb - g1 * g.G2;
     const float* __restrict__ A = g.A + g1 * g.sa1 + g2 * g.sa2;
@@ -1005,15 +1019,22 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     if (arith == PRD_ARITH_SPLIT16 && g.tile_hint == 0 && !g.b_kn && (g.K % 32) == 0 && tiles64 >= 512 && g.G1 * g.G2 == 1 &&
         (!g.a_ln || (g.K % 16) == 0)) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
+        PrdGemm gx = g;
+        // more weight bytes than row bytes and at least 8 column tiles: the XCD-aware column map (see the kernel); A/B switch
+        // PRD_TUNE bit 18 (PRD_GEMM_XCDCOLS=0) keeps the row-major block order
+        if (g.N >= 512 && (long)g.N > 2L * g.M && !((g.arith >> 8) & (1 << 18))) {
+            gx.tile_hint = -8;
+            grid.x = 8u * prd_ceil_div(g.M, 64) * prd_ceil_div(prd_ceil_div(g.N, 64), 8);
+        }
         static std::once_flag once1, once4;
         if (g.K >= 1024) {
             const size_t lds = (size_t)4 * 2 * 4 * 64 * 64 + 512;
             std::call_once(once4, [] { (void)hipFuncSetAttribute((const void*)gemm_h2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-            hipLaunchKernelGGL((gemm_h2_kernel<4>), grid, dim3(1024), lds, stream, g);
+            hipLaunchKernelGGL((gemm_h2_kernel<4>), grid, dim3(1024), lds, stream, gx);
         } else {
             const size_t lds = (size_t)2 * 4 * 64 * 64 + 512;
             std::call_once(once1, [] { (void)hipFuncSetAttribute((const void*)gemm_h2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-            hipLaunchKernelGGL((gemm_h2_kernel<1>), grid, dim3(256), lds, stream, g);
+            hipLaunchKernelGGL((gemm_h2_kernel<1>), grid, dim3(256), lds, stream, gx);
         }
         return (int)hipGetLastError();
     }

@@ -734,6 +734,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     int p1_blk = -1, p1_kinds = 0;
     if (owner) { p1_blk = wave; p1_kinds = (group_owner && gi < nhelp) ? 1 : 3; }
     else if (helper && hj < m4) { p1_blk = gbase + hj; p1_kinds = 2; }
+    // (A/B, PRD_TA2_FLAGS bit 4) The waves of a SIMD are served oldest first (profiles/r05_tri_attn_v3_phases.txt: waves 0-3 sweep their
+    // ten key tiles in 7.9 k cycles, the youngest wave of the SIMD needs 16.8 k for six and then still has its projection to do: it
+    // ends the iteration alone, while the oldest wave has been waiting at the barrier for 7 k cycles).  With this switch the projections
+    // of the shared ("group") blocks -- [K|Q] and [G, V], 2 m4 items -- move from the youngest waves (group owners, helpers) to the
+    // OLDEST ones, one extra item each on top of their own block; the group owners then read their Q from the share like the helpers.
+    const bool remap = (flags & 16) && gbase >= 2 * m4 && m4 > 0;
+    int p1b_blk = -1, p1b_kinds = 0;                    // second phase-1 item of a wave (remap only)
+    if (remap) {
+        if (wave >= gbase) { p1_blk = -1; p1_kinds = 0; }                      // group owners and helpers: no projection
+        if (wave < 2 * m4) { p1b_blk = gbase + (wave >> 1); p1b_kinds = (wave & 1) ? 2 : 1; }
+    }
     auto qtile = [&](int k) { return (nqb * k) >> 2; };
     const int own_t1 = group_owner ? qtile(m4) : nqb;
     const int work_tot = owner ? own_t1 : (helper ? m4 * (qtile(m4 + hj + 1) - qtile(m4 + hj)) : 0);
@@ -749,10 +760,9 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
 
     // ================= phase 1 of one row into buffer `par`, gate share `gpar` =================
     int it = 0;                                         // (row iteration: PRD2_STAMP)
-    auto phase1 = [&](const RowIx& row, int par, int gpar) {
-        if (p1_blk < 0) return;
+    auto phase1_item = [&](const RowIx& row, int par, int gpar, const int blk, const int kinds) {
+        if (blk < 0) return;
         const unsigned bufo = L.buf0 + (unsigned)par * L.bufsize;
-        const int blk = p1_blk;
         int r1 = r, hi1 = hi;                           // opaque (see tri_attn_core_v2_kernel)
         asm volatile("" : "+v"(r1), "+v"(hi1));
         auto wop = [&](int wrow, int s_, u32x4& wh, u32x4& wl) {
@@ -770,7 +780,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         u32x4 xs[2][P / 16];
         split2h_rn_cll<KH>(x, xs);
         PRD2_STAMP(3);                                  // (timing builds) 3: row arrived, LayerNorm-ed and split
-        if (p1_kinds & 1) {
+        if (kinds & 1) {
             {   // logit override of masked / padded keys + tile flag
                 const bool keep = valid && (mu * mk >= 0.5f);
                 if (hi1 == 0) reinterpret_cast<float*>(lds + bufo + kadd_rel)[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
@@ -790,19 +800,20 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] *= inv16;
-            u32x4 kh4, kl4;
+            u32x4 kh4, kl4, qhn, qln;
             split8_rn(acc, 0, kh4, kl4);
-            split8_rn(acc, 8, qh4, ql4);
+            split8_rn(acc, 8, qhn, qln);
             const unsigned po = bufo + (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
             *reinterpret_cast<u32x4*>(lds + po) = kh4;
             *reinterpret_cast<u32x4*>(lds + po + kl_rel) = kl4;
-            if (group_owner) {                          // the helpers of this block read Q from here
-                const unsigned qo = L.qs + (unsigned)(par * m4 + gi) * 2048u + (unsigned)hi1 * 512u + (unsigned)r1 * 16u;
-                *reinterpret_cast<u32x4*>(lds + qo) = qh4;
-                *reinterpret_cast<u32x4*>(lds + qo + 1024u) = ql4;
+            if (blk >= gbase) {                         // a shared block: its helpers (remap: and its owner) read Q from here
+                const unsigned qo = L.qs + (unsigned)(par * m4 + (blk - gbase)) * 2048u + (unsigned)hi1 * 512u + (unsigned)r1 * 16u;
+                *reinterpret_cast<u32x4*>(lds + qo) = qhn;
+                *reinterpret_cast<u32x4*>(lds + qo + 1024u) = qln;
             }
+            if (blk == wave) { qh4 = qhn; ql4 = qln; }  // the wave's own block: Q stays in registers for its key sweep
         }
-        if (p1_kinds & 2) {
+        if (kinds & 2) {
             f32x16 ag, av;
             {
                 const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
@@ -846,6 +857,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             *reinterpret_cast<u32x4*>(lds + vo) = s0;
             *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
         }
+    };
+    auto phase1 = [&](const RowIx& row, int par, int gpar) {
+        phase1_item(row, par, gpar, p1_blk, p1_kinds);
+        if (remap) phase1_item(row, par, gpar, p1b_blk, p1b_kinds);
     };
 
     auto finish = [&](const RowIx& row, int qb, const float (&o)[8], float l, const float (&g)[8], float mref) {
@@ -897,6 +912,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         finish(row, wave, o, l, g, M);
     };
 
+    // (A/B, PRD_TA2_FLAGS bit 3) static priorities against the oldest-first arbitration of a SIMD's waves: the youngest wave of a SIMD
+    // (w >> 2 = 2: the helpers / shared-block owners, which have the least work and today finish LAST, alone) first
+    const int sprio = (flags & 8) ? (wave >> 2) : 0;
+    if (flags & 8) __builtin_amdgcn_s_setprio(sprio);
     RowIx rcur = make_row(slot < nrows ? slot : 0), rprev = rcur;
     if (slot < nrows) phase1(rcur, 0, 0);
     int gpar = 0;                                       // gpar = it % 3
@@ -1020,6 +1039,11 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
         };
         if (owner) {
             float o8[8], lsum = 0.f, mref = 0.f;
+            if (remap && group_owner) {                 // Q of the shared block was projected by another wave
+                const unsigned qo = L.qs + (unsigned)(par * m4 + gi) * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
+                qh4 = *reinterpret_cast<const u32x4*>(lds + qo);
+                ql4 = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
+            }
             if (own_t1 > 0) run_piece(qh4, ql4, 0, own_t1, o8, lsum, mref);
             if (!group_owner) finish(rcur, wave, o8, lsum, gate, mref);
             else if (own_t1 > 0) put_partial((nhelp + 1) * gi, o8, lsum, mref);
@@ -1034,7 +1058,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
                 put_partial((nhelp + 1) * i + 1 + hj, o8, lsum, mref);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(sprio);
         PRD2_STAMP(2);                                  // 2: key loops done
         // ================= phase 1 of the next row =================
         rprev = rcur;

@@ -5,7 +5,7 @@
     reach, % of the 8 TB/s HBM peak the algorithmic bytes reach, MFMA-busy % (SQ_VALU_MFMA_BUSY_CYCLES), executed MFMA rate
     against the 2.5 PF 16-bit peak, VALU-active %, LDS bank-conflict share, HBM-side traffic (FETCH_SIZE x 2 + WRITE_SIZE)
 
-usage: roofline_table.py TRACE_DB PMC_DB [PMC_DB ...] [--N 320 --P 64 --S 512]
+usage: roofline_table.py TRACE_DB PMC_DB [PMC_DB ...] [--N 320 --P 64 --S 512 --b 1]
   TRACE_DB: rocprofv3 --kernel-trace of bench.py (graph replay: in-step durations); PMC_DBs: --pmc passes of bench.py --no-graph.
 Every number can be recomputed from the printed columns and the formulas at the bottom of the output."""
 import argparse
@@ -56,8 +56,9 @@ def main():
     ap.add_argument("--N", type=int, default=320)
     ap.add_argument("--P", type=int, default=64)
     ap.add_argument("--S", type=int, default=512)
+    ap.add_argument("--b", type=int, default=1, help="complexes per GPU (bench.py --samples-per-gpu): algorithmic work per launch scales with it")
     a = ap.parse_args()
-    alg = algorithmic(a.N, a.P, a.S)
+    alg = {k: (f * a.b, by * a.b) for k, (f, by) in algorithmic(a.N, a.P, a.S).items()}
     # in-graph durations: the launches between the last two step_boundary kernels
     db = sqlite3.connect(a.trace)
     rows = list(db.execute("select name, start, end from kernels order by start"))
@@ -79,7 +80,7 @@ def main():
         v = cnt[k].get(c)
         return sum(v) / len(v) if v else None
 
-    print(f"# one replayed step: {step_us:.1f} us, {hi - lo} launches (N = {a.N}, P = {a.P}, S = {a.S}, b = 1)")
+    print(f"# one replayed step: {step_us:.1f} us, {hi - lo} launches (N = {a.N}, P = {a.P}, S = {a.S}, b = {a.b})")
     hdr = (f"{'kernel':32s} {'n':>3s} {'us':>7s} {'step%':>6s} {'GFLOP':>7s} {'MB':>7s} {'%fp32pk':>8s} {'%HBMpk':>7s} "
            f"{'MFMAbusy%':>9s} {'exec16 TF/s':>11s} {'%16bitpk':>8s} {'VALUact%':>8s} {'LDSconf%':>8s} {'traffic MB':>10s}")
     print(hdr)

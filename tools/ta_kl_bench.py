@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--N", type=int, default=320)
     ap.add_argument("--b", type=int, default=1)
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--rounds", type=int, default=6)
     a = ap.parse_args()
     from protein_redesign_amd import _lib, ops
     dev = "cuda"
@@ -34,8 +35,12 @@ def main():
     base_tune = _lib.lib().prd_get_tune()
     ref = None
     forms = [("v3 form 0 (round-3 order)", 0), ("v3 form 1 (next Q K^T before the split)", 2), ("v3 form 2 (row sum by mfma_4x4x4)", 4),
-             ("v3 form 3 (both)", 6), ("v2 (barrier per phase, priorities)", None)]
-    for rnd in range(2):                    # two rounds: the clock of a box drifts, the order effect shows
+             ("v3 + key-loop priorities by remaining work", 1), ("v3 + static priority, youngest first", 8),
+             ("v3 + shared blocks projected by the oldest waves", 16), ("v3 + oldest-wave projection + static priority", 24),
+             ("v3 + oldest-wave projection + mfma row sum", 20), ("v2 (barrier per phase, priorities)", None)]
+    times = {name: [] for name, _ in forms}
+    errs = {}
+    for rnd in range(a.rounds):             # interleaved rounds: the clock of a box drifts; the median over rounds is reported
         for name, f in forms:
             tune = base_tune & ~((1 << 6) | (31 << 7) | (1 << 4))
             if f is None:
@@ -45,17 +50,21 @@ def main():
             _lib.lib().prd_set_tune(tune)
             for i in range(4):
                 ops.tri_attn_core_v2(pair, mask, wts, H, c, ending=bool(i & 1), og=og)
-            out = ops.tri_attn_core_v2(pair, mask, wts, H, c, ending=False).clone()
+            outs = [ops.tri_attn_core_v2(pair, mask, wts, H, c, ending=e).clone() for e in (False, True)]
             if ref is None:
-                ref = out
-            err = float((out - ref).norm() / ref.norm())
+                ref = outs
+            errs[name] = max(float((o - r_).norm() / r_.norm()) for o, r_ in zip(outs, ref))
+            assert all(bool(torch.isfinite(o).all()) for o in outs), name
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for i in range(a.reps):
                 ops.tri_attn_core_v2(pair, mask, wts, H, c, ending=bool(i & 1), og=og)
             e1.record()
             torch.cuda.synchronize()
-            print(f"N={a.N} b={a.b} round {rnd}  {name:<44s} {e0.elapsed_time(e1) * 1e3 / a.reps:8.2f} us   rel-L2 vs form 0 {err:.2e}", flush=True)
+            times[name].append(e0.elapsed_time(e1) * 1e3 / a.reps)
+    for name, _ in forms:
+        ts = sorted(times[name][1:]) if len(times[name]) > 1 else times[name]        # the first round warms the clock up
+        print(f"N={a.N} b={a.b}  {name:<52s} median {ts[len(ts) // 2]:7.2f} us  min {ts[0]:7.2f}  max {ts[-1]:7.2f}   rel-L2 vs form 0 {errs[name]:.2e}", flush=True)
     _lib.lib().prd_set_tune(base_tune)
 
 
