@@ -86,7 +86,7 @@ int prd_version(void);
 #define PRD_TUNE_TMS_NW12 (1 << 13)     /* PRD_TMS_NW=12 / 16: waves per workgroup of the split contraction (default 8) */
 #define PRD_TUNE_TMS_NW16 (2 << 13)
 #define PRD_TUNE_TA2_NO_XCD8 (1 << 20)  /* PRD_TA2_XCD8=0: rows in flight per head not rounded to a multiple of 8 (heads of a row spread over XCDs) */
-#define PRD_TUNE_GEMM_NO_XCD_COLS (1 << 18)     /* PRD_GEMM_XCDCOLS=0: 64 x 64-tile node-row GEMMs keep the row-major block order (round 4) */
+#define PRD_TUNE_GEMM_XCD_COLS (1 << 18)        /* PRD_GEMM_XCDCOLS=1: 64 x 64-tile node-row GEMMs with all row tiles of a column tile on one XCD (measured: no gain) */
 #define PRD_TUNE_GEMM_NO_BATCHED_RING (1 << 17) /* PRD_GEMM_BRING=0: batched / [K][N]-operand GEMMs stay on the fp32 K-split kernel */
 #define PRD_TUNE_GEMM_NO_SLAB (1 << 16) /* PRD_GEMM_SLAB=0: never split K across workgroups (round-3 kernels for the transition layers) */
 #define PRD_TUNE_GEMM_NO_KG (1 << 15)   /* PRD_GEMM_KG=0: node-row GEMMs with few tiles keep one wave group per workgroup (round-3 dispatch) */
@@ -434,6 +434,21 @@ int prd_step_boundary(float* z, float* seq_t, int64_t* t, const float* eps_raw, 
                       float* ebeta_next, const float* freqs, const float* w_beta, int* sync,
                       int b, int N, int n_cls, int num_steps, int S, int P, int time_dim,
                       const float* seq_h, int ldh, const float* w_seq, int S_h, hipStream_t stream);
+
+/* SPAttention's core with wide heads in one launch (models/AF2_modules.py:421-473 -> 251-293, 613-628: the gated attention over the
+ * node axis with head width c = single_dim and an additive pair bias; the reference builds a mask bias and drops it, :447 vs 461-463):
+ *   o[b,q,h,:] = gate[b,q,h,:] * sum_k softmax_k(q[b,q,h,:] . k[b,k,h,:] + bias[b,h,q,k]) v[b,k,h,:]
+ * qkvg = [b,N,4 H c] rows of pitch ldq: [q * 1/sqrt(c) | k | v | sigmoid(gate)] as the packed projection writes them; bias [b,H,N,N]
+ * (may be NULL); mask [b,N] (may be NULL: keys with mask < 0.5 get the reference's fill value -2^15); o [b,N,H c].  Logits, softmax
+ * never reach memory.  PRD_ARITH_SPLIT16 only, 64 <= c <= 512 a multiple of 64 (prd_spa_attn_core_supported);
+ * otherwise PRD_ERR_UNSUPPORTED and the caller runs logits GEMM + softmax + P V GEMM (prd_gemm). */
+int prd_spa_attn_core_supported(int N, int c, int arith);
+/* bytes of `ws` for these sizes (0: the keys are not split and no workspace is needed): with few (complex, head, query block)
+ * triples the KEYS are split over workgroups -- what bounds the operator is the operand stream per CU -- and a second, small launch
+ * merges the parts by their softmax statistics */
+size_t prd_spa_attn_core_workspace(int b, int N, int H, int c);
+int prd_spa_attn_core(float* o, const float* qkvg, int ldq, const float* bias, const float* mask,
+                      int b, int N, int H, int c, float* ws, size_t ws_bytes, int arith, hipStream_t stream);
 
 /* bytes of scratch an operator needs: op = "tri_mul" | "tri_attn" */
 size_t prd_workspace_bytes(const char* op, int b, int N, int S, int P);

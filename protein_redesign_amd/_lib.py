@@ -102,6 +102,9 @@ SIGNATURES = {
     "prd_tri_attn_stats_bytes": [ci] * 5,
     "prd_tri_attn_v2_supported": [ci, ci, ci],
     "prd_tri_attn_out": [vp] * 5 + [ci] * 4 + [vp, ci, vp],
+    "prd_spa_attn_core_supported": [ci, ci, ci],
+    "prd_spa_attn_core_workspace": [ci, ci, ci, ci],
+    "prd_spa_attn_core": [vp, vp, ci, vp, vp, ci, ci, ci, ci, vp, cz, ci, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
 }
 
@@ -111,10 +114,10 @@ DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (e
 # entry points that take the arithmetic as their last argument before the stream ...
 _ARITH_BEFORE_STREAM = ("prd_coord_head", "prd_pair_head", "prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
                         "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain",
-                        "prd_linear_wgrad", "prd_pair_linear")
+                        "prd_linear_wgrad", "prd_pair_linear", "prd_spa_attn_core")
 # ... and the queries that take it as their last argument
 _ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes",
-               "prd_gemm_slab_ok", "prd_pair_head_supported", "prd_pair_linear_supported")
+               "prd_gemm_slab_ok", "prd_pair_head_supported", "prd_pair_linear_supported", "prd_spa_attn_core_supported")
 # entry points without an arithmetic that still dispatch between kernel generations: the PRD_TUNE_* switch word alone
 _TUNE_BEFORE_STREAM = ("prd_tri_attn_core_v2", "prd_tri_attn_core_v2_lse")
 _TUNE_LAST = ("prd_tri_attn_v2_supported", "prd_tri_attn_v2_form")
@@ -147,7 +150,7 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 16
     if geti("PRD_GEMM_BRING", 1) == 0:
         t |= 1 << 17
-    if geti("PRD_GEMM_XCDCOLS", 1) == 0:
+    if geti("PRD_GEMM_XCDCOLS", 0) == 1:
         t |= 1 << 18
     if geti("PRD_TA2_XCD8", 1) == 0:
         t |= 1 << 20
@@ -221,7 +224,7 @@ def lib():
             fn = getattr(cdll, name)
             fn.argtypes = argtypes
             fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace", "prd_tri_attn_stats_bytes",
-                                        "prd_gemm_slab_workspace") else ci
+                                        "prd_gemm_slab_workspace", "prd_spa_attn_core_workspace") else ci
         mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)
         if os.environ.get("PRD_BF16X3"):                               # older spelling of PRD_GEMM_MODE=bf16x3
             mode = "bf16x3"

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprd_hip.so")
-SOURCES = ["prd_gemm.hip", "prd_pair.hip", "prd_tri.hip", "prd_tri2.hip", "prd_bwd.hip"]
+SOURCES = ["prd_gemm.hip", "prd_pair.hip", "prd_tri.hip", "prd_tri2.hip", "prd_bwd.hip", "prd_spa.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # per-source extras.  prd_tri2: the softmax arithmetic is placed by hand between the MFMAs of the key loop; the SLP vectoriser
 # would pack its scalar fp32 adds into v_pk_add_f32 (slower beside MFMAs on gfx950) and move them out of their slots

@@ -1020,9 +1020,10 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
         (!g.a_ln || (g.K % 16) == 0)) {
         dim3 grid(prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64), batches);
         PrdGemm gx = g;
-        // more weight bytes than row bytes and at least 8 column tiles: the XCD-aware column map (see the kernel); A/B switch
-        // PRD_TUNE bit 18 (PRD_GEMM_XCDCOLS=0) keeps the row-major block order
-        if (g.N >= 512 && (long)g.N > 2L * g.M && !((g.arith >> 8) & (1 << 18))) {
+        // more weight bytes than row bytes and at least 8 column tiles: the XCD-aware column map (see the kernel).  OPT-IN (PRD_TUNE bit
+        // 18, PRD_GEMM_XCDCOLS=1): measured in round 5 on the trunk-head projection, same box, one replayed step each: 33.8 us with the
+        // map, 33.4 us row-major -- the launch is bound by its per-chunk load -> split -> LDS -> barrier chain, not by HBM traffic
+        if (g.N >= 512 && (long)g.N > 2L * g.M && ((g.arith >> 8) & (1 << 18))) {
             gx.tile_hint = -8;
             grid.x = 8u * prd_ceil_div(g.M, 64) * prd_ceil_div(prd_ceil_div(g.N, 64), 8);
         }

@@ -915,7 +915,12 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     // (A/B, PRD_TA2_FLAGS bit 3) static priorities against the oldest-first arbitration of a SIMD's waves: the youngest wave of a SIMD
     // (w >> 2 = 2: the helpers / shared-block owners, which have the least work and today finish LAST, alone) first
     const int sprio = (flags & 8) ? (wave >> 2) : 0;
-    if (flags & 8) __builtin_amdgcn_s_setprio(sprio);
+    auto set_sprio = [&]() {                            // (s_setprio takes an immediate)
+        if (sprio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (sprio == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    };
+    if (flags & 8) set_sprio();
     RowIx rcur = make_row(slot < nrows ? slot : 0), rprev = rcur;
     if (slot < nrows) phase1(rcur, 0, 0);
     int gpar = 0;                                       // gpar = it % 3
@@ -1058,7 +1063,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
                 put_partial((nhelp + 1) * i + 1 + hj, o8, lsum, mref);
             }
         }
-        __builtin_amdgcn_s_setprio(sprio);
+        set_sprio();
         PRD2_STAMP(2);                                  // 2: key loops done
         // ================= phase 1 of the next row =================
         rprev = rcur;

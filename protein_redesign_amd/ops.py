@@ -761,6 +761,9 @@ def cached_pack(module, name: str, params, build):
     return cache[name][1]
 
 
+SPA_CORE = os.environ.get("PRD_SPA_CORE", "1") != "0"       # 0: SPAttention's logits / softmax / P V as three GEMM-path launches (A/B)
+
+
 def pack_attention(wq, wk, wv, wg, bg, q_scale: float):
     """[q | k | v | gate] projections as ONE GEMM: weight [4HC, S], bias (gate only), per-column scale (q only)."""
     HC = wq.shape[0]
@@ -811,6 +814,14 @@ def gated_attention_single(x_normed, mask, bias, packed, wo, bo, H: int, c: int,
         check(lib().prd_single_attn_core(dptr(o), qp, ldq, dptr(bias), dptr(mask) if key_mask else None,
                                          b, N, H, c, stream()), "prd_single_attn_core")
         return linear(o, wo, bo, resid=resid, rscale=rscale)
+    if SPA_CORE and not logits_fp32 and lib().prd_spa_attn_core_supported(N, c) == 1:
+        # logits + softmax + P V in one launch (prd_spa_attn_core: split-16 arithmetic; a training forward keeps the fp32-MFMA logits)
+        qp, ldq = row_block(qkvg)
+        nws = int(lib().prd_spa_attn_core_workspace(b, N, H, c))
+        wsb = torch.empty(max(nws // 4, 4), device=o.device, dtype=F32)
+        check(lib().prd_spa_attn_core(dptr(o), qp, ldq, dptr(bias), dptr(mask) if key_mask else None, b, N, H, c, dptr(wsb), nws, stream()),
+              "prd_spa_attn_core")
+        return linear(o, wo, bo, resid=resid, rscale=rscale, slab=slab_ok(b * N, wo.shape[0], HC), out_ln=out_ln)
     ldp = round_up(N, 4)
     logits = torch.empty(b, H, N, ldp, device=x_normed.device, dtype=F32)
     gemm(qkvg, qkvg, logits, N, N, c, L, L, ldp, b_off=HC, G1=b, G2=H, sa=(N * L, c), sb=(N * L, c),

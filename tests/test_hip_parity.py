@@ -1106,3 +1106,51 @@ def test_predict_step_follows_the_global_seed():
 
     a, b, c, d = run(1, 0), run(2, 0), run(1, 0), run(1, 1)
     assert torch.equal(a, c) and not torch.allclose(a, b) and not torch.allclose(a, d)
+
+
+@pytest.mark.parametrize("b,N,c,H,use_mask", [(1, 320, 512, 4, False), (2, 40, 64, 4, False), (1, 97, 256, 4, True), (3, 33, 128, 2, False),
+                                               (1, 512, 512, 4, False), (2, 130, 192, 4, True), (8, 320, 512, 4, False), (1, 769, 512, 4, False)])
+def test_spa_attention_core_one_launch(b, N, c, H, use_mask):
+    """prd_spa_attn_core (logits + softmax + P V of the wide-head gated attention in one launch, split-16 arithmetic) against
+    float64: full-size heads (c = 512, N = 320 / 512), a ragged last key tile, several complexes, the optional key mask with the
+    reference's fill value, head widths with one / two / four / six / eight channel tiles.  Also: identical between runs."""
+    from protein_redesign_amd import _lib
+    g = torch.Generator().manual_seed(N * 7 + c)
+    HC = H * c
+    qkvg = torch.randn(b, N, 4 * HC, generator=g)
+    qkvg[..., :HC] *= 2.0 / math.sqrt(c)                      # q arrives pre-scaled by 1 / sqrt(c); x 2: logits of a few units
+    qkvg[..., 3 * HC:] = torch.sigmoid(qkvg[..., 3 * HC:])    # the projection's epilogue has applied the gate's sigmoid
+    bias = torch.randn(b, H, N, N, generator=g)
+    mask = torch.ones(b, N)
+    if use_mask:
+        mask[:, N - 7:] = 0
+        mask[0, 3] = 0
+    q, k, v, gt = [t.double().view(b, N, H, c).transpose(1, 2) for t in qkvg.split(HC, dim=-1)]
+    logits = q @ k.transpose(-1, -2) + bias.double()
+    if use_mask:
+        logits = torch.where(mask[:, None, None, :] < 0.5, torch.full_like(logits, -2.0 ** 15), logits)
+    want = (gt * (torch.softmax(logits, dim=-1) @ v)).transpose(1, 2).reshape(b, N, HC)
+    prev = _lib.lib().prd_get_gemm_mode()
+    assert _lib.lib().prd_set_gemm_mode(1) == 0
+    try:
+        assert _lib.lib().prd_spa_attn_core_supported(N, c) == 1
+        outs = []
+        dq, dbias, dmask = cu(qkvg), cu(bias), cu(mask)              # (kept alive: the entry takes raw device pointers)
+        for _ in range(2):
+            o = torch.full((b, N, HC), float("nan"), device=DEV)
+            nws = int(_lib.lib().prd_spa_attn_core_workspace(b, N, H, c))
+            wsb = torch.full((max(nws // 4, 4),), float("nan"), device=DEV)
+            _lib.check(_lib.lib().prd_spa_attn_core(_lib.dptr(o), _lib.dptr(dq), 4 * HC, _lib.dptr(dbias),
+                                                    _lib.dptr(dmask) if use_mask else None, b, N, H, c, _lib.dptr(wsb), nws, _lib.stream()),
+                       "prd_spa_attn_core")
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1])
+        assert _lib.lib().prd_set_gemm_mode(0) == 0
+        assert _lib.lib().prd_spa_attn_core_supported(N, c) == 0           # fp32 arithmetic keeps the GEMM-path form
+    finally:
+        assert _lib.lib().prd_set_gemm_mode(prev) == 0
+    got = outs[0].cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 2e-6
+    row_err = (got.double() - want).norm(dim=-1) / want.norm(dim=-1).clamp_min(1e-30)
+    assert float(row_err.max()) < 1e-5
