@@ -289,7 +289,9 @@ def main():
         every = [torch.zeros_like(own) for _ in range(world)]
         dist.all_gather(every, own)
         rank_ms = [float(v.item()) for v in every]
-    finite = bool(torch.isfinite(pos_all).all() and torch.isfinite(logits_all).all())
+    # the guard of the split-16 default (diffusion_model.ReverseDiffusion.finite): the sticky flag the step-boundary kernel keeps
+    # over ALL steps of the loop or'ed with a check of the final state -- one host read, outside the timed region
+    finite = bool(loop.finite() and torch.isfinite(pos_all).all() and torch.isfinite(logits_all).all())
 
     # ---- N > 1: the product's sharded sampler end to end, against single-rank runs (bit-identical by construction) ----
     shard_check = None

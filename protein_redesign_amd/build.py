@@ -131,7 +131,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(obj, [spath] + headers):
             # (-Rpass-analysis: the per-kernel resource remarks of THIS compilation are kept in csrc/resource_usage.json)
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", spath, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics", "-c", spath, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -176,6 +176,37 @@ def build_asan(verbose: bool = True) -> str:
     return exe
 
 
+def build_ab(verbose: bool = True) -> str:
+    """libprd_hip_ab.so: the library with -DPRD_AB, i.e. INCLUDING the superseded kernels the shipped library leaves out (the
+    first-generation split-16 attention cores of csrc/prd_tri.hip, in their three wave-count forms, and the fused form built on
+    them).  For A/B measurements (PRD_LIB=<path> PRD_TA_VARIANT=10 ...) and for the parity tests of those kernels, which
+    tests/test_ab_build.py runs against this library in a child process."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(HERE, "csrc", "ab")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(HERE, "libprd_hip_ab.so")
+    headers = [os.path.join(CSRC, "prd_common.h"), os.path.join(os.path.dirname(HERE), "include", "prd_hip.h")]
+    build(verbose=verbose)                                   # sources that never test PRD_AB share the shipped objects
+    objs = []
+    for src in SOURCES:
+        spath = os.path.join(CSRC, src)
+        with open(spath) as f:
+            differs = "PRD_AB" in f.read()
+        if not differs:
+            objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
+            continue
+        obj = os.path.join(out_dir, src.replace(".hip", ".o"))
+        if _stale(obj, [spath] + headers):
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-DPRD_AB", "-c", spath, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if _stale(lib, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build_timing(verbose: bool = True) -> str:
     """Diagnostic build with in-kernel cycle stamps (-DPRD_TIMING: tools/ta_timing.py, tools/phase_timing.py read them through
     prd_debug_read); load it with PRD_LIB=<path>.  Never the shipped library: the stamps cost ~10 % of a wave's cycles."""
@@ -196,6 +227,9 @@ def build_timing(verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
+    if "--ab" in sys.argv:
+        print(build_ab())
+        sys.exit(0)
     if "--timing" in sys.argv:
         print(build_timing())
         sys.exit(0)

@@ -1251,6 +1251,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_kernel(
     }
 }
 
+// ---- FIRST-GENERATION split-16 attention cores (round 2): compiled only with -DPRD_AB (python -m protein_redesign_amd.build --ab ->
+// libprd_hip_ab.so, for A/B measurements and their own parity tests).  The shipped library serves the split-16 arithmetic with the
+// second generation (csrc/prd_tri2.hip) and, where that does not apply, with the fp32-MFMA kernels of this file. ----
+#ifdef PRD_AB
 // ---------------------------------------------------------------------------------------------------------------------
 // Triangle attention core on the 16-bit matrix pipes (gemm mode 1), fp32-accurate by operand splitting:
 //   * projections: bf16 x 3 row GEMM (rowgemm_b3), as in the kernel above;
@@ -1861,6 +1865,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_split_long_kernel(
         }
     }
 }
+#endif  // PRD_AB
 
 // Long-row variant (K/V of the row fill the LDS, no room for Q / gate tiles): queries are re-projected per
 // 32-query block in phase 2 and reach the MFMA operand layout through wave shuffles instead of LDS.
@@ -2162,6 +2167,11 @@ int grid_for(long tasks, int per_wg, int cap) {
         (void)(bytes);                                                                                          \
     } while (0)
 
+#ifdef PRD_AB
+constexpr bool PRD_FIRST_GEN = true;
+#else
+constexpr bool PRD_FIRST_GEN = false;       // first-generation split-16 cores compiled out: see the PRD_AB note above them
+#endif
 namespace {
 // LDS bytes of the triangle-attention core for rows of N positions; long_row: the re-projecting variant is needed
 size_t tri_attn_lds(int N, int P, bool b3, bool* long_row) {
@@ -2186,9 +2196,10 @@ extern "C" int prd_tri_attn_variant(int N, int P, int arith) {
     if (N <= 0) return PRD_ERR_ARG;
     if (P != 32 && P != 64) return PRD_ERR_UNSUPPORTED;
     bool long_row;
-    const bool b3 = arith == PRD_ARITH_SPLIT16;
+    const bool split = arith == PRD_ARITH_SPLIT16;
+    const bool v2 = split && PRD_TGET_TA_VARIANT(tune) == 0 && prd_tri_attn_v2_supported(N, P, tune);   // what prd_tri_attn_core dispatches to first
+    const bool b3 = split && (PRD_FIRST_GEN || v2);   // without the first generation, rows the second one does not serve run the fp32 kernels
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
-    const bool v2 = b3 && PRD_TGET_TA_VARIANT(tune) == 0 && prd_tri_attn_v2_supported(N, P, tune);      // what prd_tri_attn_core dispatches to first
     if (lds > 160 * 1024)                      // the round-3 core keeps K / V as fp16 planes: rows up to 1024; beyond: key-chunked
         return v2 ? 2 : 3;
     if (!long_row) return 0;
@@ -2419,11 +2430,12 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     if ((P != 32 && P != 64) || c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
     const int npad = prd_round_up(N, 64);
     const int nqb = prd_ceil_div(N, 32);
-    const bool b3 = arith == PRD_ARITH_SPLIT16;   // split 16-bit operands
-    const int variant = PRD_TGET_TA_VARIANT(tune);    // A/B switch: first-generation kernels
+    const bool split = arith == PRD_ARITH_SPLIT16;    // split 16-bit operands
+    const int variant = PRD_FIRST_GEN ? PRD_TGET_TA_VARIANT(tune) : 0;    // A/B switch: first-generation kernels (-DPRD_AB builds only)
     // second generation (prd_tri2.hip): short rows, and long rows as far as K / V of a row fit the LDS as fp16 planes
-    if (b3 && variant == 0 && prd_tri_attn_v2_supported(N, P, tune) && (long)b * N * N <= 0x7fffffffL / 2)
+    if (split && variant == 0 && prd_tri_attn_v2_supported(N, P, tune) && (long)b * N * N <= 0x7fffffffL / 2)
         return prd_tri_attn_core_v2(og, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, tune, stream);
+    const bool b3 = split && PRD_FIRST_GEN;           // otherwise: the fp32-MFMA kernels below (more accurate, slower)
     bool long_row;
     const size_t lds = tri_attn_lds(N, P, b3, &long_row);
     if (lds > 160 * 1024) return PRD_ERR_UNSUPPORTED;
@@ -2447,9 +2459,9 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
     // (measured: 12 waves + prefetch 142 us, 16 waves without prefetch 149 us, 8 waves + prefetch 146 us)
     const bool split_long = long_row && b3 &&
         lds == (size_t)64 * P * 4 + (size_t)npad * 68 + (size_t)64 * (npad + 8) + 128 + 8 * 4096;      // tri_attn_lds chose it
+#ifdef PRD_AB
     if (split_long) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_split_long_kernel, 8, 32, 8); }
-    else if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
-    else if (b3) {
+    else if (!long_row && b3) {
         if (P == 64) {
             if (variant == 1) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 16, 64, 16, 1, false);
             else if (variant == 2) PRD_TA_LAUNCH(tri_attn_core_split_kernel, 12, 64, 12, 1, false);
@@ -2458,7 +2470,11 @@ extern "C" int prd_tri_attn_core(float* og, const float* pair, const float* mask
         } else {
             PRD_TA_LAUNCH(tri_attn_core_split_kernel, 8, 32, 8, 2, true);
         }
-    }
+    } else
+#else
+    (void)split_long; (void)variant;
+#endif
+    if (long_row) { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 64, 8); else PRD_TA_LAUNCH(tri_attn_core_long_kernel, 8, 32, 8); }
     else { if (P == 64) PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 64, 12, true, false); else PRD_TA_LAUNCH(tri_attn_core_kernel, 12, 32, 12, true, false); }
 #undef PRD_TA_LAUNCH
     return (int)hipGetLastError();
@@ -2482,7 +2498,8 @@ static size_t tri_attn_fused_lds(int N, int P) {
 }
 
 extern "C" int prd_tri_attn_core_fused_supported(int N, int P, int arith) {
-    return (N > 0 && (P == 32 || P == 64) && arith >= 0 && (arith & 0xff) == PRD_ARITH_SPLIT16 &&
+    // (the fused form lives on the first-generation core: -DPRD_AB builds only; measured slower than two launches)
+    return (PRD_FIRST_GEN && N > 0 && (P == 32 || P == 64) && arith >= 0 && (arith & 0xff) == PRD_ARITH_SPLIT16 &&
             tri_attn_fused_lds(N, P) <= 160 * 1024) ? 1 : 0;
 }
 
@@ -2503,6 +2520,10 @@ extern "C" int prd_tri_attn_core_fused(float* og, float* pair_out, const float* 
     const long rounds = (rows_total + per_head - 1) / per_head;
     per_head = (rows_total + rounds - 1) / rounds;
     const int grid = (int)(per_head * H);
+#ifndef PRD_AB
+    (void)grid; (void)lds; (void)npad;
+    return PRD_ERR_UNSUPPORTED;
+#else
     if (P == 64) {
         PRD_SET_LDS((tri_attn_core_split_kernel<64, 8, 2, true, true>), lds);
         hipLaunchKernelGGL((tri_attn_core_split_kernel<64, 8, 2, true, true>), dim3(grid), dim3(512), lds, stream, og, pair, mask, wq, wk, wv, wg,
@@ -2513,6 +2534,7 @@ extern "C" int prd_tri_attn_core_fused(float* og, float* pair_out, const float* 
                            bg, b, N, npad, H, ending, og_in, wo_in, bo_in, pair_out);
     }
     return (int)hipGetLastError();
+#endif
 }
 
 extern "C" int prd_tri_attn_out(float* out, const float* pair, const float* og, const float* wo, const float* bo,

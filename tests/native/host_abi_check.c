@@ -103,7 +103,7 @@ int main(void) {
         EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 1 << 20, A0, s), PRD_ERR_UNSUPPORTED);     /* fp32 arithmetic has no fused chain */
         EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 16, A1 | PRD_TUNE(PRD_TUNE_TMS_NW16), s), PRD_ERR_WORKSPACE);  /* switches ride above the arithmetic */
     }
-    EXPECT(prd_tri_attn_core_fused_supported(320, 64, A1), 1);
+    EXPECT(prd_tri_attn_core_fused_supported(320, 64, A1), 0);      /* first-generation form: only in the -DPRD_AB library */
     EXPECT(prd_tri_attn_core_fused_supported(769, 64, A1), 0);      /* long rows: no fused form */
     EXPECT(prd_tri_attn_v2_supported(320, 64, 0), 1);
     EXPECT(prd_tri_attn_v2_supported(400, 64, 0), 1);                  /* long-row form */
