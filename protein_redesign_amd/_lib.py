@@ -152,6 +152,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 17
     if geti("PRD_GEMM_XCDCOLS", 0) == 1:
         t |= 1 << 18
+    if geti("PRD_TA2_TAIL", 1) == 0:
+        t |= 1 << 19
     if geti("PRD_TA2_XCD8", 1) == 0:
         t |= 1 << 20
     return t

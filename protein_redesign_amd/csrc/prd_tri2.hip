@@ -1161,23 +1161,49 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     const unsigned kl_off = L.kl - L.kh;
     const unsigned kbase = L.kh + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
     const unsigned vbase = L.v + (unsigned)hi * 512u + (unsigned)r * 16u;          // + 2048 t
-    // key tiles this wave sweeps per row (priorities only)
-    const int pj = share ? wave / G : 0, pp_ = share ? wave - pj * G : 0;
-    const int pT0 = share ? (nqb * pp_) / G : 0, pT1 = share ? (nqb * (pp_ + 1)) / G : 0;
-    const int work_tot = nfull * nqb + (share ? (wave < rem * G ? pT1 - pT0 : 0) : (wave < rem ? nqb : 0));
+    // Work items: `nfr` whole rounds of rstride rows (one row per workgroup of this head), then the Lr < rstride rows that are left.
+    // A last round of few rows would leave most of the chip idle for a whole item (N = 769: 769 = 12 x 64 + 1 rows, i.e. a 13th
+    // round for ONE row: 7.7 % of the launch): its rows are SPLIT by query blocks over tparts = min(nqb, rstride / Lr) workgroups
+    // each -- every part projects K / V of the whole row (phase 1) and sweeps its own range [q0, q1) of query blocks, whose
+    // outputs are independent.  (flag 32 = PRD_TUNE_TA2_NO_TAIL_SPLIT: A/B switch.)
+    const int nfr = nrows / rstride, Lr = nrows - nfr * rstride;
+    int tparts = (Lr > 0 && !(flags & 32)) ? rstride / Lr : 1;
+    tparts = tparts > nqb ? nqb : tparts;
+    const int nshare_room = share ? rem : 0;            // Q slots of the shared round the host made room for
+    auto item = [&](int it, int& bu_, int& q0_, int& q1_) -> bool {
+        q0_ = 0; q1_ = nqb; bu_ = 0;
+        if (it < nfr) { bu_ = slot + it * rstride; return true; }
+        if (it > nfr || Lr == 0) return false;
+        if (tparts <= 1) { bu_ = nfr * rstride + slot; return slot < Lr; }
+        const int part_ = slot / Lr;
+        if (part_ >= tparts) return false;
+        bu_ = nfr * rstride + (slot - part_ * Lr);
+        q0_ = (nqb * part_) / tparts; q1_ = (nqb * (part_ + 1)) / tparts;
+        return true;
+    };
 
     float xnext[PREFETCH ? KH : 1];                     // the wave's FIRST phase-1 block of the next row
     float mknext = 0.f, munext = 0.f;
-    RowIx rnext = make_row(slot < nrows ? slot : 0);
+    int bu, q0, q1;
+    bool have = item(0, bu, q0, q1);
+    RowIx rnext = make_row(have ? bu : 0);
     if constexpr (PREFETCH) {
         const int v = wave * 32 + r;
-        const bool ok = slot < nrows && v < N;
+        const bool ok = have && v < N;
         load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
         if (ok) mknext = mask[rnext.bb * N + v];
     }
-    if (slot < nrows) munext = mask[slot];
-    for (int bu = slot; bu < nrows; bu += rstride) {
+    if (have) munext = mask[bu];
+    for (int it = 0; have; ++it) {
         const RowIx row = rnext;
+        // the query blocks [q0, q1) of this item in rounds of NW; a last round of rem_ blocks shared by G_ waves each
+        const int nb_ = q1 - q0, nfull_ = nb_ / NW, rem_ = nb_ - nfull_ * NW;
+        const int G_ = rem_ ? NW / rem_ : 0;
+        const bool share_ = G_ >= 2 && rem_ <= nshare_room;
+        // key tiles this wave sweeps in the shared round
+        const int pj = share_ ? wave / G_ : 0, pp_ = share_ ? wave - pj * G_ : 0;
+        const int pT0 = share_ ? (nqb * pp_) / G_ : 0, pT1 = share_ ? (nqb * (pp_ + 1)) / G_ : 0;
+        const int work_tot = nfull_ * nqb + (share_ ? (wave < rem_ * G_ ? pT1 - pT0 : 0) : (wave < rem_ ? nqb : 0));   // (priorities only)
         __syncthreads();                                // previous row's LDS consumed (and the weight image staged)
         const float mu = munext;
         int r1 = r, hi1 = hi;                           // opaque per row (see tri_attn_core_v2_kernel)
@@ -1251,16 +1277,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
         }
         __syncthreads();
+        int bun, q0n, q1n;
+        const bool haven = item(it + 1, bun, q0n, q1n);
         {   // the wave's first phase-1 block of the next row: in flight during the key loops
-            const int bun = bu + rstride;
-            rnext = make_row(bun < nrows ? bun : 0);
+            rnext = make_row(haven ? bun : 0);
             if constexpr (PREFETCH) {
                 const int v = wave * 32 + r;
-                const bool ok = bun < nrows && v < N;
+                const bool ok = haven && v < N;
                 load_row_cll<P>(pair + row_pos(rnext, ok ? v : 0) * P, hi, ok, xnext);
                 mknext = ok ? mask[rnext.bb * N + v] : 0.f;
             }
-            munext = bun < nrows ? mask[bun] : 0.f;
+            munext = haven ? mask[bun] : 0.f;
         }
         // ================= phase 2 =================
         unsigned fmask;
@@ -1369,10 +1396,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             }
         };
         // ---- whole rounds (and an unshared last round): one query block per wave ----
-        const int nrounds = nfull + ((rem && !share) ? 1 : 0);
+        const int nrounds = nfull_ + ((rem_ && !share_) ? 1 : 0);
         for (int rd = 0; rd < nrounds; ++rd) {
-            const int qb = rd * NW + wave;
-            if (qb < nqb) {
+            const int qb = q0 + rd * NW + wave;
+            if (qb < q1) {
                 u32x4 qh4, ql4;
                 float gate[8], o8[8], lsum, mref;
                 project_qg(qb, qh4, ql4, gate);
@@ -1381,17 +1408,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             }
         }
         // ---- shared last round ----
-        if (share) {
+        if (share_) {
             float gate[8];
-            if (wave < rem) {
+            if (wave < rem_) {
                 u32x4 qh4, ql4;
-                project_qg(nfull * NW + wave, qh4, ql4, gate);
+                project_qg(q0 + nfull_ * NW + wave, qh4, ql4, gate);
                 const unsigned qo = L.qs + (unsigned)wave * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
                 *reinterpret_cast<u32x4*>(lds + qo) = qh4;
                 *reinterpret_cast<u32x4*>(lds + qo + 1024u) = ql4;
             }
             __syncthreads();
-            if (wave < rem * G && pT1 > pT0) {
+            if (wave < rem_ * G_ && pT1 > pT0) {
                 const unsigned qo = L.qs + (unsigned)pj * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
                 const u32x4 qh4 = *reinterpret_cast<const u32x4*>(lds + qo), ql4 = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
                 float o8[8], lsum, mref;
@@ -1404,28 +1431,29 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             }
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();
-            if (wave < rem) {                           // merge the G pieces of the wave's block (flash-decoding merge)
+            if (wave < rem_) {                          // merge the G_ pieces of the wave's block (flash-decoding merge)
                 float M = -INFINITY;
-                for (int k = 0; k < G; ++k) {
-                    const bool has = (nqb * (k + 1)) / G > (nqb * k) / G;
-                    if (has) M = max2f(M, part[(size_t)(wave * G + k) * 640 + 9 * 64 + lane]);
+                for (int k = 0; k < G_; ++k) {
+                    const bool has = (nqb * (k + 1)) / G_ > (nqb * k) / G_;
+                    if (has) M = max2f(M, part[(size_t)(wave * G_ + k) * 640 + 9 * 64 + lane]);
                 }
                 float o[8], l = 0.f;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
-                for (int k = 0; k < G; ++k) {
-                    const bool has = (nqb * (k + 1)) / G > (nqb * k) / G;
+                for (int k = 0; k < G_; ++k) {
+                    const bool has = (nqb * (k + 1)) / G_ > (nqb * k) / G_;
                     if (!has) continue;
-                    const float* pp = part + (size_t)(wave * G + k) * 640 + lane;
+                    const float* pp = part + (size_t)(wave * G_ + k) * 640 + lane;
                     const float scl = __builtin_amdgcn_exp2f(pp[9 * 64] - M);
                     l += scl * pp[8 * 64];
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
                 }
-                finish(nfull * NW + wave, o, l, gate);
+                finish(q0 + nfull_ * NW + wave, o, l, gate);
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        have = haven; bu = bun; q0 = q0n; q1 = q1n;
     }
 }
 
@@ -1977,7 +2005,7 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
     // overlapped phases (v3) an early finisher starts the next row's projection instead: 67.5 -> 65.9 us without them
     const int flags0 = flags_env >= 0 ? flags_env : (v3 ? 0 : 1);
     const int nqb_ = NP / 32, rem_ = nqb_ % 12;
-    const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0);
+    const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0) | (PRD_TGET_TA2_NO_TAIL_SPLIT(tune) ? 32 : 0);
     if (long_rows) {
 #define PRD_V2L_LAUNCH(PP, PF)                                                                                                    \
         do {                                                                                                                      \

@@ -12,7 +12,7 @@ import torch
 
 import prd_oracle as O
 from conftest import rel_l2
-from protein_redesign_amd import ops
+from protein_redesign_amd import _lib, ops
 from protein_redesign_amd.constants import make_args
 from protein_redesign_amd.diffusion_model import ProteinReDiffModel
 from protein_redesign_amd.synthetic import (NoiseSource, batch_to, clone_batch, deterministic_state_dict,
@@ -1015,6 +1015,45 @@ def test_triangle_attention_long_rows_whole_tensor(setup, mode, gemm_mode):
     assert rel_l2(got, want) < OP_TOL
     row_err = (got - want).flatten(2).norm(dim=2) / want.flatten(2).norm(dim=2).clamp_min(1e-30)
     assert float(row_err.max()) < 2 * OP_TOL, int(row_err.argmax())
+
+
+@pytest.mark.parametrize("mode", ["starting", "ending"])
+@pytest.mark.parametrize("b,N", [(1, 390), (2, 400), (1, 417)])
+def test_triangle_attention_long_rows_split_tail(setup, mode, b, N, gemm_mode):
+    """tri_attn_core_v2l: rows left over after the whole rounds of 64 rows per head are split by query blocks over the idle
+    workgroups: b N = 390 = 6 x 64 + 6 (ten parts of one or two of the 13 blocks: shared and unshared last rounds), 800 = 12 x 64 + 32
+    (two parts of 6 and 7 blocks), 417 = 6 x 64 + 33 (no split).  Whole tensor against the oracle, masked tail; and the same
+    with the split switched off (PRD_TUNE_TA2_NO_TAIL_SPLIT)."""
+    s = setup
+    P = s["P"]
+    H, c = s["args"]["num_heads"], s["args"]["head_dim"]
+    if gemm_mode == "split16":                       # (the fp32 kernels keep rows of 390 positions on their short-row form)
+        assert _lib.lib().prd_tri_attn_v2_form(N, P) == 3
+    g = torch.Generator().manual_seed(7 * N + b + (mode == "ending"))
+    pair = torch.randn(b, N, N, P, generator=g)
+    mask = torch.ones(b, N)
+    mask[0, N - 9:] = 0
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    pfx = f"Denoiser.folding_blocks.0.pair_attn_{mode}"
+    src, msrc = (pair, m2) if mode == "starting" else (pair.transpose(1, 2), m2.transpose(1, 2))
+    want = torch.empty(b, N, N, P)
+    with torch.inference_mode():
+        for r0 in range(0, N, 64):
+            want[:, r0:r0 + 64] = O.gated_attention(s["params"], pfx + ".attn", src[:, r0:r0 + 64].contiguous(), msrc[:, r0:r0 + 64].contiguous(), H, c)
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
+    lib = _lib.lib()
+    tune0 = lib.prd_get_tune()
+    try:
+        for tune in (tune0, tune0 | (1 << 19)):
+            lib.prd_set_tune(tune)
+            got = mod.run(cu(pair), cu(mask), residual=False).cpu()
+            if mode == "ending":
+                got = got.transpose(1, 2)
+            assert rel_l2(got, want) < OP_TOL
+            row_err = (got - want).flatten(2).norm(dim=2) / want.flatten(2).norm(dim=2).clamp_min(1e-30)
+            assert float(row_err.max()) < 2 * OP_TOL, (tune, int(row_err.argmax()))
+    finally:
+        lib.prd_set_tune(tune0)
 
 
 def test_eight_complexes_per_gpu_equal_single_runs(gemm_mode):
