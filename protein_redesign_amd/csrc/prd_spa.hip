@@ -250,6 +250,14 @@ __global__ __launch_bounds__(SPA_NT) void spa_attn_part_kernel(
     // key of step position (pair member m): kk = 2 vpair + m -> khalf = (kk >> 2) & 1, i = 4 (kk >> 3) + (kk & 3)
     const int kk0 = 2 * vpair;
     const unsigned vdst = (unsigned)((kk0 >> 2) & 1) * 512u + (unsigned)(4 * (kk0 >> 3) + (kk0 & 3)) * 2u;     // + plane 1024 + ch 16
+    // 16-byte slot of channel ch inside a (plane, khalf) block: a bit permutation of ch (slot bits = ch2, ch3, ch4 ^ ch0, ch1, ch0) chosen so
+    // that the eight lanes vc4 of a transposed 4-byte store hit eight different slots mod 8 (all 32 banks, two lanes each) AND the
+    // sixteen lanes of a 16-byte fragment read hit sixteen different slots mod 16; with slot = ch the stores were 8-way conflicted
+    auto vslot = [](int ch) { return ((ch >> 2) & 3) | ((((ch >> 4) ^ ch) & 1) << 2) | (((ch >> 1) & 1) << 3) | ((ch & 1) << 4); };
+    unsigned vwr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vwr[j] = (unsigned)vslot(4 * vc4 + j) * 16u;
+    const unsigned vrd = (unsigned)vslot(r) * 16u;
     const int nct = c / 32;
     const int step_lo = 2 * t0, step_end = 2 * (t0 + nlt);
     const int q = q0 + r;
@@ -279,14 +287,14 @@ __global__ __launch_bounds__(SPA_NT) void spa_attn_part_kernel(
                     for (int j = 0; j < 4; ++j) {
                         unsigned hh, ll;
                         split2h(xa[j], xb[j], hh, ll);
-                        *reinterpret_cast<unsigned*>(vbuf + vdst + (unsigned)(4 * vc4 + j) * 16u) = hh;
-                        *reinterpret_cast<unsigned*>(vbuf + 1024u + vdst + (unsigned)(4 * vc4 + j) * 16u) = ll;
+                        *reinterpret_cast<unsigned*>(vbuf + vdst + vwr[j]) = hh;
+                        *reinterpret_cast<unsigned*>(vbuf + 1024u + vdst + vwr[j]) = ll;
                     }
                 }
                 load_v(step + 2, vav[d], vbv[d]);
                 wave_lds_fence();
-                const u32x4 vh = *reinterpret_cast<const u32x4*>(vbuf + (unsigned)hi * 512u + (unsigned)r * 16u);
-                const u32x4 vl = *reinterpret_cast<const u32x4*>(vbuf + 1024u + (unsigned)hi * 512u + (unsigned)r * 16u);
+                const u32x4 vh = *reinterpret_cast<const u32x4*>(vbuf + (unsigned)hi * 512u + vrd);
+                const u32x4 vl = *reinterpret_cast<const u32x4*>(vbuf + 1024u + (unsigned)hi * 512u + vrd);
                 const int sl = step - step_lo;
                 const unsigned char* pb = lds + (unsigned)(sl >> 1) * 4096u + (unsigned)(sl & 1) * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
                 const u32x4 ph = *reinterpret_cast<const u32x4*>(pb), pl = *reinterpret_cast<const u32x4*>(pb + 1024u);
