@@ -156,6 +156,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 19
     if geti("PRD_TA2_XCD8", 1) == 0:
         t |= 1 << 20
+    if geti("PRD_TA2_GV", 1) == 0:
+        t |= 1 << 21
     return t
 
 

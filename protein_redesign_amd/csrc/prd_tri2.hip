@@ -685,7 +685,7 @@ PRD_DEV V3Lds v3_layout(int P, int NP) {
 // KL = key-loop form (A/B: PRD_TA2_FLAGS bits 1-2; measured in DESIGN.md 4.3, round 5): 0 the round-3 order (Q K^T, exp + row
 // sum, split, P V); bit 0: the NEXT tile's Q K^T is issued between the exponentials and the split of this one (one more logit
 // tile in registers); bit 1: the row sum on the matrix pipe (rowsum_mfma) instead of 18 v_add_f32
-template <int P, int NW, int KL>
+template <int P, int NW, int KL, bool GV>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -751,7 +751,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     const float inv16 = H2_INV_WSCALE;
     const unsigned kl_rel = 2u * L.plane, v_rel = 4u * L.plane, kadd_rel = 8u * L.plane, flag_rel = 8u * L.plane + (unsigned)NP * 4u;
     const unsigned klane = (unsigned)hi * L.plane + (unsigned)r * 16u;              // + buffer + 512 t
-    const unsigned vlane = v_rel + (unsigned)hi * 512u + (unsigned)r * 16u;         // + buffer + 2048 t
+    // V operand of P V: lane r = (plane, channel) reads its 16-byte slot of 8 keys of half a (16 keys) of tile t.  GV: the slot index
+    // is XORed with 2 a + khalf so that the transposed 4-byte stores of phase 1 (below) spread over all banks
+    const unsigned vlane0 = v_rel + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ hi) : r) * 16u;                  // + buffer + 2048 t
+    const unsigned vlane1 = v_rel + 1024u + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ (2 + hi)) : r) * 16u;
 
     u32x4 qh4 = {0u, 0u, 0u, 0u}, ql4 = {0u, 0u, 0u, 0u};     // Q of the wave's own block (B operands of Q K^T)
     float gate[8];                                             // the lane's gate channels of its own block (non-group owners)
@@ -814,30 +817,31 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             if (blk == wave) { qh4 = qhn; ql4 = qln; }  // the wave's own block: Q stays in registers for its key sweep
         }
         if (kinds & 2) {
-            f32x16 ag, av;
+          if constexpr (GV) {
+            // [G|V] as ONE unswapped row GEMM (image rows 32 + r: G channels | V channels): 12 MFMAs instead of the 12 + 12 of a G GEMM and
+            // a swapped V GEMM that each fill half a tile.  The lane of position r gets its 8 gate channels (registers 0-7, as before)
+            // and 8 V channels of ITS position (registers 8-15): V is position-major and goes to the channel-major operand layout
+            // through a TRANSPOSED store -- neighbouring positions (lanes r, r ^ 1) pair up by DPP, the even lane packs channels
+            // 4 hi + j, the odd lane channels 8 + 4 hi + j of the key pair into one fp16 pair per plane: 8 four-byte stores per lane
+            // (slots XORed with 2 a + khalf: two lanes per bank) instead of 2 x 16 bytes, and 4 splits instead of 8.
+            f32x16 agv;
             {
                 const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
-                ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
+                agv[0] = b0.x; agv[1] = b0.y; agv[2] = b0.z; agv[3] = b0.w; agv[4] = b1.x; agv[5] = b1.y; agv[6] = b1.z; agv[7] = b1.w;
 #pragma unroll
-                for (int e = 8; e < 16; ++e) ag[e] = 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) av[e] = 0.f;
+                for (int e = 8; e < 16; ++e) agv[e] = 0.f;
             }
 #pragma unroll
             for (int s_ = 0; s_ < P / 16; ++s_) {
-                u32x4 gh, gl, vh, vl;
-                wop(32 + (r1 & 15), s_, gh, gl);
-                wop(48 + (r1 & 15), s_, vh, vl);
-                ag = mfma_h(gh, xs[0][s_], ag);
-                av = mfma_h(xs[0][s_], vh, av);
-                ag = mfma_h(gh, xs[1][s_], ag);
-                av = mfma_h(xs[1][s_], vh, av);
-                ag = mfma_h(gl, xs[0][s_], ag);
-                av = mfma_h(xs[0][s_], vl, av);
+                u32x4 gh, gl;
+                wop(32 + r1, s_, gh, gl);
+                agv = mfma_h(gh, xs[0][s_], agv);
+                agv = mfma_h(gh, xs[1][s_], agv);
+                agv = mfma_h(gl, xs[0][s_], agv);
             }
             float gv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gv[e] = gate_from_scaled(ag[e] * inv16);
+            for (int e = 0; e < 8; ++e) gv[e] = gate_from_scaled(agv[e] * inv16);
             if (blk >= gbase) {                         // a shared block: its owner gates at the merge
                 float* gp = reinterpret_cast<float*>(lds + L.gs + (unsigned)(gpar * m4 + (blk - gbase)) * 2048u) + (r1 * 2 + hi1) * 8;
                 *reinterpret_cast<float4*>(gp) = make_float4(gv[0], gv[1], gv[2], gv[3]);
@@ -846,16 +850,68 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gate[e] = gv[e];
             }
-            u32x4 vh0, vl0, vh1, vl1;                   // V stays x 16
-            split8_rn(av, 0, vh0, vl0);
-            split8_rn(av, 8, vh1, vl1);
-            const bool lo_lane = r1 >= 16;
-            u32x4 s0, s1;
+            const bool odd = (r1 & 1) != 0;
+            const int kp0 = r1 & 30;                    // the key pair (kp0, kp0 + 1) of the block
+            const int a_ = kp0 >> 4, kk = kp0 & 15, kh_ = (kk >> 2) & 1, w_ = (kk >> 3) * 2 + ((kk & 3) >> 1);
+            const int ch0 = 4 * hi1 + (odd ? 8 : 0);    // + j
+            const unsigned vo = bufo + v_rel + (unsigned)blk * 2048u + (unsigned)a_ * 1024u + (unsigned)kh_ * 512u + (unsigned)w_ * 4u;
+            const int sx = 2 * a_ + kh_;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
-            const unsigned vo = bufo + v_rel + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
-            *reinterpret_cast<u32x4*>(lds + vo) = s0;
-            *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+            for (int j = 0; j < 4; ++j) {
+                const float mine_lo = agv[8 + j], mine_hi = agv[12 + j];
+                const float give = odd ? mine_lo : mine_hi;                 // what the neighbour packs: my value of ITS channel
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, false));
+                const float ka = odd ? got : mine_lo, kb = odd ? mine_hi : got;      // keys kp0, kp0 + 1 of channel ch0 + j (x 16)
+                unsigned hh, ll;
+                split2h_rn(ka, kb, hh, ll);
+                const unsigned so = (unsigned)((ch0 + j) ^ sx) * 16u;
+                *reinterpret_cast<unsigned*>(lds + vo + so) = hh;
+                *reinterpret_cast<unsigned*>(lds + vo + 256u + so) = ll;   // lo plane: slots 16 .. 31
+            }
+          } else {
+              f32x16 ag, av;
+              {
+                  const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
+                  ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
+  #pragma unroll
+                  for (int e = 8; e < 16; ++e) ag[e] = 0.f;
+  #pragma unroll
+                  for (int e = 0; e < 16; ++e) av[e] = 0.f;
+              }
+  #pragma unroll
+              for (int s_ = 0; s_ < P / 16; ++s_) {
+                  u32x4 gh, gl, vh, vl;
+                  wop(32 + (r1 & 15), s_, gh, gl);
+                  wop(48 + (r1 & 15), s_, vh, vl);
+                  ag = mfma_h(gh, xs[0][s_], ag);
+                  av = mfma_h(xs[0][s_], vh, av);
+                  ag = mfma_h(gh, xs[1][s_], ag);
+                  av = mfma_h(xs[1][s_], vh, av);
+                  ag = mfma_h(gl, xs[0][s_], ag);
+                  av = mfma_h(xs[0][s_], vl, av);
+              }
+              float gv[8];
+  #pragma unroll
+              for (int e = 0; e < 8; ++e) gv[e] = gate_from_scaled(ag[e] * inv16);
+              if (blk >= gbase) {                         // a shared block: its owner gates at the merge
+                  float* gp = reinterpret_cast<float*>(lds + L.gs + (unsigned)(gpar * m4 + (blk - gbase)) * 2048u) + (r1 * 2 + hi1) * 8;
+                  *reinterpret_cast<float4*>(gp) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                  *reinterpret_cast<float4*>(gp + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+              } else {
+  #pragma unroll
+                  for (int e = 0; e < 8; ++e) gate[e] = gv[e];
+              }
+              u32x4 vh0, vl0, vh1, vl1;                   // V stays x 16
+              split8_rn(av, 0, vh0, vl0);
+              split8_rn(av, 8, vh1, vl1);
+              const bool lo_lane = r1 >= 16;
+              u32x4 s0, s1;
+  #pragma unroll
+              for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
+              const unsigned vo = bufo + v_rel + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
+              *reinterpret_cast<u32x4*>(lds + vo) = s0;
+              *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+          }
         }
     };
     auto phase1 = [&](const RowIx& row, int par, int gpar) {
@@ -938,7 +994,11 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             const int f = lane < nqb ? reinterpret_cast<const int*>(lds + bufo + flag_rel)[lane] : 0;
             fmask = (unsigned)__ballot(f != 0);
         }
-        const unsigned kbase = bufo + klane, vbase = bufo + vlane, kaddo = bufo + kadd_rel;
+        const unsigned kbase = bufo + klane, vb0 = bufo + vlane0, vb1 = bufo + vlane1, kaddo = bufo + kadd_rel;
+        auto ldv = [&](int t, PBuf& p) {
+            p.va0 = *reinterpret_cast<const u32x4*>(lds + vb0 + 2048u * t);
+            p.va1 = *reinterpret_cast<const u32x4*>(lds + vb1 + 2048u * t);
+        };
         int work_rem = work_tot;
         auto run_piece = [&](const u32x4& qh, const u32x4& ql, int T0, int T1, float (&o8)[8], float& lsum, float& mref) {
             f32x16 o0, zero;
@@ -958,14 +1018,14 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
                 PBuf p;
-                load_v(lds, vbase + 2048u * T0, p);
+                ldv(T0, p);
                 exp_split(s0, lsum, big, p);
                 pv_tile(p, o0);
                 for (int t = T0 + 1; t < T1; ++t) {
                     if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
                     f32x16 s = qk_tile(k, qh, ql, negm);
                     if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_rel);
-                    load_v(lds, vbase + 2048u * t, p);
+                    ldv(t, p);
                     if ((fmask >> t) & 1) mask_tile_at(lds, kaddo, t, hi, mref, s);
                     exp_split(s, lsum, big, p);
                     pv_tile(p, o0);
@@ -985,7 +1045,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
                 for (int t = T0; t < T1; ++t) {
                     if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
                     PBuf p;
-                    load_v(lds, vbase + 2048u * t, p);
+                    ldv(t, p);
                     exp_sum<VSUM>(s, lsum, big);
                     f32x16 sn;
                     if ((KL & 1) && t + 1 < T1) {       // the next tile's logits: issued here, consumed one iteration later
@@ -1026,7 +1086,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
                     for (int e = 0; e < 16; ++e) { o0[e] *= alpha; s[e] -= mref; }
                     bool dummy = false;
                     PBuf p;
-                    load_v(lds, vbase + 2048u * t, p);
+                    ldv(t, p);
                     exp_split(s, lsum, dummy, p);
                     pv_tile(p, o0);
                 }
@@ -1113,7 +1173,7 @@ PRD_DEV V2LLds v2l_layout(int P, int NP, int nshare) {
     return L;
 }
 
-template <int P, int NW, bool PREFETCH>
+template <int P, int NW, bool PREFETCH, bool GV>
 __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -1160,7 +1220,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     const float inv16 = H2_INV_WSCALE;
     const unsigned kl_off = L.kl - L.kh;
     const unsigned kbase = L.kh + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
-    const unsigned vbase = L.v + (unsigned)hi * 512u + (unsigned)r * 16u;          // + 2048 t
+    // (GV: V slots XORed with 2 a + khalf, see tri_attn_core_v3_kernel)
+    const unsigned vb0 = L.v + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ hi) : r) * 16u;          // + 2048 t
+    const unsigned vb1 = L.v + 1024u + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ (2 + hi)) : r) * 16u;
+    auto ldv = [&](int t, PBuf& p) {
+        p.va0 = *reinterpret_cast<const u32x4*>(lds + vb0 + 2048u * t);
+        p.va1 = *reinterpret_cast<const u32x4*>(lds + vb1 + 2048u * t);
+    };
     // Work items: `nfr` whole rounds of rstride rows (one row per workgroup of this head), then the Lr < rstride rows that are left.
     // A last round of few rows would leave most of the chip idle for a whole item (N = 769: 769 = 12 x 64 + 1 rows, i.e. a 13th
     // round for ONE row: 7.7 % of the launch): its rows are SPLIT by query blocks over tparts = min(nqb, rstride / Lr) workgroups
@@ -1243,38 +1309,79 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                 const bool any_override = __any(!keep);
                 if (lane == 0) tflag[blk] = any_override ? 1 : 0;
             }
-            f32x16 acc, av;
+            if constexpr (GV) {
+                // [K|V] as ONE unswapped row GEMM (image rows 0-15 | 48-63): registers 0-7 = the lane's 8 K channels (as before),
+                // 8-15 = 8 V channels of its position, stored transposed (see tri_attn_core_v3_kernel): 12 MFMAs instead of 24
+                f32x16 akv;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[e] = 0.f; av[e] = 0.f; }
+                for (int e = 0; e < 16; ++e) akv[e] = 0.f;
 #pragma unroll
-            for (int s_ = 0; s_ < P / 16; ++s_) {
-                u32x4 wh, wl, vh, vl;
-                wop(r1, s_, wh, wl);                    // rows 0-31 = K | Q (Q discarded here)
-                wop(48 + (r1 & 15), s_, vh, vl);
-                acc = mfma_h(wh, xs[0][s_], acc);
-                av = mfma_h(xs[0][s_], vh, av);
-                acc = mfma_h(wh, xs[1][s_], acc);
-                av = mfma_h(xs[1][s_], vh, av);
-                acc = mfma_h(wl, xs[0][s_], acc);
-                av = mfma_h(xs[0][s_], vl, av);
-            }
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 wh, wl;
+                    wop(r1 < 16 ? r1 : 32 + r1, s_, wh, wl);
+                    akv = mfma_h(wh, xs[0][s_], akv);
+                    akv = mfma_h(wh, xs[1][s_], akv);
+                    akv = mfma_h(wl, xs[0][s_], akv);
+                }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] *= inv16;
-            u32x4 kh4, kl4;
-            split8_rn(acc, 0, kh4, kl4);
-            const unsigned po = (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
-            *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
-            *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
-            u32x4 vh0, vl0, vh1, vl1;                   // V stays x 16
-            split8_rn(av, 0, vh0, vl0);
-            split8_rn(av, 8, vh1, vl1);
-            const bool lo_lane = r1 >= 16;
-            u32x4 s0, s1;
+                for (int e = 0; e < 8; ++e) akv[e] *= inv16;
+                u32x4 kh4, kl4;
+                split8_rn(akv, 0, kh4, kl4);
+                const unsigned po = (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
+                *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
+                *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
+                const bool odd = (r1 & 1) != 0;
+                const int kp0 = r1 & 30;
+                const int a_ = kp0 >> 4, kk = kp0 & 15, kh_ = (kk >> 2) & 1, w_ = (kk >> 3) * 2 + ((kk & 3) >> 1);
+                const int ch0 = 4 * hi1 + (odd ? 8 : 0);
+                const unsigned vo = L.v + (unsigned)blk * 2048u + (unsigned)a_ * 1024u + (unsigned)kh_ * 512u + (unsigned)w_ * 4u;
+                const int sx = 2 * a_ + kh_;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
-            const unsigned vo = L.v + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
-            *reinterpret_cast<u32x4*>(lds + vo) = s0;
-            *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+                for (int j = 0; j < 4; ++j) {
+                    const float mine_lo = akv[8 + j], mine_hi = akv[12 + j];
+                    const float give = odd ? mine_lo : mine_hi;
+                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, false));
+                    const float ka = odd ? got : mine_lo, kb = odd ? mine_hi : got;
+                    unsigned hh, ll;
+                    split2h_rn(ka, kb, hh, ll);
+                    const unsigned so = (unsigned)((ch0 + j) ^ sx) * 16u;
+                    *reinterpret_cast<unsigned*>(lds + vo + so) = hh;
+                    *reinterpret_cast<unsigned*>(lds + vo + 256u + so) = ll;
+                }
+            } else {
+                f32x16 acc, av;
+    #pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[e] = 0.f; av[e] = 0.f; }
+    #pragma unroll
+                for (int s_ = 0; s_ < P / 16; ++s_) {
+                    u32x4 wh, wl, vh, vl;
+                    wop(r1, s_, wh, wl);                    // rows 0-31 = K | Q (Q discarded here)
+                    wop(48 + (r1 & 15), s_, vh, vl);
+                    acc = mfma_h(wh, xs[0][s_], acc);
+                    av = mfma_h(xs[0][s_], vh, av);
+                    acc = mfma_h(wh, xs[1][s_], acc);
+                    av = mfma_h(xs[1][s_], vh, av);
+                    acc = mfma_h(wl, xs[0][s_], acc);
+                    av = mfma_h(xs[0][s_], vl, av);
+                }
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] *= inv16;
+                u32x4 kh4, kl4;
+                split8_rn(acc, 0, kh4, kl4);
+                const unsigned po = (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
+                *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
+                *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
+                u32x4 vh0, vl0, vh1, vl1;                   // V stays x 16
+                split8_rn(av, 0, vh0, vl0);
+                split8_rn(av, 8, vh1, vl1);
+                const bool lo_lane = r1 >= 16;
+                u32x4 s0, s1;
+    #pragma unroll
+                for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
+                const unsigned vo = L.v + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
+                *reinterpret_cast<u32x4*>(lds + vo) = s0;
+                *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+                    }
         }
         __syncthreads();
         int bun, q0n, q1n;
@@ -1345,14 +1452,14 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
                 PBuf p;
-                load_v(lds, vbase + 2048u * T0, p);
+                ldv(T0, p);
                 exp_split(s0, lsum, big, p);
                 pv_tile(p, o0);
                 for (int t = T0 + 1; t < T1; ++t) {
                     if ((flags & 1) && ((t - T0) & 3) == 0) v2_prio(work_rem - (t - T0), work_tot);
                     f32x16 s = qk_tile(k, qh, ql, negm);
                     if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_off);
-                    load_v(lds, vbase + 2048u * t, p);
+                    ldv(t, p);
                     if ((fmask >> t) & 1) mask_tile_at(lds, L.kadd, t, hi, mref, s);
                     exp_split(s, lsum, big, p);
                     pv_tile(p, o0);
@@ -1376,7 +1483,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                     for (int e = 0; e < 16; ++e) { o0[e] *= alpha; s[e] -= mref; }
                     bool dummy = false;
                     PBuf p;
-                    load_v(lds, vbase + 2048u * t, p);
+                    ldv(t, p);
                     exp_split(s, lsum, dummy, p);
                     pv_tile(p, o0);
                 }
@@ -2007,29 +2114,43 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
     const int nqb_ = NP / 32, rem_ = nqb_ % 12;
     const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0) | (PRD_TGET_TA2_NO_TAIL_SPLIT(tune) ? 32 : 0);
     if (long_rows) {
-#define PRD_V2L_LAUNCH(PP, PF)                                                                                                    \
+#define PRD_V2L_LAUNCH(PP, PF, GVF)                                                                                               \
         do {                                                                                                                      \
-            PRD2_SET_LDS((tri_attn_core_v2l_kernel<PP, NWV, PF>));                                                                \
-            hipLaunchKernelGGL((tri_attn_core_v2l_kernel<PP, NWV, PF>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, \
+            PRD2_SET_LDS((tri_attn_core_v2l_kernel<PP, NWV, PF, GVF>));                                                           \
+            hipLaunchKernelGGL((tri_attn_core_v2l_kernel<PP, NWV, PF, GVF>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, wq, wk, \
                                wv, wg, bg, b, N, NP, H, ending, flags);                                                           \
         } while (0)
         const bool pf = (flags & 8) != 0;               // next-row prefetch of the wave's first block (costs 32 registers)
-        if (P == 64) { if (pf) PRD_V2L_LAUNCH(64, true); else PRD_V2L_LAUNCH(64, false); }
-        else { if (pf) PRD_V2L_LAUNCH(32, true); else PRD_V2L_LAUNCH(32, false); }
+        const bool gvl = !PRD_TGET_TA2_NO_GV(tune);     // phase 1 with [K|V] as one row GEMM + transposed V store
+        if (P == 64) {
+            if (gvl) { if (pf) PRD_V2L_LAUNCH(64, true, true); else PRD_V2L_LAUNCH(64, false, true); }
+            else { if (pf) PRD_V2L_LAUNCH(64, true, false); else PRD_V2L_LAUNCH(64, false, false); }
+        } else {
+            if (gvl) { if (pf) PRD_V2L_LAUNCH(32, true, true); else PRD_V2L_LAUNCH(32, false, true); }
+            else { if (pf) PRD_V2L_LAUNCH(32, true, false); else PRD_V2L_LAUNCH(32, false, false); }
+        }
 #undef PRD_V2L_LAUNCH
         return (int)hipGetLastError();
     }
     if (v3) {
         const size_t lds3 = v3_lds_bytes(N, P);
-#define PRD_V3_LAUNCH(PP, KLF)                                                                                                      \
+#define PRD_V3_LAUNCH(PP, KLF, GVF)                                                                                                 \
         do {                                                                                                                      \
-            PRD2_SET_LDS((tri_attn_core_v3_kernel<PP, NWV, KLF>));                                                                \
-            hipLaunchKernelGGL((tri_attn_core_v3_kernel<PP, NWV, KLF>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, \
+            PRD2_SET_LDS((tri_attn_core_v3_kernel<PP, NWV, KLF, GVF>));                                                           \
+            hipLaunchKernelGGL((tri_attn_core_v3_kernel<PP, NWV, KLF, GVF>), dim3(grid), dim3(NWV * 64), lds3, stream, og, pair, mask, wq, wk, wv, wg, \
                                bg, b, N, NP, H, ending, flags & ~6, lse);                                                         \
         } while (0)
         const int kl = flags_env >= 0 ? (flags >> 1) & 3 : PRD_V3_DEFAULT_KL;     // key-loop form (bits 1-2 of PRD_TA2_FLAGS; v3 has no stagger)
-        if (P == 64) { if (kl == 0) PRD_V3_LAUNCH(64, 0); else if (kl == 1) PRD_V3_LAUNCH(64, 1); else if (kl == 2) PRD_V3_LAUNCH(64, 2); else PRD_V3_LAUNCH(64, 3); }
-        else { if (kl == 0) PRD_V3_LAUNCH(32, 0); else if (kl == 1) PRD_V3_LAUNCH(32, 1); else if (kl == 2) PRD_V3_LAUNCH(32, 2); else PRD_V3_LAUNCH(32, 3); }
+        // phase 1 with [G|V] as one row GEMM + transposed V store (default); PRD_TUNE_TA2_NO_GV: the G GEMM + swapped V GEMM of round 3.
+        // The A/B key-loop forms 1-3 exist with the round-3 phase 1 only.
+        const bool gvf = !PRD_TGET_TA2_NO_GV(tune) && kl == 0;
+        if (P == 64) {
+            if (gvf) PRD_V3_LAUNCH(64, 0, true);
+            else if (kl == 0) PRD_V3_LAUNCH(64, 0, false); else if (kl == 1) PRD_V3_LAUNCH(64, 1, false); else if (kl == 2) PRD_V3_LAUNCH(64, 2, false); else PRD_V3_LAUNCH(64, 3, false);
+        } else {
+            if (gvf) PRD_V3_LAUNCH(32, 0, true);
+            else if (kl == 0) PRD_V3_LAUNCH(32, 0, false); else if (kl == 1) PRD_V3_LAUNCH(32, 1, false); else if (kl == 2) PRD_V3_LAUNCH(32, 2, false); else PRD_V3_LAUNCH(32, 3, false);
+        }
 #undef PRD_V3_LAUNCH
         return (int)hipGetLastError();
     }

@@ -34,7 +34,7 @@ def main():
     og = torch.empty(a.b, a.N, a.N, 64, device=dev)
     base_tune = _lib.lib().prd_get_tune()
     ref = None
-    forms = [("v3 form 0 (round-3 order)", 0), ("v3 form 1 (next Q K^T before the split)", 2), ("v3 form 2 (row sum by mfma_4x4x4)", 4),
+    forms = [("v3 default: [G|V] as one GEMM, transposed V store", "gv"), ("v3 form 0 (round-3 phase 1 and order)", 0), ("v3 form 1 (next Q K^T before the split)", 2), ("v3 form 2 (row sum by mfma_4x4x4)", 4),
              ("v3 + key-loop priorities by remaining work", 1), ("v3 + static priority, youngest first", 8),
              ("v3 + shared blocks projected by the oldest waves", 16), ("v3 + oldest-wave projection + static priority", 24),
              ("v3 + oldest-wave projection + mfma row sum", 20), ("v2 (barrier per phase, priorities)", None)]
@@ -42,18 +42,21 @@ def main():
     errs = {}
     for rnd in range(a.rounds):             # interleaved rounds: the clock of a box drifts; the median over rounds is reported
         for name, f in forms:
-            tune = base_tune & ~((1 << 6) | (31 << 7) | (1 << 4))
+            tune = base_tune & ~((1 << 6) | (31 << 7) | (1 << 4) | (1 << 21))
             if f is None:
                 tune |= 1 << 4              # PRD_TUNE_TA2_NO_V3
+            elif f == "gv":
+                pass                        # default dispatch
             else:
+                tune |= 1 << 21             # PRD_TUNE_TA2_NO_GV: the round-3 phase 1 (the A/B forms exist with it only)
                 tune |= (1 << 6) | ((f & 31) << 7)
             _lib.lib().prd_set_tune(tune)
             for i in range(4):
                 ops.tri_attn_core_v2(pair, mask, wts, H, c, ending=bool(i & 1), og=og)
             outs = [ops.tri_attn_core_v2(pair, mask, wts, H, c, ending=e).clone() for e in (False, True)]
-            if ref is None:
+            if f == 0 and ref is None:
                 ref = outs
-            errs[name] = max(float((o - r_).norm() / r_.norm()) for o, r_ in zip(outs, ref))
+            errs[name] = max(float((o - r_).norm() / r_.norm()) for o, r_ in zip(outs, ref)) if ref is not None else float('nan')
             assert all(bool(torch.isfinite(o).all()) for o in outs), name
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

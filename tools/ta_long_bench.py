@@ -2,7 +2,8 @@
 """Triangle attention core alone at long-row sizes (HIP events, back to back):  python tools/ta_long_bench.py [N ...]
 Environment (read once per process by the library): PRD_TA2_LONG=0 keeps the first-generation long-row kernel,
 PRD_TA2_FLAGS=9 adds the next-row prefetch to the round-3 kernel.  Every size is measured with the default dispatch and with the
-tail-row split switched off (PRD_TUNE_TA2_NO_TAIL_SPLIT), alternating, three rounds each (median)."""
+tail-row split switched off (PRD_TUNE_TA2_NO_TAIL_SPLIT) and with the round-3 phase 1 (PRD_TUNE_TA2_NO_GV: a [K|Q] GEMM + a swapped V GEMM
+instead of one [K|V] GEMM + transposed store), alternating, three rounds each (median)."""
 import os
 import sys
 
@@ -23,7 +24,7 @@ for N in [int(v) for v in sys.argv[1:]] or [449, 640, 769, 832]:
     for ending in (False, True):
         res = {}
         for rnd in range(3):
-            for name, tune in (("default", tune0), ("no tail split", tune0 | (1 << 19))):
+            for name, tune in (("default", tune0), ("no tail split", tune0 | (1 << 19)), ("round-3 phase 1", tune0 | (1 << 21))):
                 lib.prd_set_tune(tune)
                 for _ in range(2):
                     ops.tri_attn_core(pair, mask, wts, H, c, ending=ending, og=og)
@@ -39,4 +40,4 @@ for N in [int(v) for v in sys.argv[1:]] or [449, 640, 769, 832]:
         gf = (8 * N * N * P * 64 + 4 * 64 * N ** 3) / 1e9
         for name, v in res.items():
             us = sorted(v)[1]
-            print(f"N={N:4d} ending={int(ending)}  {name:14s} {us:8.1f} us  {gf / us * 1e3:6.1f} TF/s algorithmic  v2={ops.tri_attn_v2_supported(N, P)}", flush=True)
+            print(f"N={N:4d} ending={int(ending)}  {name:16s} {us:8.1f} us  {gf / us * 1e3:6.1f} TF/s algorithmic  v2={ops.tri_attn_v2_supported(N, P)}", flush=True)
