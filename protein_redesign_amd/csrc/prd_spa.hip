@@ -248,7 +248,9 @@ __global__ __launch_bounds__(SPA_NT) void spa_attn_part_kernel(
     unsigned char* vst = lds + 4u * 4096u + (unsigned)wave * 4096u;      // 2 buffers x 2 KB
     const int vpair = lane >> 3, vc4 = lane & 7;         // V staging: lane = (key pair 2 vpair | 2 vpair + 1 of the 16-key step, channels 4 vc4 ..)
     // key of step position (pair member m): kk = 2 vpair + m -> khalf = (kk >> 2) & 1, i = 4 (kk >> 3) + (kk & 3)
-    const int kk0 = 2 * vpair;
+    // (key pairs in the order 0, 2, 8, 10 | 4, 6, 12, 14: the 32 lanes of a store half then cover all four dwords w of the khalf they
+    // share -- 8 slots x 4 dwords = 32 banks; in natural order a half saw two dwords and two khalf blocks: 2-way conflicts)
+    const int kk0 = 2 * ((vpair & 1) | ((vpair & 2) << 1) | ((vpair & 4) >> 1));
     const unsigned vdst = (unsigned)((kk0 >> 2) & 1) * 512u + (unsigned)(4 * (kk0 >> 3) + (kk0 & 3)) * 2u;     // + plane 1024 + ch 16
     // 16-byte slot of channel ch inside a (plane, khalf) block: a bit permutation of ch (slot bits = ch2, ch3, ch4 ^ ch0, ch1, ch0) chosen so
     // that the eight lanes vc4 of a transposed 4-byte store hit eight different slots mod 8 (all 32 banks, two lanes each) AND the

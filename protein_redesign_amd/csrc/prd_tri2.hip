@@ -182,6 +182,12 @@ PRD_DEV void ln_cll_p(float (&x)[KH]) {
     for (int k = 0; k < KH; ++k) x[k] *= rstd;
 }
 
+// 16-byte slot of V channel ch (0-15; bit 4 = the lo plane) inside a (tile, 16-key half, khalf) block of the GV layout: bits 2 and 3
+// of the channel swapped.  The transposed 4-byte stores of phase 1 are issued 32 lanes at a time (lanes of one hi half: channels
+// {4 hi + j} on the even lanes, {8 + 4 hi + j} on the odd ones, 16 (a, khalf, w) combinations each); a bank is 4 (slot & 7) + w, so the
+// two channel sets must differ in slot bit 2, not bit 3; the reader XORs 2 a + khalf on top (sixteen-lane read groups stay distinct
+// mod 16 under both).
+PRD_DEV int gv_slot(int ch) { return (ch & ~12) | ((ch & 4) << 1) | ((ch & 8) >> 1); }
 struct KOp { u32x4 h, l; };                            // K hi | lo operands of one 32-key tile
 struct PBuf { u32x4 ph0, pl0, ph1, pl1, va0, va1; };   // probabilities of a tile (fp16 hi | lo, 2 x 16 keys) + its V operands
 
@@ -753,8 +759,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     const unsigned klane = (unsigned)hi * L.plane + (unsigned)r * 16u;              // + buffer + 512 t
     // V operand of P V: lane r = (plane, channel) reads its 16-byte slot of 8 keys of half a (16 keys) of tile t.  GV: the slot index
     // is XORed with 2 a + khalf so that the transposed 4-byte stores of phase 1 (below) spread over all banks
-    const unsigned vlane0 = v_rel + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ hi) : r) * 16u;                  // + buffer + 2048 t
-    const unsigned vlane1 = v_rel + 1024u + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ (2 + hi)) : r) * 16u;
+    const unsigned vlane0 = v_rel + (unsigned)hi * 512u + (unsigned)(GV ? (gv_slot(r) ^ hi) : r) * 16u;                  // + buffer + 2048 t
+    const unsigned vlane1 = v_rel + 1024u + (unsigned)hi * 512u + (unsigned)(GV ? (gv_slot(r) ^ (2 + hi)) : r) * 16u;
 
     u32x4 qh4 = {0u, 0u, 0u, 0u}, ql4 = {0u, 0u, 0u, 0u};     // Q of the wave's own block (B operands of Q K^T)
     float gate[8];                                             // the lane's gate channels of its own block (non-group owners)
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
                 const float ka = odd ? got : mine_lo, kb = odd ? mine_hi : got;      // keys kp0, kp0 + 1 of channel ch0 + j (x 16)
                 unsigned hh, ll;
                 split2h_rn(ka, kb, hh, ll);
-                const unsigned so = (unsigned)((ch0 + j) ^ sx) * 16u;
+                const unsigned so = (unsigned)(gv_slot(ch0 + j) ^ sx) * 16u;
                 *reinterpret_cast<unsigned*>(lds + vo + so) = hh;
                 *reinterpret_cast<unsigned*>(lds + vo + 256u + so) = ll;   // lo plane: slots 16 .. 31
             }
@@ -1221,8 +1227,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     const unsigned kl_off = L.kl - L.kh;
     const unsigned kbase = L.kh + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
     // (GV: V slots XORed with 2 a + khalf, see tri_attn_core_v3_kernel)
-    const unsigned vb0 = L.v + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ hi) : r) * 16u;          // + 2048 t
-    const unsigned vb1 = L.v + 1024u + (unsigned)hi * 512u + (unsigned)(GV ? (r ^ (2 + hi)) : r) * 16u;
+    const unsigned vb0 = L.v + (unsigned)hi * 512u + (unsigned)(GV ? (gv_slot(r) ^ hi) : r) * 16u;          // + 2048 t
+    const unsigned vb1 = L.v + 1024u + (unsigned)hi * 512u + (unsigned)(GV ? (gv_slot(r) ^ (2 + hi)) : r) * 16u;
     auto ldv = [&](int t, PBuf& p) {
         p.va0 = *reinterpret_cast<const u32x4*>(lds + vb0 + 2048u * t);
         p.va1 = *reinterpret_cast<const u32x4*>(lds + vb1 + 2048u * t);
@@ -1344,7 +1350,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                     const float ka = odd ? got : mine_lo, kb = odd ? mine_hi : got;
                     unsigned hh, ll;
                     split2h_rn(ka, kb, hh, ll);
-                    const unsigned so = (unsigned)((ch0 + j) ^ sx) * 16u;
+                    const unsigned so = (unsigned)(gv_slot(ch0 + j) ^ sx) * 16u;
                     *reinterpret_cast<unsigned*>(lds + vo + so) = hh;
                     *reinterpret_cast<unsigned*>(lds + vo + 256u + so) = ll;
                 }
