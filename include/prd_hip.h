@@ -304,6 +304,14 @@ int prd_pair_linear(float* out, const float* x, const float* w, const float* bia
 /* d/dx of nn.LayerNorm(C, elementwise_affine=False) applied to the rows of x: dx = LN'(dy; x) (+ res[row][c] when res is given:
  * the gradient that bypasses the update through its residual connection). */
 int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, const float* res, long long rows, int C, hipStream_t stream);
+
+/* Backward of an attention-bias head over the pair rows (autograd of ProteinReDiff/modules.py:300-304 and of SPAttention's linear_z,
+ * models/AF2_modules.py:454-459: bias[b,h,i,j] = (W' LN(pair[b,i,j]))[h] with W' = W diag(gamma) for the affine form), one pass:
+ * dx [b nn, P] = LN'(dbias . W'; x);  xn (may be NULL) = LN(x) and d2 (may be NULL) [b nn, H] = dbias by position, the operands of
+ * the weight-gradient reduction (prd_linear_wgrad).  dbias [b, H, nn] as the forward wrote the bias; wf [H, P]; P = 64, H = 4 or 8
+ * (PRD_ERR_UNSUPPORTED otherwise); dx, xn, x, wf 16-byte aligned. */
+int prd_pair_bias_bwd(float* dx, float* xn, float* d2, const float* dbias, const float* wf, const float* x, int b, long long nn,
+                      int H, int P, hipStream_t stream);
 /* Weight gradient of a linear applied at every pair position (autograd of nn.Linear over [b,N,N,*] activations, e.g.
  * modules.py:262-274, 321-326): dw[O][I] = sum over rows of dy[row][0..O) (x) x[row][0..I); row pitches lddy / ldx floats (for O > 16: even, and dy / x
  * 8-byte aligned -- PRD_ERR_ALIGN otherwise).

@@ -75,6 +75,7 @@ SIGNATURES = {
     "prd_tri_attn_bwd_core_v2_supported": [ci, ci],
     "prd_tri_attn_bwd_core_v2": [vp] * 12 + [ci] * 6 + [vp],
     "prd_ln_rows_bwd": [vp, vp, vp, vp, cll, ci, vp],
+    "prd_pair_bias_bwd": [vp, vp, vp, vp, vp, vp, ci, cll, ci, ci, vp],
     "prd_sym_transpose": [vp, vp, ci, ci, ci, vp],
     "prd_sym_rows": [vp, vp, cf, ci, ci, ci, vp],
     "prd_outer_linear_bwd_reduce": [vp, vp, ci, vp, vp, vp, cll, ci, ci, vp],

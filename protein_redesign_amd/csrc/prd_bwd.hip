@@ -622,6 +622,48 @@ __global__ __launch_bounds__(256) void ln_rows_bwd64_kernel(float* __restrict__ 
                                                        rstd * (gv.z - m1 - y2 * m2) + rv.z, rstd * (gv.w - m1 - y3 * m2) + rv.w);
 }
 
+// Backward of an attention-bias head over the pair rows (modules.py:300-304, AF2_modules.py:454-459): bias[b, h, i, j] = sum_c W'[h][c]
+// LN(pair[b, i, j])[c] (+ c_h).  ONE pass over the pair rows instead of a permute copy of dbias, a K = H GEMM, a LayerNorm-backward
+// pass and a LayerNorm pass for the weight gradient's operand:  dLN = sum_h dbias[b, h, p] W'[h][:]  (H <= 8 FMAs per channel, dbias read
+// in its own [b, H, N N] layout),  dx = LN'(dLN; x),  and on the side xn = LN(x) and d2[row][h] = dbias by position -- the two
+// operands of the weight-gradient reduction (prd_linear_wgrad).  Thread layout of ln_rows_bwd64_kernel: 16 lanes x float4 per row.
+template <int H>
+__global__ __launch_bounds__(256) void pair_bias_bwd64_kernel(float* __restrict__ dx, float* __restrict__ xn, float* __restrict__ d2,
+                                                              const float* __restrict__ dbias, const float* __restrict__ wf,
+                                                              const float* __restrict__ x, long rows, long nn) {
+    const int l16 = threadIdx.x & 15;
+    float4 w4[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) w4[h] = *reinterpret_cast<const float4*>(wf + h * 64 + 4 * l16);
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= rows) return;
+    const long bb = row / nn, p = row - bb * nn;
+    const float* dp = dbias + bb * H * nn + p;
+    float d[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) d[h] = dp[(long)h * nn];
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < H; ++h) { gv.x += d[h] * w4[h].x; gv.y += d[h] * w4[h].y; gv.z += d[h] * w4[h].z; gv.w += d[h] * w4[h].w; }
+    const long off = row * 64 + 4 * l16;
+    const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    const float mean = row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 64);
+    const float d0 = xv.x - mean, d1 = xv.y - mean, d2_ = xv.z - mean, d3 = xv.w - mean;
+    const float rstd = 1.0f / sqrtf(row16_sum((d0 * d0 + d1 * d1) + (d2_ * d2_ + d3 * d3)) * (1.0f / 64) + 1e-5f);
+    const float y0 = d0 * rstd, y1 = d1 * rstd, y2 = d2_ * rstd, y3 = d3 * rstd;
+    const float m1 = row16_sum((gv.x + gv.y) + (gv.z + gv.w)) * (1.0f / 64);
+    const float m2 = row16_sum((gv.x * y0 + gv.y * y1) + (gv.z * y2 + gv.w * y3)) * (1.0f / 64);
+    *reinterpret_cast<float4*>(dx + off) = make_float4(rstd * (gv.x - m1 - y0 * m2), rstd * (gv.y - m1 - y1 * m2),
+                                                       rstd * (gv.z - m1 - y2 * m2), rstd * (gv.w - m1 - y3 * m2));
+    if (xn) *reinterpret_cast<float4*>(xn + off) = make_float4(y0, y1, y2, y3);
+    if (d2 && l16 < H) {
+        float v = d[0];
+#pragma unroll
+        for (int h = 1; h < H; ++h) v = l16 == h ? d[h] : v;
+        d2[row * H + l16] = v;
+    }
+}
+
 // ---- weight gradient of a pair-position linear: dW[o][i] = sum_rows dy[row][o] * x[row][i] --------------------------------
 // rows = b N N (2e5 at N = 320), O, I <= 256: a reduction over a huge K with a tiny output, for which the BLAS picks an
 // 8-workgroup kernel (450 us per call, 35 % of the first-cut training step).  Here the rows are dealt to ~256 slabs; a
@@ -1540,6 +1582,18 @@ extern "C" int prd_ln_rows_bwd(float* dx, const float* dy, const float* x, const
         hipLaunchKernelGGL(ln_rows_bwd64_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, dx, dy, x, res, (long)rows);
     else
         hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dx, dy, x, res, (long)rows, C);
+    return (int)hipGetLastError();
+}
+
+extern "C" int prd_pair_bias_bwd(float* dx, float* xn, float* d2, const float* dbias, const float* wf, const float* x, int b, long long nn,
+                                 int H, int P, hipStream_t stream) {
+    if (!dx || !dbias || !wf || !x || b <= 0 || nn <= 0) return PRD_ERR_ARG;
+    if (P != 64 || (H != 4 && H != 8)) return PRD_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wf)) & 15) return PRD_ERR_ALIGN;
+    const long rows = (long)b * nn;
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    if (H == 4) hipLaunchKernelGGL(pair_bias_bwd64_kernel<4>, grid, dim3(256), 0, stream, dx, xn, d2, dbias, wf, x, rows, (long)nn);
+    else hipLaunchKernelGGL(pair_bias_bwd64_kernel<8>, grid, dim3(256), 0, stream, dx, xn, d2, dbias, wf, x, rows, (long)nn);
     return (int)hipGetLastError();
 }
 

@@ -505,6 +505,22 @@ def ln_rows_bwd(dy2: torch.Tensor, x2: torch.Tensor, res: Optional[torch.Tensor]
     return dx
 
 
+def pair_bias_bwd(dbias: torch.Tensor, wf: torch.Tensor, pair: torch.Tensor):
+    """Backward of an attention-bias head in one pass over the pair rows (prd_pair_bias_bwd): dbias [b, H, N, N] (any layout: made
+    contiguous), wf [H, P] (W diag(gamma) for the affine form), pair [b, N, N, P] -> (dx [b N N, P], xn = LN(pair) rows, d2 [b N N, H]);
+    None where the kernel does not cover the shape (P = 64, H in (4, 8))."""
+    b, N, _, P = pair.shape
+    H = wf.shape[0]
+    if P != 64 or H not in (4, 8) or not pair.is_cuda:
+        return None
+    x2 = pair.contiguous().view(-1, P)
+    dx, xn = torch.empty_like(x2), torch.empty_like(x2)
+    d2 = torch.empty(x2.shape[0], H, device=pair.device, dtype=F32)
+    check(lib().prd_pair_bias_bwd(dptr(dx), dptr(xn), dptr(d2), dptr(dbias.contiguous()), dptr(wf.contiguous()), dptr(x2), b, N * N, H, P,
+                                  stream()), "prd_pair_bias_bwd")
+    return dx, xn, d2
+
+
 def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor, bias: bool = False):
     """dW [O, I] = dy2^T x2 for row-major 2-D views dy2 [rows, O] and x2 [rows, I] (row stride = their stride(0), unit column
     stride): the weight gradient of a linear applied at every pair position; with ``bias`` also db [O] = column sums of dy2 from the

@@ -39,6 +39,8 @@ INPUT_STAGE_BWD = os.environ.get("PRD_INPUT_STAGE_BWD", "1") != "0"     # 0: the
 # 1: the residual adds of a folding block's pair updates ride in the kernels' own residual paths (pair + update written by the
 # operator, dy added to its input gradient) instead of eight torch adds over the pair tensor per block; 0: A/B measurements
 FUSED_RESIDUAL = os.environ.get("PRD_TRAIN_FUSED_RESIDUAL", "1") != "0"
+# 0: the attention-bias backward as permute copy + K = H GEMM + LayerNorm-backward pass + LayerNorm pass (A/B; round 4)
+PAIR_BIAS_BWD = os.environ.get("PRD_PAIR_BIAS_BWD", "1") != "0"
 
 
 class HipOp(torch.autograd.Function):
@@ -254,11 +256,16 @@ class PairBiasFn(torch.autograd.Function):
         P, H = pair.shape[-1], w.shape[0]
         with torch.no_grad():
             x2 = pair.detach().contiguous().view(-1, P)
-            d2 = dbias.permute(0, 2, 3, 1).contiguous().view(-1, H)           # [rows, H]
             wf = w * aff[0] if ctx.affine else w                              # W diag(gamma)
-            dxn = d2 @ wf                                                     # [rows, P]: K = H = 4, not a matrix-pipe shape
-            dx = ops.ln_rows_bwd(dxn, x2)
-            dwf, dcf = ops.linear_wgrad(d2, ops.layer_norm(x2), bias=True)
+            fused = ops.pair_bias_bwd(dbias, wf, pair.detach()) if PAIR_BIAS_BWD else None
+            if fused is not None:                                             # one pass over the pair rows (prd_pair_bias_bwd)
+                dx, xn, d2 = fused
+            else:
+                d2 = dbias.permute(0, 2, 3, 1).contiguous().view(-1, H)       # [rows, H]
+                dxn = d2 @ wf                                                 # [rows, P]: K = H = 4, not a matrix-pipe shape
+                dx = ops.ln_rows_bwd(dxn, x2)
+                xn = ops.layer_norm(x2)
+            dwf, dcf = ops.linear_wgrad(d2, xn, bias=True)
             if not ctx.affine:
                 return dx.view_as(pair), dwf, (dcf if ctx.has_c else None), None, None
             gamma, beta = aff

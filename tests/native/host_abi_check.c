@@ -153,6 +153,9 @@ int main(void) {
     EXPECT(prd_tri_attn_bwd_core_v2_supported(384, 64), 1);
     EXPECT(prd_tri_attn_bwd_core_v2_supported(385, 64), 0);
     EXPECT(prd_ln_rows_bwd(0, p, p, 0, 8, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_bias_bwd(0, p, p, p, p, p, 1, 64, 4, 64, s), PRD_ERR_ARG);
+    EXPECT(prd_pair_bias_bwd(p, p, p, p, p, p, 1, 64, 3, 64, s), PRD_ERR_UNSUPPORTED);      /* H = 4 or 8 */
+    EXPECT(prd_pair_bias_bwd(p, p, p, p, p, p, 1, 64, 4, 32, s), PRD_ERR_UNSUPPORTED);      /* P = 64 */
     EXPECT(prd_pair_linear(0, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, 1, s), PRD_ERR_ARG);
     EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 128, 0, 0, 0, 0, 0, 1, s), PRD_ERR_UNSUPPORTED);        /* (K, OUT) not served */
     EXPECT(prd_pair_linear(p, p, p, p, 100, 64, 64, 0, 0, 0, 0, 0, 0, s), PRD_ERR_UNSUPPORTED);          /* fp32 arithmetic: the caller's GEMM */

@@ -541,3 +541,40 @@ def test_gradient_with_respect_to_the_coordinates(golden, gemm_mode):
     assert zh.grad is not None
     assert rel_l2(zh.grad.cpu(), zo.grad) < GRAD_TOL
     assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,affine", [(4, False), (8, True)])
+def test_attention_bias_backward_in_one_pass(H, affine):
+    """prd_pair_bias_bwd (dLN = dbias . W', LayerNorm backward, LN(x) rows and dbias by position in one pass over the pair rows)
+    against float64 autograd of bias = (W diag(gamma)) LN(pair) (+ c), the weight gradients through PairBiasFn, and against the
+    round-4 composition (permute copy + GEMM + LayerNorm-backward pass + LayerNorm pass)."""
+    from protein_redesign_amd import ops
+    g = torch.Generator().manual_seed(100 + H)
+    b, N, P = 2, 96, 64
+    pair = (torch.randn(b, N, N, P, generator=g) * 1.7 + 0.3).cuda()
+    w = (torch.randn(H, P, generator=g) / 8).cuda()
+    c = torch.randn(H, generator=g).cuda() if not affine else None
+    gamma = (1 + 0.2 * torch.randn(P, generator=g)).cuda() if affine else None
+    beta = (0.1 * torch.randn(P, generator=g)).cuda() if affine else None
+    dbias = torch.randn(b, H, N, N, generator=g).cuda() * 1e-3
+    leaves = [t.double().detach().requires_grad_(True) for t in (pair, w) + ((gamma, beta) if affine else (c,))]
+    x64 = torch.nn.functional.layer_norm(leaves[0], (P,), leaves[2] if affine else None, leaves[3] if affine else None)
+    bias64 = torch.einsum("bijc,hc->bhij", x64, leaves[1]) + (0 if affine else leaves[2].view(1, H, 1, 1))
+    want = torch.autograd.grad(bias64, leaves, dbias.double())
+    outs = {}
+    for fused in (True, False):
+        training.PAIR_BIAS_BWD = fused
+        try:
+            p_, w_ = pair.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            extra = [t.clone().requires_grad_(True) for t in ((gamma, beta) if affine else (c,))]
+            out = training.PairBiasFn.apply(p_, w_, None, *extra) if affine else training.PairBiasFn.apply(p_, w_, extra[0])
+            outs[fused] = torch.autograd.grad(out, [p_, w_] + extra, dbias)
+        finally:
+            training.PAIR_BIAS_BWD = True
+    for got, ref in zip(outs[True], want):
+        assert rel_l2(got.double().cpu(), ref.cpu()) < 2e-6
+    for a_, b_ in zip(outs[True], outs[False]):
+        assert rel_l2(a_.cpu(), b_.cpu()) < 2e-6
+    fused = ops.pair_bias_bwd(dbias, w * gamma if affine else w, pair)
+    assert fused is not None and torch.equal(fused[2], dbias.permute(0, 2, 3, 1).reshape(-1, H))
