@@ -426,8 +426,10 @@ PRD_DEV void split2h_cll(const float (&x)[NE], u32x4 (&p)[2][NE / 8]) {
         }
 }
 // LDS image of W [nout][K] fp32: plane pl (hi / lo) at Wh + pl * nout * (K/8) (in 16-byte units), row o = K/8 slots of 8 fp16
-// without padding; slot j of row o is stored at j ^ (o & SWZ) with SWZ = min(K/8, 16) - 1... see h2_slot: the sixteen lanes of a
-// ds_read_b128 group read one logical slot of sixteen rows that are distinct mod 16 -> sixteen different 16-byte bank groups.
+// without padding; slot j of row o is stored at h2_slot(o, j): j ^ (o & 15) for rows of >= 16 slots, j ^ ((o >> 1) & 7) for rows of 8
+// slots (K = 64: two rows share a 256-byte bank line, the row's low bit already selects its half) -- the sixteen lanes of a
+// ds_read_b128 group (non-contiguous lane sets, MI355X_MICROARCH.md: LDS) read one logical slot of sixteen rows that are distinct
+// mod 16 -> sixteen different 16-byte bank groups (4 LDS cycles per read: tools/ubench/lds_pattern_bench.hip).
 template <int K>
 PRD_DEV int h2_slot(int row, int j) {
     constexpr int SL = K / 8;                     // slots per row (8: K = 64, 32: K = 256)

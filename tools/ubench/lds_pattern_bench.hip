@@ -8,7 +8,7 @@
 //   w_t_gv      ... slot = gv_slot(channel) ^ (2 a + khalf)   (bits 2, 3 of the channel swapped: the shipped form)
 //   r_plain     the P V operand read: lane (r, hi) -> 16 bytes at hi * 512 + r * 16                   (ds_read_b128)
 //   r_gv        ... at hi * 512 + (gv_slot(r) ^ hi) * 16
-//   r_w_full    weight operand read of a full row group: row 32 + r, slot (2 s + hi) ^ (row & 7), 128-byte rows
+//   r_w_full    weight operand read of a full row group: row 32 + r, slot (2 s + hi) ^ ((row >> 1) & 7) (h2_slot), 128-byte rows
 //   r_w_dup     ... rows 32 + (r & 15) (the round-3 G / V groups: lanes r and r + 16 read the same address)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,8 +35,8 @@ __global__ void pat(unsigned long long* out, int reps, unsigned* sink) {
         if (KIND == 3) addr = vo + (gv_slot(ch) ^ sx) * 16u;
         if (KIND == 4) addr = hi * 512u + r * 16u;
         if (KIND == 5) addr = hi * 512u + (gv_slot(r) ^ hi) * 16u;
-        if (KIND == 6) { const int row = 32 + r; addr = 4096u + row * 128u + (((2 * 1 + hi) ^ (row & 7)) << 4); }
-        if (KIND == 7) { const int row = 32 + (r & 15); addr = 4096u + row * 128u + (((2 * 1 + hi) ^ (row & 7)) << 4); }
+        if (KIND == 6) { const int row = 32 + r; addr = 4096u + row * 128u + (((2 * 1 + hi) ^ ((row >> 1) & 7)) << 4); }
+        if (KIND == 7) { const int row = 32 + (r & 15); addr = 4096u + row * 128u + (((2 * 1 + hi) ^ ((row >> 1) & 7)) << 4); }
     }
     addr += wave * 13312u;
     unsigned d0 = lane, d1 = lane + 1, d2 = lane + 2, d3 = lane + 3;
