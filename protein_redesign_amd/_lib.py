@@ -159,6 +159,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 20
     if geti("PRD_TA2_GV", 1) == 0:
         t |= 1 << 21
+    if geti("PRD_TMP_NW", 12) == 16:
+        t |= 1 << 22
     return t
 
 
@@ -174,7 +176,7 @@ class _Library:
         self._wrapped = {}
 
     def prd_set_tune(self, tune: int) -> int:
-        if tune < 0 or tune >= (1 << 22):
+        if tune < 0 or tune >= (1 << 23):
             return -1
         self._tune = int(tune)
         return 0

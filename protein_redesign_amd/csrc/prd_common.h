@@ -694,6 +694,7 @@ struct WaveTasks {
 #define PRD_TGET_TA2_FLAGS(t) ((((t) >> 6) & 1) ? (((t) >> 7) & 31) : -1)
 #define PRD_TGET_TA2_NO_TAIL_SPLIT(t) (((t) >> 19) & 1)
 #define PRD_TGET_TA2_NO_GV(t) (((t) >> 21) & 1)
+#define PRD_TGET_TMP_NW16(t) (((t) >> 22) & 1)
 #define PRD_TGET_OL_GEN2(t) (((t) >> 12) & 1)
 #define PRD_TGET_TMS_NW(t) ((((t) >> 13) & 3) == 1 ? 12 : (((t) >> 13) & 3) == 2 ? 16 : 8)
 

@@ -2290,7 +2290,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
                                w_proj, b_proj, w_gate, b_gate, b, N, ldn, incoming);                                 \
         } while (0)
         // (the split operands of the bf16 x 3 form need the registers of a 12-wave workgroup)
-        if (P == 64) { if (b3) PRD_PROJ_LAUNCH(64, true, 12); else PRD_PROJ_LAUNCH(64, false, NWP); }
+        if (P == 64) { if (b3) { if (PRD_TGET_TMP_NW16(tune)) PRD_PROJ_LAUNCH(64, true, 16); else PRD_PROJ_LAUNCH(64, true, 12); } else PRD_PROJ_LAUNCH(64, false, NWP); }
         else { if (b3) PRD_PROJ_LAUNCH(32, true, 12); else PRD_PROJ_LAUNCH(32, false, NWP); }
 #undef PRD_PROJ_LAUNCH
         int e = (int)hipGetLastError();
@@ -2376,7 +2376,11 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     // a failed launch must not let the later stages run over a half-written workspace: checked after every stage
 #define PRD_CHAIN_STAGE_OK() do { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
     // 1. a | b of the outgoing module
-    if (P == 64) {
+    if (P == 64 && PRD_TGET_TMP_NW16(tune)) {           // (A/B: PRD_TUNE_TMP_NW16)
+        PRD_SET_LDS((tri_mul_proj_kernel<64, 16, true>), ldsp);
+        hipLaunchKernelGGL((tri_mul_proj_kernel<64, 16, true>), dim3(pgrid), dim3(16 * 64), ldsp, stream, (int*)nullptr, AB, pair, mask,
+                           wa[0], wa[1], wa[2], wa[3], b, N, ldn, 0);
+    } else if (P == 64) {
         PRD_SET_LDS((tri_mul_proj_kernel<64, 12, true>), ldsp);
         hipLaunchKernelGGL((tri_mul_proj_kernel<64, 12, true>), dim3(pgrid), dim3(12 * 64), ldsp, stream, (int*)nullptr, AB, pair, mask,
                            wa[0], wa[1], wa[2], wa[3], b, N, ldn, 0);
