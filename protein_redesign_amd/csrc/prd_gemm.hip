@@ -838,191 +838,6 @@ __global__ __launch_bounds__(SL_NW * 64) void gemm_slab_kernel(const float* __re
     }
 }
 
-// The same 160 x 64 tile with ALL K slabs walked by one workgroup and the epilogue applied here (no partials, no second launch):
-// for wide outputs on few rows whose tiles already fill the chip -- the merged projection at the head of the trunk (M = b N rows,
-// N = 8448, K = 512: 264 tiles at b = 1).  The 64 x 64 tiles of gemm_h2 make a CU ingest 0.39 MB per 4 096 outputs (operands +
-// the statistics pass over its A rows) at the ~50-80 GB/s a CU sustains; this tile takes 0.46 MB per 10 240.  Two slabs of operands
-// are in flight in registers (the loads of slab s + 2 are issued before the MFMAs of slab s).  LayerNorm of the A rows BY LINEARITY
-// as in the reduce kernel below, with the statistics gathered from the raw pieces as they are staged: per row sums of (x - p) and
-// (x - p)^2 about a pivot p = the row's first element (single pass; the 32 lanes that stage a row reduce them at the end).
-// ln_out: workgroup (tile_m, tile_n) writes the normalised rows m0 + tile_n, + tiles_n, ... (the rows of a block are dealt to its column tiles).
-constexpr int SLF_NW = 8;                                               // 8 waves: two per SIMD, 256 registers (two slabs of operands in flight)
-__global__ __launch_bounds__(SLF_NW * 64) void gemm_slabfull_kernel(PrdGemm g, int tiles_m, int tiles_n, int nslab, float wscale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sl[];      // A hi [160][256 B] | A lo | W hi [64][256 B] | W lo | mean | rstd
-    constexpr int APL = SL_BM * 256, WOFF = 2 * APL, WPL = SL_BN * 256, NA = SL_BM / 16, NB = SL_BN / 16;
-    float* mean_l = reinterpret_cast<float*>(sl + SL_LDS);
-    float* rstd_l = mean_l + SL_BM;
-    const int tid = threadIdx.x, lane = tid & 63, r_ = lane & 31, hi_ = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // the ten 32 x 32 sub-tiles (5 row blocks x 2 column blocks) on eight waves: wave w takes sub-tile w, waves 0 and 1 also 8 and 9
-    const int nsub = wave < 2 ? 2 : 1;
-    // all row blocks of a column tile next to each other and on one XCD (block b on XCD b % 8): its W slabs cross the fabric once
-    int tile_m, tile_n;
-    {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        tile_m = j % tiles_m;
-        tile_n = (j / tiles_m) * 8 + xcd;
-        if (tile_n >= tiles_n) return;
-    }
-    const int m0 = tile_m * SL_BM, n0 = tile_n * SL_BN;
-    const int prow_ = tid >> 5, piece_ = tid & 31;                          // 32 threads per row: 512 contiguous bytes; rows prow + 16 i
-    const float* __restrict__ A = g.A;
-    const float* __restrict__ W = g.B;
-    const int M = g.M, N = g.N, lda = g.lda, ldb = g.ldb;
-    f32x16 acc[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[k][q] = 0.f;
-    float s1[NA], s2[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    if (tid < SL_BM) mean_l[tid] = (g.a_ln && m0 + tid < M) ? A[(size_t)(m0 + tid) * lda] : 0.f;     // the pivots (visible after the first barrier... see stage)
-    __syncthreads();
-    u32x4 va[2][NA], vb[NB];
-    // (lane coordinates opaque per call: the fourteen lane-invariant offsets are cheaper to recompute than to keep)
-    auto load_a = [&](int sl_i, u32x4 (&a)[NA]) {
-        if (sl_i >= nslab) return;                                          // (wave-uniform)
-        const int sc = sl_i;
-        const prd_rsrc ra = make_rsrc(A + (size_t)m0 * lda + (size_t)sc * SL_KS);
-        int pr = prow_, pc = piece_;
-        asm volatile("" : "+v"(pr), "+v"(pc));
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int row = pr + 16 * i;
-            a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (m0 + row < M) ? ((unsigned)row * lda + 4 * pc) * 4u : BUF_OOB, 0, 0));
-        }
-    };
-    auto load_b = [&](int sl_i, u32x4 (&b)[NB]) {
-        if (sl_i >= nslab) return;
-        const int sc = sl_i;
-        const prd_rsrc rb = make_rsrc(W + (size_t)n0 * ldb + (size_t)sc * SL_KS);
-        int pr = prow_, pc = piece_;
-        asm volatile("" : "+v"(pr), "+v"(pc));
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int row = pr + 16 * i;
-            b[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (n0 + row < N) ? ((unsigned)row * ldb + 4 * pc) * 4u : BUF_OOB, 0, 0));
-        }
-    };
-    auto stage = [&](const u32x4 (&a)[NA], const u32x4 (&b)[NB]) {
-        int prow = prow_, piece = piece_;                                   // (opaque per call, as in the loads)
-        asm volatile("" : "+v"(prow), "+v"(piece));
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int row = prow + 16 * i;
-            const float x0 = __uint_as_float(a[i][0]), x1 = __uint_as_float(a[i][1]), x2 = __uint_as_float(a[i][2]), x3 = __uint_as_float(a[i][3]);
-            if (g.a_ln) {
-                const float pv = mean_l[row];
-                const float d0 = x0 - pv, d1 = x1 - pv, d2 = x2 - pv, d3 = x3 - pv;
-                s1[i] += (d0 + d1) + (d2 + d3);
-                s2[i] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-            unsigned h0, l0, h1, l1;
-            split2h(x0, x1, h0, l0);
-            split2h(x2, x3, h1, l1);
-            unsigned char* d_ = sl + row * 256 + (((piece >> 1) ^ (row & 15)) << 4) + (piece & 1) * 8;
-            *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(d_ + APL) = u32x2{l0, l1};
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int row = prow + 16 * i;
-            unsigned h0, l0, h1, l1;
-            split2h(wscale * __uint_as_float(b[i][0]), wscale * __uint_as_float(b[i][1]), h0, l0);
-            split2h(wscale * __uint_as_float(b[i][2]), wscale * __uint_as_float(b[i][3]), h1, l1);
-            unsigned char* d_ = sl + WOFF + row * 256 + (((piece >> 1) ^ (row & 15)) << 4) + (piece & 1) * 8;
-            *reinterpret_cast<u32x2*>(d_) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(d_ + WPL) = u32x2{l0, l1};
-        }
-    };
-    auto mfmas = [&]() {
-        int r = r_, hi = hi_;
-        asm volatile("" : "+v"(r), "+v"(hi));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (k < nsub) {
-                const int sub = wave + 8 * k, rt = sub >> 1, ct = sub & 1;
-                const unsigned char* ab = sl + (rt * 32 + r) * 256;
-                const unsigned char* bb = sl + WOFF + (ct * 32 + r) * 256;
-#pragma unroll
-                for (int st = 0; st < SL_KS / 16; ++st) {
-                    const unsigned so = (unsigned)((2 * st + hi) ^ (r & 15)) << 4;
-                    const u32x4 ah = *reinterpret_cast<const u32x4*>(ab + so), al = *reinterpret_cast<const u32x4*>(ab + APL + so);
-                    const u32x4 bh = *reinterpret_cast<const u32x4*>(bb + so), bl = *reinterpret_cast<const u32x4*>(bb + WPL + so);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bh), acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bl), acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al), __builtin_bit_cast(f16x8_t, bh), acc[k], 0, 0, 0);
-                }
-            }
-        }
-    };
-    load_a(0, va[0]);
-    load_b(0, vb);
-    load_a(1, va[1]);
-    for (int s0 = 0; s0 < nslab; s0 += 2) {                                 // A: two slabs in flight, W (a quarter of the bytes): one
-        if (s0 > 0) __syncthreads();                                        // the previous slab's fragments have been read
-        stage(va[0], vb);
-        __syncthreads();
-        load_b(s0 + 1, vb);
-        load_a(s0 + 2, va[0]);
-        mfmas();
-        if (s0 + 1 < nslab) {
-            __syncthreads();
-            stage(va[1], vb);
-            __syncthreads();
-            load_b(s0 + 2, vb);
-            load_a(s0 + 3, va[1]);
-            mfmas();
-        }
-    }
-    if (g.a_ln) {                                                           // row statistics: the 32 lanes of a half wave hold one row's pieces
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            float a1 = s1[i], a2 = s2[i];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
-            const int row = prow_ + 16 * i;
-            if (piece_ == 0) {                                               // (only this lane touches mean_l[row] from here on)
-                const float dm = a1 / (float)g.K;
-                mean_l[row] = mean_l[row] + dm;
-                rstd_l[row] = 1.0f / sqrtf(fmaxf(a2 / (float)g.K - dm * dm, 0.f) + 1e-5f);
-            }
-        }
-        __syncthreads();
-    }
-    const float inv = 1.0f / wscale;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k < nsub) {
-            const int sub = wave + 8 * k, rt = sub >> 1, ct = sub & 1;
-            const int n = n0 + ct * 32 + r_;
-            if (n < N) {
-                const float cs = g.a_ln ? g.wsum[n] : 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int lr = rt * 32 + drow32(q, hi_), m = m0 + lr;
-                    if (m < M) {
-                        float v = acc[k][q] * inv;
-                        if (g.a_ln) v = (v - mean_l[lr] * cs) * rstd_l[lr];
-                        epilogue_store(g, 0, 0, m, n, v, g.C);
-                    }
-                }
-            }
-        }
-    }
-    if (g.ln_out && g.a_ln && tid < 128) {                                 // normalised rows tile_n, tile_n + tiles_n, ... of the block (re-read: L2-hot)
-        for (int lr = tile_n; lr < SL_BM && m0 + lr < M; lr += tiles_n) {
-            const int m = m0 + lr;
-            const float mu = mean_l[lr], rz = rstd_l[lr];
-            for (int k = 4 * tid; k < g.K; k += 512) {
-                const float4 a = *reinterpret_cast<const float4*>(A + (size_t)m * lda + k);
-                *reinterpret_cast<float4*>(g.ln_out + (size_t)m * g.ldlo + k) = make_float4((a.x - mu) * rz, (a.y - mu) * rz, (a.z - mu) * rz, (a.w - mu) * rz);
-            }
-        }
-    }
-}
-
 // Sum of the K slabs + epilogue of gemm_slab_kernel: one workgroup of 128 threads per (row, 512-column chunk), 16 bytes per
 // thread and slab, all slab loads in flight together, summed in slab order.  With a_ln the GEMM ran on the RAW rows and the
 // LayerNorm is applied here by linearity: LN(x) W^T = rstd (x W^T - mean colsum(W)) -- the workgroup computes the statistics
@@ -1189,20 +1004,6 @@ extern "C" int prd_gemm(const PrdGemm* args, hipStream_t stream) {
     if (g.ln_out && (!g.a_ln || batches != 1 || (g.ldlo & 3) || g.ldlo < g.K)) return PRD_ERR_ARG;
     if (g.C2 && (batches != 1 || g.n_split <= 0 || g.n_split >= g.N || g.ldc2 < g.N - g.n_split)) return PRD_ERR_ARG;
     const long tiles64 = (long)prd_ceil_div(g.M, 64) * prd_ceil_div(g.N, 64) * batches;
-    // gemm mode 1, wide outputs whose 160 x 64 tiles fill the chip by themselves: every workgroup walks all K slabs, epilogue in place
-    // (PrdGemm.ws set = the caller allows the slab kernels; no workspace is used here)
-    if (g.ws && g.tile_hint == -16 && !g.b_kn && batches == 1 && !g.out_ln && (!g.a_ln || (g.a_ln == 1 && g.wsum)) && arith == PRD_ARITH_SPLIT16 &&
-        !((g.arith >> 8) & (1 << 16)) && g.M >= 96 && (g.K % SL_KS) == 0 && g.K >= 2 * SL_KS && (!g.ln_out || (g.K & 3) == 0)) {
-        const int tiles_m = prd_ceil_div(g.M, SL_BM), tiles_n = prd_ceil_div(g.N, SL_BN);
-        if ((long)tiles_m * tiles_n >= 200) {
-            static std::once_flag oncef;
-            std::call_once(oncef, [] { (void)hipFuncSetAttribute((const void*)gemm_slabfull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-            const int tn8 = (tiles_n + 7) / 8 * 8;
-            hipLaunchKernelGGL(gemm_slabfull_kernel, dim3((unsigned)(tiles_m * tn8)), dim3(SLF_NW * 64), SL_LDS + 2 * SL_BM * sizeof(float), stream,
-                               g, tiles_m, tiles_n, g.K / SL_KS, H2_WSCALE);
-            return (int)hipGetLastError();
-        }
-    }
     // gemm mode 1, large weights on few rows (the transition layers): K split across workgroups + reduce / epilogue launch
     if (g.ws && g.tile_hint == 0 && !g.b_kn && batches == 1 && !g.addmat && !g.colmask && !g.mulmat &&
         (!g.C2 || ((g.n_split & 3) == 0 && (g.ldc2 & 3) == 0 && !g.out_ln)) && (!g.ln_out || (g.wsum && (g.K & 3) == 0)) &&

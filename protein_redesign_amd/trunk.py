@@ -163,7 +163,7 @@ _TRI_MUL_CHAIN = os.environ.get("PRD_TRI_MUL_CHAIN", "1") != "0"      # 0: two p
 _TRI_ATTN_FUSE = os.environ.get("PRD_TRI_ATTN_FUSE", "0") == "1"
 _PAIR_HEAD = os.environ.get("PRD_PAIR_HEAD", "1") != "0"              # 0: pair_init, OPM tail and the first bias heads as three launches
 _MERGE_HEAD = os.environ.get("PRD_MERGE_HEAD", "1") != "0"            # 0: OPM / SPA LayerNorms and projections as four launches
-_HEAD_SLAB = os.environ.get("PRD_HEAD_SLAB", "0") == "1"              # 1: the merged head projection on 160 x 64 tiles walking all K slabs (measured slower)
+_HEAD_SLAB = os.environ.get("PRD_HEAD_SLAB", "0") == "1"              # 1: the merged head projection on the K-slab kernel + reduce launch (measured slower: 40.8 vs 31.4 us)
 _MERGE_PROJ = os.environ.get("PRD_MERGE_PROJ", "1") != "0"            # 0: u and the next q|k|v|gate as two launches (A/B measurements)
 
 
@@ -380,12 +380,10 @@ class Denoiser(nn.Module):
         ab = torch.empty(b, N, Ch2, device=single.device, dtype=torch.float32)
         qkvg = torch.empty(b, N, 4 * HS, device=single.device, dtype=torch.float32)
         xhat = torch.empty_like(single)
-        # _HEAD_SLAB: 160 x 64 tiles of the K-slab kernel (every workgroup walks all K slabs: one partial per tile) + its epilogue
-        # launch, LayerNorm by linearity -- a workgroup ingests 0.46 MB for 10 240 outputs where the 64 x 64 tiles of gemm_h2 take
-        # 0.39 MB (with their statistics pass) for 4 096
+        # _HEAD_SLAB (A/B): the K-slab kernel (every workgroup walks all four K slabs of its 160 x 64 tile) + its epilogue launch
         slab = _HEAD_SLAB and ops.slab_ok(b * N, Ch2 + 4 * HS, S)
         ops.gemm(single, w, ab, b * N, Ch2 + 4 * HS, S, S, S, Ch2, bias=bias, colscale=cs, act=2, act_from=Ch2 + 3 * HS,
-                 rowmask=mask, rowmask_cols=Ch2, a_ln=True, ln_out=xhat, c2=qkvg, n_split=Ch2, slab=slab, wsum=wsum if slab else None, tile_hint=-16 if slab else 0)
+                 rowmask=mask, rowmask_cols=Ch2, a_ln=True, ln_out=xhat, c2=qkvg, n_split=Ch2, slab=slab, wsum=wsum if slab else None)
         return ab, xhat, qkvg, True
 
     def run_(self, single: torch.Tensor, pair: torch.Tensor, mask: torch.Tensor, ws=None, pre=None, join=None, tail=None, pair_init=None):

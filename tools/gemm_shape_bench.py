@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""One LayerNorm-fused linear y = LN(x) W^T + b at a given shape through ops.gemm: 160 x 64 tiles that walk all K slabs with the epilogue in
-place (gemm_slabfull, tile_hint -16), the K-slab kernel + reduce launch (slab=True), or the tile kernels (gemm_h2 / gemm_ring): HIP events back to back and the rel-L2 distance from float64.
+"""One LayerNorm-fused linear y = LN(x) W^T + b at a given shape through ops.gemm: the K-slab kernel + reduce launch (slab=True) or the tile kernels (gemm_h2 / gemm_ring)
+(commit 6485dc3 also had 160 x 64 tiles walking all K slabs with the epilogue in place, gemm_slabfull_kernel: profiles/r05_gemm_head_variants.txt): HIP events back to back and the rel-L2 distance from float64.
 usage: gemm_shape_bench.py M N K [M N K ...]"""
 import os
 import sys
@@ -18,7 +18,7 @@ for M, N, K in zip(a[0::3], a[1::3], a[2::3]):
     bias = torch.randn(N, generator=g).cuda()
     wsum = w.double().sum(1).float().contiguous()
     want = torch.nn.functional.layer_norm(x.double(), (K,)) @ w.double().t() + bias.double()
-    for name, kw in (("160 x 64 tiles, all K slabs", dict(slab=True, wsum=wsum, tile_hint=-16)), ("K-slab kernels allowed", dict(slab=True, wsum=wsum)), ("tile kernels", dict())):
+    for name, kw in (("K-slab kernels allowed", dict(slab=True, wsum=wsum)), ("tile kernels", dict())):
         y = torch.empty(M, N, device="cuda")
         for _ in range(3):
             ops.gemm(x, w, y, M, N, K, K, K, N, bias=bias, a_ln=True, **kw)
