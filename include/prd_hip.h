@@ -87,6 +87,7 @@ int prd_version(void);
 #define PRD_TUNE_TMS_NW16 (2 << 13)
 #define PRD_TUNE_TA2_NO_XCD8 (1 << 20)  /* PRD_TA2_XCD8=0: rows in flight per head not rounded to a multiple of 8 (heads of a row spread over XCDs) */
 #define PRD_TUNE_TA2_NO_GV (1 << 21)            /* PRD_TA2_GV=0: short-row core with the round-3 phase 1 (a G row GEMM + a swapped V GEMM instead of one [G|V] GEMM + transposed store) */
+#define PRD_TUNE_TMS_DEPTH3 (3 << 13)           /* PRD_TMS_DEPTH=3: the split contraction (8 waves) with three chunks of operands in flight (default 2) */
 #define PRD_TUNE_TMP_NW16 (1 << 22)             /* PRD_TMP_NW=16: the projection stage of the triangle multiplication on 16 waves per workgroup (default 12) */
 #define PRD_TUNE_TA2_NO_TAIL_SPLIT (1 << 19)    /* PRD_TA2_TAIL=0: long rows: a last round of few rows is not split by query blocks over the idle workgroups */
 #define PRD_TUNE_GEMM_XCD_COLS (1 << 18)        /* PRD_GEMM_XCDCOLS=1: 64 x 64-tile node-row GEMMs with all row tiles of a column tile on one XCD (measured: no gain) */

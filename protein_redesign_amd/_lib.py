@@ -161,6 +161,8 @@ def tune_from_env(env=None) -> int:
         t |= 1 << 21
     if geti("PRD_TMP_NW", 12) == 16:
         t |= 1 << 22
+    if geti("PRD_TMS_DEPTH", 2) == 3 and nw == 8:
+        t |= 3 << 13
     return t
 
 

@@ -695,6 +695,7 @@ struct WaveTasks {
 #define PRD_TGET_TA2_NO_TAIL_SPLIT(t) (((t) >> 19) & 1)
 #define PRD_TGET_TA2_NO_GV(t) (((t) >> 21) & 1)
 #define PRD_TGET_TMP_NW16(t) (((t) >> 22) & 1)
+#define PRD_TGET_TMS_D3(t) ((((t) >> 13) & 3) == 3)             /* 8 waves, three chunks of operands in flight */
 #define PRD_TGET_OL_GEN2(t) (((t) >> 12) & 1)
 #define PRD_TGET_TMS_NW(t) ((((t) >> 13) & 3) == 1 ? 12 : (((t) >> 13) & 3) == 2 ? 16 : 8)
 

@@ -440,7 +440,7 @@ constexpr int TMS_T = 160, TMS_PLANE = TMS_T * 64, TMS_OPER = 2 * TMS_PLANE;    
 // waves per workgroup of the split contraction: 8 by default; 16 (PRD_TMS_NW=16) makes the kernel itself 1 us faster (18.8 vs
 // 19.8 us) but the whole step 15 us slower in the same run (1.932 vs 1.918 ms, twice); 12 waves: 22.5 vs 22.7 us -- A/B switch
 // PRD_TUNE_TMS_NW in the upper bits of `arith`
-template <int NWV>                                  // 8 or 16 waves: 25 sub-tiles dealt round-robin, 4 or 2 accumulators per wave
+template <int NWV, int DEPTH = 2>                   // 8 or 16 waves: 25 sub-tiles dealt round-robin, 4 or 2 accumulators per wave; DEPTH: chunks of operands in flight
 __global__ __launch_bounds__(NWV * 64) void tri_mul_contract_split_kernel(float* __restrict__ O, const float* __restrict__ AB,
                                                                           int N, int ldn, int P, int nbatch, int tiles, int swap) {
     constexpr int NT = NWV * 64, NPT = (2560 + NT - 1) / NT, NSUB = (25 + NWV - 1) / NWV;
@@ -549,6 +549,54 @@ __global__ __launch_bounds__(NWV * 64) void tri_mul_contract_split_kernel(float*
         pt.mark(2);                                     /* 2: barrier */                                            \
     }
         pt.mark(6);                                     // 6: tile decode (and, for the first tile, kernel entry)
+        if constexpr (DEPTH == 3) {
+            // three register sets: while chunk c is multiplied from LDS, chunk c + 1 is in registers (staged at the end of c), c + 2
+            // and c + 3 are in flight.  What a CU ingests is set by the bytes it has in flight (gemm_h2): 123 KB here
+            // against 82 KB with two sets
+            u32x4 w[NPT];
+#define PRD_TMS_CHUNK3(C, R, NX)                                                                                      \
+    {                                                                                                               \
+        const int c3 = (C) + 3 < nchunk ? (C) + 3 : nchunk - 1;                                                     \
+        PRD_TMS_LOAD(NX, c3)                                                                                        \
+        const int cur_ = (C) & 1;                                                                                   \
+        const unsigned char* base = tms + cur_ * 2 * TMS_OPER;                                                      \
+        _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                          \
+            const unsigned col = (((unsigned)(2 * st + hi)) ^ swz) << 4;                                            \
+            _Pragma("unroll") for (int k = 0; k < NSUB; ++k) {                                                      \
+                if (sv[k]) {                                                                                        \
+                    const unsigned char* ap = base + (32 * si[k] + r) * 64 + col;                                   \
+                    const unsigned char* bp = base + TMS_OPER + (32 * sj[k] + r) * 64 + col;                        \
+                    u32x4 a[2], bq[2];                                                                              \
+                    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                              \
+                        a[pl] = *reinterpret_cast<const u32x4*>(ap + pl * TMS_PLANE);                               \
+                        bq[pl] = *reinterpret_cast<const u32x4*>(bp + pl * TMS_PLANE);                              \
+                    }                                                                                               \
+                    const int pa[3] = {0, 0, 1}, pb[3] = {0, 1, 0};                                                 \
+                    _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                   \
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[pa[t]]),      \
+                                                                        __builtin_bit_cast(f16x8_t, bq[pb[t]]), acc[k], 0, 0, 0); \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        pt.mark(0);                                                                                                 \
+        if ((C) + 1 < nchunk) { PRD_TMS_STAGE(R, cur_ ^ 1) }                                                        \
+        pt.mark(1);                                                                                                 \
+        __syncthreads();                                                                                            \
+        pt.mark(2);                                                                                                 \
+    }
+            PRD_TMS_LOAD(u, 0)
+            PRD_TMS_STAGE(u, 0)
+            PRD_TMS_LOAD(u, (1 < nchunk ? 1 : 0))
+            PRD_TMS_LOAD(v, (2 < nchunk ? 2 : nchunk - 1))
+            __syncthreads();
+            pt.mark(3);
+            for (int c = 0; c < nchunk; c += 3) {
+                PRD_TMS_CHUNK3(c, u, w)
+                if (c + 1 < nchunk) PRD_TMS_CHUNK3(c + 1, v, u)
+                if (c + 2 < nchunk) PRD_TMS_CHUNK3(c + 2, w, v)
+            }
+#undef PRD_TMS_CHUNK3
+        } else {
         PRD_TMS_LOAD(u, 0)
         PRD_TMS_STAGE(u, 0)
         {
@@ -560,6 +608,7 @@ __global__ __launch_bounds__(NWV * 64) void tri_mul_contract_split_kernel(float*
         for (int c = 0; c < nchunk; c += 2) {
             PRD_TMS_CHUNK(c, 0, u, v)
             if (c + 1 < nchunk) PRD_TMS_CHUNK(c + 1, 1, v, u)
+        }
         }
 #undef PRD_TMS_LOAD
 #undef PRD_TMS_STAGE
@@ -2167,6 +2216,26 @@ int grid_for(long tasks, int per_wg, int cap) {
         (void)(bytes);                                                                                          \
     } while (0)
 
+// the split contraction by the A/B switches of the caller (waves per workgroup; chunks of operands in flight)
+static void launch_contract_split(int tune, int grid, size_t lds3, hipStream_t stream, float* O, const float* AB, int N, int ldn, int P, int nbatch,
+                                  int tiles, int swap) {
+    const int nw = PRD_TGET_TMS_NW(tune);
+    if (nw == 8 && PRD_TGET_TMS_D3(tune)) {
+        PRD_SET_LDS((tri_mul_contract_split_kernel<8, 3>), lds3);
+        hipLaunchKernelGGL((tri_mul_contract_split_kernel<8, 3>), dim3(grid), dim3(512), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
+    } else if (nw == 8) {
+        PRD_SET_LDS((tri_mul_contract_split_kernel<8>), lds3);
+        hipLaunchKernelGGL((tri_mul_contract_split_kernel<8>), dim3(grid), dim3(512), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
+    } else if (nw == 12) {
+        PRD_SET_LDS((tri_mul_contract_split_kernel<12>), lds3);
+        hipLaunchKernelGGL((tri_mul_contract_split_kernel<12>), dim3(grid), dim3(768), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
+    } else {
+        PRD_SET_LDS((tri_mul_contract_split_kernel<16>), lds3);
+        hipLaunchKernelGGL((tri_mul_contract_split_kernel<16>), dim3(grid), dim3(1024), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
+    }
+}
+
+
 #ifdef PRD_AB
 constexpr bool PRD_FIRST_GEN = true;
 #else
@@ -2303,9 +2372,7 @@ extern "C" int prd_tri_mul(float* out, const float* pair, const float* mask, con
             const int tl = prd_ceil_div(N, TMS_T);
             const int vb3 = b * P * tl * tl;
             const size_t lds3 = (size_t)4 * TMS_OPER;
-                        if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+        launch_contract_split(tune, vb3 < 256 ? vb3 : 256, lds3, stream, O, AB, N, ldn, P, b, tl, 0);
         }
         else
             hipLaunchKernelGGL(tri_mul_contract_kernel, dim3(vblocks < 1024 ? vblocks : 1024), dim3(256), 0, stream, O, AB, N, ldn, P, b, tiles);
@@ -2336,9 +2403,7 @@ extern "C" int prd_tri_mul_contract(float* O, const float* AB, int b, int N, int
         const int tl = prd_ceil_div(N, TMS_T);
         const int vb3 = b * P * tl * tl;
         const size_t lds3 = (size_t)4 * TMS_OPER;
-                if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+        launch_contract_split(tune, vb3 < 256 ? vb3 : 256, lds3, stream, O, AB, N, ldn, P, b, tl, 0);
     } else {
         const int tiles = prd_ceil_div(N, 64);
         const int vblocks = b * P * tiles * tiles;
@@ -2391,9 +2456,7 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     }
     PRD_CHAIN_STAGE_OK();
     // 2. its contraction, transposed: O^T[c][j][i]
-    if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
-    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
-    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 1); }
+        launch_contract_split(tune, vb3 < 256 ? vb3 : 256, lds3, stream, O, AB, N, ldn, P, b, tl, 1);
     PRD_CHAIN_STAGE_OK();
     // 3. output stage of the outgoing module + a | b of the incoming one.  P = 64: 12 waves (168 VGPRs, three per SIMD) cover the
     // task's latency chain better than 8 (36.6 -> 31.7 us at N = 320; the plain output stage below needs 192 VGPRs and stays at 8:
@@ -2409,9 +2472,7 @@ extern "C" int prd_tri_mul_chain(float* pair, const float* mask, const float* co
     }
     PRD_CHAIN_STAGE_OK();
     // 4. contraction of the incoming module
-    if (PRD_TGET_TMS_NW(tune) == 8) { PRD_SET_LDS(tri_mul_contract_split_kernel<8>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<8>, dim3(vb3 < 256 ? vb3 : 256), dim3(512), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else if (PRD_TGET_TMS_NW(tune) == 12) { PRD_SET_LDS(tri_mul_contract_split_kernel<12>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<12>, dim3(vb3 < 256 ? vb3 : 256), dim3(768), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
-    else { PRD_SET_LDS(tri_mul_contract_split_kernel<16>, lds3); hipLaunchKernelGGL(tri_mul_contract_split_kernel<16>, dim3(vb3 < 256 ? vb3 : 256), dim3(1024), lds3, stream, O, AB, N, ldn, P, b, tl, 0); }
+        launch_contract_split(tune, vb3 < 256 ? vb3 : 256, lds3, stream, O, AB, N, ldn, P, b, tl, 0);
     PRD_CHAIN_STAGE_OK();
     // 5. its output stage
     {
