@@ -376,7 +376,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
     const float inv16 = H2_INV_WSCALE;
     const unsigned kl_off = L.kl - L.kh;
     const unsigned kbase = L.kh + (unsigned)hi * L.plane + (unsigned)r * 16u;      // + 512 t
-    const unsigned vbase = L.v + (unsigned)hi * 512u + (unsigned)r * 16u;          // + 2048 t
+    // (V slots in the GV layout of tri_attn_core_v3_kernel: channel bits 2 / 3 swapped, XORed with 2 a + khalf)
+    const unsigned vb0 = L.v + (unsigned)hi * 512u + (unsigned)(gv_slot(r) ^ hi) * 16u;              // + 2048 t
+    const unsigned vb1 = L.v + 1024u + (unsigned)hi * 512u + (unsigned)(gv_slot(r) ^ (2 + hi)) * 16u;
+    auto ldv = [&](int t, PBuf& p) {
+        p.va0 = *reinterpret_cast<const u32x4*>(lds + vb0 + 2048u * t);
+        p.va1 = *reinterpret_cast<const u32x4*>(lds + vb1 + 2048u * t);
+    };
 
     float xnext[KH];                                    // the rows of the wave's phase-1 block of the NEXT row
     float mknext = 0.f, munext = 0.f;                   // ... and its mask values (the block's positions; the row itself)
@@ -444,44 +450,45 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                 *reinterpret_cast<u32x4*>(lds + L.ql + po) = ql4;
             }
             if (p1_kinds & 2) {
-                // [G]: A = G rows 32 + (r1 & 15) (lanes 16-31 repeat them): registers 0-7 = gate channels {4hi+e, 8+4hi+e}
-                // [V]: SWAPPED, B = V rows 48 + (r1 & 15): lane (n, hi1) register j = V channel n & 15 of position drow32(j, hi1)
-                f32x16 ag, av;
+                // [G|V] as ONE unswapped row GEMM (image rows 32 + r1) + transposed V store: see tri_attn_core_v3_kernel
+                f32x16 agv;
                 {
                     const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
-                    ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
+                    agv[0] = b0.x; agv[1] = b0.y; agv[2] = b0.z; agv[3] = b0.w; agv[4] = b1.x; agv[5] = b1.y; agv[6] = b1.z; agv[7] = b1.w;
 #pragma unroll
-                    for (int e = 8; e < 16; ++e) ag[e] = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) av[e] = 0.f;
+                    for (int e = 8; e < 16; ++e) agv[e] = 0.f;
                 }
 #pragma unroll
                 for (int s_ = 0; s_ < P / 16; ++s_) {
-                    u32x4 gh, gl, vh, vl;
-                    wop(32 + (r1 & 15), s_, gh, gl);
-                    wop(48 + (r1 & 15), s_, vh, vl);
-                    ag = mfma_h(gh, xs[0][s_], ag);
-                    av = mfma_h(xs[0][s_], vh, av);
-                    ag = mfma_h(gh, xs[1][s_], ag);
-                    av = mfma_h(xs[1][s_], vh, av);
-                    ag = mfma_h(gl, xs[0][s_], ag);
-                    av = mfma_h(xs[0][s_], vl, av);
+                    u32x4 gh, gl;
+                    wop(32 + r1, s_, gh, gl);
+                    agv = mfma_h(gh, xs[0][s_], agv);
+                    agv = mfma_h(gh, xs[1][s_], agv);
+                    agv = mfma_h(gl, xs[0][s_], agv);
                 }
                 float* gp = Gl + (size_t)((blk * 32 + r1) * 2 + hi1) * 8;
-                *reinterpret_cast<float4*>(gp) = make_float4(gate_from_scaled(ag[0] * inv16), gate_from_scaled(ag[1] * inv16),
-                                                             gate_from_scaled(ag[2] * inv16), gate_from_scaled(ag[3] * inv16));
-                *reinterpret_cast<float4*>(gp + 4) = make_float4(gate_from_scaled(ag[4] * inv16), gate_from_scaled(ag[5] * inv16),
-                                                                 gate_from_scaled(ag[6] * inv16), gate_from_scaled(ag[7] * inv16));
-                u32x4 vh0, vl0, vh1, vl1;               // V stays x 16
-                split8_rn(av, 0, vh0, vl0);
-                split8_rn(av, 8, vh1, vl1);
-                const bool lo_lane = r1 >= 16;
-                u32x4 s0, s1;
+                *reinterpret_cast<float4*>(gp) = make_float4(gate_from_scaled(agv[0] * inv16), gate_from_scaled(agv[1] * inv16),
+                                                             gate_from_scaled(agv[2] * inv16), gate_from_scaled(agv[3] * inv16));
+                *reinterpret_cast<float4*>(gp + 4) = make_float4(gate_from_scaled(agv[4] * inv16), gate_from_scaled(agv[5] * inv16),
+                                                                 gate_from_scaled(agv[6] * inv16), gate_from_scaled(agv[7] * inv16));
+                const bool odd = (r1 & 1) != 0;
+                const int kp0 = r1 & 30;
+                const int a_ = kp0 >> 4, kk = kp0 & 15, kh_ = (kk >> 2) & 1, w_ = (kk >> 3) * 2 + ((kk & 3) >> 1);
+                const int ch0 = 4 * hi1 + (odd ? 8 : 0);
+                const unsigned vo = L.v + (unsigned)blk * 2048u + (unsigned)a_ * 1024u + (unsigned)kh_ * 512u + (unsigned)w_ * 4u;
+                const int sx = 2 * a_ + kh_;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
-                const unsigned vo = L.v + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
-                *reinterpret_cast<u32x4*>(lds + vo) = s0;
-                *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
+                for (int j = 0; j < 4; ++j) {
+                    const float mine_lo = agv[8 + j], mine_hi = agv[12 + j];
+                    const float give = odd ? mine_lo : mine_hi;
+                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, false));
+                    const float ka = odd ? got : mine_lo, kb = odd ? mine_hi : got;
+                    unsigned hh, ll;
+                    split2h_rn(ka, kb, hh, ll);
+                    const unsigned so = (unsigned)(gv_slot(ch0 + j) ^ sx) * 16u;
+                    *reinterpret_cast<unsigned*>(lds + vo + so) = hh;
+                    *reinterpret_cast<unsigned*>(lds + vo + 256u + so) = ll;
+                }
             }
         }
         PRD2_STAMP(1);
@@ -530,14 +537,14 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
                 PBuf p;
-                load_v(lds, vbase + 2048u * T0, p);
+                ldv(T0, p);
                 exp_split(s0, lsum, big, p);
                 pv_tile(p, o0);
                 for (int t = T0 + 1; t < T1; ++t) {
                     if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
                     f32x16 s = qk_tile(k, qh, ql, negm);
                     if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_off);
-                    load_v(lds, vbase + 2048u * t, p);
+                    ldv(t, p);
                     if ((fmask >> t) & 1) mask_tile(lds, L, t, hi, mref, s);
                     exp_split(s, lsum, big, p);
                     pv_tile(p, o0);
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2_kernel(
                     for (int e = 0; e < 16; ++e) { o0[e] *= alpha; s[e] -= mref; }
                     bool dummy = false;
                     PBuf p;
-                    load_v(lds, vbase + 2048u * t, p);
+                    ldv(t, p);
                     exp_split(s, lsum, dummy, p);
                     pv_tile(p, o0);
                 }
