@@ -36,7 +36,13 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define PRD_VERSION 100
+/* ABI version: bumped whenever the meaning or the SIZE of a caller-owned buffer changes, so that a binding built against an older
+ * header can refuse to run (compare prd_version() with the PRD_VERSION it was compiled with).
+ *   100  rounds 1-4;
+ *   101  round 5: prd_step_boundary's `sync` buffer grew from ONE int32 to TWO (sync[1] = sticky non-finite flag): a caller that still
+ *        allocates 4 bytes would take a 4-byte out-of-bounds device write the first time a step goes non-finite. */
+#define PRD_VERSION 101
+#define PRD_STEP_BOUNDARY_SYNC_INTS 2   /* int32 entries of prd_step_boundary's `sync` buffer */
 #define PRD_ERR_ARG (-1)        /* null pointer / non-positive dimension */
 #define PRD_ERR_ALIGN (-2)      /* leading dimension not a multiple of 4 floats */
 #define PRD_ERR_UNSUPPORTED (-3)/* pair_dim / head layout outside the compiled set */
@@ -430,7 +436,7 @@ int prd_reverse_update(float* z, float* seq_t, int64_t* t, const float* noise_pr
 /* The whole step boundary of the sampling loop in one launch (model.py:373, 405-420 and the next step's model.py:341-346):
  * noise_pred = remove_mean(eps_raw); z, seq_t advanced as in prd_reverse_update; t <- t - 1; and the NEXT step's inputs
  * ebeta_next[b,P] = time embedding of t - 1 (prd_time_embed) and single_next[b,N,S] = prd_single_init of the new seq_t.
- * sync: TWO int32, zero before the first launch, owned by the caller and shared only by stream-ordered launches: sync[0] is the
+ * sync: TWO int32 (PRD_STEP_BOUNDARY_SYNC_INTS; ONE before PRD_VERSION 101), zero before the first launch, owned by the caller and shared only by stream-ordered launches: sync[0] is the
  * arrival counter (the last workgroup to arrive advances t and resets it); sync[1] is a STICKY non-finite flag -- set to 1, never
  * cleared by the library, as soon as a new coordinate or a new sequence entry is inf / NaN.  The reference is fp32 end to end
  * (model.py:377-422) and cannot overflow at 65504; under PRD_ARITH_SPLIT16 an out-of-range operand can (OPERAND RANGE above) and

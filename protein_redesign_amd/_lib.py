@@ -166,6 +166,9 @@ def tune_from_env(env=None) -> int:
     return t
 
 
+ABI_VERSION = 101          # include/prd_hip.h PRD_VERSION this binding is written against (101: prd_step_boundary's sync = 2 int32)
+
+
 class _Library:
     """The loaded C library plus the ONE piece of state of the host side: the arithmetic (prd_hip.h: PRD_ARITH_*) that the
     Python operators pass to every call.  The C ABI itself is stateless; ``prd_set_gemm_mode`` / ``prd_get_gemm_mode`` live
@@ -234,6 +237,9 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = cz if name in ("prd_workspace_bytes", "prd_linear_wgrad_workspace", "prd_embed_wgrad_workspace", "prd_tri_attn_stats_bytes",
                                         "prd_gemm_slab_workspace", "prd_spa_attn_core_workspace") else ci
+        if cdll.prd_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports PRD_VERSION {cdll.prd_version()}, this binding was written against {ABI_VERSION} "
+                               "(include/prd_hip.h lists what changed): rebuild with `python -m protein_redesign_amd.build`")
         mode = os.environ.get("PRD_GEMM_MODE", DEFAULT_GEMM_MODE)
         if os.environ.get("PRD_BF16X3"):                               # older spelling of PRD_GEMM_MODE=bf16x3
             mode = "bf16x3"

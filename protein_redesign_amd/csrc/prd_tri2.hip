@@ -1169,7 +1169,8 @@ size_t v3_lds_bytes(int N, int P) {
 //            Blocks go to the waves in rounds of 12; the last round of rem = nqb mod 12 blocks is shared when rem <= 6: the
 //            owner publishes Q of its block (2 KB), G = 12 / rem waves take a G-th of the keys each, partials (reference,
 //            sum, O) meet in LDS and the owner merges (nqb = 25 at N = 769: twelve waves share the 25th block).
-struct V2LLds { unsigned kh, kl, v, kadd, flag, bias, qs, part, plane; };
+struct V2LLds { unsigned kh, kl, v, kadd, flag, bias, tail, qs, part, plane; };
+constexpr int V2L_TAIL_MAX = 4;                         // a ragged last key tile of up to this many keys is swept as rank-1 updates
 
 PRD_DEV V2LLds v2l_layout(int P, int NP, int nshare) {
     V2LLds L;
@@ -1181,6 +1182,7 @@ PRD_DEV V2LLds v2l_layout(int P, int NP, int nshare) {
     L.kadd = off; off += (unsigned)NP * 4u;
     L.flag = off; off += 128u;
     L.bias = off; off += 64u;
+    L.tail = off; off += (unsigned)V2L_TAIL_MAX * 128u; // [key][hi][K 8 | V 8] fp32: the keys of a ragged last tile (rank-1 sweep)
     L.qs = off; off += (unsigned)nshare * 2048u;       // [block][qh | ql][hi][32 positions][16 B]
     L.part = off;                                      // [12 pieces][10][64] fp32
     return L;
@@ -1207,6 +1209,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
     int* tflag = reinterpret_cast<int*>(lds + L.flag);
     float* biasl = reinterpret_cast<float*>(lds + L.bias);
     float* part = reinterpret_cast<float*>(lds + L.part);
+    // Ragged last key tile (flag 64, set by the host when it holds 1 .. V2L_TAIL_MAX keys and GV): its keys are NOT swept as a 32-key
+    // tile step (7 MFMAs, 16 exponentials and splits per lane for 1-4 useful columns: N = 769 = 24 x 32 + 1, BASELINE configs[4], paid
+    // a 25th tile step in every sweep) but as rank-1 updates in fp32 from K / V rows that phase 1 leaves un-split in `tail`:
+    // s = q . k_j, p = 2^(s - ref), l += p, o += p v_j.  The tile's regular K / V planes are still written: the online redo of an
+    // overflowed piece sweeps all tiles the usual way.
+    const int ntail = (GV && (flags & 64)) ? N - 32 * (nqb - 1) : 0;
+    const float* tailkv = reinterpret_cast<const float*>(lds + L.tail);
     const int rstride = gridDim.x / H;
     int h, slot;
     if ((rstride & 7) == 0) {                           // the H heads of one row on one XCD
@@ -1343,6 +1352,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                 const unsigned po = (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
                 *reinterpret_cast<u32x4*>(lds + L.kh + po) = kh4;
                 *reinterpret_cast<u32x4*>(lds + L.kl + po) = kl4;
+                if (ntail > 0 && blk == nqb - 1 && r1 < ntail) {        // the lane's 8 K channels and 8 V channels (x 16) of a tail key, fp32
+                    float* tp = reinterpret_cast<float*>(lds + L.tail) + (r1 * 2 + hi1) * 16;
+                    *reinterpret_cast<float4*>(tp) = make_float4(akv[0], akv[1], akv[2], akv[3]);
+                    *reinterpret_cast<float4*>(tp + 4) = make_float4(akv[4], akv[5], akv[6], akv[7]);
+                    *reinterpret_cast<float4*>(tp + 8) = make_float4(akv[8], akv[9], akv[10], akv[11]);
+                    *reinterpret_cast<float4*>(tp + 12) = make_float4(akv[12], akv[13], akv[14], akv[15]);
+                }
                 const bool odd = (r1 & 1) != 0;
                 const int kp0 = r1 & 30;
                 const int a_ = kp0 >> 4, kk = kp0 & 15, kh_ = (kk >> 2) & 1, w_ = (kk >> 3) * 2 + ((kk & 3) >> 1);
@@ -1454,10 +1470,13 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             lsum = 0.f;
             bool big = false;
             if (flags & 1) v2_prio(work_rem, work_tot);
+            // the ragged last tile as rank-1 updates (a piece that consists of that tile alone has no reference yet: swept as a tile)
+            const bool tail1 = ntail > 0 && T1 == nqb && T1 - 1 > T0;
+            const int T1m = tail1 ? T1 - 1 : T1;
             {
                 KOp k = load_k(lds, kbase + 512u * T0, kl_off);
                 f32x16 s0 = qk_tile(k, qh, ql, zero);
-                if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_off);
+                if (T0 + 1 < T1m) k = load_k(lds, kbase + 512u * (T0 + 1), kl_off);
                 if ((fmask >> T0) & 1) mask_tile_at(lds, L.kadd, T0, hi, 0.f, s0);
                 const float tmax = xhalf_max(max16_mfma(s0));
                 mref = tmax - P_SHIFT;
@@ -1468,14 +1487,41 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                 ldv(T0, p);
                 exp_split(s0, lsum, big, p);
                 pv_tile(p, o0);
-                for (int t = T0 + 1; t < T1; ++t) {
+                for (int t = T0 + 1; t < T1m; ++t) {
                     if ((flags & 1) && ((t - T0) & 3) == 0) v2_prio(work_rem - (t - T0), work_tot);
                     f32x16 s = qk_tile(k, qh, ql, negm);
-                    if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_off);
+                    if (t + 1 < T1m) k = load_k(lds, kbase + 512u * (t + 1), kl_off);
                     ldv(t, p);
                     if ((fmask >> t) & 1) mask_tile_at(lds, L.kadd, t, hi, mref, s);
                     exp_split(s, lsum, big, p);
                     pv_tile(p, o0);
+                }
+            }
+            if (tail1) {
+                float qf[8];                            // the lane's 8 query channels in fp32 (hi + lo parts of the B operands)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const h16x2 a = __builtin_bit_cast(h16x2, qh[w]), c_ = __builtin_bit_cast(h16x2, ql[w]);
+                    qf[2 * w] = (float)a[0] + (float)c_[0];
+                    qf[2 * w + 1] = (float)a[1] + (float)c_[1];
+                }
+                for (int j = 0; j < ntail; ++j) {
+                    const float* tk = tailkv + (j * 2 + hi) * 16;
+                    const float4 k0 = *reinterpret_cast<const float4*>(tk), k1 = *reinterpret_cast<const float4*>(tk + 4);
+                    float sh = qf[0] * k0.x;
+                    sh = __builtin_fmaf(qf[1], k0.y, sh); sh = __builtin_fmaf(qf[2], k0.z, sh); sh = __builtin_fmaf(qf[3], k0.w, sh);
+                    sh = __builtin_fmaf(qf[4], k1.x, sh); sh = __builtin_fmaf(qf[5], k1.y, sh); sh = __builtin_fmaf(qf[6], k1.z, sh);
+                    sh = __builtin_fmaf(qf[7], k1.w, sh);
+                    const float sd = xhalf_add(sh);     // (both halves hold the whole dot product now)
+                    const float ka = kadd[32 * (nqb - 1) + j];
+                    const float sj = ((ka == 0.f) ? sd : ka) - mref;
+                    const float pj = __builtin_amdgcn_exp2f(sj);
+                    if (hi == 0) lsum += pj;            // (the halves of a query add their row sums in finish / the merge)
+                    const float4 v0 = *reinterpret_cast<const float4*>(tk + 8), v1 = *reinterpret_cast<const float4*>(tk + 12);
+                    o0[0] = __builtin_fmaf(pj, v0.x, o0[0]); o0[1] = __builtin_fmaf(pj, v0.y, o0[1]);
+                    o0[2] = __builtin_fmaf(pj, v0.z, o0[2]); o0[3] = __builtin_fmaf(pj, v0.w, o0[3]);
+                    o0[4] = __builtin_fmaf(pj, v1.x, o0[4]); o0[5] = __builtin_fmaf(pj, v1.y, o0[5]);
+                    o0[6] = __builtin_fmaf(pj, v1.z, o0[6]); o0[7] = __builtin_fmaf(pj, v1.w, o0[7]);
                 }
             }
             if (__any(big || !(lsum < 3.0e38f))) {      // rare: redo the piece with the online update in every tile
@@ -2053,7 +2099,7 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_bwd_core_v2_kernel(
 
 size_t v2l_lds_bytes(int N, int P, bool* share_out = nullptr) {
     const int NP = prd_round_up(N, 32), nqb = NP / 32, rem = nqb % 12, G = rem ? 12 / rem : 0;
-    const size_t base = (size_t)64 * P * 4 + (size_t)NP * (2 * 32 + 64 + 4) + 128 + 64;
+    const size_t base = (size_t)64 * P * 4 + (size_t)NP * (2 * 32 + 64 + 4) + 128 + 64 + (size_t)V2L_TAIL_MAX * 128;
     const size_t extra = G >= 2 ? (size_t)rem * 2048 + 12 * 2560 : 0;
     const bool share = G >= 2 && base + extra <= 160 * 1024;       // else the last round runs unshared (idle waves, same result)
     if (share_out) *share_out = share;
@@ -2125,7 +2171,12 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
     // overlapped phases (v3) an early finisher starts the next row's projection instead: 67.5 -> 65.9 us without them
     const int flags0 = flags_env >= 0 ? flags_env : (v3 ? 0 : 1);
     const int nqb_ = NP / 32, rem_ = nqb_ % 12;
-    const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0) | (PRD_TGET_TA2_NO_TAIL_SPLIT(tune) ? 32 : 0);
+    // long rows: a ragged last key tile of 1 .. V2L_TAIL_MAX keys is swept as rank-1 updates (flag 64; needs the [K|V] phase 1;
+    // A/B: PRD_TA2_FLAGS with bit 1 set keeps it a regular tile)
+    const int ntail_ = N - 32 * (nqb_ - 1);
+    const bool tail1 = long_rows && nqb_ >= 2 && ntail_ >= 1 && ntail_ <= V2L_TAIL_MAX && !PRD_TGET_TA2_NO_GV(tune) && !(flags0 & 2);
+    const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0) | (PRD_TGET_TA2_NO_TAIL_SPLIT(tune) ? 32 : 0)
+                      | (tail1 ? 64 : 0);
     if (long_rows) {
 #define PRD_V2L_LAUNCH(PP, PF, GVF)                                                                                               \
         do {                                                                                                                      \

@@ -213,6 +213,7 @@ class ProteinReDiffModel(_Base):
         self.nonfinite_policy = "fp32"
         self.arithmetic = None                  # None: the process default (_lib); "fp32" / "split16": this model's calls pin it
         self.arith_fallbacks = 0                # how many calls were repeated in fp32 by the policy above
+        self.nonfinite_group = None             # process group over which a non-finite verdict is agreed (None: the default group)
         self._side = None                       # ops.SideStream of the device the model runs on (created on first use)
         self._sample_counter = 0
 
@@ -366,7 +367,7 @@ class ProteinReDiffModel(_Base):
 
         with _lib.arithmetic(self.arithmetic):
             loss = forward_loss()
-        if check_finite and self.nonfinite_policy != "off" and loss.is_cuda and not bool(torch.isfinite(loss.detach())):
+        if check_finite and self.nonfinite_policy != "off" and loss.is_cuda and self._any_rank(not bool(torch.isfinite(loss.detach()))):
             loss = self._nonfinite_training_step(forward_loss)
         self.log("train_loss", loss, on_step=True, on_epoch=True, sync_dist=True, batch_size=x.size(0))
         return loss
@@ -374,26 +375,42 @@ class ProteinReDiffModel(_Base):
     def _current_arith(self) -> int:
         return _lib.GEMM_MODES[self.arithmetic] if self.arithmetic is not None else _lib.arith()
 
+    def _any_rank(self, flag: bool) -> bool:
+        """``flag`` OR-ed over the data-parallel ranks (``self.nonfinite_group``, default: the default process group) so that every
+        rank takes the SAME branch of the non-finite policy: a rank that alone switched arithmetic would train a different model, and
+        a rank that alone raised would leave the others waiting in the gradient all-reduce."""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return flag
+        group = getattr(self, "nonfinite_group", None)
+        if torch.distributed.get_world_size(group) < 2:
+            return flag
+        dev = self.device if torch.distributed.get_backend(group) == "nccl" else "cpu"
+        f = torch.tensor([1.0 if flag else 0.0], device=dev)
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX, group=group)
+        return bool(f.item() != 0)
+
     def _nonfinite_training_step(self, forward_loss):
-        """The loss of a training step came out inf / NaN.  Under split-16 arithmetic with policy "fp32": the PROCESS default
-        becomes PRD_ARITH_FP32 from here on (the backward of the returned loss runs after this function returns and reads the
-        default when it runs -- a scoped switch would put the split-16 backward kernels behind an fp32 forward) and the forward is
-        repeated; anything else raises."""
+        """The loss of a training step came out inf / NaN (on this rank or on another one: ``_any_rank``).  Under split-16 arithmetic
+        with policy "fp32": THIS MODEL is pinned to PRD_ARITH_FP32 from here on (``self.arithmetic``, as sample()'s fallback does; the
+        process default is left alone) and the forward is repeated under it.  The backward of the returned loss runs after this
+        function returns; every autograd node of training.py records the arithmetic of its forward and re-enters it in its backward
+        (training._pin_arithmetic), so the fp32 forward gets fp32 recomputes and fp32 backward kernels.  Anything else raises."""
         import warnings
         cur = self._current_arith()
         if cur == 1 and self.nonfinite_policy == "fp32":
             warnings.warn("training_step: non-finite loss under split-16 arithmetic (an operand beyond the fp16 range: include/prd_hip.h, "
-                          "OPERAND RANGE); switching this process to PRD_ARITH_FP32 and repeating the step", RuntimeWarning, stacklevel=3)
-            self.arithmetic = None
-            _lib.lib().prd_set_gemm_mode(0)
+                          "OPERAND RANGE); pinning this model to PRD_ARITH_FP32 and repeating the step", RuntimeWarning, stacklevel=3)
+            self.arithmetic = "fp32"
             self.arith_fallbacks += 1
-            loss = forward_loss()
-            if bool(torch.isfinite(loss.detach())):
+            with _lib.arithmetic("fp32"):
+                loss = forward_loss()
+            if not self._any_rank(not bool(torch.isfinite(loss.detach()))):
                 return loss
             cur = 0
         raise _lib.NonFiniteError(f"training_step: non-finite loss under {_lib.ARITH_NAMES[cur]} arithmetic"
-                                  + (" (the fp32 repeat of a non-finite split-16 step)" if self.arith_fallbacks else "")
-                                  + ": the weights / inputs themselves produce inf or NaN")
+                                  + (" (the fp32 repeat of a non-finite split-16 step)" if self.arith_fallbacks and cur == 0 else "")
+                                  + (": outside the operand range of the split arithmetic (include/prd_hip.h); set model.arithmetic = 'fp32' "
+                                     "or nonfinite_policy = 'fp32'" if cur == 1 else ": the weights / inputs themselves produce inf or NaN"))
 
     def predict_step(self, batch, batch_idx):
         with self.ema.average_parameters(self.parameters()):

@@ -190,8 +190,9 @@ class PDBDataModule:
     the cache); 0 reproduces the reference's free shuffling."""
 
     def __init__(self, data_dir: Union[str, Path] = "data", batch_size: int = 1, num_workers: int = 1, bucket_width: int = 32,
-                 world_size: int = 1, rank: int = 0, seed: int = 0):
+                 world_size: int = 1, rank: int = 0, seed: int = 0, group=None):
         self.data_dir = Path(data_dir)
+        self.group = group                  # process group of the data-parallel ranks (None: the default group) -- _train_sizes
         self.cache_dir = self.data_dir / "PDB_processed_cache"
         self.batch_size, self.num_workers, self.bucket_width = batch_size, num_workers, bucket_width
         self.world_size, self.rank, self.seed = world_size, rank, seed
@@ -224,8 +225,9 @@ class PDBDataModule:
         """num_atoms + num_residues of every training complex.  Read from ``<cache>/sizes_index.json`` where an entry's
         FINGERPRINT -- (mtime_ns, size) of the complex's two cache files -- still matches: a cache that was re-preprocessed
         (other cropping / featurisation) is re-scanned instead of driving the buckets with stale sizes.  Under an initialised
-        process group rank 0 alone scans and writes the index, the other ranks wait at a barrier and read it (ranks that start
-        together on a shared cache neither scan it N times nor overwrite each other's file).  Best effort on a read-only cache:
+        process group rank 0 alone scans and writes the index and broadcasts its verdict, the other ranks then read the file (ranks that
+        start together on a shared cache neither scan it N times nor overwrite each other's file; a scan that raises on rank 0 raises
+        on every rank instead of leaving the others in a barrier).  Best effort on a read-only cache:
         it is scanned every time."""
         import json
         index_path = self.cache_dir / "sizes_index.json"
@@ -271,10 +273,24 @@ class PDBDataModule:
         if not distributed:
             index = scan_and_store(load())
         else:
-            if torch.distributed.get_rank() == 0:
-                index = scan_and_store(load())
-            torch.distributed.barrier()
-            if torch.distributed.get_rank() != 0:
+            # Rank 0 scans; its verdict travels as an object broadcast (which is also the rendezvous: a bare barrier would leave the
+            # other ranks waiting for ever when rank 0's scan raises -- a corrupt cache item -- and, with NCCL, needs a device already
+            # set).  ``self.group`` (None: the default group) is the group the loaders of this module are sharded over.
+            group = getattr(self, "group", None)
+            rank = torch.distributed.get_rank(group)
+            verdict = [None]
+            index = None
+            if rank == 0:
+                try:
+                    index = scan_and_store(load())
+                    verdict = [("ok", None)]
+                except Exception as exc:                # noqa: BLE001 -- re-raised on every rank below
+                    verdict = [("error", f"{type(exc).__name__}: {exc}")]
+            src = torch.distributed.get_global_rank(group, 0) if group is not None else 0
+            torch.distributed.broadcast_object_list(verdict, src=src, group=group)
+            if verdict[0][0] != "ok":
+                raise RuntimeError(f"PDBDataModule: rank 0 failed while scanning the cache for complex sizes ({verdict[0][1]})")
+            if rank != 0:
                 index = load()
                 if any(pid not in index or index[pid][1] != fingerprint(pid) for pid in ds.pdb_ids):
                     index = scan_and_store(index)       # rank 0 could not write (read-only cache): scan here too

@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 from torch.utils.checkpoint import checkpoint
 
+from . import _lib
 from . import ops
 from . import torch_ref as R
 
@@ -43,6 +44,37 @@ FUSED_RESIDUAL = os.environ.get("PRD_TRAIN_FUSED_RESIDUAL", "1") != "0"
 PAIR_BIAS_BWD = os.environ.get("PRD_PAIR_BIAS_BWD", "1") != "0"
 
 
+def _forward_arith() -> Optional[int]:
+    try:
+        return _lib.arith()
+    except RuntimeError:            # library not built (host-only tests of the restatement): nothing to pin
+        return None
+
+
+def _pin_arithmetic(cls):
+    """Class decorator for the operator nodes below: the arithmetic (prd_hip.h PRD_ARITH_*) in force when the node's FORWARD ran is
+    recorded in ``ctx`` and put back in force around its BACKWARD.  The binding injects the *current* default into every library
+    call, and autograd runs a backward long after the ``with _lib.arithmetic(...)`` of ``training_step`` has exited: without the pin a
+    model held to "fp32" (``model.arithmetic``, or sample()'s fallback) ran its recompute and its hand-written backward kernels in
+    split-16 -- the operand overflow the pin is there to avoid came back in the gradients."""
+    import functools
+    f, b = cls.__dict__["forward"].__func__, cls.__dict__["backward"].__func__
+
+    @functools.wraps(f)
+    def forward(ctx, *args, **kwargs):
+        ctx.prd_arith = _forward_arith()
+        return f(ctx, *args, **kwargs)
+
+    @functools.wraps(b)
+    def backward(ctx, *gouts):
+        with _lib.arithmetic(getattr(ctx, "prd_arith", None)):
+            return b(ctx, *gouts)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+@_pin_arithmetic
 class HipOp(torch.autograd.Function):
     """``HipOp.apply(fwd, ref, *tensors)``: ``fwd(*tensors)`` runs HIP kernels (no autograd), ``ref(*tensors)`` is the same
     operator in differentiable torch ops and is only evaluated inside ``backward``.  Both return one tensor or a tuple."""
@@ -70,6 +102,7 @@ class HipOp(torch.autograd.Function):
         return (None, None) + tuple(next(it) if i.requires_grad else None for i in ins)
 
 
+@_pin_arithmetic
 class InputStageFn(torch.autograd.Function):
     """The input stage (model.py:332-361) with a hand-written backward of its PAIR half.  Forward: the HIP input kernels.  Backward:
     the single half (a few [b, N, S] operators) through its torch restatement; the pair half without an autograd graph over
@@ -148,6 +181,7 @@ class InputStageFn(torch.autograd.Function):
         return (None, None, *grads)
 
 
+@_pin_arithmetic
 class HeadsFn(torch.autograd.Function):
     """The two heads (modules.py:403 + model.py:364-374) with a hand-written backward of the coordinate head.  Forward: the HIP
     kernels.  Backward: the sequence head (single-sized) through its torch restatement; the coordinate head without an autograd graph
@@ -197,6 +231,7 @@ class HeadsFn(torch.autograd.Function):
         return (None, None, None, gs, gp, *gw)
 
 
+@_pin_arithmetic
 class PairTransitionFn(torch.autograd.Function):
     """pair_fc (modules.py:321-326): y = W2 relu(W1 LN(x) + b1) + b2 at every pair position.  Forward: the row kernel of the
     inference path.  Backward entirely on the library's kernels (no torch restatement, no autograd graph over [b N N, 256]
@@ -235,6 +270,7 @@ class PairTransitionFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None
 
 
+@_pin_arithmetic
 class PairBiasFn(torch.autograd.Function):
     """attn_bias of a folding block (modules.py:300-304): bias[b,h,i,j] = (W LN(pair[b,i,j]) + c)[h], and SPAttention's pair bias
     (AF2_modules.py:454-459): the same with an affine LayerNorm (gamma, beta) and no c.  Backward on the library's kernels:
@@ -275,6 +311,7 @@ class PairBiasFn(torch.autograd.Function):
         return dx.view_as(pair), dw, (dcf if ctx.has_c else None), dgamma, dbeta
 
 
+@_pin_arithmetic
 class OuterLinearFn(torch.autograd.Function):
     """OuterLinear (modules.py:283-287) in the split form out[i,j] = W1 (x_i * x_j) + u_i - u_j + c, x = LN(single), u = W2 x.
     Forward: the HIP kernels of the inference path.  Backward without re-running the forward and without a [b,N,N,S] tensor:
@@ -323,6 +360,7 @@ class OuterLinearFn(torch.autograd.Function):
         return dsingle, torch.cat([dw1, dw2], dim=1), dc, None, (dy if ctx.residual else None)
 
 
+@_pin_arithmetic
 class TriMulFn(torch.autograd.Function):
     """TriangleMultiplication update with a hand-written backward (csrc/prd_bwd.hip through ops.tri_mul_backward): output-stage and
     projection-stage row kernels, the two gradient contractions on the forward contraction kernel; only the weight-gradient
@@ -353,6 +391,7 @@ class TriMulFn(torch.autograd.Function):
         return (dpair, None, None, None, *grads)
 
 
+@_pin_arithmetic
 class TriAttnFn(torch.autograd.Function):
     """TriangleAttention update with a hand-written backward (ops.tri_attn_backward: out-projection backward, flash-style attention
     core backward per (row, head), projection + LayerNorm backward on HIP kernels; weight-gradient reductions through BLAS).
@@ -580,8 +619,11 @@ def network(model, batch: Dict[str, torch.Tensor], z: torch.Tensor, seq_t: torch
     # ---- folding blocks, each under activation checkpointing like the reference (modules.py:399-401) ----
     for blk in den.folding_blocks:
         if use_checkpoint and pair.requires_grad:
-            single, pair = checkpoint(lambda s_, p_, blk=blk: folding_block(blk, s_, p_, mask), single, pair,
-                                      use_reentrant=False)
+            def run_block(s_, p_, blk=blk, mode=_forward_arith()):
+                # the recompute inside the backward pass runs in the arithmetic of the forward (see _pin_arithmetic)
+                with _lib.arithmetic(mode):
+                    return folding_block(blk, s_, p_, mask)
+            single, pair = checkpoint(run_block, single, pair, use_reentrant=False)
         else:
             single, pair = folding_block(blk, single, pair, mask)
 
@@ -728,17 +770,17 @@ class Fitter:
             return
         self.skipped_steps += 1
         import warnings
-        from . import _lib
         pol = getattr(self.model, "nonfinite_policy", "raise")
-        if pol == "fp32" and _lib.arith() == 1:
+        cur = self.model._current_arith() if hasattr(self.model, "_current_arith") else _lib.arith()
+        if pol == "fp32" and cur == 1:
+            # (the flag is the all-reduced found_inf: every rank takes this branch together)
             warnings.warn("fit: an optimisation step produced non-finite loss / gradients under split-16 arithmetic (skipped on the "
-                          "device, parameters untouched); switching this process to PRD_ARITH_FP32", RuntimeWarning, stacklevel=3)
-            _lib.lib().prd_set_gemm_mode(0)
-            self.model.arithmetic = None
+                          "device, parameters untouched); pinning the model to PRD_ARITH_FP32", RuntimeWarning, stacklevel=3)
+            self.model.arithmetic = "fp32"
             self.model.arith_fallbacks += 1
             return
         if pol != "off":
-            raise _lib.NonFiniteError(f"fit: non-finite loss / gradients under {_lib.ARITH_NAMES[_lib.arith()]} arithmetic; the optimiser "
+            raise _lib.NonFiniteError(f"fit: non-finite loss / gradients under {_lib.ARITH_NAMES[cur]} arithmetic; the optimiser "
                                       "step was skipped on the device (parameters untouched)")
 
     def step(self, batch, batch_idx: int, **step_kwargs) -> torch.Tensor:
@@ -797,23 +839,42 @@ class Fitter:
         return losses
 
 
+def _cached_fitter(model, optimizer, scheduler, group, k: int) -> "Fitter":
+    """The Fitter behind ``fit_step`` for this (model, optimizer): kept on the model object, rebuilt when the optimiser, the
+    scheduler, the group or k changes (a pending incomplete group of the old one is flushed first)."""
+    store = model.__dict__.setdefault("_prd_fitters", {})
+    f = store.get(id(optimizer))
+    if f is not None and (f.optimizer is not optimizer or f.scheduler is not scheduler or f.group is not group or f.k != k):
+        if f.optimizer is optimizer:
+            f.finish_accumulation()
+        f = None
+    if f is None:
+        f = store[id(optimizer)] = Fitter(model, optimizer, scheduler, group, accumulate_grad_batches=k)
+    return f
+
+
 def fit_step(model, batch, batch_idx: int, optimizer, scheduler=None, group: Optional[dist.ProcessGroup] = None,
              accumulate_grad_batches: int = 1, **step_kwargs) -> torch.Tensor:
     """One MICRO-batch of the optimisation the way ``train.py`` drives it through Lightning: training_step -> backward of
-    loss / k; on every k-th micro-batch (``(batch_idx + 1) % k == 0``, k = ``accumulate_grad_batches``, train.py:57) gradient average
-    over the data-parallel ranks -> Adam step -> LinearLR step -> EMA update (model.py:203-217, 528-549).  Stateless convenience
-    form of ``Fitter`` (which adds the device-side non-finite guard); with k = 1 every call is a full optimisation step."""
+    loss / k; on every k-th micro-batch (k = ``accumulate_grad_batches``, train.py:57) gradient average over the data-parallel
+    ranks -> Adam step -> LinearLR step -> EMA update (model.py:203-217, 528-549).  Convenience form of ``Fitter``: the call goes
+    to a Fitter cached on the model for this optimiser, so the group boundaries follow the COUNT of micro-batches seen (not
+    ``batch_idx % k``: a loader may start anywhere), a non-finite step is skipped on the device without a host read-back per
+    micro-batch, and ``fit_flush`` steps a trailing incomplete group at the end of an epoch as Lightning does.  With k = 1 every call
+    is a full optimisation step."""
     k = int(accumulate_grad_batches)
     if k < 1:
         raise ValueError("accumulate_grad_batches must be >= 1")
-    if batch_idx % k == 0:
-        optimizer.zero_grad(set_to_none=True)
-    loss = model.training_step(batch, batch_idx, **step_kwargs)
-    (loss / k if k > 1 else loss).backward()
-    if (batch_idx + 1) % k == 0:
-        all_reduce_gradients(list(model.parameters()), group)
-        optimizer.step()
-        if scheduler is not None:
-            scheduler.step()
-        model.ema.update(model.parameters())
-    return loss.detach()
+    return _cached_fitter(model, optimizer, scheduler, group, k).step(batch, batch_idx, **step_kwargs)
+
+
+def fit_flush(model, optimizer) -> int:
+    """End of an epoch for the ``fit_step`` form: optimiser step for a trailing incomplete group of micro-batches (Lightning flushes
+    it; nothing happens when none is pending) and read-back of the last step's non-finite flag.  Returns the number of optimiser
+    steps taken so far."""
+    f = model.__dict__.get("_prd_fitters", {}).get(id(optimizer))
+    if f is None or f.optimizer is not optimizer:
+        return 0
+    f.finish_accumulation()
+    f._settle()
+    return f.optimizer_steps

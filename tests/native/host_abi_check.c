@@ -34,6 +34,7 @@ int main(void) {
     float* p = buf;
     hipStream_t s = 0;
     EXPECT(prd_version(), PRD_VERSION);
+    EXPECT(PRD_VERSION >= 101 && PRD_STEP_BOUNDARY_SYNC_INTS == 2, 1);      /* the sync buffer of prd_step_boundary: two int32 since 101 */
     const int A1 = PRD_ARITH_SPLIT16, A0 = PRD_ARITH_FP32;     /* the arithmetic is an argument of every call: no library state */
     PrdGemm g;
     memset(&g, 0, sizeof g);

@@ -1056,6 +1056,48 @@ def test_triangle_attention_long_rows_split_tail(setup, mode, b, N, gemm_mode):
         lib.prd_set_tune(tune0)
 
 
+@pytest.mark.parametrize("mode", ["starting", "ending"])
+@pytest.mark.parametrize("N,masked_from", [(385, 385), (386, 385), (387, 380), (388, 388), (417, 416)])
+def test_triangle_attention_long_rows_ragged_key_tail(setup, mode, N, masked_from, gemm_mode):
+    """tri_attn_core_v2l: a last key tile of 1 .. 4 keys (N = 769 = 24 x 32 + 1 is BASELINE configs[4]) is swept as rank-1 updates in
+    fp32 instead of a 32-key tile step.  Whole tensor against the oracle for 1, 2, 3 and 4 tail keys -- all valid, some masked (386: the
+    second one; 387: all three and five keys before them), 417 = 13 x 32 + 1 with its lone tail key masked -- and the same with the tail
+    swept as a regular tile (PRD_TA2_FLAGS bit 1), which must agree with the rank-1 form far below the tolerance."""
+    s = setup
+    P = s["P"]
+    H, c = s["args"]["num_heads"], s["args"]["head_dim"]
+    if gemm_mode == "split16":
+        assert _lib.lib().prd_tri_attn_v2_form(N, P) == 3
+    g = torch.Generator().manual_seed(11 * N + (mode == "ending"))
+    pair = torch.randn(1, N, N, P, generator=g)
+    mask = torch.ones(1, N)
+    mask[0, masked_from:] = 0
+    m2 = mask.unsqueeze(-1) * mask.unsqueeze(-2)
+    pfx = f"Denoiser.folding_blocks.0.pair_attn_{mode}"
+    src, msrc = (pair, m2) if mode == "starting" else (pair.transpose(1, 2), m2.transpose(1, 2))
+    want = torch.empty(1, N, N, P)
+    with torch.inference_mode():
+        for r0 in range(0, N, 64):
+            want[:, r0:r0 + 64] = O.gated_attention(s["params"], pfx + ".attn", src[:, r0:r0 + 64].contiguous(), msrc[:, r0:r0 + 64].contiguous(), H, c)
+    mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
+    lib = _lib.lib()
+    tune0 = lib.prd_get_tune()
+    outs = []
+    try:
+        for tune in (tune0, tune0 | (1 << 6) | (3 << 7)):        # default | PRD_TA2_FLAGS = 3: priorities + the tail as a regular tile
+            lib.prd_set_tune(tune)
+            got = mod.run(cu(pair), cu(mask), residual=False).cpu()
+            if mode == "ending":
+                got = got.transpose(1, 2)
+            assert rel_l2(got, want) < OP_TOL
+            row_err = (got - want).flatten(2).norm(dim=2) / want.flatten(2).norm(dim=2).clamp_min(1e-30)
+            assert float(row_err.max()) < 2 * OP_TOL, (tune, int(row_err.argmax()))
+            outs.append(got)
+    finally:
+        lib.prd_set_tune(tune0)
+    assert rel_l2(outs[0], outs[1]) < 2e-6
+
+
 def test_eight_complexes_per_gpu_equal_single_runs(gemm_mode):
     """BASELINE configs[2] per-GPU share: b = 8 complexes of the N = 320 shape (4 blocks) through the first three steps of the
     reverse loop (eager step, graph capture, replay) == each sample run alone; and sample 0 against the oracle's first step."""

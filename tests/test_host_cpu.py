@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/prd_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding table out of sync with the header"
-    assert L.prd_version() == 100
+    assert L.prd_version() == 101      # 101: prd_step_boundary's sync buffer is two int32 (include/prd_hip.h)
 
 
 def test_workspace_query_is_host_only():

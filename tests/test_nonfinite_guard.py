@@ -88,8 +88,8 @@ def test_in_range_model_never_trips(split16):
     assert int(loop.sync[1]) == 0 and loop.finite()
 
 
-def test_training_step_repeats_in_fp32_and_meets_the_oracle(split16):
-    model, args, params = out_of_range_model(num_steps=50, train=True)
+def _oracle_step(args, params):
+    """One training step of the out-of-range network on the oracle: (batch, t, noises, leaf tensors with .grad, loss)."""
     batch = synthetic_batch([(4, 18), (3, 14)], esm_dim=16, seed=6, n_total=24)
     perms = [NoiseSource(1, k).randperm(n) for k, n in enumerate((18, 14))]
     pb = O.prepare_batch(clone_batch(batch), args["mask_prob"], perms)
@@ -101,23 +101,76 @@ def test_training_step_repeats_in_fp32_and_meets_the_oracle(split16):
     want = oracle_training_loss(leaf, args, pb, t, nz, ns)
     want.backward()
     assert torch.isfinite(want)
+    return batch, t, nz, ns, leaf, want
+
+
+def _assert_gradients_meet_the_oracle(model, leaf, what):
+    worst = 0.0
+    scale = float(torch.cat([v.grad.reshape(-1) for v in leaf.values() if v.grad is not None]).double().norm())
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), (what, k)
+        w = leaf[k].grad.double()
+        err = float((p.grad.detach().cpu().double() - w).norm())
+        assert err < 1e-4 * float(w.norm()) + 1e-6 * scale, (what, k, err, float(w.norm()))
+        worst = max(worst, err / max(float(w.norm()), 1e-3 * scale))
+    print(f"\n{what}: worst gradient rel-L2 vs oracle autograd {worst:.2e}")
+
+
+@pytest.mark.parametrize("checkpoint", [False, True])
+def test_model_pinned_to_fp32_runs_its_backward_in_fp32(split16, checkpoint, monkeypatch):
+    """``model.arithmetic = "fp32"`` used to cover the forward only -- autograd runs the backward after training_step's
+    ``with`` has exited, and the recompute / the hand-written backward kernels then read the split-16 process default: finite loss, NaN
+    gradients for exactly the models the pin is for.  Every node now carries the arithmetic of its forward.  Tolerance as everywhere:
+    each gradient <= 1e-4 of its norm against the oracle's autograd."""
+    monkeypatch.setattr(training, "USE_CHECKPOINT", checkpoint)
+    model, args, params = out_of_range_model(num_steps=50, train=True)
+    model.arithmetic = "fp32"
+    model.nonfinite_policy = "raise"
+    batch, t, nz, ns, leaf, want = _oracle_step(args, params)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        loss = model.training_step(batch_to(clone_batch(batch), DEV), 0, t=t.to(DEV), noise_z=nz.to(DEV), noise_seq=ns.to(DEV),
+                                   sources=[NoiseSource(1, k) for k in range(2)])
+    assert abs(float(loss.detach()) - float(want.detach())) < 1e-4 * abs(float(want.detach()))
+    assert _lib.lib().prd_get_gemm_mode() == 1          # the process default is split-16 while the backward runs
+    loss.backward()
+    assert _lib.lib().prd_get_gemm_mode() == 1
+    _assert_gradients_meet_the_oracle(model, leaf, f"model pinned to fp32, checkpoint={checkpoint}")
+
+
+def test_sample_fallback_then_training_stays_in_fp32(split16):
+    """sample()'s fallback pins the model; a training step of the same object afterwards must be fp32 end to end (no second warning,
+    finite gradients that meet the oracle)."""
+    model, args, params = out_of_range_model(num_steps=50)
+    one = synthetic_batch([(5, 27)], esm_dim=16, seed=3)
+    with pytest.warns(RuntimeWarning, match="PRD_ARITH_FP32"):
+        model.sample(batch_to(clone_batch(one), DEV), sources=[NoiseSource(9, 0)])
+    assert model.arithmetic == "fp32"
+    model.train()
+    batch, t, nz, ns, leaf, want = _oracle_step(args, params)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        loss = model.training_step(batch_to(clone_batch(batch), DEV), 0, t=t.to(DEV), noise_z=nz.to(DEV), noise_seq=ns.to(DEV),
+                                   sources=[NoiseSource(1, k) for k in range(2)])
+        loss.backward()
+    assert model.arith_fallbacks == 1
+    _assert_gradients_meet_the_oracle(model, leaf, "sample() fallback, then training_step")
+
+
+def test_training_step_repeats_in_fp32_and_meets_the_oracle(split16):
+    model, args, params = out_of_range_model(num_steps=50, train=True)
+    batch, t, nz, ns, leaf, want = _oracle_step(args, params)
     try:
         with pytest.warns(RuntimeWarning, match="PRD_ARITH_FP32"):
             loss = model.training_step(batch_to(clone_batch(batch), DEV), 0, t=t.to(DEV), noise_z=nz.to(DEV), noise_seq=ns.to(DEV),
                                        sources=[NoiseSource(1, k) for k in range(2)])
-        assert torch.isfinite(loss) and abs(float(loss) - float(want)) < 1e-4 * abs(float(want))
-        assert _lib.lib().prd_get_gemm_mode() == 0, "the backward of the repeated step must run in fp32 too: the process default moves"
+        assert torch.isfinite(loss) and abs(float(loss.detach()) - float(want.detach())) < 1e-4 * abs(float(want.detach()))
+        assert model.arithmetic == "fp32" and model.arith_fallbacks == 1
+        assert _lib.lib().prd_get_gemm_mode() == 1, "the repeat pins the MODEL; the process default stays (the nodes carry their arithmetic)"
         loss.backward()
-        worst = 0.0
-        scale = float(torch.cat([v.grad.reshape(-1) for v in leaf.values() if v.grad is not None]).double().norm())
-        for k, p in model.named_parameters():
-            if not p.requires_grad:
-                continue
-            w = leaf[k].grad.double()
-            err = float((p.grad.detach().cpu().double() - w).norm())
-            assert err < 1e-4 * float(w.norm()) + 1e-6 * scale, (k, err, float(w.norm()))
-            worst = max(worst, err / max(float(w.norm()), 1e-3 * scale))
-        print(f"\nrepeated training step: worst gradient rel-L2 vs oracle autograd {worst:.2e}")
+        _assert_gradients_meet_the_oracle(model, leaf, "repeated training step")
     finally:
         _lib.lib().prd_set_gemm_mode(1)
 
@@ -146,7 +199,7 @@ def test_fitter_skips_the_step_on_the_device_and_moves_to_fp32(split16):
         assert all(torch.equal(a, b) for a, b in zip(before, model.parameters())), "a non-finite step must not move the parameters"
         with pytest.warns(RuntimeWarning, match="PRD_ARITH_FP32"):
             l1 = fitter.step(clone_batch(batch), 1)
-        assert fitter.skipped_steps == 1 and _lib.lib().prd_get_gemm_mode() == 0
+        assert fitter.skipped_steps == 1 and model.arithmetic == "fp32" and _lib.lib().prd_get_gemm_mode() == 1
         l2 = fitter.step(clone_batch(batch), 2)
         assert torch.isfinite(l1) and torch.isfinite(l2)
         assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))

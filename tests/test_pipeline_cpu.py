@@ -196,3 +196,50 @@ def test_pdb_datamodule_round_trip(tmp_path):
         dmr.set_epoch(1)
         seen.append(sorted(pid for bt in loader for pid in bt["pdb_id"]))
     assert len(seen[0]) == len(seen[1]) == 3 and sorted(seen[0] + seen[1]) == sorted(ids[:6])
+
+
+def _sizes_worker(rank, world, port, data_dir, out_dir):
+    import torch.distributed as dist
+    from protein_redesign_amd.pipeline import PDBDataModule, PDBDataset
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dm = PDBDataModule(data_dir, batch_size=1, num_workers=0, bucket_width=8, world_size=world, rank=rank)
+    dm.setup()
+    out = {}
+    # (1) a scan that raises on rank 0 (a corrupt cache item) raises on EVERY rank -- nobody is left waiting in a collective
+    broken = type("D", (), {"pdb_ids": dm.train_pdb_ids, "__getitem__": lambda self, i: 1 / 0})()
+    try:
+        dm._train_sizes(broken)
+        out["raised"] = None
+    except RuntimeError as exc:
+        out["raised"] = str(exc)
+    # (2) the healthy path: rank 0 scans and writes, the others read the same sizes
+    out["sizes"] = dm._train_sizes(PDBDataset(dm.cache_dir, dm.train_pdb_ids))
+    torch.save(out, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_train_sizes_scan_failure_reaches_every_rank(tmp_path):
+    """rank 0 scanned behind a bare barrier; when its scan raised, the other ranks waited for ever.  The verdict now
+    travels by broadcast_object_list and is re-raised everywhere (gloo, world size 2)."""
+    import torch.multiprocessing as mp
+    from protein_redesign_amd.synthetic import synthetic_sample
+    data = tmp_path / "data"
+    cache = data / "PDB_processed_cache"
+    ids = [f"c{k:02d}" for k in range(4)]
+    for k, pid in enumerate(ids):
+        d = synthetic_sample(3 + k, 6 + 2 * k, esm_dim=8, seed=k)
+        (cache / pid).mkdir(parents=True)
+        torch.save({kk: v for kk, v in d.items() if kk.startswith(("atom", "bond", "num_atoms"))}, cache / pid / "ligand_data.pt")
+        torch.save({kk: v for kk, v in d.items() if kk.startswith(("residue", "num_residues"))}, cache / pid / "protein_data.pt")
+    for name in ("PRD_train_pdb_ids", "PRD_val_pdb_ids", "PRD_test_pdb_ids"):
+        (data / name).write_text("\n".join(ids) + "\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    port = 29700 + (os.getpid() % 200)
+    mp.spawn(_sizes_worker, args=(2, port, str(data), str(out)), nprocs=2, join=True)
+    r0, r1 = (torch.load(out / f"s{r}.pt") for r in range(2))
+    for r in (r0, r1):
+        assert r["raised"] is not None and "rank 0 failed" in r["raised"] and "ZeroDivisionError" in r["raised"]
+    assert r0["sizes"] == r1["sizes"] == [3 + k + 6 + 2 * k for k in range(4)]
