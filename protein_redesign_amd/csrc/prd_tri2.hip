@@ -1499,11 +1499,15 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             }
             if (tail1) {
                 float qf[8];                            // the lane's 8 query channels in fp32 (hi + lo parts of the B operands)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const h16x2 a = __builtin_bit_cast(h16x2, qh[w]), c_ = __builtin_bit_cast(h16x2, ql[w]);
-                    qf[2 * w] = (float)a[0] + (float)c_[0];
-                    qf[2 * w + 1] = (float)a[1] + (float)c_[1];
+                {   // (explicit half-word extraction: indexing the operand vector inside an unrolled loop and bit-casting the word to a
+                    // 2 x fp16 vector compiled to four copies of word 0 with hipcc 7.2 -- found by the parity tests)
+                    auto lo16 = [](unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); };
+                    auto hi16 = [](unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); };
+                    const unsigned h0 = qh[0], h1 = qh[1], h2 = qh[2], h3 = qh[3], l0 = ql[0], l1 = ql[1], l2 = ql[2], l3 = ql[3];
+                    qf[0] = lo16(h0) + lo16(l0); qf[1] = hi16(h0) + hi16(l0);
+                    qf[2] = lo16(h1) + lo16(l1); qf[3] = hi16(h1) + hi16(l1);
+                    qf[4] = lo16(h2) + lo16(l2); qf[5] = hi16(h2) + hi16(l2);
+                    qf[6] = lo16(h3) + lo16(l3); qf[7] = hi16(h3) + hi16(l3);
                 }
                 for (int j = 0; j < ntail; ++j) {
                     const float* tk = tailkv + (j * 2 + hi) * 16;

@@ -22,6 +22,26 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+def mismatch_report(got, want, rerun=None, limit=8):
+    """Assertion message for a failed whole-tensor comparison: HOW MANY elements are off by more than 1e-3 of the rms of ``want``, WHERE
+    the first of them sit, and -- with ``rerun`` (a callable that evaluates the GPU operator again) -- whether a second launch
+    reproduces ``got`` bit for bit (a deterministic error of the kernel) or not (a race, or a box that drops bits).  The kernels are
+    deterministic by construction (static task order, no atomics on the data path), so the second case never is "noise"."""
+    got, want = torch.as_tensor(got), torch.as_tensor(want)
+    d = (got.double() - want.double()).abs()
+    rms = float(want.double().pow(2).mean().sqrt())
+    bad = torch.nonzero(d > 1e-3 * rms)
+    msg = f"rel-L2 {rel_l2(got, want):.3e}; {bad.shape[0]} of {d.numel()} elements off by > 1e-3 rms; first at {bad[:limit].tolist()}"
+    if not torch.isfinite(got).all():
+        msg += f"; {int((~torch.isfinite(got)).sum())} non-finite"
+    if rerun is not None:
+        again = torch.as_tensor(rerun())
+        same = torch.equal(again, got)
+        msg += ("; a second launch reproduces it bit for bit" if same else
+                f"; a second launch DIFFERS (rel-L2 of the second one against the oracle {rel_l2(again, want):.3e}): race or faulty box")
+    return msg
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import prd_oracle as O
-from conftest import rel_l2
+from conftest import mismatch_report, rel_l2
 from protein_redesign_amd import _lib, ops
 from protein_redesign_amd.constants import make_args
 from protein_redesign_amd.diffusion_model import ProteinReDiffModel
@@ -981,9 +981,11 @@ def test_triangle_attention_long_rows(setup, mode, N, valid, gemm_mode):
             sub, msub = pair[:, :, rows].transpose(1, 2), m2[:, :, rows].transpose(1, 2)
         want = O.gated_attention(s["params"], pfx + ".attn", sub, msub, H, c)          # [1, rows, N, P]
     mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
-    got = mod.run(cu(pair), cu(mask), residual=False).cpu()
-    got = got[:, rows] if mode == "starting" else got[:, :, rows].transpose(1, 2)
-    assert rel_l2(got, want) < OP_TOL
+    def evaluate():
+        full = mod.run(cu(pair), cu(mask), residual=False).cpu()
+        return full[:, rows] if mode == "starting" else full[:, :, rows].transpose(1, 2)
+    got = evaluate()
+    assert rel_l2(got, want) < OP_TOL, mismatch_report(got, want, evaluate)
     for k in range(len(rows)):                       # no single row may hide behind the aggregate
         assert rel_l2(got[:, k], want[:, k]) < 2 * OP_TOL, rows[k]
 
@@ -1009,12 +1011,13 @@ def test_triangle_attention_long_rows_whole_tensor(setup, mode, gemm_mode):
         for r0 in range(0, N, 64):
             want[:, r0:r0 + 64] = O.gated_attention(s["params"], pfx + ".attn", src[:, r0:r0 + 64].contiguous(), msrc[:, r0:r0 + 64].contiguous(), H, c)
     mod = getattr(s["model"].Denoiser.folding_blocks[0], f"pair_attn_{mode}")
-    got = mod.run(cu(pair), cu(mask), residual=False).cpu()
-    if mode == "ending":
-        got = got.transpose(1, 2)
-    assert rel_l2(got, want) < OP_TOL
+    def evaluate():
+        full = mod.run(cu(pair), cu(mask), residual=False).cpu()
+        return full.transpose(1, 2) if mode == "ending" else full
+    got = evaluate()
+    assert rel_l2(got, want) < OP_TOL, mismatch_report(got, want, evaluate)
     row_err = (got - want).flatten(2).norm(dim=2) / want.flatten(2).norm(dim=2).clamp_min(1e-30)
-    assert float(row_err.max()) < 2 * OP_TOL, int(row_err.argmax())
+    assert float(row_err.max()) < 2 * OP_TOL, (int(row_err.argmax()), mismatch_report(got, want, evaluate))
 
 
 @pytest.mark.parametrize("mode", ["starting", "ending"])
@@ -1046,12 +1049,13 @@ def test_triangle_attention_long_rows_split_tail(setup, mode, b, N, gemm_mode):
     try:
         for tune in (tune0, tune0 | (1 << 19)):
             lib.prd_set_tune(tune)
-            got = mod.run(cu(pair), cu(mask), residual=False).cpu()
-            if mode == "ending":
-                got = got.transpose(1, 2)
-            assert rel_l2(got, want) < OP_TOL
+            def evaluate():
+                full = mod.run(cu(pair), cu(mask), residual=False).cpu()
+                return full.transpose(1, 2) if mode == "ending" else full
+            got = evaluate()
+            assert rel_l2(got, want) < OP_TOL, (tune, mismatch_report(got, want, evaluate))
             row_err = (got - want).flatten(2).norm(dim=2) / want.flatten(2).norm(dim=2).clamp_min(1e-30)
-            assert float(row_err.max()) < 2 * OP_TOL, (tune, int(row_err.argmax()))
+            assert float(row_err.max()) < 2 * OP_TOL, (tune, int(row_err.argmax()), mismatch_report(got, want, evaluate))
     finally:
         lib.prd_set_tune(tune0)
 
@@ -1086,12 +1090,13 @@ def test_triangle_attention_long_rows_ragged_key_tail(setup, mode, N, masked_fro
     try:
         for tune in (tune0, tune0 | (1 << 6) | (3 << 7)):        # default | PRD_TA2_FLAGS = 3: priorities + the tail as a regular tile
             lib.prd_set_tune(tune)
-            got = mod.run(cu(pair), cu(mask), residual=False).cpu()
-            if mode == "ending":
-                got = got.transpose(1, 2)
-            assert rel_l2(got, want) < OP_TOL
+            def evaluate():
+                full = mod.run(cu(pair), cu(mask), residual=False).cpu()
+                return full.transpose(1, 2) if mode == "ending" else full
+            got = evaluate()
+            assert rel_l2(got, want) < OP_TOL, (tune, mismatch_report(got, want, evaluate))
             row_err = (got - want).flatten(2).norm(dim=2) / want.flatten(2).norm(dim=2).clamp_min(1e-30)
-            assert float(row_err.max()) < 2 * OP_TOL, (tune, int(row_err.argmax()))
+            assert float(row_err.max()) < 2 * OP_TOL, (tune, int(row_err.argmax()), mismatch_report(got, want, evaluate))
             outs.append(got)
     finally:
         lib.prd_set_tune(tune0)

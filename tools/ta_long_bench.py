@@ -3,7 +3,8 @@
 Environment (read once per process by the library): PRD_TA2_LONG=0 keeps the first-generation long-row kernel,
 PRD_TA2_FLAGS=9 adds the next-row prefetch to the round-3 kernel.  Every size is measured with the default dispatch and with the
 tail-row split switched off (PRD_TUNE_TA2_NO_TAIL_SPLIT) and with the round-3 phase 1 (PRD_TUNE_TA2_NO_GV: a [K|Q] GEMM + a swapped V GEMM
-instead of one [K|V] GEMM + transposed store), alternating, three rounds each (median)."""
+instead of one [K|V] GEMM + transposed store) and with a ragged last key tile of <= 4 keys swept as a regular tile instead of
+rank-1 updates (round 6), alternating, three rounds each (median)."""
 import os
 import sys
 
@@ -24,7 +25,8 @@ for N in [int(v) for v in sys.argv[1:]] or [449, 640, 769, 832]:
     for ending in (False, True):
         res = {}
         for rnd in range(3):
-            for name, tune in (("default", tune0), ("no tail split", tune0 | (1 << 19)), ("round-3 phase 1", tune0 | (1 << 21))):
+            for name, tune in (("default", tune0), ("no tail split", tune0 | (1 << 19)), ("round-3 phase 1", tune0 | (1 << 21)),
+                               ("tail as a tile", tune0 | (1 << 6) | (3 << 7))):        # PRD_TA2_FLAGS=3: ragged last key tile swept as a 32-key tile (round 5)
                 lib.prd_set_tune(tune)
                 for _ in range(2):
                     ops.tri_attn_core(pair, mask, wts, H, c, ending=ending, og=og)
