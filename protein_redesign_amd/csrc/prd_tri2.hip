@@ -1282,6 +1282,49 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
         if (ok) mknext = mask[rnext.bb * N + v];
     }
     if (have) munext = mask[bu];
+    // Shared last round (flag 128 = its round-5 form, A/B): the [Q|G] projection of a shared block is done INSIDE phase 1 by one of the
+    // waves that have a block less to project there (N = 769: 25 blocks on 12 waves -- wave 0 projects three, the others two), the
+    // key pieces are swept FIRST in phase 2 (Q is in LDS behind phase 1's closing barrier) and the merge waits behind the barrier
+    // that opens the NEXT row anyway: no projection with eleven waves idle, no two extra barriers per row.
+    const bool early_share = (flags & 128) == 0;
+    bool last_shared = false;                           // (workgroup-uniform) the item just finished had a shared round in the early form
+    bool m_pending = false;                             // a merge of the previous item is due (wave-uniform; the gate is in m_gate)
+    int m_blk = 0, m_G = 0, m_j = 0;
+    RowIx m_row = make_row(0);
+    float m_gate[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m_gate[e] = 0.f;
+    auto store_out = [&](const RowIx& rw, int qb, const float (&o)[8], float l, const float (&gate)[8]) {
+        const float ltot = xhalf_add(l);
+        const int v = 32 * qb + r;
+        if (v < N) {
+            const float il = 1.0f / (VSCALE * ltot);
+            float* dst = og + row_pos(rw, v) * HC + h * C + 4 * hi;
+            *reinterpret_cast<float4*>(dst) = make_float4(gate[0] * (o[0] * il), gate[1] * (o[1] * il), gate[2] * (o[2] * il), gate[3] * (o[3] * il));
+            *reinterpret_cast<float4*>(dst + 8) = make_float4(gate[4] * (o[4] * il), gate[5] * (o[5] * il), gate[6] * (o[6] * il), gate[7] * (o[7] * il));
+        }
+    };
+    // merge of the m_G key pieces of shared block m_j (flash-decoding merge), gated and stored
+    auto merge_shared = [&](const RowIx& rw, int j, int G_, int qb, const float (&gate)[8]) {
+        float M = -INFINITY;
+        for (int k = 0; k < G_; ++k) {
+            const bool has = (nqb * (k + 1)) / G_ > (nqb * k) / G_;
+            if (has) M = max2f(M, part[(size_t)(j * G_ + k) * 640 + 9 * 64 + lane]);
+        }
+        float o[8], l = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
+        for (int k = 0; k < G_; ++k) {
+            const bool has = (nqb * (k + 1)) / G_ > (nqb * k) / G_;
+            if (!has) continue;
+            const float* pp = part + (size_t)(j * G_ + k) * 640 + lane;
+            const float scl = __builtin_amdgcn_exp2f(pp[9 * 64] - M);
+            l += scl * pp[8 * 64];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
+        }
+        store_out(rw, qb, o, l, gate);
+    };
     for (int it = 0; have; ++it) {
         const RowIx row = rnext;
         // the query blocks [q0, q1) of this item in rounds of NW; a last round of rem_ blocks shared by G_ waves each
@@ -1293,6 +1336,10 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
         const int pT0 = share_ ? (nqb * pp_) / G_ : 0, pT1 = share_ ? (nqb * (pp_ + 1)) / G_ : 0;
         const int work_tot = nfull_ * nqb + (share_ ? (wave < rem_ * G_ ? pT1 - pT0 : 0) : (wave < rem_ ? nqb : 0));   // (priorities only)
         __syncthreads();                                // previous row's LDS consumed (and the weight image staged)
+        if (m_pending) {                                // (wave-uniform) the previous item's shared block: its pieces are all in LDS now
+            merge_shared(m_row, m_j, m_G, m_blk, m_gate);
+            m_pending = false;
+        }
         const float mu = munext;
         int r1 = r, hi1 = hi;                           // opaque per row (see tri_attn_core_v2_kernel)
         asm volatile("" : "+v"(r1), "+v"(hi1));
@@ -1300,6 +1347,36 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi1);
             wh = Wb[(size_t)wrow * (P / 8) + slot_];
             wl = Wb[(size_t)(64 + wrow) * (P / 8) + slot_];
+        };
+        // [Q|G] of query block qb: Q as the B operands of Q K^T (fp16 hi | lo), the lane's 8 gate channels
+        auto project_qg = [&](int qb, u32x4& qh4, u32x4& ql4, float (&gate)[8]) {
+            float x[KH];
+            const int v = qb * 32 + r1;
+            const bool ok = v < N;
+            load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi1, ok, x);
+            ln_cll_p<KH>(x);
+            u32x4 xs[2][P / 16];
+            split2h_rn_cll<KH>(x, xs);
+            f32x16 acc;
+            {
+                const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+                acc[8] = b0.x; acc[9] = b0.y; acc[10] = b0.z; acc[11] = b0.w; acc[12] = b1.x; acc[13] = b1.y; acc[14] = b1.z; acc[15] = b1.w;
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < P / 16; ++s_) {
+                u32x4 wh, wl;
+                wop(16 + r1, s_, wh, wl);               // image rows 16-47 = Q | G
+                acc = mfma_h(wh, xs[0][s_], acc);
+                acc = mfma_h(wh, xs[1][s_], acc);
+                acc = mfma_h(wl, xs[0][s_], acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= inv16;
+            split8_rn(acc, 0, qh4, ql4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gate[e] = gate_from_scaled(acc[8 + e]);
         };
         // ================= phase 1: K and V of every block =================
         for (int blk = wave; blk < nqb; blk += NW) {
@@ -1412,6 +1489,17 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                 *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
                     }
         }
+        // shared block j of this item: projected here by wave NW - 1 - j (those waves have the fewest blocks above), Q published for the
+        // waves that sweep its key pieces, the gate kept by the projecting wave, which merges after the next barrier but one
+        const bool sh_early = share_ && early_share;
+        const int sh_j = NW - 1 - wave;                 // the shared block this wave owns (if < rem_)
+        if (sh_early && sh_j < rem_) {
+            u32x4 qh4, ql4;
+            project_qg(q0 + nfull_ * NW + sh_j, qh4, ql4, m_gate);
+            const unsigned qo = L.qs + (unsigned)sh_j * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
+            *reinterpret_cast<u32x4*>(lds + qo) = qh4;
+            *reinterpret_cast<u32x4*>(lds + qo + 1024u) = ql4;
+        }
         __syncthreads();
         int bun, q0n, q1n;
         const bool haven = item(it + 1, bun, q0n, q1n);
@@ -1432,36 +1520,6 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             fmask = (unsigned)__ballot(f != 0);
         }
         int work_rem = work_tot;
-        // [Q|G] of query block qb: Q as the B operands of Q K^T (fp16 hi | lo), the lane's 8 gate channels
-        auto project_qg = [&](int qb, u32x4& qh4, u32x4& ql4, float (&gate)[8]) {
-            float x[KH];
-            const int v = qb * 32 + r1;
-            const bool ok = v < N;
-            load_row_cll<P>(pair + row_pos(row, ok ? v : 0) * P, hi1, ok, x);
-            ln_cll_p<KH>(x);
-            u32x4 xs[2][P / 16];
-            split2h_rn_cll<KH>(x, xs);
-            f32x16 acc;
-            {
-                const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-                acc[8] = b0.x; acc[9] = b0.y; acc[10] = b0.z; acc[11] = b0.w; acc[12] = b1.x; acc[13] = b1.y; acc[14] = b1.z; acc[15] = b1.w;
-            }
-#pragma unroll
-            for (int s_ = 0; s_ < P / 16; ++s_) {
-                u32x4 wh, wl;
-                wop(16 + r1, s_, wh, wl);               // image rows 16-47 = Q | G
-                acc = mfma_h(wh, xs[0][s_], acc);
-                acc = mfma_h(wh, xs[1][s_], acc);
-                acc = mfma_h(wl, xs[0][s_], acc);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] *= inv16;
-            split8_rn(acc, 0, qh4, ql4);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gate[e] = gate_from_scaled(acc[8 + e]);
-        };
         // key tiles [T0, T1) for the queries (qh, ql): o8 = O (x 16, relative to mref), lsum = the lane's part of the row sum
         auto run_piece = [&](const u32x4& qh, const u32x4& ql, int T0, int T1, float (&o8)[8], float& lsum, float& mref) {
             f32x16 o0, zero;
@@ -1565,6 +1623,21 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                 *reinterpret_cast<float4*>(dst + 8) = make_float4(gate[4] * (o[4] * il), gate[5] * (o[5] * il), gate[6] * (o[6] * il), gate[7] * (o[7] * il));
             }
         };
+        // ---- shared last round, early form: the key pieces first; the merge follows the barrier that opens the next item ----
+        if (sh_early) {
+            if (wave < rem_ * G_ && pT1 > pT0) {
+                const unsigned qo = L.qs + (unsigned)pj * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
+                const u32x4 qh4 = *reinterpret_cast<const u32x4*>(lds + qo), ql4 = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
+                float o8[8], lsum, mref;
+                run_piece(qh4, ql4, pT0, pT1, o8, lsum, mref);
+                float* pp = part + (size_t)wave * 640 + lane;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pp[jj * 64] = o8[jj];
+                pp[8 * 64] = lsum;
+                pp[9 * 64] = mref;
+            }
+            if (sh_j < rem_) { m_pending = true; m_row = row; m_j = sh_j; m_G = G_; m_blk = q0 + nfull_ * NW + sh_j; }
+        }
         // ---- whole rounds (and an unshared last round): one query block per wave ----
         const int nrounds = nfull_ + ((rem_ && !share_) ? 1 : 0);
         for (int rd = 0; rd < nrounds; ++rd) {
@@ -1577,8 +1650,8 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
                 finish(qb, o8, lsum, gate);
             }
         }
-        // ---- shared last round ----
-        if (share_) {
+        // ---- shared last round, round-5 form (flag 128): projection, barrier, pieces, barrier, merge ----
+        if (share_ && !sh_early) {
             float gate[8];
             if (wave < rem_) {
                 u32x4 qh4, ql4;
@@ -1623,7 +1696,12 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v2l_kernel(
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        last_shared = sh_early;
         have = haven; bu = bun; q0 = q0n; q1 = q1n;
+    }
+    if (last_shared) {                                  // (workgroup-uniform) the last item's shared block
+        __syncthreads();
+        if (m_pending) merge_shared(m_row, m_j, m_G, m_blk, m_gate);
     }
 }
 
@@ -2180,7 +2258,7 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
     const int ntail_ = N - 32 * (nqb_ - 1);
     const bool tail1 = long_rows && nqb_ >= 2 && ntail_ >= 1 && ntail_ <= V2L_TAIL_MAX && !PRD_TGET_TA2_NO_GV(tune) && !(flags0 & 2);
     const int flags = flags0 | ((long_rows && rem_ && 12 / rem_ >= 2 && !share) ? 16 : 0) | (PRD_TGET_TA2_NO_TAIL_SPLIT(tune) ? 32 : 0)
-                      | (tail1 ? 64 : 0);
+                      | (tail1 ? 64 : 0) | ((long_rows && (flags0 & 4)) ? 128 : 0);    // (PRD_TA2_FLAGS bit 2: the shared last round in its round-5 form)
     if (long_rows) {
 #define PRD_V2L_LAUNCH(PP, PF, GVF)                                                                                               \
         do {                                                                                                                      \

@@ -1026,7 +1026,9 @@ def test_triangle_attention_long_rows_split_tail(setup, mode, b, N, gemm_mode):
     """tri_attn_core_v2l: rows left over after the whole rounds of 64 rows per head are split by query blocks over the idle
     workgroups: b N = 390 = 6 x 64 + 6 (ten parts of one or two of the 13 blocks: shared and unshared last rounds), 800 = 12 x 64 + 32
     (two parts of 6 and 7 blocks), 417 = 6 x 64 + 33 (no split).  Whole tensor against the oracle, masked tail; and the same
-    with the split switched off (PRD_TUNE_TA2_NO_TAIL_SPLIT)."""
+    with the split switched off (PRD_TUNE_TA2_NO_TAIL_SPLIT) and with the shared last round in its round-5 form (projection, barrier,
+    pieces, barrier, merge inside phase 2; round 6 projects the shared block in phase 1, sweeps its pieces first and merges behind the
+    next item's opening barrier)."""
     s = setup
     P = s["P"]
     H, c = s["args"]["num_heads"], s["args"]["head_dim"]
@@ -1047,7 +1049,7 @@ def test_triangle_attention_long_rows_split_tail(setup, mode, b, N, gemm_mode):
     lib = _lib.lib()
     tune0 = lib.prd_get_tune()
     try:
-        for tune in (tune0, tune0 | (1 << 19)):
+        for tune in (tune0, tune0 | (1 << 19), tune0 | (1 << 6) | (5 << 7)):     # default | no tail split | PRD_TA2_FLAGS = 5: the shared round in its round-5 form
             lib.prd_set_tune(tune)
             def evaluate():
                 full = mod.run(cu(pair), cu(mask), residual=False).cpu()
