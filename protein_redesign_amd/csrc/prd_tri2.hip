@@ -1126,14 +1126,19 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
             if (!group_owner) finish(rcur, wave, o8, lsum, gate, mref);
             else if (own_t1 > 0) put_partial((nhelp + 1) * gi, o8, lsum, mref);
         } else if (helper) {
-            const int T0 = qtile(m4 + hj), T1 = qtile(m4 + hj + 1);
+            // Helper hj sweeps key piece (hj + i) mod nhelp of shared block i: the pieces differ by a tile (N = 320: [5, 7) and [7, 10)),
+            // and with a fixed piece per helper the two helpers -- the youngest waves of SIMDs 2 and 3, which end the iteration -- carried
+            // 4 and 6 tile steps (24 / 26 per SIMD); rotating gives 5 and 5 (25 on every SIMD).  Same pieces, same partial slots (by
+            // piece), same merge: bit-identical results.  (flag 32: the fixed assignment, A/B)
             for (int i = 0; i < m4; ++i) {
-                if (T1 <= T0) break;
+                const int pc = (flags & 32) ? hj : (hj + i) % nhelp;
+                const int T0 = qtile(m4 + pc), T1 = qtile(m4 + pc + 1);
+                if (T1 <= T0) continue;
                 const unsigned qo = L.qs + (unsigned)(par * m4 + i) * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
                 const u32x4 qh = *reinterpret_cast<const u32x4*>(lds + qo), ql = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
                 float o8[8], lsum, mref;
                 run_piece(qh, ql, T0, T1, o8, lsum, mref);
-                put_partial((nhelp + 1) * i + 1 + hj, o8, lsum, mref);
+                put_partial((nhelp + 1) * i + 1 + pc, o8, lsum, mref);
             }
         }
         set_sprio();
