@@ -23,13 +23,15 @@ og = ops.tri_attn_core_v2_lse(pair, mask, (wq, wk, wv, wg, bg), H, c, ending=Fal
 out = torch.empty(b, N, N, 4, 64, device="cuda")
 
 
-def v2(stats=None):
+def v2(stats=None, ending=0):
     check(lib().prd_tri_attn_bwd_core_v2(dptr(out), dptr(dog), dptr(og), dptr(pair), dptr(mask), dptr(wq), dptr(wk), dptr(wv), dptr(wg), dptr(bg),
-                                         dptr(stats) if stats is not None else None, None, 0, b, N, P, H, c, stream()), "v2")
+                                         dptr(stats) if stats is not None else None, None, ending, b, N, P, H, c, stream()), "v2")
 
 
 def v2s():
     v2(lse)
+
+
 
 
 def v1():
@@ -37,14 +39,23 @@ def v1():
                                       0, b, N, P, H, c, stream()), "v1")
 
 
-for name, fn in (("fp32", v1), ("split16", v2), ("split16 + kept statistics", v2s)):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    print(f"{name}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us  (b={b}, N={N})")
+res = {}
+outs = {}
+for rnd in range(3):                # arms alternate: the clock of a box drifts
+    for name, fn in (("fp32", v1), ("split16", v2), ("split16 + kept statistics", v2s)):
+        for _ in range(3):
+            fn()
+        if rnd == 0:
+            outs[name] = out.clone()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.setdefault(name, []).append(e0.elapsed_time(e1) / 10 * 1e3)
+for name, v in res.items():
+    print(f"{name}: {sorted(v)[1]:.1f} us  (b={b}, N={N}; median of 3 alternating rounds)")
+a_ = outs["split16 + kept statistics"]
+print(f"split16 + kept statistics vs fp32 core: rel-L2 {float((a_ - outs['fp32']).norm() / outs['fp32'].norm()):.2e}")
