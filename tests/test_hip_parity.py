@@ -311,6 +311,37 @@ def test_triangle_multiplication(setup, mode, gemm_mode):
     assert rel_l2(got.cpu(), want) < OP_TOL
 
 
+@pytest.mark.parametrize("P,b,N", [(64, 2, 320), (64, 1, 449), (32, 1, 769), (64, 3, 200), (64, 1, 320)])
+def test_triangle_multiplication_contraction_direct(P, b, N):
+    """prd_tri_mul_contract in split-16 arithmetic, called directly: O[p, m, n] = sum_k A[p, m, k] B[p, n, k] against float64 (split
+    operands: 22 bits) and BIT FOR BIT between the 8-wave default and the 12-wave form (PRD_TUNE_TMS_NW12): the K order of every output
+    element does not depend on how the 25 sub-tiles of a 160 x 160 tile are dealt.  One to 25 tiles per channel, ragged edges (449, 769,
+    200), batches.  (Written for the 320 x 160-tile experiment of round 6, profiles/r06_contract_tall_tiles.patch: slower, not kept.)"""
+    from protein_redesign_amd import _lib
+    from protein_redesign_amd._lib import check, dptr, stream
+    lib = _lib.lib()
+    prev, tune0 = lib.prd_get_gemm_mode(), lib.prd_get_tune()
+    ldn = (N + 31) // 32 * 32
+    g = torch.Generator().manual_seed(1000 + N + b)
+    ab = torch.zeros(b, 2 * P, N, ldn)
+    ab[..., :N] = torch.randn(b, 2 * P, N, N, generator=g)
+    want = torch.einsum("bpmk,bpnk->bpmn", ab[:, :P, :, :N].double(), ab[:, P:, :, :N].double())
+    outs = []
+    try:
+        assert lib.prd_set_gemm_mode(1) == 0
+        for tune in (tune0, tune0 | (1 << 13)):
+            lib.prd_set_tune(tune)
+            o = torch.full((b, P, N, ldn), float("nan"), device=DEV)
+            check(lib.prd_tri_mul_contract(dptr(o), dptr(cu(ab)), b, N, P, stream()), "prd_tri_mul_contract")
+            outs.append(o[..., :N].cpu())
+    finally:
+        lib.prd_set_tune(tune0)
+        assert lib.prd_set_gemm_mode(prev) == 0
+    assert torch.isfinite(outs[0]).all()
+    assert rel_l2(outs[0], want) < 2e-6
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("P,b,N", [(64, 2, 40), (32, 1, 70), (64, 1, 192)])
 def test_triangle_multiplication_chain(P, b, N):
     """prd_tri_mul_chain (gemm mode 1): pair += outgoing(pair); pair += incoming(pair) with the output stage of the first module
