@@ -274,6 +274,21 @@ int prd_tri_mul_proj_bwd(float* dpair, float* dpp, float* dpg, const float* dAB,
                          const float* mask, const float* w_proj, const float* b_proj, const float* w_gate, const float* b_gate,
                          const float* w_proj_t, const float* w_gate_t, int incoming, int b, int N, int P, int arith, hipStream_t stream);
 
+/* SURVEY 8(f)#4 "persistent per-block kernels", built for one seam of the folding block: the STARTING triangle attention (core +
+ * output projection + residual, modules.py:338 -> 236-243 -> 185-225) and the core of the ENDING one (modules.py:339) as ONE persistent
+ * launch with two in-kernel grid barriers, instead of prd_tri_attn_core_v2 + prd_tri_attn_out + prd_tri_attn_core_v2.  In: pair
+ * [b,N,N,P] (updated IN PLACE by the starting attention), mask [b,N]; w_start = {q.w, k.w, v.w, gate.w, gate.b, out.w, out.b} of
+ * pair_attn_starting, w_end = {q.w, k.w, v.w, gate.w, gate.b} of pair_attn_ending.  Out: og [b,N,N,64] = the gated head outputs of the
+ * ENDING attention (prd_block_tail applies its output projection).  Bit-identical to the three launches.  bar: 32 uint32 of device
+ * memory owned by the caller (counters, memberships, bar[1] = timeout flag), zeroed by the call itself; after the stream has run,
+ * bar[1] != 0 means a barrier gave up waiting (the grid was not fully resident: the results are then NOT valid).  Refused (PRD_ERR_UNSUPPORTED) unless
+ * prd_tri_attn_pair_supported: split-16 arithmetic, rows on the overlapped-phase short-row core (N <= 320-odd), default kernel
+ * switches, at most one workgroup per CU.  Opt-in on the Python side (PRD_PERSISTENT_ATTN=1): measured against the three launches in
+ * DESIGN.md 4.3. */
+int prd_tri_attn_pair_supported(int N, int P, int arith);
+int prd_tri_attn_pair(float* og, float* pair, const float* mask, const float* const* w_start, const float* const* w_end,
+                      int b, int N, int P, int H, int c, unsigned* bar, int arith, hipStream_t stream);
+
 /* ---- backward of TriangleAttention (autograd of modules.py:236-243 -> 185-225; used by training.py) -------------------------
  * Core: dog = W_out^T d(update) [b,N,N,64] (a row GEMM by the caller) -> dqkvg[b,N,N,4,64] by pair position =
  * d(W_q x) | d(W_k x) | d(W_v x) | d(gate pre-activation), channels head-major (x = LN(pair row)).  Rows up to N ~ 400. */

@@ -107,6 +107,8 @@ SIGNATURES = {
     "prd_spa_attn_core_workspace": [ci, ci, ci, ci],
     "prd_spa_attn_core": [vp, vp, ci, vp, vp, ci, ci, ci, ci, vp, cz, ci, vp],
     "prd_workspace_bytes": [C.c_char_p, ci, ci, ci, ci],
+    "prd_tri_attn_pair_supported": [ci, ci, ci],
+    "prd_tri_attn_pair": [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp],
 }
 
 GEMM_MODES = {"fp32": 0, "split16": 1, "bf16x3": 1}      # "bf16x3": earlier name of the split-operand mode
@@ -115,10 +117,11 @@ DEFAULT_GEMM_MODE = "split16"       # process default of the Python host side (e
 # entry points that take the arithmetic as their last argument before the stream ...
 _ARITH_BEFORE_STREAM = ("prd_coord_head", "prd_pair_head", "prd_pair_init", "prd_opm_pair", "prd_outer_linear", "prd_tri_mul", "prd_tri_mul_contract", "prd_tri_mul_proj_bwd",
                         "prd_tri_attn", "prd_tri_attn_core", "prd_tri_attn_out", "prd_pair_transition", "prd_block_tail", "prd_tri_mul_chain",
-                        "prd_linear_wgrad", "prd_pair_linear", "prd_spa_attn_core")
+                        "prd_linear_wgrad", "prd_pair_linear", "prd_spa_attn_core", "prd_tri_attn_pair")
 # ... and the queries that take it as their last argument
 _ARITH_LAST = ("prd_tri_attn_variant", "prd_tri_mul_chain_supported", "prd_tri_attn_core_fused_supported", "prd_tri_attn_stats_bytes",
-               "prd_gemm_slab_ok", "prd_pair_head_supported", "prd_pair_linear_supported", "prd_spa_attn_core_supported")
+               "prd_gemm_slab_ok", "prd_pair_head_supported", "prd_pair_linear_supported", "prd_spa_attn_core_supported",
+               "prd_tri_attn_pair_supported")
 # entry points without an arithmetic that still dispatch between kernel generations: the PRD_TUNE_* switch word alone
 _TUNE_BEFORE_STREAM = ("prd_tri_attn_core_v2", "prd_tri_attn_core_v2_lse")
 _TUNE_LAST = ("prd_tri_attn_v2_supported", "prd_tri_attn_v2_form")

@@ -69,7 +69,7 @@ def resource_usage(verbose: bool = False):
         except (OSError, ValueError):
             have = {}
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "prd_common.h"), os.path.join(os.path.dirname(HERE), "include", "prd_hip.h")]
+    headers = [os.path.join(CSRC, "prd_common.h"), os.path.join(CSRC, "prd_tri2_v3_body.inc"), os.path.join(os.path.dirname(HERE), "include", "prd_hip.h")]
     changed = False
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
@@ -122,7 +122,7 @@ def _record_resources(src, stderr_text, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "prd_common.h"), os.path.join(os.path.dirname(HERE), "include", "prd_hip.h")]
+    headers = [os.path.join(CSRC, "prd_common.h"), os.path.join(CSRC, "prd_tri2_v3_body.inc"), os.path.join(os.path.dirname(HERE), "include", "prd_hip.h")]
     objs = []
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
@@ -185,7 +185,7 @@ def build_ab(verbose: bool = True) -> str:
     out_dir = os.path.join(HERE, "csrc", "ab")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(HERE, "libprd_hip_ab.so")
-    headers = [os.path.join(CSRC, "prd_common.h"), os.path.join(os.path.dirname(HERE), "include", "prd_hip.h")]
+    headers = [os.path.join(CSRC, "prd_common.h"), os.path.join(CSRC, "prd_tri2_v3_body.inc"), os.path.join(os.path.dirname(HERE), "include", "prd_hip.h")]
     build(verbose=verbose)                                   # sources that never test PRD_AB share the shipped objects
     objs = []
     for src in SOURCES:

@@ -707,456 +707,151 @@ __global__ __launch_bounds__(NW * 64) void tri_attn_core_v3_kernel(
     constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
     constexpr float VSCALE = H2_WSCALE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const V3Lds L = v3_layout(P, NP);
-    u32x4* Wb = reinterpret_cast<u32x4*>(lds);
-    float* biasl = reinterpret_cast<float*>(lds + L.bias);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hi = lane >> 5;
-    const int nqb = NP / 32;                            // query blocks = key tiles (<= NW)
-    const int rstride = gridDim.x / H;
-    int h, slot;
-    if ((rstride & 7) == 0) {                           // the H heads of one row on one XCD
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        h = idx % H;
-        slot = (idx / H) * 8 + xcd;
-    } else {
-        h = blockIdx.x % H;
-        slot = blockIdx.x / H;
+#include "prd_tri2_v3_body.inc"
+}
+
+// The same statements as a device function, for tri_attn_pair_kernel (below), which runs them twice inside one persistent launch.
+// (__restrict__ on og / pair says what it always said -- no two of these pointers overlap; what OTHER workgroups wrote before a grid
+// barrier is the barrier's business: agent-scope release / acquire; the rows are per-lane vector loads, not the scalar cache.)
+template <int P, int NW, int KL, bool GV>
+PRD_DEV void tri_attn_core_v3_body(
+    float* __restrict__ og, const float* __restrict__ pair, const float* __restrict__ mask,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ wg, const float* __restrict__ bg, int b, int N, int NP, int H, int ending, int flags,
+    float* __restrict__ lse_out, unsigned char* lds) {
+    constexpr int C = 16, HC = 64, NT = NW * 64, KH = P / 2;
+    constexpr float VSCALE = H2_WSCALE;
+#include "prd_tri2_v3_body.inc"
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// SURVEY 8(f)#4 "persistent per-block kernels", built for one seam of the folding block (modules.py:338-339): the starting triangle
+// attention's core, its output projection + residual, and the ending attention's core as ONE persistent launch --
+//     core(starting): og <- attention(pair rows)  |  grid barrier  |  pair <- pair + W_o og + b_o  |  grid barrier  |  core(ending)
+// instead of three launches (prd_tri_attn_core_v2 + prd_tri_attn_out + prd_tri_attn_core_v2).  Same stage bodies, same task order:
+// bit-identical results.  Two barrier forms of the MI355X guide, both placement-independent: the XCD-hierarchical one (default) and the
+// plain counter (every workgroup releases at agent scope and polls ONE word; A/B).  Every spin is BOUNDED: a grid that is not fully
+// resident (a CU less than workgroups) sets the timeout word and runs on unsynchronised instead of hanging the box; the host entry
+// refuses grids above the CU count.  Opt-in (PRD_PERSISTENT_ATTN=1): measured in DESIGN.md 4.3.
+// bar (uint32 words, zeroed by the host entry before EVERY launch):
+//   [0] arrivals of the plain counter form   [1] timeout flag   [2] registrations   [3] top counter (one arrival per XCD and barrier)
+//   [8 + x] members of XCD x   [16 + x] arrivals on XCD x   [24 + x] generation published to XCD x     (x = hardware XCC id, 0-7)
+constexpr unsigned PRD_SPIN_LIMIT = 1u << 22;          // ~ a second of polling: the grid is not resident
+
+PRD_DEV bool spin_until_ge(unsigned* word, unsigned target, unsigned* tmo) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > PRD_SPIN_LIMIT) {
+            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
     }
-    const float sc = 0.25f * LOG2E_2;
-    stage_weight_h2_rows<P>(Wb, 64, 0, wk + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
-    stage_weight_h2_rows<P>(Wb, 64, C, wq + (long)h * C * P, C, P, tid, NT, sc * H2_WSCALE);
-    stage_weight_h2_rows<P>(Wb, 64, 2 * C, wg + (long)h * C * P, C, P, tid, NT, NEG_LOG2E * H2_WSCALE);
-    stage_weight_h2_rows<P>(Wb, 64, 3 * C, wv + (long)h * C * P, C, P, tid, NT, H2_WSCALE);
-    if (tid < 16) {
-        const int hh = tid >> 3, e = tid & 7;
-        biasl[tid] = H2_WSCALE * NEG_LOG2E * bg[h * C + 4 * hh + (e & 3) + 8 * (e >> 2)];
+    return true;
+}
+
+PRD_DEV void grid_barrier_counter(unsigned* bar, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every wave: its stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the compiler may drop the wait behind buffer_wbl2: restated)
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        spin_until_ge(bar, epoch * gridDim.x, bar + 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    const int nrows = b * N;
-    struct RowIx { int bu, bb, u; };
-    auto make_row = [&](int bu) { RowIx x; x.bu = bu; x.bb = bu / N; x.u = bu - x.bb * N; return x; };
-    auto row_pos = [&](const RowIx& x, int v) -> long { return ending ? (long)((x.bb * N + v) * N + x.u) : (long)(x.bu * N + v); };
-    // ---- static work split: as tri_attn_core_v2_kernel ----
-    const int m4 = nqb & 3, gbase = nqb - m4, nhelp = m4 ? 4 - m4 : 0;
-    const bool owner = wave < nqb, helper = wave >= nqb && wave < nqb + nhelp;
-    const int hj = wave - nqb;
-    const bool group_owner = owner && wave >= gbase;
-    const int gi = wave - gbase;
-    int p1_blk = -1, p1_kinds = 0;
-    if (owner) { p1_blk = wave; p1_kinds = (group_owner && gi < nhelp) ? 1 : 3; }
-    else if (helper && hj < m4) { p1_blk = gbase + hj; p1_kinds = 2; }
-    // (A/B, PRD_TA2_FLAGS bit 4) The waves of a SIMD are served oldest first (profiles/r05_tri_attn_v3_phases.txt: waves 0-3 sweep their
-    // ten key tiles in 7.9 k cycles, the youngest wave of the SIMD needs 16.8 k for six and then still has its projection to do: it
-    // ends the iteration alone, while the oldest wave has been waiting at the barrier for 7 k cycles).  With this switch the projections
-    // of the shared ("group") blocks -- [K|Q] and [G, V], 2 m4 items -- move from the youngest waves (group owners, helpers) to the
-    // OLDEST ones, one extra item each on top of their own block; the group owners then read their Q from the share like the helpers.
-    const bool remap = (flags & 16) && gbase >= 2 * m4 && m4 > 0;
-    int p1b_blk = -1, p1b_kinds = 0;                    // second phase-1 item of a wave (remap only)
-    if (remap) {
-        if (wave >= gbase) { p1_blk = -1; p1_kinds = 0; }                      // group owners and helpers: no projection
-        if (wave < 2 * m4) { p1b_blk = gbase + (wave >> 1); p1b_kinds = (wave & 1) ? 2 : 1; }
+}
+
+// XCD-hierarchical form ("barrier-xcd" of the guide): a release fence writes back the dirty lines of the issuing workgroup's WHOLE L2, so one
+// per XCD and barrier is enough -- 256 of them (the plain form above) cost 40 us per folding block.  Which workgroups share an L2 is read
+// from the hardware (HW_REG_XCC_ID), never assumed from blockIdx: every workgroup registers with its XCD at kernel entry; at a barrier the
+// LAST arriver of an XCD (all its peers' stores have been acknowledged by that L2: s_waitcnt vmcnt(0) before the arrival) releases, arrives
+// on the top counter, waits for the other XCDs there and publishes the generation to its peers; everybody acquires.
+PRD_DEV unsigned xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7u;
+}
+
+PRD_DEV void grid_barrier_register(unsigned* bar, unsigned xcc) {
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(bar + 8 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the membership is counted before the registration is
+        if (old < 0xffffffffu) __hip_atomic_fetch_add(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    auto qtile = [&](int k) { return (nqb * k) >> 2; };
-    const int own_t1 = group_owner ? qtile(m4) : nqb;
-    const int work_tot = owner ? own_t1 : (helper ? m4 * (qtile(m4 + hj + 1) - qtile(m4 + hj)) : 0);
-    const float inv16 = H2_INV_WSCALE;
-    const unsigned kl_rel = 2u * L.plane, v_rel = 4u * L.plane, kadd_rel = 8u * L.plane, flag_rel = 8u * L.plane + (unsigned)NP * 4u;
-    const unsigned klane = (unsigned)hi * L.plane + (unsigned)r * 16u;              // + buffer + 512 t
-    // V operand of P V: lane r = (plane, channel) reads its 16-byte slot of 8 keys of half a (16 keys) of tile t.  GV: the slot index
-    // is XORed with 2 a + khalf so that the transposed 4-byte stores of phase 1 (below) spread over all banks
-    const unsigned vlane0 = v_rel + (unsigned)hi * 512u + (unsigned)(GV ? (gv_slot(r) ^ hi) : r) * 16u;                  // + buffer + 2048 t
-    const unsigned vlane1 = v_rel + 1024u + (unsigned)hi * 512u + (unsigned)(GV ? (gv_slot(r) ^ (2 + hi)) : r) * 16u;
+}
 
-    u32x4 qh4 = {0u, 0u, 0u, 0u}, ql4 = {0u, 0u, 0u, 0u};     // Q of the wave's own block (B operands of Q K^T)
-    float gate[8];                                             // the lane's gate channels of its own block (non-group owners)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) gate[e] = 0.f;
-
-    // ================= phase 1 of one row into buffer `par`, gate share `gpar` =================
-    int it = 0;                                         // (row iteration: PRD2_STAMP)
-    auto phase1_item = [&](const RowIx& row, int par, int gpar, const int blk, const int kinds) {
-        if (blk < 0) return;
-        const unsigned bufo = L.buf0 + (unsigned)par * L.bufsize;
-        int r1 = r, hi1 = hi;                           // opaque (see tri_attn_core_v2_kernel)
-        asm volatile("" : "+v"(r1), "+v"(hi1));
-        auto wop = [&](int wrow, int s_, u32x4& wh, u32x4& wl) {
-            const int slot_ = h2_slot<P>(wrow, 2 * s_ + hi1);
-            wh = Wb[(size_t)wrow * (P / 8) + slot_];
-            wl = Wb[(size_t)(64 + wrow) * (P / 8) + slot_];
-        };
-        float x[KH];
-        const int v = blk * 32 + r1;
-        const bool valid = v < N;
-        load_row_cll<P>(pair + row_pos(row, valid ? v : 0) * P, hi1, valid, x);
-        const float mu = mask[row.bu];
-        const float mk = valid ? mask[row.bb * N + v] : 0.f;
-        ln_cll_p<KH>(x);
-        u32x4 xs[2][P / 16];
-        split2h_rn_cll<KH>(x, xs);
-        PRD2_STAMP(3);                                  // (timing builds) 3: row arrived, LayerNorm-ed and split
-        if (kinds & 1) {
-            {   // logit override of masked / padded keys + tile flag
-                const bool keep = valid && (mu * mk >= 0.5f);
-                if (hi1 == 0) reinterpret_cast<float*>(lds + bufo + kadd_rel)[v] = keep ? 0.f : (valid ? -32768.0f * LOG2E_2 : -INFINITY);
-                const bool any_override = __any(!keep);
-                if (lane == 0) reinterpret_cast<int*>(lds + bufo + flag_rel)[blk] = any_override ? 1 : 0;
-            }
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int s_ = 0; s_ < P / 16; ++s_) {
-                u32x4 wh, wl;
-                wop(r1, s_, wh, wl);
-                acc = mfma_h(wh, xs[0][s_], acc);
-                acc = mfma_h(wh, xs[1][s_], acc);
-                acc = mfma_h(wl, xs[0][s_], acc);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] *= inv16;
-            u32x4 kh4, kl4, qhn, qln;
-            split8_rn(acc, 0, kh4, kl4);
-            split8_rn(acc, 8, qhn, qln);
-            const unsigned po = bufo + (unsigned)hi1 * L.plane + (unsigned)(blk * 32 + r1) * 16u;
-            *reinterpret_cast<u32x4*>(lds + po) = kh4;
-            *reinterpret_cast<u32x4*>(lds + po + kl_rel) = kl4;
-            if (blk >= gbase) {                         // a shared block: its helpers (remap: and its owner) read Q from here
-                const unsigned qo = L.qs + (unsigned)(par * m4 + (blk - gbase)) * 2048u + (unsigned)hi1 * 512u + (unsigned)r1 * 16u;
-                *reinterpret_cast<u32x4*>(lds + qo) = qhn;
-                *reinterpret_cast<u32x4*>(lds + qo + 1024u) = qln;
-            }
-            if (blk == wave) { qh4 = qhn; ql4 = qln; }  // the wave's own block: Q stays in registers for its key sweep
+PRD_DEV void grid_barrier_xcd(unsigned* bar, unsigned epoch, unsigned xcc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every wave: its stores are in this XCD's L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* tmo = bar + 1;
+        bool ok = spin_until_ge(bar + 2, gridDim.x, tmo);                   // everybody has registered (true long before the first barrier)
+        const unsigned mine = __hip_atomic_load(bar + 8 + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned nx = 0;
+        for (int x = 0; x < 8; ++x) nx += __hip_atomic_load(bar + 8 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        const unsigned arrived = __hip_atomic_fetch_add(bar + 16 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (ok && arrived == mine * epoch) {                                // the last of this XCD: release for all of it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(bar + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            spin_until_ge(bar + 3, nx * epoch, tmo);
+            __hip_atomic_store(bar + 24 + xcc, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            spin_until_ge(bar + 24 + xcc, epoch, tmo);
         }
-        if (kinds & 2) {
-          if constexpr (GV) {
-            // [G|V] as ONE unswapped row GEMM (image rows 32 + r: G channels | V channels): 12 MFMAs instead of the 12 + 12 of a G GEMM and
-            // a swapped V GEMM that each fill half a tile.  The lane of position r gets its 8 gate channels (registers 0-7, as before)
-            // and 8 V channels of ITS position (registers 8-15): V is position-major and goes to the channel-major operand layout
-            // through a TRANSPOSED store -- neighbouring positions (lanes r, r ^ 1) pair up by DPP, the even lane packs channels
-            // 4 hi + j, the odd lane channels 8 + 4 hi + j of the key pair into one fp16 pair per plane: 8 four-byte stores per lane
-            // (slots XORed with 2 a + khalf: two lanes per bank) instead of 2 x 16 bytes, and 4 splits instead of 8.
-            f32x16 agv;
-            {
-                const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
-                agv[0] = b0.x; agv[1] = b0.y; agv[2] = b0.z; agv[3] = b0.w; agv[4] = b1.x; agv[5] = b1.y; agv[6] = b1.z; agv[7] = b1.w;
-#pragma unroll
-                for (int e = 8; e < 16; ++e) agv[e] = 0.f;
-            }
-#pragma unroll
-            for (int s_ = 0; s_ < P / 16; ++s_) {
-                u32x4 gh, gl;
-                wop(32 + r1, s_, gh, gl);
-                agv = mfma_h(gh, xs[0][s_], agv);
-                agv = mfma_h(gh, xs[1][s_], agv);
-                agv = mfma_h(gl, xs[0][s_], agv);
-            }
-            float gv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gv[e] = gate_from_scaled(agv[e] * inv16);
-            if (blk >= gbase) {                         // a shared block: its owner gates at the merge
-                float* gp = reinterpret_cast<float*>(lds + L.gs + (unsigned)(gpar * m4 + (blk - gbase)) * 2048u) + (r1 * 2 + hi1) * 8;
-                *reinterpret_cast<float4*>(gp) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-                *reinterpret_cast<float4*>(gp + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gate[e] = gv[e];
-            }
-            const bool odd = (r1 & 1) != 0;
-            const int kp0 = r1 & 30;                    // the key pair (kp0, kp0 + 1) of the block
-            const int a_ = kp0 >> 4, kk = kp0 & 15, kh_ = (kk >> 2) & 1, w_ = (kk >> 3) * 2 + ((kk & 3) >> 1);
-            const int ch0 = 4 * hi1 + (odd ? 8 : 0);    // + j
-            const unsigned vo = bufo + v_rel + (unsigned)blk * 2048u + (unsigned)a_ * 1024u + (unsigned)kh_ * 512u + (unsigned)w_ * 4u;
-            const int sx = 2 * a_ + kh_;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float mine_lo = agv[8 + j], mine_hi = agv[12 + j];
-                const float give = odd ? mine_lo : mine_hi;                 // what the neighbour packs: my value of ITS channel
-                const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, false));
-                const float ka = odd ? got : mine_lo, kb = odd ? mine_hi : got;      // keys kp0, kp0 + 1 of channel ch0 + j (x 16)
-                unsigned hh, ll;
-                split2h_rn(ka, kb, hh, ll);
-                const unsigned so = (unsigned)(gv_slot(ch0 + j) ^ sx) * 16u;
-                *reinterpret_cast<unsigned*>(lds + vo + so) = hh;
-                *reinterpret_cast<unsigned*>(lds + vo + 256u + so) = ll;   // lo plane: slots 16 .. 31
-            }
-          } else {
-              f32x16 ag, av;
-              {
-                  const float4 b0 = *reinterpret_cast<const float4*>(biasl + 8 * hi1), b1 = *reinterpret_cast<const float4*>(biasl + 8 * hi1 + 4);
-                  ag[0] = b0.x; ag[1] = b0.y; ag[2] = b0.z; ag[3] = b0.w; ag[4] = b1.x; ag[5] = b1.y; ag[6] = b1.z; ag[7] = b1.w;
-  #pragma unroll
-                  for (int e = 8; e < 16; ++e) ag[e] = 0.f;
-  #pragma unroll
-                  for (int e = 0; e < 16; ++e) av[e] = 0.f;
-              }
-  #pragma unroll
-              for (int s_ = 0; s_ < P / 16; ++s_) {
-                  u32x4 gh, gl, vh, vl;
-                  wop(32 + (r1 & 15), s_, gh, gl);
-                  wop(48 + (r1 & 15), s_, vh, vl);
-                  ag = mfma_h(gh, xs[0][s_], ag);
-                  av = mfma_h(xs[0][s_], vh, av);
-                  ag = mfma_h(gh, xs[1][s_], ag);
-                  av = mfma_h(xs[1][s_], vh, av);
-                  ag = mfma_h(gl, xs[0][s_], ag);
-                  av = mfma_h(xs[0][s_], vl, av);
-              }
-              float gv[8];
-  #pragma unroll
-              for (int e = 0; e < 8; ++e) gv[e] = gate_from_scaled(ag[e] * inv16);
-              if (blk >= gbase) {                         // a shared block: its owner gates at the merge
-                  float* gp = reinterpret_cast<float*>(lds + L.gs + (unsigned)(gpar * m4 + (blk - gbase)) * 2048u) + (r1 * 2 + hi1) * 8;
-                  *reinterpret_cast<float4*>(gp) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-                  *reinterpret_cast<float4*>(gp + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
-              } else {
-  #pragma unroll
-                  for (int e = 0; e < 8; ++e) gate[e] = gv[e];
-              }
-              u32x4 vh0, vl0, vh1, vl1;                   // V stays x 16
-              split8_rn(av, 0, vh0, vl0);
-              split8_rn(av, 8, vh1, vl1);
-              const bool lo_lane = r1 >= 16;
-              u32x4 s0, s1;
-  #pragma unroll
-              for (int w = 0; w < 4; ++w) { s0[w] = lo_lane ? vl0[w] : vh0[w]; s1[w] = lo_lane ? vl1[w] : vh1[w]; }
-              const unsigned vo = bufo + v_rel + (unsigned)(blk * 4 + hi1) * 512u + (unsigned)r1 * 16u;
-              *reinterpret_cast<u32x4*>(lds + vo) = s0;
-              *reinterpret_cast<u32x4*>(lds + vo + 1024u) = s1;
-          }
-        }
-    };
-    auto phase1 = [&](const RowIx& row, int par, int gpar) {
-        phase1_item(row, par, gpar, p1_blk, p1_kinds);
-        if (remap) phase1_item(row, par, gpar, p1b_blk, p1b_kinds);
-    };
-
-    auto finish = [&](const RowIx& row, int qb, const float (&o)[8], float l, const float (&g)[8], float mref) {
-        const float ltot = xhalf_add(l);
-        const int v = 32 * qb + r;
-        if (v < N) {
-            if (lse_out && hi == 0)
-                *reinterpret_cast<float2*>(lse_out + (((long)row.bu * H + h) * N + v) * 2) = make_float2(mref, __builtin_amdgcn_logf(ltot));
-            const float il = 1.0f / (VSCALE * ltot);
-            float* dst = og + row_pos(row, v) * HC + h * C + 4 * hi;
-            *reinterpret_cast<float4*>(dst) = make_float4(g[0] * (o[0] * il), g[1] * (o[1] * il), g[2] * (o[2] * il), g[3] * (o[3] * il));
-            *reinterpret_cast<float4*>(dst + 8) = make_float4(g[4] * (o[4] * il), g[5] * (o[5] * il), g[6] * (o[6] * il), g[7] * (o[7] * il));
-        }
-    };
-    // merge of the wave's shared block of `row` (partials in part[ppar], gate in gs[gpar])
-    auto merge = [&](const RowIx& row, int ppar, int gpar) {
-        const float* part = reinterpret_cast<const float*>(lds + L.part) + (size_t)ppar * L.nslot * 640;
-        const int s0 = (nhelp + 1) * gi;
-        float mm[5];
-        bool has[5];
-        int kv = 0;                                     // a piece that exists (see tri_attn_core_v2_kernel's merge)
-#pragma unroll
-        for (int k = 4; k >= 0; --k) {
-            has[k] = k == 0 ? own_t1 > 0 : (k - 1 < nhelp && qtile(m4 + k) > qtile(m4 + k - 1));
-            if (has[k]) kv = k;
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const float v_ = part[(size_t)(s0 + (has[k] ? k : kv)) * 640 + 9 * 64 + lane];
-            mm[k] = has[k] ? v_ : -INFINITY;
-        }
-        float M = mm[0];
-#pragma unroll
-        for (int k = 1; k < 5; ++k) M = max2f(M, mm[k]);
-        float o[8], l = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) o[jj] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const float* pp = part + (size_t)(s0 + (has[k] ? k : kv)) * 640 + lane;
-            const float scl = has[k] ? __builtin_amdgcn_exp2f(mm[k] - M) : 0.f;
-            l += scl * pp[8 * 64];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o[jj] += scl * pp[jj * 64];
-        }
-        const float* gp = reinterpret_cast<const float*>(lds + L.gs + (unsigned)(gpar * m4 + gi) * 2048u) + (r * 2 + hi) * 8;
-        const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
-        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        finish(row, wave, o, l, g, M);
-    };
-
-    // (A/B, PRD_TA2_FLAGS bit 3) static priorities against the oldest-first arbitration of a SIMD's waves: the youngest wave of a SIMD
-    // (w >> 2 = 2: the helpers / shared-block owners, which have the least work and today finish LAST, alone) first
-    const int sprio = (flags & 8) ? (wave >> 2) : 0;
-    auto set_sprio = [&]() {                            // (s_setprio takes an immediate)
-        if (sprio == 2) __builtin_amdgcn_s_setprio(2);
-        else if (sprio == 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-    };
-    if (flags & 8) set_sprio();
-    RowIx rcur = make_row(slot < nrows ? slot : 0), rprev = rcur;
-    if (slot < nrows) phase1(rcur, 0, 0);
-    int gpar = 0;                                       // gpar = it % 3
-    for (int bu = slot; bu < nrows; bu += rstride, ++it) {
-        const int par = it & 1;
-        const unsigned bufo = L.buf0 + (unsigned)par * L.bufsize;
-        PRD2_STAMP(5);                                  // 5: arrival at the barrier
-        __syncthreads();
-        PRD2_STAMP(0);                                  // 0: released
-        if (it > 0 && group_owner) merge(rprev, par ^ 1, gpar == 0 ? 2 : gpar - 1);
-        PRD2_STAMP(1);                                  // 1: merge of the previous row done
-        // ================= phase 2 of row rcur =================
-        unsigned fmask;
-        {
-            const int f = lane < nqb ? reinterpret_cast<const int*>(lds + bufo + flag_rel)[lane] : 0;
-            fmask = (unsigned)__ballot(f != 0);
-        }
-        const unsigned kbase = bufo + klane, vb0 = bufo + vlane0, vb1 = bufo + vlane1, kaddo = bufo + kadd_rel;
-        auto ldv = [&](int t, PBuf& p) {
-            p.va0 = *reinterpret_cast<const u32x4*>(lds + vb0 + 2048u * t);
-            p.va1 = *reinterpret_cast<const u32x4*>(lds + vb1 + 2048u * t);
-        };
-        int work_rem = work_tot;
-        auto run_piece = [&](const u32x4& qh, const u32x4& ql, int T0, int T1, float (&o8)[8], float& lsum, float& mref) {
-            f32x16 o0, zero;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { o0[e] = 0.f; zero[e] = 0.f; }
-            lsum = 0.f;
-            bool big = false;
-            if (flags & 1) v2_prio(work_rem, work_tot);
-            if (KL == 0) {
-                KOp k = load_k(lds, kbase + 512u * T0, kl_rel);
-                f32x16 s0 = qk_tile(k, qh, ql, zero);
-                if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_rel);
-                if ((fmask >> T0) & 1) mask_tile_at(lds, kaddo, T0, hi, 0.f, s0);
-                const float tmax = xhalf_max(max16_mfma(s0));
-                mref = tmax - P_SHIFT;
-                f32x16 negm;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { negm[e] = -mref; s0[e] -= mref; }
-                PBuf p;
-                ldv(T0, p);
-                exp_split(s0, lsum, big, p);
-                pv_tile(p, o0);
-                for (int t = T0 + 1; t < T1; ++t) {
-                    if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
-                    f32x16 s = qk_tile(k, qh, ql, negm);
-                    if (t + 1 < T1) k = load_k(lds, kbase + 512u * (t + 1), kl_rel);
-                    ldv(t, p);
-                    if ((fmask >> t) & 1) mask_tile_at(lds, kaddo, t, hi, mref, s);
-                    exp_split(s, lsum, big, p);
-                    pv_tile(p, o0);
-                }
-            } else {
-                constexpr bool VSUM = (KL & 2) == 0;    // row sum on the VALU (else: rowsum_mfma)
-                f32x4 la0 = {0.f, 0.f, 0.f, 0.f}, la1 = {0.f, 0.f, 0.f, 0.f};
-                KOp k = load_k(lds, kbase + 512u * T0, kl_rel);
-                f32x16 s = qk_tile(k, qh, ql, zero);
-                if (T0 + 1 < T1) k = load_k(lds, kbase + 512u * (T0 + 1), kl_rel);
-                if ((fmask >> T0) & 1) mask_tile_at(lds, kaddo, T0, hi, 0.f, s);
-                const float tmax = xhalf_max(max16_mfma(s));
-                mref = tmax - P_SHIFT;
-                f32x16 negm;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { negm[e] = -mref; s[e] -= mref; }
-                for (int t = T0; t < T1; ++t) {
-                    if (flags & 1) v2_prio(work_rem - (t - T0), work_tot);
-                    PBuf p;
-                    ldv(t, p);
-                    exp_sum<VSUM>(s, lsum, big);
-                    f32x16 sn;
-                    if ((KL & 1) && t + 1 < T1) {       // the next tile's logits: issued here, consumed one iteration later
-                        sn = qk_tile(k, qh, ql, negm);
-                        if (t + 2 < T1) k = load_k(lds, kbase + 512u * (t + 2), kl_rel);
-                    }
-                    split_p(s, p);
-                    if (!VSUM) rowsum_mfma(p, la0, la1);
-                    pv_tile(p, o0);
-                    if (t + 1 < T1) {
-                        if (!(KL & 1)) {
-                            sn = qk_tile(k, qh, ql, negm);
-                            if (t + 2 < T1) k = load_k(lds, kbase + 512u * (t + 2), kl_rel);
-                        }
-                        s = sn;
-                        if ((fmask >> (t + 1)) & 1) mask_tile_at(lds, kaddo, t + 1, hi, mref, s);
-                    }
-                }
-                if (!VSUM) lsum = la0[0] + la1[0];
-            }
-            // (forms with the row sum on the matrix pipe have no per-tile `big` test: an overflowed probability is +inf in fp16
-            // and makes the sum inf)
-            if (__any(big || !(lsum < 3.0e38f))) {      // rare: redo the piece with the online update in every tile
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o0[e] = 0.f;
-                lsum = 0.f;
-                float m_run = -1e30f;
-                for (int t = T0; t < T1; ++t) {
-                    const KOp k = load_k(lds, kbase + 512u * t, kl_rel);
-                    f32x16 s = qk_tile(k, qh, ql, zero);
-                    if ((fmask >> t) & 1) mask_tile_at(lds, kaddo, t, hi, 0.f, s);
-                    const float m_new = max2f(m_run, xhalf_max(max16_mfma(s)));
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    m_run = m_new;
-                    mref = m_new - P_SHIFT;
-                    lsum *= alpha;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; s[e] -= mref; }
-                    bool dummy = false;
-                    PBuf p;
-                    ldv(t, p);
-                    exp_split(s, lsum, dummy, p);
-                    pv_tile(p, o0);
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o8[jj] = o0[jj] + o0[jj + 8];
-            work_rem -= T1 - T0;
-        };
-        auto put_partial = [&](int pslot, const float (&o8)[8], float lsum, float mref) {
-            float* pp = reinterpret_cast<float*>(lds + L.part) + ((size_t)par * L.nslot + pslot) * 640 + lane;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) pp[jj * 64] = o8[jj];
-            pp[8 * 64] = lsum;
-            pp[9 * 64] = mref;
-        };
-        if (owner) {
-            float o8[8], lsum = 0.f, mref = 0.f;
-            if (remap && group_owner) {                 // Q of the shared block was projected by another wave
-                const unsigned qo = L.qs + (unsigned)(par * m4 + gi) * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
-                qh4 = *reinterpret_cast<const u32x4*>(lds + qo);
-                ql4 = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
-            }
-            if (own_t1 > 0) run_piece(qh4, ql4, 0, own_t1, o8, lsum, mref);
-            if (!group_owner) finish(rcur, wave, o8, lsum, gate, mref);
-            else if (own_t1 > 0) put_partial((nhelp + 1) * gi, o8, lsum, mref);
-        } else if (helper) {
-            // Helper hj sweeps key piece (hj + i) mod nhelp of shared block i: the pieces differ by a tile (N = 320: [5, 7) and [7, 10)),
-            // and with a fixed piece per helper the two helpers -- the youngest waves of SIMDs 2 and 3, which end the iteration -- carried
-            // 4 and 6 tile steps (24 / 26 per SIMD); rotating gives 5 and 5 (25 on every SIMD).  Same pieces, same partial slots (by
-            // piece), same merge: bit-identical results.  (flag 32: the fixed assignment, A/B)
-            for (int i = 0; i < m4; ++i) {
-                const int pc = (flags & 32) ? hj : (hj + i) % nhelp;
-                const int T0 = qtile(m4 + pc), T1 = qtile(m4 + pc + 1);
-                if (T1 <= T0) continue;
-                const unsigned qo = L.qs + (unsigned)(par * m4 + i) * 2048u + (unsigned)hi * 512u + (unsigned)r * 16u;
-                const u32x4 qh = *reinterpret_cast<const u32x4*>(lds + qo), ql = *reinterpret_cast<const u32x4*>(lds + qo + 1024u);
-                float o8[8], lsum, mref;
-                run_piece(qh, ql, T0, T1, o8, lsum, mref);
-                put_partial((nhelp + 1) * i + 1 + pc, o8, lsum, mref);
-            }
-        }
-        set_sprio();
-        PRD2_STAMP(2);                                  // 2: key loops done
-        // ================= phase 1 of the next row =================
-        rprev = rcur;
-        const int bun = bu + rstride;
-        if (bun < nrows) {
-            rcur = make_row(bun);
-            phase1(rcur, par ^ 1, gpar == 2 ? 0 : gpar + 1);
-        }
-        PRD2_STAMP(4);                                  // 4: projection of the next row done
-        gpar = gpar == 2 ? 0 : gpar + 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    if (it > 0 && m4 > 0) {
-        __syncthreads();
-        if (group_owner) merge(rprev, (it - 1) & 1, gpar == 0 ? 2 : gpar - 1);
+    __syncthreads();
+}
+
+// output projection + residual of the triangle attention (tri_attn_out_kernel of prd_tri.hip, split-16 form), in place on `pair`
+template <int P, int NW>
+PRD_DEV void tri_attn_out_body(float* pair, const float* og, const float* __restrict__ wo, const float* __restrict__ bo, long rows,
+                               unsigned char* lds) {
+    constexpr int KH = P / 2, NB = P / 32, HC = 64;
+    float* Wl = reinterpret_cast<float*>(lds);                           // fp16 hi | lo planes of W_o (P x 64)
+    float* bl = Wl + P * HC;
+    stage_weight_h2<HC>(reinterpret_cast<u32x4*>(Wl), wo, P, HC, threadIdx.x, NW * 64, H2_WSCALE);
+    stage_vec_cll(bl, bo, P, threadIdx.x, NW * 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const long ntask = (rows + 31) / 32;
+    WaveTasks tasks(nullptr, ntask, NW);
+    for (long task = tasks.next(); task >= 0; task = tasks.next()) {
+        const long pos = task * 32 + r;
+        const bool valid = pos < rows;
+        float x[HC / 2];
+        load_row_cll<HC>(og + pos * HC, hi, valid, x);
+        f32x16 acc[NB];
+        zero_acc(acc);
+        u32x4 xs[2][HC / 16];
+        split2h_cll<HC / 2>(x, xs);
+        rowgemm_h2<HC, NB>(reinterpret_cast<const u32x4*>(Wl), P, 0, xs, acc, r, hi);
+        float pr[KH];
+        load_row_cll<P>(pair + pos * P, hi, valid, pr);
+#pragma unroll
+        for (int s_ = 0; s_ < KH; ++s_) pr[s_] = pr[s_] + (acc[s_ >> 4][s_ & 15] * H2_INV_WSCALE + bl[hi * KH + s_]);
+        store_row_cll<P>(pair + pos * P, hi, valid, pr);
     }
+}
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void tri_attn_pair_kernel(
+    float* og, float* pair, const float* __restrict__ mask,
+    const float* __restrict__ wq1, const float* __restrict__ wk1, const float* __restrict__ wv1, const float* __restrict__ wg1,
+    const float* __restrict__ bg1, const float* __restrict__ wo1, const float* __restrict__ bo1,
+    const float* __restrict__ wq2, const float* __restrict__ wk2, const float* __restrict__ wv2, const float* __restrict__ wg2,
+    const float* __restrict__ bg2, int b, int N, int NP, int H, unsigned* bar, int plain_barrier) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const unsigned xcc = xcc_id();
+    if (!plain_barrier) grid_barrier_register(bar, xcc);
+    tri_attn_core_v3_body<P, NW, 0, true>(og, pair, mask, wq1, wk1, wv1, wg1, bg1, b, N, NP, H, 0, 0, nullptr, lds);
+    if (plain_barrier) grid_barrier_counter(bar, 1u); else grid_barrier_xcd(bar, 1u, xcc);
+    tri_attn_out_body<P, NW>(pair, og, wo1, bo1, (long)b * N * N, lds);
+    if (plain_barrier) grid_barrier_counter(bar, 2u); else grid_barrier_xcd(bar, 2u, xcc);
+    tri_attn_core_v3_body<P, NW, 0, true>(og, pair, mask, wq2, wk2, wv2, wg2, bg2, b, N, NP, H, 1, 0, nullptr, lds);
 }
 
 size_t v3_lds_bytes(int N, int P) {
@@ -2321,6 +2016,66 @@ extern "C" int prd_tri_attn_core_v2(float* og, const float* pair, const float* m
                                     const float* wv, const float* wg, const float* bg, int ending,
                                     int b, int N, int P, int H, int c, int tune, hipStream_t stream) {
     return prd_tri_attn_core_v2_lse(og, nullptr, pair, mask, wq, wk, wv, wg, bg, ending, b, N, P, H, c, tune, stream);
+}
+
+// ---- the triangle-attention pair of a folding block as ONE persistent launch (tri_attn_pair_kernel) ----
+static int prd_cu_count() {
+    static int cus = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = n;
+    });
+    return cus;
+}
+
+// 1 when prd_tri_attn_pair serves (N, P): split-16 arithmetic, rows on the overlapped-phase short-row core (the form the default
+// dispatch takes for N <= 320-odd), default kernel switches
+extern "C" int prd_tri_attn_pair_supported(int N, int P, int arith) {
+    PRD_SPLIT_ARITH(arith);
+    if (N <= 0 || (P != 32 && P != 64) || arith != PRD_ARITH_SPLIT16) return 0;
+    if (N > V2_MAXN || PRD_TGET_TA2_NO_V3(tune) || PRD_TGET_TA2_NO_GV(tune) || PRD_TGET_TA2_FLAGS(tune) >= 0) return 0;
+    return v3_lds_bytes(N, P) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int prd_tri_attn_pair(float* og, float* pair, const float* mask, const float* const* w_start, const float* const* w_end,
+                                 int b, int N, int P, int H, int c, unsigned* bar, int arith, hipStream_t stream) {
+    if (!og || !pair || !mask || !w_start || !w_end || !bar || b <= 0 || N <= 0 || arith < 0) return PRD_ERR_ARG;
+    const int tune = arith >> 8;                        // (the PRD_TUNE_* word above the arithmetic)
+    for (int k = 0; k < 7; ++k) if (!w_start[k]) return PRD_ERR_ARG;
+    for (int k = 0; k < 5; ++k) if (!w_end[k]) return PRD_ERR_ARG;
+    if (c != 16 || H * c != 64) return PRD_ERR_UNSUPPORTED;
+    if (!prd_tri_attn_pair_supported(N, P, arith)) return PRD_ERR_UNSUPPORTED;
+    if ((long)b * N * N > 0x7fffffffL / 2) return PRD_ERR_UNSUPPORTED;
+    const int NP = prd_round_up(N, 32);
+    const long rows_total = (long)b * N, cap = 256 / H;                 // the grid of prd_tri_attn_core_v2 (heads of a row on one XCD)
+    long per_head = cap < rows_total ? cap : rows_total;
+    if (per_head < 1) per_head = 1;
+    const long rounds = (rows_total + per_head - 1) / per_head;
+    per_head = (rows_total + rounds - 1) / rounds;
+    if (per_head >= 8) per_head = (per_head + 7) / 8 * 8;
+    if (per_head > cap) per_head = cap;
+    const int grid = (int)(per_head * H);
+    // every workgroup must be resident for the in-kernel barriers: one workgroup of 12 waves + ~150 KB of LDS per CU
+    const int cus = prd_cu_count();
+    if (cus <= 0 || grid > cus) return PRD_ERR_UNSUPPORTED;
+    const size_t lds3 = v3_lds_bytes(N, P);
+    const size_t ldso = (size_t)P * 64 * 4 + (size_t)P * 4;
+    const size_t lds = lds3 > ldso ? lds3 : ldso;
+    hipError_t e = hipMemsetAsync(bar, 0, 32 * sizeof(unsigned), stream);     // counters, timeout flag, memberships: zero before EVERY launch
+    const int plain = PRD_TGET_TA2_NO_TAIL_SPLIT(tune) ? 1 : 0;               // (A/B: PRD_TA2_TAIL=0 selects the plain counter barrier here)
+    if (e != hipSuccess) return (int)e;
+    constexpr int NWV = 12;
+    if (P == 64) {
+        PRD2_SET_LDS((tri_attn_pair_kernel<64, NWV>));
+        hipLaunchKernelGGL((tri_attn_pair_kernel<64, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, w_start[0], w_start[1], w_start[2],
+                           w_start[3], w_start[4], w_start[5], w_start[6], w_end[0], w_end[1], w_end[2], w_end[3], w_end[4], b, N, NP, H, bar, plain);
+    } else {
+        PRD2_SET_LDS((tri_attn_pair_kernel<32, NWV>));
+        hipLaunchKernelGGL((tri_attn_pair_kernel<32, NWV>), dim3(grid), dim3(NWV * 64), lds, stream, og, pair, mask, w_start[0], w_start[1], w_start[2],
+                           w_start[3], w_start[4], w_start[5], w_start[6], w_end[0], w_end[1], w_end[2], w_end[3], w_end[4], b, N, NP, H, bar, plain);
+    }
+    return (int)hipGetLastError();
 }
 
 // ---- backward core, split-16 arithmetic (tri_attn_bwd_core_v2_kernel) ----

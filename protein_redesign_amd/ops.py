@@ -359,6 +359,46 @@ def tri_mul_chain_(pair, mask, wts_outgoing, wts_incoming, ws=None) -> torch.Ten
     return pair
 
 
+# 1: the starting triangle attention (core + output projection + residual) and the ending attention's core as ONE persistent launch with
+# two in-kernel grid barriers (prd_tri_attn_pair) instead of three launches.  Bit-identical; measured in DESIGN.md 4.3.
+PERSISTENT_ATTN = os.environ.get("PRD_PERSISTENT_ATTN", "0") == "1"
+_PAIR_BARS = {}
+
+
+def tri_attn_pair_supported(N: int, P: int) -> bool:
+    return lib().prd_tri_attn_pair_supported(N, P) == 1
+
+
+def tri_attn_pair_bar(device) -> torch.Tensor:
+    """The 32 uint32 (counters, memberships, [1] = timeout flag) of prd_tri_attn_pair on ``device``: zeroed by every call, stream-ordered."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    bar = _PAIR_BARS.get(key)
+    if bar is None:
+        bar = _PAIR_BARS[key] = torch.zeros(32, dtype=torch.int32, device=f"cuda:{key}")
+    return bar
+
+
+def tri_attn_pair_(pair, mask, wts_start, wts_end, H: int, c: int, og=None) -> torch.Tensor:
+    """pair += TriangleAttention_starting(pair) in place, then og [b,N,N,64] = the gated head outputs of the ENDING attention on the
+    updated pair (its output projection rides in block_tail_): modules.py:338-339 as ONE persistent launch (prd_tri_attn_pair).
+    wts_start = (q.w, k.w, v.w, gate.w, gate.b, out.w, out.b), wts_end = (q.w, k.w, v.w, gate.w, gate.b)."""
+    import ctypes
+    b, N, _, P = pair.shape
+    if og is None:
+        og = torch.empty(b, N, N, 64, device=pair.device, dtype=F32)
+    wa = (ctypes.c_void_p * 7)(*[dptr(w) for w in wts_start])
+    wb = (ctypes.c_void_p * 5)(*[dptr(w) for w in wts_end])
+    bar = tri_attn_pair_bar(pair.device)
+    check(lib().prd_tri_attn_pair(dptr(og), dptr(pair), dptr(mask), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(wb, ctypes.c_void_p),
+                                  b, N, P, H, c, bar.data_ptr(), stream()), "prd_tri_attn_pair")
+    return og
+
+
+def tri_attn_pair_timed_out(device) -> bool:
+    """True when a grid barrier of the last prd_tri_attn_pair on ``device`` gave up (synchronises; tests and the sampler's final check)."""
+    return int(tri_attn_pair_bar(device)[1].item()) != 0
+
+
 def tri_mul_backward(dy, pair, mask, wts, *, incoming: bool, ws=None):
     """Gradients of the TriangleMultiplication update (ops.tri_mul with residual=False) with respect to ``pair`` and its eight
     weight tensors, on the hand-written backward kernels (csrc/prd_bwd.hip): forward recompute (projection, contraction) ->

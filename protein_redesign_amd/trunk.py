@@ -309,6 +309,10 @@ class FoldingBlock(nn.Module):
             pair, spare = spare, pair
             if spare_holder is not None:
                 spare_holder[0] = spare          # the buffer the residual stream just left: the next block's target
+        elif ops.PERSISTENT_ATTN and ops.tri_attn_pair_supported(N, pair.shape[-1]):
+            # (opt-in, PRD_PERSISTENT_ATTN=1) the starting attention and the ending core as ONE persistent launch
+            ts = self.pair_attn_starting.attn
+            og = ops.tri_attn_pair_(pair, mask, ts.weights(), ta.weights()[:5], ta.num_heads, ta.head_dim, og=ws[:nog].view(b, N, N, 64))
         else:
             self.pair_attn_starting.run(pair, mask, residual=True, out=pair, ws=ws)
             # ending triangle attention: core kernel, then ONE fused row pass = its output projection + the pair

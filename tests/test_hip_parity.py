@@ -311,6 +311,66 @@ def test_triangle_multiplication(setup, mode, gemm_mode):
     assert rel_l2(got.cpu(), want) < OP_TOL
 
 
+@pytest.mark.parametrize("P,b,N,valid", [(64, 1, 320, 320), (32, 1, 96, 90), (64, 2, 200, 187), (64, 1, 45, 45), (32, 3, 288, 288)])
+def test_triangle_attention_pair_persistent(P, b, N, valid):
+    """SURVEY 8(f)#4, built for one seam of the folding block: prd_tri_attn_pair = the starting attention (core + output projection +
+    residual) and the ending attention's core as ONE persistent launch with two in-kernel grid barriers (agent-scope release / acquire on
+    a monotonic counter) against the three launches it replaces: pair and og BIT FOR BIT (same stage bodies), no barrier timed out.
+    Shapes: the bench shape (256 workgroups = every CU), small grids, batches with a masked tail, P = 32.  Repeated: a hand-off that
+    is only sometimes stale shows up as a differing repeat."""
+    from protein_redesign_amd import _lib
+    from protein_redesign_amd.trunk import TriangleAttention
+    lib = _lib.lib()
+    prev = lib.prd_get_gemm_mode()
+    assert lib.prd_set_gemm_mode(1) == 0
+    try:
+        if not ops.tri_attn_pair_supported(N, P):
+            pytest.skip("rows of this length do not run on the overlapped-phase core")
+        g = torch.Generator().manual_seed(500 + N + P)
+        mods = {m: TriangleAttention(P, 16, 4, m) for m in ("starting", "ending")}
+        for m, mod in mods.items():
+            sd = {k: torch.randn(v.shape, generator=g) / (math.sqrt(v.shape[-1]) if v.dim() == 2 else 3.0) for k, v in mod.state_dict().items()}
+            mod.load_state_dict(sd)
+            mod.to(DEV)
+        pair = torch.randn(b, N, N, P, generator=g)
+        mask = torch.ones(b, N)
+        mask[b - 1, valid:] = 0
+        ts, te = mods["starting"].attn, mods["ending"].attn
+        # the three launches
+        want_pair = cu(pair).clone()
+        mods["starting"].run(want_pair, cu(mask), residual=True, out=want_pair)
+        want_og = ops.tri_attn_core(want_pair, cu(mask), te.weights()[:5], 4, 16, ending=True)
+        for rep in range(3):
+            got_pair = cu(pair).clone()
+            og = torch.full((b, N, N, 64), float("nan"), device=DEV)
+            ops.tri_attn_pair_(got_pair, cu(mask), ts.weights(), te.weights()[:5], 4, 16, og=og)
+            assert not ops.tri_attn_pair_timed_out(DEV), "a grid barrier gave up: the grid was not resident"
+            assert torch.equal(got_pair, want_pair), (rep, rel_l2(got_pair.cpu(), want_pair.cpu()))
+            assert torch.equal(og, want_og), (rep, rel_l2(og.cpu(), want_og.cpu()))
+    finally:
+        assert lib.prd_set_gemm_mode(prev) == 0
+
+
+def test_folding_block_with_the_persistent_attention_pair(setup, monkeypatch):
+    """The opt-in switch (PRD_PERSISTENT_ATTN=1 -> ops.PERSISTENT_ATTN) inside FoldingBlock.run_: same single / pair outputs bit for bit."""
+    from protein_redesign_amd import _lib
+    s = setup
+    lib = _lib.lib()
+    prev = lib.prd_get_gemm_mode()
+    assert lib.prd_set_gemm_mode(1) == 0
+    try:
+        blk = s["model"].Denoiser.folding_blocks[0]
+        outs = []
+        for flag in (False, True):
+            monkeypatch.setattr(ops, "PERSISTENT_ATTN", flag)
+            gs, gp = blk(cu(s["single"]), cu(s["pair"]), cu(s["mask"]))
+            outs.append((gs.clone(), gp.clone()))
+        assert not ops.tri_attn_pair_timed_out(DEV)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        assert lib.prd_set_gemm_mode(prev) == 0
+
+
 @pytest.mark.parametrize("P,b,N", [(64, 2, 320), (64, 1, 449), (32, 1, 769), (64, 3, 200), (64, 1, 320)])
 def test_triangle_multiplication_contraction_direct(P, b, N):
     """prd_tri_mul_contract in split-16 arithmetic, called directly: O[p, m, n] = sum_k A[p, m, k] B[p, n, k] against float64 (split
