@@ -104,6 +104,21 @@ int main(void) {
         EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 1 << 20, A0, s), PRD_ERR_UNSUPPORTED);     /* fp32 arithmetic has no fused chain */
         EXPECT(prd_tri_mul_chain(p, p, w8, w8, 1, 8, 64, p, 16, A1 | PRD_TUNE(PRD_TUNE_TMS_NW16), s), PRD_ERR_WORKSPACE);  /* switches ride above the arithmetic */
     }
+    {   /* the persistent attention pair: every rejection below happens before any HIP call */
+        const float* w7[7] = {p, p, p, p, p, p, p};
+        const float* w6[7] = {p, p, p, p, p, 0, p};
+        const float* w5[5] = {p, p, p, p, p};
+        EXPECT(prd_tri_attn_pair_supported(320, 64, A1), 1);
+        EXPECT(prd_tri_attn_pair_supported(320, 64, A0), 0);            /* split-16 arithmetic only */
+        EXPECT(prd_tri_attn_pair_supported(769, 64, A1), 0);            /* long rows stay three launches */
+        EXPECT(prd_tri_attn_pair_supported(320, 48, A1), 0);
+        EXPECT(prd_tri_attn_pair(0, p, p, w7, w5, 1, 320, 64, 4, 16, (unsigned*)ibuf, A1, s), PRD_ERR_ARG);
+        EXPECT(prd_tri_attn_pair(p, p, p, w6, w5, 1, 320, 64, 4, 16, (unsigned*)ibuf, A1, s), PRD_ERR_ARG);     /* a missing weight pointer */
+        EXPECT(prd_tri_attn_pair(p, p, p, w7, w5, 1, 320, 64, 4, 16, 0, A1, s), PRD_ERR_ARG);                    /* no barrier words */
+        EXPECT(prd_tri_attn_pair(p, p, p, w7, w5, 1, 320, 64, 2, 32, (unsigned*)ibuf, A1, s), PRD_ERR_UNSUPPORTED);   /* head layout */
+        EXPECT(prd_tri_attn_pair(p, p, p, w7, w5, 1, 320, 64, 4, 16, (unsigned*)ibuf, A0, s), PRD_ERR_UNSUPPORTED);
+        EXPECT(prd_tri_attn_pair(p, p, p, w7, w5, 1, 769, 64, 4, 16, (unsigned*)ibuf, A1, s), PRD_ERR_UNSUPPORTED);
+    }
     EXPECT(prd_tri_attn_core_fused_supported(320, 64, A1), 0);      /* first-generation form: only in the -DPRD_AB library */
     EXPECT(prd_tri_attn_core_fused_supported(769, 64, A1), 0);      /* long rows: no fused form */
     EXPECT(prd_tri_attn_v2_supported(320, 64, 0), 1);
