@@ -353,7 +353,7 @@ def main():
                                  "above 1 it only says the 16-bit pipe is in use.  frac_of_16bit_peak prices what the kernel EXECUTES "
                                  "(MFMA instructions x 32768 flops) against 2.5 PF/s; mfma_busy_frac / valu_active_frac are the measured "
                                  "pipe occupancies (eager launches under the profiler).  The kernel is VALU-bound, not MFMA-bound: one "
-                                 "v_exp_f32 and one fp16 hi|lo split per logit (DESIGN.md 4.3; profiles/r05_roofline.txt covers every "
+                                 "v_exp_f32 and one fp16 hi|lo split per logit (DESIGN.md 4.3; profiles/r06_roofline.txt covers every "
                                  "kernel of the step)"}
         if v2:         # every MFMA is a 32x32x16 (32768 flops): 36 per 32-position block of a row (3 row GEMMs x 4 k-steps x 3
             nqb = (N + 31) // 32                                     # products; long rows: [K|Q] + [V] + [Q|G] = 36 too),
