@@ -776,9 +776,9 @@ PRD_DEV unsigned xcc_id() {
 
 PRD_DEV void grid_barrier_register(unsigned* bar, unsigned xcc) {
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(bar + 8 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(bar + 8 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the membership is counted before the registration is
-        if (old < 0xffffffffu) __hip_atomic_fetch_add(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
