@@ -1968,6 +1968,7 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
         } while (0)
         const bool pf = (flags & 8) != 0;               // next-row prefetch of the wave's first block (costs 32 registers)
         const bool gvl = !PRD_TGET_TA2_NO_GV(tune);     // phase 1 with [K|V] as one row GEMM + transposed V store
+#ifdef PRD_AB       // (libprd_hip_ab.so) the measured-and-superseded forms: next-row prefetch (spills), the round-3 phase 1
         if (P == 64) {
             if (gvl) { if (pf) PRD_V2L_LAUNCH(64, true, true); else PRD_V2L_LAUNCH(64, false, true); }
             else { if (pf) PRD_V2L_LAUNCH(64, true, false); else PRD_V2L_LAUNCH(64, false, false); }
@@ -1975,6 +1976,10 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
             if (gvl) { if (pf) PRD_V2L_LAUNCH(32, true, true); else PRD_V2L_LAUNCH(32, false, true); }
             else { if (pf) PRD_V2L_LAUNCH(32, true, false); else PRD_V2L_LAUNCH(32, false, false); }
         }
+#else               // the shipped library carries the default form only; the switches that select another one are ignored
+        (void)pf; (void)gvl;
+        if (P == 64) PRD_V2L_LAUNCH(64, false, true); else PRD_V2L_LAUNCH(32, false, true);
+#endif
 #undef PRD_V2L_LAUNCH
         return (int)hipGetLastError();
     }
@@ -1990,6 +1995,7 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
         // phase 1 with [G|V] as one row GEMM + transposed V store (default); PRD_TUNE_TA2_NO_GV: the G GEMM + swapped V GEMM of round 3.
         // The A/B key-loop forms 1-3 exist with the round-3 phase 1 only.
         const bool gvf = !PRD_TGET_TA2_NO_GV(tune) && kl == 0;
+#ifdef PRD_AB       // (libprd_hip_ab.so) the key-loop forms 1-3 and the round-3 phase 1: measured in round 5, none faster
         if (P == 64) {
             if (gvf) PRD_V3_LAUNCH(64, 0, true);
             else if (kl == 0) PRD_V3_LAUNCH(64, 0, false); else if (kl == 1) PRD_V3_LAUNCH(64, 1, false); else if (kl == 2) PRD_V3_LAUNCH(64, 2, false); else PRD_V3_LAUNCH(64, 3, false);
@@ -1997,6 +2003,10 @@ extern "C" int prd_tri_attn_core_v2_lse(float* og, float* lse, const float* pair
             if (gvf) PRD_V3_LAUNCH(32, 0, true);
             else if (kl == 0) PRD_V3_LAUNCH(32, 0, false); else if (kl == 1) PRD_V3_LAUNCH(32, 1, false); else if (kl == 2) PRD_V3_LAUNCH(32, 2, false); else PRD_V3_LAUNCH(32, 3, false);
         }
+#else               // the shipped library carries the default form only (the scheduling switches -- bits 0, 3, 4 -- still reach it)
+        (void)gvf;
+        if (P == 64) PRD_V3_LAUNCH(64, 0, true); else PRD_V3_LAUNCH(32, 0, true);
+#endif
 #undef PRD_V3_LAUNCH
         return (int)hipGetLastError();
     }

@@ -35,3 +35,15 @@ def test_first_generation_kernels_in_the_ab_library():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+
+
+@pytest.mark.gpu
+def test_superseded_second_generation_forms_in_the_ab_library():
+    """Round 6: the shipped library carries ONE form of tri_attn_core_v3 / _v2l per pair_dim; key-loop forms 1-3, the round-3 phase 1 and the
+    next-row prefetch (measured in rounds 3-5, none faster) compile only with -DPRD_AB and are checked here against the default form."""
+    from protein_redesign_amd import build
+    lib = build.build_ab(verbose=False)
+    env = dict(os.environ, PRD_LIB=lib, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("PRD_LDS_POISON", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ab_forms_check.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ab forms ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

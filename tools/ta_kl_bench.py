@@ -2,7 +2,9 @@
 """Same-box A/B of the key-loop forms of tri_attn_core_v3_kernel (PRD_TA2_FLAGS bits 1-2: bit 1 = the next tile's Q K^T issued before
 the split of this one, bit 2 = row sum on the matrix pipe) and of tri_attn_core_v2 for reference: average launch time with HIP events
 (back-to-back launches, starting / ending alternating) and the rel-L2 distance of the result from form 0.
-usage: ta_kl_bench.py [--N 320] [--b 1] [--reps 40]"""
+usage: PRD_LIB=protein_redesign_amd/libprd_hip_ab.so ta_kl_bench.py [--N 320] [--b 1] [--reps 40]
+(since round 6 the forms other than the default exist in the -DPRD_AB library only: python -m protein_redesign_amd.build --ab; the shipped
+library ignores the switches and runs the default form in every arm)"""
 import argparse
 import os
 import sys

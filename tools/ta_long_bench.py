@@ -25,7 +25,7 @@ for N in [int(v) for v in sys.argv[1:]] or [449, 640, 769, 832]:
     for ending in (False, True):
         res = {}
         for rnd in range(3):
-            for name, tune in (("default", tune0), ("no tail split", tune0 | (1 << 19)), ("round-3 phase 1", tune0 | (1 << 21)),
+            for name, tune in (("default", tune0), ("no tail split", tune0 | (1 << 19)), ("round-3 phase 1 (A/B library only)", tune0 | (1 << 21)),
                                ("tail as a tile", tune0 | (1 << 6) | (3 << 7)),
                                ("r5 shared round", tune0 | (1 << 6) | (5 << 7))):       # PRD_TA2_FLAGS=5: shared last round projected / merged inside phase 2        # PRD_TA2_FLAGS=3: ragged last key tile swept as a 32-key tile (round 5)
                 lib.prd_set_tune(tune)
