@@ -2220,18 +2220,24 @@ int grid_for(long tasks, int per_wg, int cap) {
 static void launch_contract_split(int tune, int grid, size_t lds3, hipStream_t stream, float* O, const float* AB, int N, int ldn, int P, int nbatch,
                                   int tiles, int swap) {
     const int nw = PRD_TGET_TMS_NW(tune);
+#ifdef PRD_AB       // (libprd_hip_ab.so) three chunks in flight / 16 waves: measured in rounds 3 and 5, not faster
     if (nw == 8 && PRD_TGET_TMS_D3(tune)) {
         PRD_SET_LDS((tri_mul_contract_split_kernel<8, 3>), lds3);
         hipLaunchKernelGGL((tri_mul_contract_split_kernel<8, 3>), dim3(grid), dim3(512), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
-    } else if (nw == 8) {
-        PRD_SET_LDS((tri_mul_contract_split_kernel<8>), lds3);
-        hipLaunchKernelGGL((tri_mul_contract_split_kernel<8>), dim3(grid), dim3(512), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
-    } else if (nw == 12) {
+        return;
+    }
+    if (nw == 16) {
+        PRD_SET_LDS((tri_mul_contract_split_kernel<16>), lds3);
+        hipLaunchKernelGGL((tri_mul_contract_split_kernel<16>), dim3(grid), dim3(1024), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
+        return;
+    }
+#endif
+    if (nw == 12) {     // (kept in the shipped library: the second arm of the direct parity test -- same results bit for bit)
         PRD_SET_LDS((tri_mul_contract_split_kernel<12>), lds3);
         hipLaunchKernelGGL((tri_mul_contract_split_kernel<12>), dim3(grid), dim3(768), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
     } else {
-        PRD_SET_LDS((tri_mul_contract_split_kernel<16>), lds3);
-        hipLaunchKernelGGL((tri_mul_contract_split_kernel<16>), dim3(grid), dim3(1024), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
+        PRD_SET_LDS((tri_mul_contract_split_kernel<8>), lds3);
+        hipLaunchKernelGGL((tri_mul_contract_split_kernel<8>), dim3(grid), dim3(512), lds3, stream, O, AB, N, ldn, P, nbatch, tiles, swap);
     }
 }
 
